@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- hypotheses scored / s over a 640x480 scene-coordinate map (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic frame of BASELINE.json configs[1]
+("chess"-like single frame, 256 hypotheses, 640x480 coordinate map, one MI355X):
+    K1 sample 256 minimal sets + P3P   ->  K2 reproject all 307 200 points under all 256 poses
+    (error images, the score-CNN input of the reference, + fused soft-inlier sums)  ->  K3 softmax.
+The frame is resident in HBM before the timed region; every output stays in HBM.  With --gpus N every rank
+owns its own frame (images shard across GPUs, no data-path collective: "scaling": "weak").
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel K2 (k_reproject): algorithmic bytes
+per launch (12*P + 48*N + 4*N*P + 4*N) over the average launch duration measured with HIP
+events on the engine's stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of the
+reference path, g++ -Ofast -fopenmp) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
+    # B_fwd(N,P) = 12 P (xyz f32) + 8 P [explicit uv] + 48 N (R|t f32) + 4 N P (err f32 out) + 4 N (score out)
+    return 12 * P + (8 * P if explicit_uv else 0) + 48 * N + (4 * N * P if write_err else 0) + 4 * N
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--hyps", type=int, default=256)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "1")),
+                    help="engine contexts (HIP streams) per GPU; frames are dealt round-robin")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] style)")
+    args = ap.parse_args()
+
+    import torch
+    import dsac_amd
+    from dsac_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    N, H, W = args.hyps, args.height, args.width
+    P = H * W
+    K, Wm = args.steps, args.warmup
+
+    # one frame per rank (seed 1305 + rank: the reference's ThreadRand seed), uploaded before timing
+    fr = synth.chess_like_frame(H, W, seed=1305 + rank)
+    xyz = torch.from_numpy(fr["xyz"]).to(dev)
+    n_ctx = max(1, args.streams)
+    engines, bufs = [], []
+    for i in range(n_ctx):
+        st = torch.cuda.Stream(device=dev)
+        eng = dsac_amd.Engine(local_rank, stream=st)
+        eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
+        eng.profile_enable(True)
+        engines.append((eng, st))
+        bufs.append(dict(
+            poses=torch.zeros(N, 6, dtype=torch.float64, device=dev), sets=torch.zeros(N, 4, dtype=torch.int32, device=dev),
+            ok=torch.zeros(N, dtype=torch.uint8, device=dev), err=torch.empty(N, P, dtype=torch.float32, device=dev),
+            soft=torch.zeros(N, dtype=torch.float64, device=dev), w=torch.zeros(N, dtype=torch.float64, device=dev),
+            ent=torch.zeros(1, dtype=torch.float64, device=dev), avg=torch.zeros(6, dtype=torch.float64, device=dev)))
+    if args.kernel_only:
+        rp = synth.random_poses(N, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])
+        for b in bufs:
+            b["poses"].copy_(torch.from_numpy(rp))
+    torch.cuda.synchronize(dev)
+
+    def step(i):
+        eng, _ = engines[i % n_ctx]
+        b = bufs[i % n_ctx]
+        if not args.kernel_only:
+            eng.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
+        eng.reproject(b["poses"], N=N, clamp=100.0, err=b["err"], soft=b["soft"], tau=10.0, beta=0.5)
+        if not args.kernel_only:
+            eng.softMax(b["soft"], 0.1, b["poses"], N=N, out=(b["w"], b["ent"], b["avg"]))
+
+    def sync_all():
+        for eng, _ in engines:
+            eng.synchronize()
+        torch.cuda.synchronize(dev)
+
+    for i in range(Wm):
+        step(i)
+    sync_all()
+    for eng, _ in engines:
+        eng.profile_read(0, reset=True)
+
+    if distributed:
+        dist.barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(Wm + i)
+    sync_all()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    k2_ms, k2_n = 0.0, 0
+    for eng, _ in engines:
+        ms, n = eng.profile_read(0, reset=True)
+        k2_ms += ms
+        k2_n += n
+    ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
+    wsum = float(bufs[0]["w"].sum().item()) if not args.kernel_only else 1.0
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        kk = torch.tensor([k2_ms, float(k2_n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(kk, op=dist.ReduceOp.SUM)
+        k2_ms, k2_n = float(kk[0].item()), int(kk[1].item())
+
+    if rank == 0:
+        total_hyps = N * K * world
+        value = total_hyps / elapsed
+        k2_avg_s = (k2_ms / max(1, k2_n)) * 1e-3
+        abytes = algorithmic_bytes_k2(N, P, explicit_uv=False)
+        achieved = abytes / k2_avg_s / 1e9 if k2_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("N") == N and tj.get("P") == P:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "hypotheses scored/sec over 640x480 coord map",
+            "value": value, "unit": "hyp/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[1]: 'chess'-like single frame, %d hypotheses, %dx%d coord map, %s"
+                                    % (N, W, H, "K2 only on random poses" if args.kernel_only else
+                                       "K1 sample+P3P -> K2 reproject (error images + soft-inlier) -> K3 softmax")),
+                       "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": 1, "streams_per_gpu": n_ctx,
+                       "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
+                       "accepted_fraction": ok_frac, "softmax_sum": wsum},
+            "roofline": {"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": abytes,
+                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle as orc
+            orc.build()
+            cores = orc.num_threads()
+            sec1, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=1)
+            reps = int(max(1, min(64, round(args.cpu_seconds / max(sec1, 1e-3)))))
+            sec, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=reps)
+            out["cpu_baseline"] = {"value": N * reps / sec, "unit": "hyp/s", "cores": cores, "kind": "port",
+                                   "sample": "%d frame(s) x %d hypotheses x %dx%d, same workload (sample+P3P, error images, soft-inlier, softmax), "
+                                             "oracle built g++ -Ofast -fopenmp, %.1f s" % (reps, N, W, H, sec)}
+        print(json.dumps(out), flush=True)
+
+    for eng, _ in engines:
+        eng.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,418 @@
+// api.hip -- the C ABI of libdsac_hip.so (include/dsac_hip.h): context, device scratch, host/device
+// pointer handling, and the launch sequences.  No CPU compute path exists in this library.
+#include "../../include/dsac_hip.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// A growable device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct dsac_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // frame
+    bool have_frame = false;
+    dk::FrameDev F{};
+    DevBuf frame_xyz, frame_uv;
+
+    // scratch, one buffer per role so that calls can be chained without aliasing
+    DevBuf staged, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
+    // staging for host-pointer arguments: slots are bump-allocated per call
+    std::vector<DevBuf> slots;
+    size_t slot_next = 0;
+    struct Pending { void* host; const void* dev; size_t bytes; };
+    std::vector<Pending> pending;
+    int reproject_variant = 0;
+
+    // measurement hooks: event pairs around the dominant kernels
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; };
+    std::vector<EvPair> ev[2];
+    std::vector<EvPair> ev_free;
+};
+
+namespace {
+
+int fail(dsac_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                                           \
+    do {                                                                                                           \
+        hipError_t e__ = (call);                                                                                   \
+        if (e__ != hipSuccess) return fail((c), DSAC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__));      \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
+}
+
+// Begin a call: reset the staging slots.
+void begin_call(dsac_ctx* c) {
+    c->slot_next = 0;
+    c->pending.clear();
+}
+
+DevBuf& next_slot(dsac_ctx* c) {
+    if (c->slot_next >= c->slots.size()) c->slots.emplace_back();
+    return c->slots[c->slot_next++];
+}
+
+// Input argument: returns a device pointer holding `bytes` of *p (copying if p is a host pointer).
+template <typename T>
+int in_arg(dsac_ctx* c, const T* p, size_t count, const T** out) {
+    if (!p || count == 0) { *out = nullptr; return DSAC_OK; }
+    if (is_device_ptr(p)) { *out = p; return DSAC_OK; }
+    DevBuf& s = next_slot(c);
+    HIP_TRY(c, s.reserve(count * sizeof(T)));
+    HIP_TRY(c, hipMemcpyAsync(s.p, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *out = s.as<T>();
+    return DSAC_OK;
+}
+
+// Output argument: device pointer to write into; host destinations are copied back by end_call.
+// `preload` copies the current host contents up first (for accumulated outputs).
+template <typename T>
+int out_arg(dsac_ctx* c, T* p, size_t count, T** out, bool preload = false) {
+    if (!p || count == 0) { *out = nullptr; return DSAC_OK; }
+    if (is_device_ptr(p)) { *out = p; return DSAC_OK; }
+    DevBuf& s = next_slot(c);
+    HIP_TRY(c, s.reserve(count * sizeof(T)));
+    if (preload) HIP_TRY(c, hipMemcpyAsync(s.p, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    c->pending.push_back({p, s.p, count * sizeof(T)});
+    *out = s.as<T>();
+    return DSAC_OK;
+}
+
+// End a call: copy pending host outputs back (synchronous only when there are any).
+int end_call(dsac_ctx* c) {
+    if (c->pending.empty()) return DSAC_OK;
+    for (auto& pd : c->pending) HIP_TRY(c, hipMemcpyAsync(pd.host, pd.dev, pd.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pending.clear();
+    return DSAC_OK;
+}
+
+// RAII-ish helper: records an event pair around a launch when profiling is on.
+struct ProfScope {
+    dsac_ctx* c;
+    int which;
+    dsac_ctx::EvPair p{};
+    bool on = false;
+    ProfScope(dsac_ctx* c_, int which_) : c(c_), which(which_) {
+        if (!c->profiling) return;
+        if (!c->ev_free.empty()) { p = c->ev_free.back(); c->ev_free.pop_back(); }
+        else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        on = hipEventRecord(p.a, c->stream) == hipSuccess;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        if (hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
+    }
+};
+
+#define ARG_TRY(expr)                \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != DSAC_OK) return rc__; \
+    } while (0)
+
+__global__ void k_quantise_int16(float* xyz, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // cv::saturate_cast<short>(float): round to nearest (even), then saturate
+    float v = rintf(xyz[i]);
+    v = fminf(fmaxf(v, -32768.0f), 32767.0f);
+    xyz[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsac_version(void) { return "dsac_hip 0.1 (gfx950)"; }
+
+const char* dsac_last_error(dsac_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int dsac_create(dsac_ctx** out, int device) {
+    if (!out) return fail(nullptr, DSAC_ERR_INVALID, "dsac_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, DSAC_ERR_NO_DEVICE, "dsac_create: no HIP device (%s); this engine has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    }
+    if (device < 0 || device >= count) return fail(nullptr, DSAC_ERR_INVALID, "dsac_create: device %d out of range [0,%d)", device, count);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    dsac_ctx* c = new (std::nothrow) dsac_ctx();
+    if (!c) return fail(nullptr, DSAC_ERR_ALLOC, "dsac_create: out of host memory");
+    c->device = device;
+    e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) { delete c; return fail(nullptr, DSAC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string n = c->prop.gcnArchName;
+        delete c;
+        return fail(nullptr, DSAC_ERR_NO_DEVICE, "dsac_create: device %d is %s; this library carries gfx950 code only", device, n.c_str());
+    }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(nullptr, DSAC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->own_stream = true;
+    const char* v = getenv("DSAC_K2_VARIANT");
+    if (v) c->reproject_variant = atoi(v);
+    *out = c;
+    return DSAC_OK;
+}
+
+void dsac_destroy(dsac_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->frame_xyz.release(); c->frame_uv.release();
+    c->staged.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
+    c->grad_part.release(); c->g12_part.release(); c->g6.release();
+    for (auto& s : c->slots) s.release();
+    for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dsac_set_stream(dsac_ctx* c, void* hip_stream) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_stream: ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+    return DSAC_OK;
+}
+
+void* dsac_get_stream(dsac_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+
+int dsac_synchronize(dsac_ctx* c) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_synchronize: ctx is NULL");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DSAC_OK;
+}
+
+int dsac_device_info(dsac_ctx* c, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_device_info: ctx is NULL");
+    if (cus) *cus = c->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = c->prop.clockRate;
+    if (mem_bytes) *mem_bytes = (uint64_t)c->prop.totalGlobalMem;
+    if (name64) { strncpy(name64, c->prop.gcnArchName, 63); name64[63] = 0; }
+    return DSAC_OK;
+}
+
+int dsac_set_frame(dsac_ctx* c, const float* xyz, const float* uv, int H, int W, float fx, float fy, float cx, float cy, unsigned flags) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_frame: ctx is NULL");
+    if (!xyz || H <= 0 || W <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: need xyz and H, W > 0 (got H=%d W=%d)", H, W);
+    if ((long long)H * W > (1ll << 28)) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: H*W too large");
+    if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: zero focal length");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t P = (size_t)H * W;
+    const bool borrow = (flags & DSAC_FRAME_BORROW) != 0;
+    if (borrow) {
+        if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
+        if (flags & DSAC_FRAME_QUANTISE_INT16) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: cannot quantise a borrowed frame");
+        c->F.xyz = xyz;
+        c->F.uv = uv;
+    } else {
+        HIP_TRY(c, c->frame_xyz.reserve(P * 3 * sizeof(float)));
+        HIP_TRY(c, hipMemcpyAsync(c->frame_xyz.p, xyz, P * 3 * sizeof(float), hipMemcpyDefault, c->stream));
+        c->F.xyz = c->frame_xyz.as<float>();
+        if (uv) {
+            HIP_TRY(c, c->frame_uv.reserve(P * 2 * sizeof(float)));
+            HIP_TRY(c, hipMemcpyAsync(c->frame_uv.p, uv, P * 2 * sizeof(float), hipMemcpyDefault, c->stream));
+            c->F.uv = c->frame_uv.as<float>();
+        } else {
+            c->F.uv = nullptr;
+        }
+        if (flags & DSAC_FRAME_QUANTISE_INT16) {
+            const size_t n = P * 3;
+            hipLaunchKernelGGL(k_quantise_int16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->frame_xyz.as<float>(), n);
+            HIP_TRY(c, hipGetLastError());
+        }
+        if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) HIP_TRY(c, hipStreamSynchronize(c->stream));  // host source may be freed after return
+    }
+    c->F.H = H; c->F.W = W; c->F.P = (int)P;
+    c->F.fx = fx; c->F.fy = fy; c->F.cx = cx; c->F.cy = cy;
+    c->have_frame = true;
+    return DSAC_OK;
+}
+
+int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses, int32_t* sets_out,
+                uint8_t* ok) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample: no frame set");
+    if (N < 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample: N >= 0 and poses/sets_out/ok must be non-NULL");
+    if (N == 0) return DSAC_OK;
+    if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_sample: max_tries must be > 0");
+    if (!sets_or_null && c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_sample: frame has fewer than 4 cells");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const int32_t* d_sets_in;
+    double* d_poses;
+    int32_t* d_sets_out;
+    uint8_t* d_ok;
+    ARG_TRY(in_arg(c, sets_or_null, (size_t)N * 4, &d_sets_in));
+    ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
+    ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok));
+    return end_call(c);
+}
+
+int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float* err_or_null, float tau, float beta, double* soft_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_reproject: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_reproject: no frame set");
+    if (N < 0 || !poses) return fail(c, DSAC_ERR_INVALID, "dsac_reproject: N >= 0 and poses must be non-NULL");
+    if (N == 0 || (!err_or_null && !soft_or_null)) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double* d_poses;
+    float* d_err;
+    double* d_soft;
+    ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, err_or_null, (size_t)N * P, &d_err));
+    ARG_TRY(out_arg(c, soft_or_null, (size_t)N, &d_soft));
+    HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    HIP_TRY(c, dk::pose_prep(c->stream, N, d_poses, c->F, c->staged.as<float>()));
+    float* d_part = nullptr;
+    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    if (d_soft) {
+        HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+        d_part = c->soft_part.as<float>();
+    }
+    int used = 0;
+    {
+        ProfScope ps(c, 0);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, c->reproject_variant, &used));
+    }
+    if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
+    return end_call(c);
+}
+
+int dsac_softmax(dsac_ctx* c, int N, const double* scores, double scale, double* w, double* entropy_or_null, const double* poses_or_null,
+                 double* avg6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_softmax: ctx is NULL");
+    if (N <= 0 || !scores || !w) return fail(c, DSAC_ERR_INVALID, "dsac_softmax: N > 0 and scores/w must be non-NULL");
+    if ((avg6_or_null != nullptr) != (poses_or_null != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_softmax: avg6 and poses go together");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const double *d_scores, *d_poses;
+    double *d_w, *d_ent, *d_avg;
+    ARG_TRY(in_arg(c, scores, (size_t)N, &d_scores));
+    ARG_TRY(in_arg(c, poses_or_null, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(out_arg(c, entropy_or_null, 1, &d_ent));
+    ARG_TRY(out_arg(c, avg6_or_null, 6, &d_avg));
+    HIP_TRY(c, dk::softmax(c->stream, N, d_scores, scale, d_w, d_ent, d_poses, d_avg));
+    return end_call(c);
+}
+
+int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_dpnp: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_dpnp: no frame set");
+    if (N < 0 || !sets || !J || !(eps > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: need sets, J and eps > 0");
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const int32_t* d_sets;
+    double* d_J;
+    ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
+    ARG_TRY(out_arg(c, J, (size_t)N * 72, &d_J));
+    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, eps, d_J));
+    return end_call(c);
+}
+
+int dsac_profile_enable(dsac_ctx* c, int on) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_profile_enable: ctx is NULL");
+    c->profiling = on != 0;
+    return DSAC_OK;
+}
+
+int dsac_profile_read(dsac_ctx* c, int which, double* ms_total, int* launches, int reset) {
+    if (!c || which < 0 || which > 1) return fail(c, DSAC_ERR_INVALID, "dsac_profile_read: bad arguments");
+    double total = 0;
+    int n = 0;
+    for (auto& p : c->ev[which]) {
+        HIP_TRY(c, hipEventSynchronize(p.b));
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, p.a, p.b));
+        total += ms;
+        n++;
+    }
+    if (ms_total) *ms_total = total;
+    if (launches) *launches = n;
+    if (reset) {
+        for (auto& p : c->ev[which]) c->ev_free.push_back(p);
+        c->ev[which].clear();
+    }
+    return DSAC_OK;
+}
+
+// ---- not yet implemented (round-1 work in progress) --------------------------------------------------
+int dsac_score_backward(dsac_ctx* c, int, const double*, const int32_t*, const float*, const double*, unsigned, double*) {
+    return fail(c, DSAC_ERR_INVALID, "dsac_score_backward: not implemented yet");
+}
+int dsac_soft_score_backward(dsac_ctx* c, int, const double*, const int32_t*, const double*, float, float, float, const double*, unsigned, double*) {
+    return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_backward: not implemented yet");
+}
+int dsac_refine(dsac_ctx* c, int, const double*, const int32_t*, int, int, int, float, const int32_t*, const float*, double*, int32_t*, int32_t*) {
+    return fail(c, DSAC_ERR_INVALID, "dsac_refine: not implemented yet");
+}
+int dsac_refine_fd(dsac_ctx* c, const double*, const int32_t*, int, int, int, float, const int32_t*, float, float, float, double*, int32_t*, double*, int, int32_t*) {
+    return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: not implemented yet");
+}
+int dsac_loss(dsac_ctx* c, const double*, const double*, double*, double*) { return fail(c, DSAC_ERR_INVALID, "dsac_loss: not implemented yet"); }
+int dsac_path1_and_softmax_backward(dsac_ctx* c, int, const double*, const double*, const double*, const int32_t*, const double*, double*, double*) {
+    return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: not implemented yet");
+}
+
+}  // extern "C"

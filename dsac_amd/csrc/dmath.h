@@ -1,0 +1,463 @@
+// dmath.h -- fp64 device math of the gfx950 DSAC engine: Rodrigues (both ways + derivative), pinhole
+// projection, minimal-set P3P (Gao's quartic + Horn's quaternion alignment), pose-convention flips.
+//
+// Everything here runs on one lane in registers: all loops have compile-time bounds and every array
+// index is static after unrolling, so nothing lands in scratch because of dynamic indexing.
+// Semantics follow the routines the reference calls through OpenCV 2.4 (cv::Rodrigues, cv::projectPoints,
+// cv::solvePnP(CV_P3P)) at core/cnn_softam.h:66,351,507-508,1042-1046 and core/types.h:186-214.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dm {
+
+#define DM_INLINE __device__ __forceinline__
+
+struct Cam {
+    double fx, fy, cx, cy;
+};
+
+struct Pose6 {
+    double v[6];  // rvec | tvec (mm)
+};
+
+DM_INLINE bool isnan_d(double x) { return x != x; }
+
+// ------------------------------------------------------------------------------------------------
+// Rodrigues: vector -> matrix (row-major R[9]); optional 3x9 derivative J[i*9+k] = dR_k / dr_i
+// ------------------------------------------------------------------------------------------------
+template <bool WITH_J>
+DM_INLINE void rodrigues_v2m(const double r[3], double R[9], double* J) {
+    const double rx = r[0], ry = r[1], rz = r[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < 2.220446049250313e-16) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+        if (WITH_J) {
+#pragma unroll
+            for (int k = 0; k < 27; k++) J[k] = 0;
+            J[5] = -1; J[15] = -1; J[19] = -1;
+            J[7] = 1; J[11] = 1; J[21] = 1;
+        }
+        return;
+    }
+    double s, c;
+    sincos(theta, &s, &c);
+    const double c1 = 1.0 - c, it = 1.0 / theta;
+    const double ax = rx * it, ay = ry * it, az = rz * it;
+    const double aat[9] = {ax * ax, ax * ay, ax * az, ax * ay, ay * ay, ay * az, ax * az, ay * az, az * az};
+    const double skew[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * aat[k] + s * skew[k];
+    if (WITH_J) {
+        const double a[3] = {ax, ay, az};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double ai = a[i];
+            const double k0 = -s * ai, k1 = (s - 2 * c1 * it) * ai, k2 = c1 * it, k3 = (c - s * it) * ai, k4 = s * it;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int row = k / 3, col = k % 3;
+                // d(a a^T)/d a_i  at (row, col):  delta(row,i) a_col + delta(col,i) a_row
+                const double daat = ((row == i) ? a[col] : 0.0) + ((col == i) ? a[row] : 0.0);
+                // d[a]x/d a_i at (row, col): -eps(row, col, i)
+                double dsk = 0.0;
+                if (row != col && row != i && col != i) dsk = (((col - row + 3) % 3) == 1) ? -1.0 : 1.0;
+                J[i * 9 + k] = k0 * ((k % 4 == 0) ? 1.0 : 0.0) + k1 * aat[k] + k2 * daat + k3 * skew[k] + k4 * dsk;
+            }
+        }
+    }
+}
+
+// Rodrigues: matrix -> vector.  Inputs on this path are rotation matrices to rounding (outputs of P3P,
+// of rodrigues_v2m, or their sign flips), so OpenCV's SVD re-orthonormalisation is the identity to
+// ~1e-16 and is skipped.
+DM_INLINE void rodrigues_m2v(const double R[9], double r[3]) {
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) bad |= !(R[k] > -100.0 && R[k] < 100.0);
+    if (bad) { r[0] = r[1] = r[2] = 0; return; }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : (c < -1. ? -1. : c);
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) { rx = ry = rz = 0; }
+        else {
+            double t;
+            t = (R[0] + 1) * 0.5; rx = sqrt(fmax(t, 0.));
+            t = (R[4] + 1) * 0.5; ry = sqrt(fmax(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5; rz = sqrt(fmax(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        const double vth = theta / (2 * s);
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+DM_INLINE double det3(const double A[9]) {
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// jp::cv2our (core/types.h:186-214): R = Rodrigues(rvec) with rows 1,2 negated, t.y,t.z negated;
+// if det < 0 negate everything; NaN translation -> 0.
+DM_INLINE void cv2our(const double cv6[6], double R[9], double t[3]) {
+    rodrigues_v2m<false>(cv6, R, nullptr);
+    t[0] = cv6[3]; t[1] = -cv6[4]; t[2] = -cv6[5];
+#pragma unroll
+    for (int j = 3; j < 9; j++) R[j] = -R[j];
+    if (det3(R) < 0) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) R[j] = -R[j];
+        t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2];
+    }
+    if (isnan_d(t[0]) || isnan_d(t[1]) || isnan_d(t[2])) { t[0] = t[1] = t[2] = 0; }
+}
+
+// getRodVecAndTrans(Hypothesis(cv2our(cv pose)))  (core/cnn_softam.h:121-122, Hypothesis.cpp:274-289)
+DM_INLINE void cv_to_jp6(const double cv6[6], double jp6[6]) {
+    double R[9], t[3];
+    cv2our(cv6, R, t);
+    rodrigues_m2v(R, jp6);
+    jp6[3] = t[0]; jp6[4] = t[1]; jp6[5] = t[2];
+}
+
+// projectPoints for one point, double inside, float out (Point2f).
+DM_INLINE void project_f(const double R[9], const double t[3], const Cam& K, float X, float Y, float Z, float& u, float& v) {
+    const double Mx = X, My = Y, Mz = Z;
+    const double Xc = R[0] * Mx + R[1] * My + R[2] * Mz + t[0];
+    const double Yc = R[3] * Mx + R[4] * My + R[5] * Mz + t[1];
+    const double Zc = R[6] * Mx + R[7] * My + R[8] * Mz + t[2];
+    const double z = (Zc != 0.0) ? 1. / Zc : 1.;
+    u = (float)(Xc * z * K.fx + K.cx);
+    v = (float)(Yc * z * K.fy + K.cy);
+}
+
+// getDiffMap's residual for one cell (core/cnn_softam.h:351-358): float difference, double norm, clamp.
+DM_INLINE float residual_f(const double R[9], const double t[3], const Cam& K, float X, float Y, float Z, float pu, float pv, double clampv) {
+    float u, v;
+    project_f(R, t, K, X, Y, Z, u, v);
+    const float dx = pu - u, dy = pv - v;
+    return (float)fmin(sqrt((double)dx * dx + (double)dy * dy), clampv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// real roots of polynomials of degree <= 4 (closed forms)
+// ------------------------------------------------------------------------------------------------
+DM_INLINE int roots2(double a, double b, double c, double& x0, double& x1) {
+    const double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    const double inv_2a = 0.5 / a;
+    if (delta == 0) { x0 = x1 = -b * inv_2a; return 1; }
+    const double sq = sqrt(delta);
+    x0 = (-b + sq) * inv_2a;
+    x1 = (-b - sq) * inv_2a;
+    return 2;
+}
+
+DM_INLINE int roots3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+    if (a == 0) {
+        if (b == 0) {
+            if (c == 0) return 0;
+            x0 = -d / c;
+            return 1;
+        }
+        x2 = 0;
+        return roots2(b, c, d, x0, x1);
+    }
+    const double inv_a = 1. / a;
+    const double b_a = inv_a * b, b_a2 = b_a * b_a, c_a = inv_a * c, d_a = inv_a * d;
+    const double Q = (3 * c_a - b_a2) / 9;
+    const double Rr = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+    const double Q3 = Q * Q * Q;
+    const double D = Q3 + Rr * Rr;
+    const double b_a_3 = (1. / 3.) * b_a;
+    if (Q == 0) {
+        if (Rr == 0) { x0 = x1 = x2 = -b_a_3; return 3; }
+        x0 = pow(2 * Rr, 1 / 3.0) - b_a_3;
+        return 1;
+    }
+    if (D <= 0) {
+        const double theta = acos(Rr / sqrt(-Q3));
+        const double sqrt_Q = sqrt(-Q);
+        x0 = 2 * sqrt_Q * cos(theta / 3.0) - b_a_3;
+        x1 = 2 * sqrt_Q * cos((theta + 2 * 3.14159265358979323846) / 3.0) - b_a_3;
+        x2 = 2 * sqrt_Q * cos((theta + 4 * 3.14159265358979323846) / 3.0) - b_a_3;
+        return 3;
+    }
+    const double AD = cbrt(fabs(Rr) + sqrt(D)) * (Rr > 0 ? 1 : (Rr < 0 ? -1 : 0));
+    const double BD = (AD == 0) ? 0 : -Q / AD;
+    x0 = AD + BD - b_a_3;
+    return 1;
+}
+
+DM_INLINE int roots4(double a, double b, double c, double d, double e, double x[4]) {
+    if (a == 0) { x[3] = 0; return roots3(b, c, d, e, x[0], x[1], x[2]); }
+    const double inv_a = 1. / a;
+    b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    double r0, r1, r2;
+    const int n = roots3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2);
+    if (n == 0) return 0;
+    const double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    const double Rr = sqrt(R2), inv_R = 1. / Rr;
+    int nb = 0;
+    double D2, E2;
+    if (Rr < 10E-12) {
+        const double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else {
+            const double st = sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * st;
+            E2 = D2 - 4 * st;
+        }
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v;
+        E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * Rr;
+    if (D2 >= 0) {
+        const double D = sqrt(D2);
+        nb = 2;
+        x[0] = R_2 + 0.5 * D - b_4;
+        x[1] = x[0] - D;
+    }
+    if (E2 >= 0) {
+        const double E = sqrt(E2);
+        if (nb == 0) {
+            x[0] = -R_2 + 0.5 * E - b_4;
+            x[1] = x[0] - E;
+            nb = 2;
+        } else {
+            x[2] = -R_2 + 0.5 * E - b_4;
+            x[3] = x[2] - E;
+            nb = 4;
+        }
+    }
+    return nb;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Horn's absolute orientation for 3 correspondences: largest eigenvector of the 4x4 N matrix by cyclic
+// Jacobi sweeps (the threshold schedule of the classic routine: 0.2*sum/16 for the first three sweeps).
+// ------------------------------------------------------------------------------------------------
+DM_INLINE void jrot(double& g_, double& h_, double s, double tau) {
+    const double g = g_, h = h_;
+    g_ = g - s * (h + g * tau);
+    h_ = h + s * (g - h * tau);
+}
+
+DM_INLINE void jacobi4(double A[16], double D[4], double U[16]) {
+    double B[4], Z[4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { D[i] = B[i]; Z[i] = 0; }
+    for (int iter = 0; iter < 50; iter++) {
+        const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+        if (sum == 0.0) return;
+        const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) {
+                const double Aij = A[4 * i + j];
+                const double eps_machine = 100.0 * fabs(Aij);
+                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) {
+                    A[4 * i + j] = 0.0;
+                } else if (fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+                    else {
+                        const double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
+                    A[4 * i + j] = 0.0;
+                    const double c = 1.0 / sqrt(1 + t * t), s = t * c, tau = s / (1.0 + c);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < i) jrot(A[k * 4 + i], A[k * 4 + j], s, tau);
+                        else if (k > i && k < j) jrot(A[i * 4 + k], A[k * 4 + j], s, tau);
+                        else if (k > j) jrot(A[i * 4 + k], A[j * 4 + k], s, tau);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) jrot(U[k * 4 + i], U[k * 4 + j], s, tau);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
+    }
+}
+
+// M[k] (camera-frame points) ~= R * X[k] + T  for k = 0..2
+DM_INLINE void align3(const double M[3][3], const double X[3][3], double R[9], double T[3]) {
+    double Cs[3], Ce[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Ce[j] = (M[0][j] + M[1][j] + M[2][j]) / 3;
+        Cs[j] = (X[0][j] + X[1][j] + X[2][j]) / 3;
+    }
+    double s[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[a * 3 + j] = (X[0][a] * M[0][j] + X[1][a] * M[1][j] + X[2][a] * M[2][j]) / 3 - Ce[j] * Cs[a];
+    double Q[16], ev[4], U[16];
+    Q[0] = s[0] + s[4] + s[8];
+    Q[5] = s[0] - s[4] - s[8];
+    Q[10] = s[4] - s[8] - s[0];
+    Q[15] = s[8] - s[0] - s[4];
+    Q[4] = Q[1] = s[5] - s[7];
+    Q[8] = Q[2] = s[6] - s[2];
+    Q[12] = Q[3] = s[1] - s[3];
+    Q[9] = Q[6] = s[3] + s[1];
+    Q[13] = Q[7] = s[6] + s[2];
+    Q[14] = Q[11] = s[7] + s[5];
+    jacobi4(Q, ev, U);
+    // eigenvector of the largest eigenvalue, first maximum wins
+    double evm = ev[0];
+    double q0 = U[0], q1 = U[4], q2 = U[8], q3 = U[12];
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if (ev[i] > evm) { evm = ev[i]; q0 = U[i]; q1 = U[4 + i]; q2 = U[8 + i]; q3 = U[12 + i]; }
+    }
+    const double q02 = q0 * q0, q12 = q1 * q1, q22 = q2 * q2, q32 = q3 * q3;
+    const double q0_1 = q0 * q1, q0_2 = q0 * q2, q0_3 = q0 * q3, q1_2 = q1 * q2, q1_3 = q1 * q3, q2_3 = q2 * q3;
+    R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q1_2 - q0_3); R[2] = 2. * (q1_3 + q0_2);
+    R[3] = 2. * (q1_2 + q0_3); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q2_3 - q0_1);
+    R[6] = 2. * (q1_3 - q0_2); R[7] = 2. * (q2_3 + q0_1); R[8] = q02 + q32 - q12 - q22;
+#pragma unroll
+    for (int i = 0; i < 3; i++) T[i] = Ce[i] - (R[i * 3] * Cs[0] + R[i * 3 + 1] * Cs[1] + R[i * 3 + 2] * Cs[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// solvePnP(CV_P3P): 4 correspondences -> cv pose.  Returns false when there is no real solution.
+// X: 4 object points (float, mm), uv: 4 pixel positions (float).
+// ------------------------------------------------------------------------------------------------
+DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, double cv6[6]) {
+    // undistortPoints (zero distortion) rounds the normalised coordinates to float; the solver then maps
+    // them back to pixels and normalises again in double.
+    double mu[4], mv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float xn = (float)(((double)uv[i][0] - K.cx) * (1. / K.fx));
+        const float yn = (float)(((double)uv[i][1] - K.cy) * (1. / K.fy));
+        mu[i] = (double)xn * K.fx + K.cx;
+        mv[i] = (double)yn * K.fy + K.cy;
+    }
+    const double inv_fx = 1. / K.fx, inv_fy = 1. / K.fy, cx_fx = K.cx / K.fx, cy_fy = K.cy / K.fy;
+    double f[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double u = inv_fx * mu[i] - cx_fx, v = inv_fy * mv[i] - cy_fy;
+        const double k = 1. / sqrt(u * u + v * v + 1);
+        f[i][0] = u * k; f[i][1] = v * k; f[i][2] = k;
+    }
+    double Xw[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Xw[i][j] = X[i][j];
+    const double X3x = X[3][0], X3y = X[3][1], X3z = X[3][2];
+
+    auto dist = [&](int a, int b) {
+        const double dx = Xw[a][0] - Xw[b][0], dy = Xw[a][1] - Xw[b][1], dz = Xw[a][2] - Xw[b][2];
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    auto dot = [&](int a, int b) { return f[a][0] * f[b][0] + f[a][1] * f[b][1] + f[a][2] * f[b][2]; };
+    const double d0 = dist(1, 2), d1 = dist(0, 2), d2 = dist(0, 1);
+    const double p = dot(1, 2) * 2, q = dot(0, 2) * 2, r = dot(0, 1) * 2;
+
+    const double inv_d22 = 1. / (d2 * d2);
+    const double a = inv_d22 * (d0 * d0), b = inv_d22 * (d1 * d1);
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const double pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return false;
+    const double ab = a * b, a_2 = 2 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return false;
+    const double a_4 = 4 * a;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return false;
+    double roots[4];
+    const int n = roots4(A, B, C, D, E, roots);
+    if (n == 0) return false;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q, inv_b0 = 1. / b0;
+
+    bool have = false;
+    double best = 0, Rb[9], Tb[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i >= n) continue;
+        const double x = roots[i];
+        if (!(x > 0)) continue;
+        const double x2 = x * x;
+        const double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+                          (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+                            (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+                           (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+                            pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+                           2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+                           p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (!(b1 > 0)) continue;
+        const double y = inv_b0 * b1;
+        const double v = x2 + y * y - x * y * r;
+        if (!(v > 0)) continue;
+        const double Zl = d2 / sqrt(v);
+        const double L[3] = {x * Zl, y * Zl, Zl};
+        double M[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) M[k][j] = L[k] * f[k][j];
+        double Rc[9], Tc[3];
+        align3(M, Xw, Rc, Tc);
+        const double X3p = Rc[0] * X3x + Rc[1] * X3y + Rc[2] * X3z + Tc[0];
+        const double Y3p = Rc[3] * X3x + Rc[4] * X3y + Rc[5] * X3z + Tc[1];
+        const double Z3p = Rc[6] * X3x + Rc[7] * X3y + Rc[8] * X3z + Tc[2];
+        const double mu3p = K.cx + K.fx * X3p / Z3p, mv3p = K.cy + K.fy * Y3p / Z3p;
+        const double reproj = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+        if (!have || best > reproj) {
+            have = true;
+            best = reproj;
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rb[k] = Rc[k];
+            Tb[0] = Tc[0]; Tb[1] = Tc[1]; Tb[2] = Tc[2];
+        }
+    }
+    if (!have) return false;
+    rodrigues_m2v(Rb, cv6);
+    cv6[3] = Tb[0]; cv6[4] = Tb[1]; cv6[5] = Tb[2];
+    return true;
+}
+
+// ---- sampling RNG (include/dsac_hip.h) ------------------------------------------------------------
+DM_INLINE uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+DM_INLINE uint32_t draw_below(uint64_t key, uint32_t attempt, uint32_t k, uint32_t n) {
+    const uint64_t v = mix64(key + (((uint64_t)attempt << 16) | k));
+    return (uint32_t)(((v >> 32) * (uint64_t)n) >> 32);
+}
+DM_INLINE uint64_t hyp_key(uint64_t seed, uint32_t hyp) { return mix64(seed ^ mix64((uint64_t)hyp)); }
+
+}  // namespace dm

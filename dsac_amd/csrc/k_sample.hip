@@ -1,0 +1,191 @@
+// k_sample.hip -- K1 (minimal-set sampling + P3P) and K5 (dPNP) of the gfx950 DSAC engine.
+//
+// K1 replaces the rejection loop of processImage (core/cnn_softam.h:1010-1060).  The reference runs one
+// OpenMP thread per hypothesis and retries sequentially; here ONE WAVE owns a hypothesis and its 64 lanes
+// evaluate 64 consecutive attempts at once (attempt index = round*64 + lane, each with its own counter-
+// based draws).  A ballot picks the lowest accepted attempt, which is exactly the attempt the sequential
+// loop would have stopped at, so the result does not depend on the wave width or on scheduling.  P3P runs
+// in fp64 in registers (dmath.h).
+//
+// K5 replaces dPNP (core/cnn_softam.h:101-146): one lane per (hypothesis, coordinate, +/-) P3P solve,
+// 24 lanes per hypothesis; central differences are formed after a wave-local exchange.
+#include "kernels.h"
+#include "dmath.h"
+
+namespace dk {
+
+DM_INLINE dm::Cam make_cam(const FrameDev& F) { return dm::Cam{(double)F.fx, (double)F.fy, (double)F.cx, (double)F.cy}; }
+
+DM_INLINE void load_point(const FrameDev& F, int p, float X[3], float uv[2]) {
+    p = min(max(p, 0), F.P - 1);  // never fault on a bad index
+    X[0] = F.xyz[(size_t)p * 3]; X[1] = F.xyz[(size_t)p * 3 + 1]; X[2] = F.xyz[(size_t)p * 3 + 2];
+    if (F.uv) { uv[0] = F.uv[(size_t)p * 2]; uv[1] = F.uv[(size_t)p * 2 + 1]; }
+    else { const int y = p / F.W; uv[0] = (float)(p - y * F.W); uv[1] = (float)y; }
+}
+
+// P3P + the 4-point re-projection check of core/cnn_softam.h:1042-1059.
+DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr_int, double cv6[6]) {
+    float X[4][3], uv[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+    const dm::Cam K = make_cam(F);
+    if (!dm::p3p(X, uv, K, cv6)) return false;
+    double R[9];
+    dm::rodrigues_v2m<false>(cv6, R, nullptr);
+    bool good = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float u, v;
+        dm::project_f(R, cv6 + 3, K, X[j][0], X[j][1], X[j][2], u, v);
+        const float dx = uv[j][0] - u, dy = uv[j][1] - v;
+        good = good && (sqrt((double)dx * dx + (double)dy * dy) < (double)thr_int);
+    }
+    return good;
+}
+
+__global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
+                                               int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok) {
+    const int h = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t key = dm::hyp_key(seed, (uint32_t)h);
+    for (int base = 0; base < max_tries; base += 64) {
+        const uint32_t attempt = (uint32_t)(base + lane);
+        int32_t set4[4] = {0, 0, 0, 0};
+        bool good = (int)attempt < max_tries;
+        if (good) {
+            uint32_t k = 0;
+            int cnt = 0;
+            while (cnt < 4) {
+                if (k >= 64) { good = false; break; }
+                const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
+                const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
+                const int idx = y * F.W + x;
+                const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
+                if (dup) continue;
+                if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
+                cnt++;
+            }
+        }
+        double cv6[6] = {0, 0, 0, 0, 0, 0};
+        if (good) good = solve_and_check(F, set4, thr_int, cv6);
+        const unsigned long long m = __ballot(good);
+        if (m != 0ull) {
+            const int win = __ffsll((long long)m) - 1;
+            if (lane == win) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = cv6[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
+                ok[h] = 1;
+            }
+            return;
+        }
+    }
+    // no accepted attempt: zero pose, ok = 0; sets_out holds the last attempt's set (lane of attempt max_tries-1)
+    const int last = (max_tries - 1) & 63;
+    if (lane == last) {
+        // recompute the last attempt's set for reporting
+        int32_t set4[4] = {0, 0, 0, 0};
+        const uint32_t attempt = (uint32_t)(max_tries - 1);
+        uint32_t k = 0;
+        int cnt = 0;
+        while (cnt < 4 && k < 64) {
+            const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
+            const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
+            const int idx = y * F.W + x;
+            const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
+            if (dup) continue;
+            if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
+            cnt++;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) poses[(size_t)h * 6 + kk] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) sets_out[(size_t)h * 4 + kk] = set4[kk];
+        ok[h] = 0;
+    }
+}
+
+// Given sets: one lane per hypothesis.
+__global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restrict__ sets_in, FrameDev F, int thr_int,
+                                                  double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= N) return;
+    int32_t set4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) set4[k] = sets_in[(size_t)h * 4 + k];
+    double cv6[6] = {0, 0, 0, 0, 0, 0};
+    const bool good = solve_and_check(F, set4, thr_int, cv6);
+#pragma unroll
+    for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = good ? cv6[k] : 0.0;
+    if (sets_out != sets_in) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
+    }
+    ok[h] = good ? 1 : 0;
+}
+
+hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries, double* poses,
+                  int32_t* sets_out, uint8_t* ok) {
+    if (N <= 0) return hipSuccess;
+    if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok);
+    else hipLaunchKernelGGL(k_sample, dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// K5: dPNP.  Lane l of hypothesis h: coordinate c = l / 2 (point i = c / 3, axis j = c % 3), sign = l & 1.
+// The object points are perturbed in float, sequentially (+eps, -2 eps, +eps) like the reference
+// (core/cnn_softam.h:115-135), so a lane first replays the float round trips of the coordinates before
+// its own.  32 lanes per hypothesis (24 active), two hypotheses per wave.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dpnp(int N, const int32_t* __restrict__ sets, FrameDev F, float eps, double* __restrict__ J) {
+    const int h = blockIdx.x * 2 + (threadIdx.x >> 5);
+    const int l = threadIdx.x & 31;
+    const bool active = (h < N) && (l < 24);
+    const int c = l >> 1;
+    double jp6[6] = {0, 0, 0, 0, 0, 0};
+    if (active) {
+        float X[4][3], uv[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; j++) load_point(F, sets[(size_t)h * 4 + j], X[j], uv[j]);
+        // replay the float round trips of coordinates 0..c-1, then apply this lane's own perturbation
+#pragma unroll
+        for (int cc = 0; cc < 12; cc++) {
+            float& v = X[cc / 3][cc % 3];
+            if (cc < c) { v += eps; v -= 2 * eps; v += eps; }
+            else if (cc == c) { v += eps; if (l & 1) v -= 2 * eps; }
+        }
+        double cv6[6];
+        if (!dm::p3p(X, uv, make_cam(F), cv6)) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cv6[k] = 0;  // safeSolvePnP's zero pose
+        }
+        dm::cv_to_jp6(cv6, jp6);
+    }
+    // central difference: forward lane (even) minus backward lane (odd neighbour)
+    const double inv = 1.0 / (double)(2 * eps);
+    bool nan = false;
+    double d[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double other = __shfl_xor(jp6[k], 1, 64);
+        d[k] = (jp6[k] - other) * inv;
+        nan = nan || (d[k] != d[k]);
+    }
+    // any NaN in any column -> whole Jacobian zero (core/cnn_softam.h:141-142)
+    const unsigned long long m = __ballot(nan && active && !(l & 1));
+    const unsigned long long mine = (threadIdx.x >> 5) ? (m >> 32) : (m & 0xffffffffull);
+    if (active && !(l & 1)) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) J[(size_t)h * 72 + k * 12 + c] = (mine != 0ull) ? 0.0 : d[k];
+    }
+}
+
+hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dpnp, dim3((N + 1) / 2), dim3(64), 0, st, N, sets, F, eps, J);
+    return hipGetLastError();
+}
+
+}  // namespace dk

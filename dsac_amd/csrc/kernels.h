@@ -1,0 +1,73 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (one .hip translation unit per group).
+// All pointers are DEVICE pointers; every launcher only enqueues work on `st` and returns the HIP status
+// of the last launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dk {
+
+struct FrameDev {
+    const float* xyz;  // P x 3 (mm)
+    const float* uv;   // P x 2 or nullptr (implicit grid u = x, v = y)
+    int H, W, P;
+    float fx, fy, cx, cy;
+};
+
+// Staged pose record used by K2, 12 floats (48 B, three float4 rows) per hypothesis:
+//   [0..3]  fx*R0 | fx*tx      [4..7] fy*R1 | fy*ty      [8..11] R2 | tz
+constexpr int POSE_STRIDE = 12;
+
+// ---- k_forward.hip ---------------------------------------------------------------------------------
+// fp64 Rodrigues of N cv poses -> staged float records.
+hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
+
+// K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
+int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
+// *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
+hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
+                     float* soft_part, int variant, int* tiles_used);
+// soft[h] = sum over pixel tiles of soft_part[tile][h]   (double, deterministic)
+hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft);
+
+// K3.
+hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6);
+
+// ---- k_sample.hip ----------------------------------------------------------------------------------
+hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
+                  double* poses, int32_t* sets_out, uint8_t* ok);
+hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
+
+// ---- k_backward.hip --------------------------------------------------------------------------------
+// jp-convention staged records for the backward pass, 32 floats per hypothesis (see k_backward.hip).
+constexpr int BWD_STRIDE = 32;
+int backward_num_pixel_tiles(int P);
+int backward_hyp_tile();
+hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
+// K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
+//   grad_part : [hyp_tiles][P*3] floats       G12_part : [pixel_tiles][N][12] floats
+hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
+                          float clampv, float tau, float beta, float* grad_part, float* G12_part);
+// Epilogue: grad_xyz (P x 3 double) += sum over hyp tiles; then per hypothesis G6 = [G9 * dRdH, G3],
+// S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
+hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
+                                 int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
+                                 double* grad_xyz, double* G6_scratch);
+hipError_t path1_softmax_backward(hipStream_t st, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
+                                  const double* dpnp, double* grad_xyz, double* g);
+
+// ---- k_refine.hip ----------------------------------------------------------------------------------
+hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                  const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
+                  int32_t* steps_done);
+// builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
+hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
+                          float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,
+                          int32_t* n_obj);
+hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_hyp, float eps_obj,
+                            double* J_hyp, double* J_obj);
+
+// ---- k_loss.hip ------------------------------------------------------------------------------------
+hipError_t pose_loss(hipStream_t st, const double* est_cv6, const double* gt_jp6, double* out4, double* J6);
+
+}  // namespace dk

@@ -1,0 +1,246 @@
+"""Host-side mirror of the reference's soft-argmax interface on top of the C ABI (dsac_amd.capi).
+
+Method names follow core/cnn_softam.h / core/maxloss.h of cvlab-dresden/DSAC (getDiffMap, softMax, entropy,
+dPNP, dScore, refine, dRefineHyp, dRefineObj, maxLoss, dLossMax, processImage) so that the parity tests
+read like calls into the reference; argument meaning and failure behaviour are the reference's (zero pose
+for a failed P3P, zero Jacobian on NaN, stop refining below 50 inliers).  The differences are the ones
+include/dsac_hip.h documents: the frame (estObj, sampling, camMat) is set once, hypotheses are batched,
+and every array argument may live on the host (numpy) or on the GPU (torch).
+
+Outputs: each method accepts preallocated `out=` buffers (numpy or torch, host or device); without them
+it returns fresh numpy arrays (host), which makes the call synchronous.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib, ptr
+
+CNN_OBJ_MAXINPUT = 100.0  # core/lua_calls.h:36
+DEFAULTS = dict(rI=256, rRI=8, rB=100, rSS=0.01, rT2D=10, fl=525.0, iw=640, ih=480)  # core/properties.cpp:42-64
+
+
+def _f64(a):
+    return a if not isinstance(a, (list, tuple)) else np.asarray(a, dtype=np.float64)
+
+
+def _np(a, dtype):
+    if isinstance(a, np.ndarray):
+        return np.ascontiguousarray(a, dtype=dtype)
+    if isinstance(a, (list, tuple)):
+        return np.asarray(a, dtype=dtype)
+    return a  # torch tensor or address: caller guarantees dtype/layout
+
+
+class Engine:
+    """One DSAC engine context = one GPU stream.  Not thread-safe (one per host thread)."""
+
+    def __init__(self, device=0, stream=None):
+        self._ctx = C.c_void_p()
+        rc = lib.dsac_create(C.byref(self._ctx), int(device))
+        if rc != capi.DSAC_OK:
+            raise capi.DsacError(rc, lib.dsac_last_error(None).decode("utf-8", "replace"))
+        self.device = int(device)
+        self.H = self.W = self.P = 0
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            lib.dsac_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- context ----------------------------------------------------------------------------------
+    def set_stream(self, stream):
+        """stream: raw hipStream_t address or a torch.cuda.Stream."""
+        addr = getattr(stream, "cuda_stream", stream)
+        check(self._ctx, lib.dsac_set_stream(self._ctx, addr))
+
+    @property
+    def stream(self):
+        return lib.dsac_get_stream(self._ctx)
+
+    def synchronize(self):
+        check(self._ctx, lib.dsac_synchronize(self._ctx))
+
+    def device_info(self):
+        cus, clk, mem = C.c_int(), C.c_int(), C.c_uint64()
+        name = C.create_string_buffer(64)
+        check(self._ctx, lib.dsac_device_info(self._ctx, C.byref(cus), C.byref(clk), C.byref(mem), name))
+        return dict(cus=cus.value, clock_khz=clk.value, mem_bytes=mem.value, arch=name.value.decode())
+
+    def profile_enable(self, on=True):
+        check(self._ctx, lib.dsac_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self, which=0, reset=True):
+        """(total ms, launches) of the dominant kernel measured with HIP events on this context's stream
+        (which = 0: K2 reprojection, 1: K4 score backward)."""
+        ms, n = C.c_double(), C.c_int()
+        check(self._ctx, lib.dsac_profile_read(self._ctx, int(which), C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    # ---- frame ------------------------------------------------------------------------------------
+    def set_frame(self, xyz, uv=None, H=None, W=None, cam=(525.0, 525.0, 320.0, 240.0), quantise_int16=False, borrow=False):
+        """(estObj, sampling, camMat) of the reference.  xyz: H*W x 3 float32 mm; uv: H*W x 2 float32 or None."""
+        xyz = _np(xyz, np.float32)
+        uv = _np(uv, np.float32) if uv is not None else None
+        flags = (capi.DSAC_FRAME_QUANTISE_INT16 if quantise_int16 else 0) | (capi.DSAC_FRAME_BORROW if borrow else 0)
+        fx, fy, cx, cy = [float(c) for c in cam]
+        check(self._ctx, lib.dsac_set_frame(self._ctx, ptr(xyz), ptr(uv), int(H), int(W), fx, fy, cx, cy, flags))
+        self.H, self.W, self.P = int(H), int(W), int(H) * int(W)
+        self._keep = (xyz, uv) if borrow else None
+
+    # ---- K1 ---------------------------------------------------------------------------------------
+    def sample(self, N, seed=1305, thr=10.0, max_tries=1 << 20, sets=None, out=None):
+        """Sampling loop of processImage (cnn_softam.h:1010-1060).  Returns (poses N x 6, sets N x 4, ok N)."""
+        if out is None:
+            out = (np.zeros((N, 6)), np.zeros((N, 4), np.int32), np.zeros(N, np.uint8))
+        poses, sets_out, ok = out
+        sets = _np(sets, np.int32) if sets is not None else None
+        check(self._ctx, lib.dsac_sample(self._ctx, int(N), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(sets), float(thr), int(max_tries), ptr(poses),
+                                         ptr(sets_out), ptr(ok)))
+        return poses, sets_out, ok
+
+    # ---- K2 ---------------------------------------------------------------------------------------
+    def reproject(self, poses, N=None, clamp=CNN_OBJ_MAXINPUT, err=None, soft=None, tau=10.0, beta=0.5):
+        """err[h] = getDiffMap(pose_h) (cnn_softam.h:319-362) and/or soft[h] = sum_p sigmoid(beta*(tau - err))."""
+        poses = _np(poses, np.float64)
+        if N is None:
+            N = int(poses.shape[0])
+        check(self._ctx, lib.dsac_reproject(self._ctx, int(N), ptr(poses), float(clamp), ptr(err), float(tau), float(beta), ptr(soft)))
+        return err, soft
+
+    def getDiffMap(self, poses, clamp=CNN_OBJ_MAXINPUT):
+        """N error images (N x H x W float32) for N cv poses."""
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(-1, 6))
+        err = np.zeros((poses.shape[0], self.H, self.W), np.float32)
+        self.reproject(poses, err=err, clamp=clamp)
+        return err
+
+    def softInlierScores(self, poses, tau=10.0, beta=0.5, clamp=CNN_OBJ_MAXINPUT):
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float64).reshape(-1, 6))
+        soft = np.zeros(poses.shape[0])
+        self.reproject(poses, soft=soft, tau=tau, beta=beta, clamp=clamp)
+        return soft
+
+    # ---- K3 ---------------------------------------------------------------------------------------
+    def softMax(self, scores, scale=1.0, poses=None, N=None, out=None):
+        """softMax (cnn_softam.h:535-553) + entropy (:80-88) + weighted pose average (:1082-1094).
+        Returns (w, entropy, avg6); entropy/avg6 are 1- and 6-element buffers."""
+        scores = _np(scores, np.float64)
+        poses = _np(poses, np.float64) if poses is not None else None
+        if N is None:
+            N = int(scores.shape[0])
+        if out is None:
+            out = (np.zeros(N), np.zeros(1), np.zeros(6) if poses is not None else None)
+        w, ent, avg = out
+        check(self._ctx, lib.dsac_softmax(self._ctx, int(N), ptr(scores), float(scale), ptr(w), ptr(ent), ptr(poses), ptr(avg)))
+        return w, ent, avg
+
+    # ---- K5 ---------------------------------------------------------------------------------------
+    def dPNP(self, sets, eps=0.1, out=None):
+        """dPNP (cnn_softam.h:101-146) for N minimal sets -> N x 6 x 12."""
+        sets = _np(sets, np.int32)
+        N = int(sets.shape[0])
+        J = out if out is not None else np.zeros((N, 6, 12))
+        check(self._ctx, lib.dsac_dpnp(self._ctx, N, ptr(sets), float(eps), ptr(J)))
+        return J
+
+    # ---- K4 ---------------------------------------------------------------------------------------
+    def dScore(self, poses, sets, d_err, dpnp=None, quirk_transpose=False, grad=None):
+        """dScore part (iii) (cnn_softam.h:609-645) summed over hypotheses (train_ransac_softam.cpp:382-383).
+        grad (H*W x 3 float64) is accumulated into and returned."""
+        poses = _np(poses, np.float64)
+        sets = _np(sets, np.int32)
+        d_err = _np(d_err, np.float32)
+        N = int(sets.shape[0])
+        if grad is None:
+            grad = np.zeros((self.P, 3))
+        flags = capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0
+        check(self._ctx, lib.dsac_score_backward(self._ctx, N, ptr(poses), ptr(sets), ptr(d_err), ptr(_np(dpnp, np.float64) if dpnp is not None else None),
+                                                 flags, ptr(grad)))
+        return grad
+
+    def dSoftScore(self, poses, sets, g, tau=10.0, beta=0.5, clamp=CNN_OBJ_MAXINPUT, dpnp=None, quirk_transpose=False, grad=None):
+        poses = _np(poses, np.float64)
+        sets = _np(sets, np.int32)
+        g = _np(g, np.float64)
+        N = int(sets.shape[0])
+        if grad is None:
+            grad = np.zeros((self.P, 3))
+        flags = capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0
+        check(self._ctx, lib.dsac_soft_score_backward(self._ctx, N, ptr(poses), ptr(sets), ptr(g), float(clamp), float(tau), float(beta),
+                                                      ptr(_np(dpnp, np.float64) if dpnp is not None else None), flags, ptr(grad)))
+        return grad
+
+    # ---- K6 ---------------------------------------------------------------------------------------
+    def refine(self, init_poses, perm, max_inl=100, min_inl=50, thr=10.0, pert_px_c=None, pert_value=None, want_inlier_map=False):
+        """refine() (cnn_softam.h:663-723) for B start poses / replicas; with want_inlier_map the forward
+        form of processImage (:1099-1154).  Returns (poses B x 6 [cv], steps_done B[, inlier_map])."""
+        init_poses = np.ascontiguousarray(np.asarray(init_poses, dtype=np.float64).reshape(-1, 6))
+        B = init_poses.shape[0]
+        perm = _np(perm, np.int32)
+        steps = int(perm.shape[0])
+        out = np.zeros((B, 6))
+        sd = np.zeros(B, np.int32)
+        imap = np.zeros(self.P, np.int32) if want_inlier_map else None
+        px = _np(pert_px_c, np.int32) if pert_px_c is not None else None
+        pv = _np(pert_value, np.float32) if pert_value is not None else None
+        check(self._ctx, lib.dsac_refine(self._ctx, B, ptr(init_poses), ptr(perm), steps, int(max_inl), int(min_inl), float(thr), ptr(px), ptr(pv),
+                                         ptr(out), ptr(imap), ptr(sd)))
+        return (out, sd, imap) if want_inlier_map else (out, sd)
+
+    def dRefine(self, init_pose, perm, inlier_map, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01, eps_hyp=0.001, eps_obj=2.0, cap=4096):
+        """dRefineHyp (cnn_softam.h:738-836) and dRefineObj (:853-923) as one batch.
+        Returns (J_hyp 6 x 6, obj_pixels n, J_obj n x 6 x 3)."""
+        init_pose = np.ascontiguousarray(np.asarray(init_pose, dtype=np.float64).reshape(6))
+        perm = _np(perm, np.int32)
+        inlier_map = _np(inlier_map, np.int32)
+        J_hyp = np.zeros((6, 6))
+        px = np.zeros(cap, np.int32)
+        J_obj = np.zeros((cap, 6, 3))
+        n = np.zeros(1, np.int32)
+        check(self._ctx, lib.dsac_refine_fd(self._ctx, ptr(init_pose), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl), float(thr),
+                                            ptr(inlier_map), float(sub_sample), float(eps_hyp), float(eps_obj), ptr(J_hyp), ptr(px), ptr(J_obj),
+                                            int(cap), ptr(n)))
+        k = int(n[0])
+        return J_hyp, px[:k].copy(), J_obj[:k].copy()
+
+    # ---- K7 ---------------------------------------------------------------------------------------
+    def maxLoss(self, est_cv6, gt_jp6, want_grad=False):
+        """maxLoss (maxloss.h:69-79) [+ dLossMax :87-198].  Returns dict(loss, rotErr, tErr, correct[, grad])."""
+        est = np.ascontiguousarray(np.asarray(est_cv6, dtype=np.float64).reshape(6))
+        gt = np.ascontiguousarray(np.asarray(gt_jp6, dtype=np.float64).reshape(6))
+        out4 = np.zeros(4)
+        J = np.zeros(6) if want_grad else None
+        check(self._ctx, lib.dsac_loss(self._ctx, ptr(est), ptr(gt), ptr(out4), ptr(J)))
+        r = dict(loss=out4[0], rotErr=out4[1], tErr=out4[2], correct=bool(out4[3] > 0.5))
+        if want_grad:
+            r["grad"] = J
+        return r
+
+    def dLossMax(self, est_cv6, gt_jp6):
+        return self.maxLoss(est_cv6, gt_jp6, want_grad=True)["grad"]
+
+    def path1AndSoftmaxBackward(self, v6, w, poses, sets, dpnp, grad=None):
+        """train_ransac_softam.cpp:344-376.  Returns (grad, g)."""
+        N = int(np.asarray(w).shape[0]) if isinstance(w, np.ndarray) else int(w.shape[0])
+        if grad is None:
+            grad = np.zeros((self.P, 3))
+        g = np.zeros(N)
+        check(self._ctx, lib.dsac_path1_and_softmax_backward(self._ctx, N, ptr(_np(v6, np.float64)), ptr(_np(w, np.float64)), ptr(_np(poses, np.float64)),
+                                                             ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
+        return grad, g

@@ -1,0 +1,179 @@
+/* dsac_hip.h -- C ABI of libdsac_hip.so, the MI355X (gfx950) DSAC hypothesis-scoring engine.
+ *
+ * This is the drop-in boundary for the soft-argmax hot path of cvlab-dresden/DSAC.  The reference has no
+ * FFI seam for its geometry: every function below is a free function defined in a header and compiled
+ * into each executable (core/cnn_softam.h is #included by core/train_ransac_softam.cpp:39 and
+ * core/test_ransac_softam.cpp:37).  The boundary is therefore cut at those function signatures; each
+ * export cites the reference function (file:line under /root/reference/core) it replaces.  The C++ host
+ * shim dsac_amd/host/ keeps the reference's own names (Hypothesis, getDiffMap, softMax, dPNP, refine,
+ * dScore, dLossMax, processImage) on top of this ABI; INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions (identical to the reference):
+ *   pose      : 6 doubles  rvec[3] (Rodrigues, rad) | tvec[3] (mm), OpenCV convention (jp::cv_trans_t,
+ *               core/types.h:91) unless a parameter is explicitly called "jp6" (jp::jp_trans_t as the
+ *               6-vector Hypothesis::getRodVecAndTrans returns, core/Hypothesis.cpp:274-289).
+ *   frame     : scene-coordinate map H x W x 3 float32 millimetres, row-major (y, x, c) -- the reference's
+ *               jp::img_coord_t (int16 mm, core/types.h:43-51) generalised to float; DSAC_FRAME_QUANTISE_INT16
+ *               rounds/saturates to the int16 grid on upload (core/cnn_softam.h:265).  Pixel positions
+ *               ("sampling", core/cnn_softam.h:283-309) are H x W x 2 float32 (u, v) or NULL for the
+ *               implicit full-resolution grid u = x, v = y.  A pixel index is y*W + x.
+ *   camera    : fx, fy, cx, cy (core/properties.cpp:308-323: fx = fy = 525, cx = 320, cy = 240).
+ *   err image : N x (H*W) float32, hypothesis-major, each image row-major -- the order the reference
+ *               pushes diffMaps to the score CNN (core/lua_calls.h:98-104).
+ *
+ * Memory: every pointer argument may be a host pointer or a device (HIP) pointer; the library detects
+ * which (hipPointerGetAttributes).  With device pointers a call only enqueues work on the context's
+ * stream and returns; with host pointers it stages through its own scratch and returns after the result
+ * has landed.  The caller owns every buffer; the library owns only the context and its device scratch,
+ * and retains nothing after return except the frame copied by dsac_set_frame (or borrowed when asked).
+ *
+ * Errors: every call returns DSAC_OK (0) or a negative dsac_status; nothing throws across the ABI.
+ * Per-hypothesis failure (no P3P solution within max_tries) is reported in ok[] with a zero pose, which
+ * is the reference's safeSolvePnP behaviour (core/cnn_softam.h:66-71).  NaN policy as the reference
+ * (zero Jacobians).
+ *
+ * Threading: a context is single-threaded; use one context per host thread / stream / GPU.  No global
+ * state.  There is NO CPU fallback: without a HIP device dsac_create fails with DSAC_ERR_NO_DEVICE.
+ *
+ * Sampling RNG (shared bit-exactly with the CPU oracle so that minimal sets are identical):
+ *   mix64(z): z += 0x9E3779B97F4A7C15; z = (z ^ (z>>30)) * 0xBF58476D1CE4E5B9;
+ *             z = (z ^ (z>>27)) * 0x94D049BB133111EB; return z ^ (z>>31);
+ *   key(h)          = mix64(seed ^ mix64(h))                       h = hypothesis index
+ *   draw(h,a,k,n)   = ((mix64(key(h) + ((a << 16) | k)) >> 32) * n) >> 32      in [0, n)
+ *   attempt a of hypothesis h draws x = draw(.,k++,W) then y = draw(.,k++,H) until 4 distinct cells
+ *   (core/cnn_softam.h:1021-1039: x before y, duplicates redrawn); the first accepted attempt in
+ *   a = 0,1,2,... wins, which is the reference's while(true) loop made order-independent.
+ */
+#ifndef DSAC_HIP_H
+#define DSAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsac_ctx dsac_ctx;
+
+typedef enum dsac_status {
+    DSAC_OK = 0,
+    DSAC_ERR_INVALID = -1,   /* bad argument */
+    DSAC_ERR_NO_DEVICE = -2, /* no HIP device / wrong architecture */
+    DSAC_ERR_HIP = -3,       /* a HIP runtime call failed; see dsac_last_error */
+    DSAC_ERR_NO_FRAME = -4,  /* dsac_set_frame has not been called */
+    DSAC_ERR_ALLOC = -5
+} dsac_status;
+
+/* dsac_set_frame flags */
+#define DSAC_FRAME_QUANTISE_INT16 1u /* xyz <- saturate_cast<short>(round(xyz)), core/cnn_softam.h:265, types.h:43 */
+#define DSAC_FRAME_BORROW 2u         /* xyz/uv are device pointers that outlive the frame: use in place, no copy */
+
+/* backward flags */
+#define DSAC_BWD_QUIRK_TRANSPOSE 1u /* reproduce core/cnn_softam.h:628,641 (index x*W*3 + y*3); needs H == W */
+
+/* ---- context ---------------------------------------------------------------------------------- */
+const char* dsac_version(void);
+int dsac_create(dsac_ctx** out, int device);
+void dsac_destroy(dsac_ctx* ctx);
+const char* dsac_last_error(dsac_ctx* ctx_or_null);
+int dsac_set_stream(dsac_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (e.g. torch's) */
+void* dsac_get_stream(dsac_ctx* ctx);
+int dsac_synchronize(dsac_ctx* ctx);
+/* device facts for reports: CU count, clock (kHz), total memory (bytes), gcnArchName into name[64] */
+int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64);
+
+/* ---- frame ------------------------------------------------------------------------------------ */
+/* Replaces the (estObj, sampling, camMat) triple every reference function takes
+ * (core/cnn_softam.h:319-323, 564-570, 663-671, 960-988). */
+int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int H, int W, float fx, float fy, float cx, float cy,
+                   unsigned flags);
+
+/* ---- K1: minimal-set sampling + P3P ------------------------------------------------------------ */
+/* Replaces the sampling loop of processImage, core/cnn_softam.h:1010-1060 (irand x4, alreadyChosen,
+ * safeSolvePnP(CV_P3P) :1042, projectPoints :1046, 4-point re-projection check :1050-1059 with the
+ * threshold truncated to int as at test_ransac_softam.cpp:51).  sets_or_null == NULL draws the sets with
+ * the counter RNG above; otherwise the given N x 4 pixel indices are evaluated once each (this is also the
+ * "re-solve P3P from the stored minimal set" step of dScore, core/cnn_softam.h:583-598).
+ * Outputs: poses N x 6, sets_out N x 4 (pixel index y*W+x, the reference's imgIdx), ok N. */
+int dsac_sample(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
+                int32_t* sets_out, uint8_t* ok);
+
+/* ---- K2: batched reprojection -> error images and/or soft-inlier scores -------------------------- */
+/* Replaces the N getDiffMap calls of core/cnn_softam.h:1067-1069 (getDiffMap :319-362):
+ * err[h][p] = min(|uv_p - project(K, pose_h, xyz_p)|, clamp)  (clamp = CNN_OBJ_MAXINPUT = 100, lua_calls.h:36).
+ * soft[h] = sum_p sigmoid(beta * (tau - err[h][p]))  is the DSAC++-style soft-inlier count named by
+ * north_star (not in the reference).  Either output may be NULL. */
+int dsac_reproject(dsac_ctx* ctx, int N, const double* poses, float clamp, float* err_or_null, float tau, float beta,
+                   double* soft_or_null);
+
+/* ---- K3: softmax / entropy / soft-argmax pose --------------------------------------------------- */
+/* Replaces softMax core/cnn_softam.h:535-553, entropy :80-88 and the weighted pose average :1082-1094.
+ * w = softmax(scale * scores); entropy in bits; avg6 = sum_h w_h * poses[h].  entropy/avg6/poses may be NULL. */
+int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, double* w, double* entropy_or_null,
+                 const double* poses_or_null, double* avg6_or_null);
+
+/* ---- K5: dPNP ------------------------------------------------------------------------------------ */
+/* Replaces dPNP core/cnn_softam.h:101-146 for the minimal (4-point, CV_P3P) case: central differences
+ * (float eps, sequential float perturbation of the object points) of the jp 6-vector of the P3P pose.
+ * J is N x 6 x 12; all-zero for a hypothesis whose differences contain NaN (:141-142). */
+int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, double* J);
+
+/* ---- K4: score backward -------------------------------------------------------------------------- */
+/* Replaces dScore part (iii), core/cnn_softam.h:609-645, plus the sum over hypotheses at
+ * core/train_ransac_softam.cpp:382-383:  grad_xyz[p] += sum_h ( d_err[h][p] * dProjectdObj(h,p) )
+ * and, for the 4 support pixels of h, += (sum_p d_err[h][p] * dProjectdHyp(h,p)) * dPNP(h).
+ * poses are the cv poses of the hypotheses (as re-solved at :597-598); dpnp N x 72 or NULL (computed
+ * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into. */
+int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
+                        unsigned flags, double* grad_xyz);
+/* Same with the soft-inlier score: d_err[h][p] = g[h] * d soft[h] / d err[h][p], formed in-kernel
+ * (no N x P read).  g = dLoss/d soft[h]. */
+int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
+                             float beta, const double* dpnp_or_null, unsigned flags, double* grad_xyz);
+
+/* ---- K6: inlier refinement (LM-PnP) and its finite-difference Jacobians -------------------------- */
+/* Replaces the refinement loop of processImage core/cnn_softam.h:1099-1154 (B = 1, fills inlier_map) and
+ * the replay helper refine() :663-723 (B replicas).  perm is steps x H*W pixel indices (the reference's
+ * pixelIdxs); per step the first max_inl cells along perm with err < thr are collected, the loop stops if
+ * fewer than min_inl (50), otherwise solvePnP(CV_ITERATIVE, useExtrinsicGuess) restarts from the current
+ * pose.  pert_px_c (B x 2: pixel or -1, channel) / pert_value (B) replace one coordinate per replica, which
+ * is dRefineObj's localEstObj (:887,901).  out_poses B x 6 (cv).  inlier_map (H*W int32, += 1 per
+ * selection) is only written for replica 0 and only when non-NULL. */
+int dsac_refine(dsac_ctx* ctx, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                const int32_t* pert_px_c_or_null, const float* pert_value_or_null, double* out_poses, int32_t* inlier_map_or_null,
+                int32_t* steps_done_or_null);
+/* Replaces dRefineHyp core/cnn_softam.h:738-836 (J_hyp 6 x 6; eps_hyp = 0.001f) and dRefineObj :853-923
+ * (eps_obj = 2.f, every skip = (int)(1/sub_sample)-th cell of inlier_map > 0 in x-outer/y-inner order,
+ * scaled by skip).  All 12 + 6*n_obj replicas run as one batch.  dRefineObj's 6 x 3P matrix is returned
+ * sparse: obj_pixels[i] = pixel index, J_obj[i] = 6 x 3 block, i < *n_obj <= cap. */
+int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                   const int32_t* inlier_map, float sub_sample, float eps_hyp, float eps_obj, double* J_hyp, int32_t* obj_pixels,
+                   double* J_obj, int cap, int32_t* n_obj);
+
+/* ---- K7: pose loss ---------------------------------------------------------------------------------- */
+/* Replaces maxLoss core/maxloss.h:69-79 (+ getInvHyp :39-61, Hypothesis::calcAngularDistance
+ * Hypothesis.cpp:137-143) and dLossMax :87-198.  est is a cv pose (converted with cv2our, types.h:186-214,
+ * as at cnn_softam.h:1160-1163 / train_ransac_softam.cpp:301-304); gt_jp6 is the ground truth as the jp
+ * 6-vector poseGT.getRodVecAndTrans().  out4 = {loss, rotErr[deg], tErr[mm], correct(5deg/50mm)};
+ * J6_or_null = dLossMax w.r.t. the jp 6-vector of est. */
+int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+
+/* ---- gradient assembly ------------------------------------------------------------------------------ */
+/* Replaces core/train_ransac_softam.cpp:344-376: with v6 = dLoss/dRef * dRef/dAvg (1 x 6),
+ * grad_xyz[support px of h] += v6 * w_h * dPNP_h  (path I, second term) and the softmax backward
+ * g_j = w_j * (F_j - sum_h w_h F_h),  F_h = v6 . [rvec_h ; tvec_h / 1000]  (written O(N^2) in the reference). */
+int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
+                                    const double* dpnp, double* grad_xyz, double* g);
+
+/* ---- measurement hooks (bench.py's roofline leg) ----------------------------------------------------- */
+/* When enabled, a hipEvent pair is recorded on the context's stream immediately around every launch of the
+ * dominant kernel (K2 k_reproject, and K4 k_score_backward).  dsac_profile_read waits for the recorded
+ * events and returns the summed kernel time in ms and the launch count per kernel (which = 0: K2, 1: K4). */
+int dsac_profile_enable(dsac_ctx* ctx, int on);
+int dsac_profile_read(dsac_ctx* ctx, int which, double* ms_total, int* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSAC_HIP_H */

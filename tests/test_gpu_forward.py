@@ -1,0 +1,205 @@
+"""GPU parity of the forward path (K1 sample+P3P, K2 reprojection, K3 softmax, K5 dPNP) against the CPU
+oracle, through the C ABI.  Tolerances:
+  residuals  <= 1e-3 px abs, clamp-edge pixels excluded  (fp32 projection on the GPU, fp64 in the oracle)
+  soft score <= 1e-4 relative
+  softmax w  <= 1e-12 abs given equal scores (both fp64)
+  poses      <= 1e-6 relative (fp64 P3P on both sides; libm vs ocml transcendental differences)
+  minimal sets: bit-identical (shared counter-based RNG)
+"""
+import numpy as np
+import pytest
+
+from conftest import excl_clamp_edge
+
+pytestmark = pytest.mark.gpu
+
+CLAMP = 100.0
+
+
+def _set(engine, fr, implicit_uv=False, **kw):
+    engine.set_frame(fr["xyz"], None if implicit_uv else fr["uv"], fr["H"], fr["W"], fr["cam"], **kw)
+
+
+def test_reproject_parity_reference_size(engine, orc, frame40):
+    fr = frame40
+    _set(engine, fr)
+    poses, sets, ok, _ = orc.sample(256, 1305, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    ref = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    got = engine.getDiffMap(poses).reshape(256, -1)
+    m = excl_clamp_edge(got, ref)
+    assert m.mean() > 0.2
+    assert np.abs(got - ref)[m].max() <= 1e-3
+    assert np.abs(got - ref).max() <= 2e-3  # clamp-edge entries can only differ by the tolerance as well
+
+
+def test_reproject_parity_full_resolution(engine, orc, frame_full):
+    fr = frame_full
+    _set(engine, fr, implicit_uv=True)  # u = x, v = y generated in-kernel
+    poses, sets, ok, _ = orc.sample(64, 7, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    ref = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    got = engine.getDiffMap(poses).reshape(64, -1)
+    m = excl_clamp_edge(got, ref)
+    assert np.abs(got - ref)[m].max() <= 1e-3
+    # explicit uv must give the same bits as the implicit grid
+    _set(engine, fr, implicit_uv=False)
+    got2 = engine.getDiffMap(poses).reshape(64, -1)
+    assert np.array_equal(got, got2)
+
+
+@pytest.mark.parametrize("H,W,N", [(37, 41, 1), (37, 41, 33), (3, 5, 7), (1, 4, 2), (64, 64, 100)])
+def test_reproject_ragged_shapes(engine, orc, synth, H, W, N):
+    fr = synth.chess_like_frame(H, W, seed=H * 100 + W)
+    _set(engine, fr)
+    poses = synth.random_poses(N, seed=3, rot_sigma=0.1, trans_sigma_mm=100.0) + np.concatenate([np.zeros(3), [0, 0, 2000.0]])
+    ref = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], H, W, fr["cam"])
+    got = engine.getDiffMap(poses).reshape(N, -1)
+    m = excl_clamp_edge(got, ref)
+    assert np.abs(got - ref)[m].max(initial=0.0) <= 1e-3
+
+
+def test_reproject_zero_pose_and_zero_depth(engine, orc, frame40):
+    """Failed hypotheses carry the zero pose (cnn_softam.h:66-71); cells with Z == 0 take projectPoints'
+    z = 1 branch (quirk 6)."""
+    fr = dict(frame40)
+    xyz = fr["xyz"].copy()
+    xyz[:50, 2] = 0.0
+    xyz[0] = 0.0
+    fr["xyz"] = xyz
+    _set(engine, fr)
+    poses = np.zeros((2, 6))
+    poses[1, 5] = 0.0
+    ref = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    got = engine.getDiffMap(poses).reshape(2, -1)
+    m = excl_clamp_edge(got, ref)
+    assert np.abs(got - ref)[m].max(initial=0.0) <= 1e-3
+    assert np.all(np.isfinite(got))
+
+
+def test_soft_inlier_scores(engine, orc, frame40, frame_full):
+    for fr, N in ((frame40, 256), (frame_full, 40)):
+        _set(engine, fr)
+        poses, *_ = orc.sample(N, 11, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+        ref_err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+        ref = orc.soft_inlier(ref_err, 10.0, 0.5)
+        got = engine.softInlierScores(poses, tau=10.0, beta=0.5)
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        # err + soft in one launch gives the same numbers as the separate launches
+        err = np.zeros((N, fr["H"] * fr["W"]), np.float32)
+        soft = np.zeros(N)
+        engine.reproject(poses, err=err, soft=soft)
+        assert np.array_equal(soft, got)
+        assert np.array_equal(err, engine.getDiffMap(poses).reshape(N, -1))
+
+
+def test_softmax_entropy_avg(engine, orc):
+    rng = np.random.default_rng(0)
+    for N in (1, 2, 255, 256, 257, 4096):
+        scores = rng.normal(scale=5.0, size=N)
+        poses = rng.normal(size=(N, 6))
+        w, ent, avg = engine.softMax(scores, 1.0, poses)
+        wr = orc.softMax(scores)
+        assert np.abs(w - wr).max() <= 1e-12
+        assert abs(ent[0] - orc.entropy(wr)) <= 1e-10
+        assert np.abs(avg - orc.avg_pose(wr, poses)).max() <= 1e-10
+    # scale argument
+    w, _, _ = engine.softMax(scores, 0.1)
+    assert np.abs(w - orc.softMax(0.1 * scores)).max() <= 1e-12
+
+
+def test_sample_parity(engine, orc, frame40, frame_full):
+    for fr, N, seed in ((frame40, 256, 1305), (frame_full, 256, 99)):
+        _set(engine, fr)
+        pr, sr, okr, tries = orc.sample(N, seed, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"], thr=10.0, max_tries=4096)
+        pg, sg, okg = engine.sample(N, seed=seed, thr=10.0, max_tries=4096)
+        assert np.array_equal(okg, okr)
+        good = okr.astype(bool)
+        assert good.sum() >= N - 2
+        assert np.array_equal(sg[good], sr[good]), "minimal sets must be bit-identical (shared counter RNG)"
+        assert np.allclose(pg[good], pr[good], rtol=1e-6, atol=1e-7)
+        # every accepted pose re-projects its 4 points to < thr (the reference's in-loop check, cnn_softam.h:1045-1059)
+        for h in np.flatnonzero(good)[:32]:
+            uv = orc.project_points(fr["xyz"][sg[h]], pg[h], fr["cam"])
+            assert np.all(np.linalg.norm(uv - fr["uv"][sg[h]], axis=1) < 10.0)
+
+
+def test_sample_given_sets_and_failures(engine, orc, frame40):
+    fr = frame40
+    _set(engine, fr)
+    rng = np.random.default_rng(5)
+    sets = np.stack([rng.choice(1600, 4, replace=False) for _ in range(128)]).astype(np.int32)
+    pr, sr, okr, _ = orc.sample(128, 0, fr["xyz"], fr["uv"], 40, 40, fr["cam"], sets=sets)
+    pg, sg, okg = engine.sample(128, sets=sets)
+    assert np.array_equal(sg, sets)
+    assert np.array_equal(okg, okr)
+    assert 0 < okr.sum() < 128  # random sets: some pass the 10 px check, most do not
+    assert np.allclose(pg, pr, rtol=1e-6, atol=1e-7)
+    assert np.all(pg[~okg.astype(bool)] == 0.0)  # zero pose on failure (safeSolvePnP)
+    # max_tries exhausted -> ok = 0, zero pose
+    pg, sg, okg = engine.sample(16, seed=3, thr=0.0, max_tries=70)
+    assert not okg.any() and np.all(pg == 0)
+
+
+def test_dpnp_parity(engine, orc, frame40):
+    fr = frame40
+    _set(engine, fr)
+    poses, sets, ok, _ = orc.sample(64, 21, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    J = engine.dPNP(sets, eps=0.1)
+    for h in range(64):
+        Jr = orc.dPNP(fr["uv"][sets[h]], fr["xyz"][sets[h]], fr["cam"], eps=0.1)
+        scale = max(1.0, np.abs(Jr).max())
+        assert np.abs(J[h] - Jr).max() <= 1e-5 * scale, h
+
+
+def test_device_pointers_through_torch(engine, orc, frame40):
+    """Inputs and outputs resident in HBM (torch tensors): no host staging, asynchronous until synchronize()."""
+    import torch
+    fr = frame40
+    dev = torch.device("cuda:0")
+    xyz = torch.from_numpy(fr["xyz"]).to(dev)
+    uv = torch.from_numpy(fr["uv"]).to(dev)
+    engine.set_frame(xyz, uv, 40, 40, fr["cam"])
+    torch.cuda.synchronize()
+    N = 128
+    poses = torch.zeros(N, 6, dtype=torch.float64, device=dev)
+    sets = torch.zeros(N, 4, dtype=torch.int32, device=dev)
+    ok = torch.zeros(N, dtype=torch.uint8, device=dev)
+    err = torch.zeros(N, 1600, dtype=torch.float32, device=dev)
+    soft = torch.zeros(N, dtype=torch.float64, device=dev)
+    w = torch.zeros(N, dtype=torch.float64, device=dev)
+    ent = torch.zeros(1, dtype=torch.float64, device=dev)
+    avg = torch.zeros(6, dtype=torch.float64, device=dev)
+    engine.sample(N, seed=1305, out=(poses, sets, ok))
+    engine.reproject(poses, N=N, err=err, soft=soft)
+    engine.softMax(soft, 0.1, poses, N=N, out=(w, ent, avg))
+    engine.synchronize()
+    pr, sr, okr, _ = orc.sample(N, 1305, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    assert np.array_equal(sets.cpu().numpy(), sr)
+    ref = orc.get_diff_maps(pr, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    got = err.cpu().numpy()
+    m = excl_clamp_edge(got, ref)
+    assert np.abs(got - ref)[m].max() <= 1e-3
+    wr = orc.softMax(0.1 * orc.soft_inlier(ref, 10.0, 0.5))
+    assert np.abs(w.cpu().numpy() - wr).max() <= 1e-4  # end-to-end tolerance
+    assert abs(w.sum().item() - 1.0) < 1e-12
+
+
+def test_quantise_flag(engine, orc, synth):
+    fr = synth.chess_like_frame(40, 40, seed=4, quantise_int16=False)
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"], quantise_int16=True)
+    q = np.clip(np.rint(fr["xyz"]), -32768, 32767).astype(np.float32)
+    poses = synth.random_poses(4, seed=1, rot_sigma=0.05, trans_sigma_mm=50.0) + np.array([0, 0, 0, 0, 0, 2500.0])
+    ref = orc.get_diff_maps(poses, q, fr["uv"], 40, 40, fr["cam"])
+    got = engine.getDiffMap(poses).reshape(4, -1)
+    m = excl_clamp_edge(got, ref)
+    assert np.abs(got - ref)[m].max(initial=0.0) <= 1e-3
+
+
+def test_error_behaviour(engine):
+    import dsac_amd
+    e2 = dsac_amd.Engine(0)
+    with pytest.raises(dsac_amd.capi.DsacError) as ei:
+        e2.sample(4)
+    assert ei.value.code == dsac_amd.capi.DSAC_ERR_NO_FRAME
+    with pytest.raises(dsac_amd.capi.DsacError):
+        e2.set_frame(np.zeros((4, 3), np.float32), None, 0, 4)
+    e2.close()
