@@ -398,11 +398,64 @@ int dsac_profile_read(dsac_ctx* c, int which, double* ms_total, int* launches, i
 }
 
 // ---- not yet implemented (round-1 work in progress) --------------------------------------------------
-int dsac_score_backward(dsac_ctx* c, int, const double*, const int32_t*, const float*, const double*, unsigned, double*) {
-    return fail(c, DSAC_ERR_INVALID, "dsac_score_backward: not implemented yet");
+static int score_backward_common(dsac_ctx* c, const char* who, int N, const double* poses, const int32_t* sets, const float* d_err,
+                                 const double* g, float clampv, float tau, float beta, const double* dpnp_or_null, unsigned flags,
+                                 double* grad_xyz) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "%s: ctx is NULL", who);
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "%s: no frame set", who);
+    if (N < 0 || !poses || !sets || !grad_xyz || (!d_err && !g)) return fail(c, DSAC_ERR_INVALID, "%s: NULL argument", who);
+    if ((flags & DSAC_BWD_QUIRK_TRANSPOSE) && c->F.H != c->F.W)
+        return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_QUIRK_TRANSPOSE needs a square map (H=%d W=%d)", who, c->F.H, c->F.W);
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double *d_poses, *d_dpnp, *d_g;
+    const int32_t* d_sets;
+    const float* d_derr;
+    double* d_grad;
+    ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
+    ARG_TRY(in_arg(c, d_err, (size_t)N * P, &d_derr));
+    ARG_TRY(in_arg(c, g, (size_t)N, &d_g));
+    ARG_TRY(in_arg(c, dpnp_or_null, (size_t)N * 72, &d_dpnp));
+    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    if (!d_dpnp) {  // dPNP with the reference's default eps (core/cnn_softam.h:104)
+        DevBuf& s = next_slot(c);
+        HIP_TRY(c, s.reserve((size_t)N * 72 * sizeof(double)));
+        HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>()));
+        d_dpnp = s.as<double>();
+    }
+    const int HT = dk::backward_hyp_tile();
+    const int NT = (N + HT - 1) / HT;
+    const int PTmax = dk::backward_num_pixel_tiles(c->F.P);
+    HIP_TRY(c, c->bwd_staged.reserve((size_t)N * 12 * sizeof(float)));
+    HIP_TRY(c, c->dRdH.reserve((size_t)N * 27 * sizeof(double)));
+    HIP_TRY(c, c->grad_part.reserve((size_t)NT * P * 3 * sizeof(float)));
+    HIP_TRY(c, c->g12_part.reserve((size_t)PTmax * N * 12 * sizeof(float)));
+    HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
+    HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
+    int PT = 0;
+    {
+        ProfScope ps(c, 1);
+        HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
+                                      c->g12_part.as<float>(), &PT));
+    }
+    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), NT, c->g12_part.as<float>(), PT, c->dRdH.as<double>(), d_dpnp,
+                                         d_sets, flags, d_grad, c->g6.as<double>()));
+    return end_call(c);
 }
-int dsac_soft_score_backward(dsac_ctx* c, int, const double*, const int32_t*, const double*, float, float, float, const double*, unsigned, double*) {
-    return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_backward: not implemented yet");
+
+int dsac_score_backward(dsac_ctx* c, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
+                        unsigned flags, double* grad_xyz) {
+    if (c && !d_err) return fail(c, DSAC_ERR_INVALID, "dsac_score_backward: d_err is NULL");
+    return score_backward_common(c, "dsac_score_backward", N, poses, sets, d_err, nullptr, 100.0f, 0.f, 0.f, dpnp_or_null, flags, grad_xyz);
+}
+
+int dsac_soft_score_backward(dsac_ctx* c, int N, const double* poses, const int32_t* sets, const double* g, float clampv, float tau, float beta,
+                             const double* dpnp_or_null, unsigned flags, double* grad_xyz) {
+    if (c && !g) return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_backward: g is NULL");
+    return score_backward_common(c, "dsac_soft_score_backward", N, poses, sets, nullptr, g, clampv, tau, beta, dpnp_or_null, flags, grad_xyz);
 }
 int dsac_refine(dsac_ctx* c, int, const double*, const int32_t*, int, int, int, float, const int32_t*, const float*, double*, int32_t*, int32_t*) {
     return fail(c, DSAC_ERR_INVALID, "dsac_refine: not implemented yet");
@@ -411,8 +464,28 @@ int dsac_refine_fd(dsac_ctx* c, const double*, const int32_t*, int, int, int, fl
     return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: not implemented yet");
 }
 int dsac_loss(dsac_ctx* c, const double*, const double*, double*, double*) { return fail(c, DSAC_ERR_INVALID, "dsac_loss: not implemented yet"); }
-int dsac_path1_and_softmax_backward(dsac_ctx* c, int, const double*, const double*, const double*, const int32_t*, const double*, double*, double*) {
-    return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: not implemented yet");
+int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
+                                    const double* dpnp, double* grad_xyz, double* g) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_path1_and_softmax_backward: no frame set");
+    if (N <= 0 || !v6 || !w || !poses || !g) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: NULL argument");
+    if ((grad_xyz != nullptr) != (dpnp != nullptr) || (grad_xyz && !sets))
+        return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: grad_xyz, dpnp and sets go together");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double *d_v6, *d_w, *d_poses, *d_dpnp;
+    const int32_t* d_sets;
+    double *d_grad, *d_g;
+    ARG_TRY(in_arg(c, v6, 6, &d_v6));
+    ARG_TRY(in_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
+    ARG_TRY(in_arg(c, dpnp, (size_t)N * 72, &d_dpnp));
+    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    ARG_TRY(out_arg(c, g, (size_t)N, &d_g));
+    HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, d_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g));
+    return end_call(c);
 }
 
 }  // extern "C"

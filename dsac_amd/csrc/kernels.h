@@ -47,13 +47,13 @@ hipError_t backward_prep(hipStream_t st, int N, const double* poses, const Frame
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [pixel_tiles][N][12] floats
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
-                          float clampv, float tau, float beta, float* grad_part, float* G12_part);
+                          float clampv, float tau, float beta, float* grad_part, float* G12_part, int* pixel_tiles_used);
 // Epilogue: grad_xyz (P x 3 double) += sum over hyp tiles; then per hypothesis G6 = [G9 * dRdH, G3],
 // S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
                                  double* grad_xyz, double* G6_scratch);
-hipError_t path1_softmax_backward(hipStream_t st, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
+hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                   const double* dpnp, double* grad_xyz, double* g);
 
 // ---- k_refine.hip ----------------------------------------------------------------------------------

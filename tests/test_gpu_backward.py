@@ -1,0 +1,112 @@
+"""GPU parity of the backward path (K4 score backward, path-I / softmax backward) against the CPU oracle.
+
+Tolerances: the oracle differentiates in fp64 like the reference; K4 projects in fp32 and accumulates in
+fp32 per tile / fp64 across tiles.  Gradients are compared on the scale of the largest entry:
+  max |grad_gpu - grad_oracle| <= 2e-3 * max |grad_oracle|     (1e-3 "fp32 fast mode"; the
+  extra factor covers cells whose error sits within fp32 rounding of the clamp / inlier guards)
+and the relative l2 error must be <= 5e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30), np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def _setup(engine, orc, fr, N, seed):
+    engine.set_frame(fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    poses, sets, ok, _ = orc.sample(N, seed, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    return poses, sets
+
+
+@pytest.mark.parametrize("quirk", [False, True])
+def test_dscore_parity_reference_size(engine, orc, frame40, quirk):
+    fr = frame40
+    N = 64
+    poses, sets = _setup(engine, orc, fr, N, 5)
+    rng = np.random.default_rng(1)
+    d_err = rng.normal(size=(N, 1600)).astype(np.float32)
+    ref, G6, S = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], 40, 40, fr["cam"], quirk_transpose=quirk)
+    got = engine.dScore(poses, sets, d_err, quirk_transpose=quirk)
+    emax, el2 = _rel(got, ref)
+    print("dScore 40x40 quirk=%s: max-rel %.3e l2-rel %.3e" % (quirk, emax, el2))
+    assert emax <= 2e-3 and el2 <= 5e-4
+    # supplied dPNP gives the same result as the internally computed one
+    J = engine.dPNP(sets)
+    got2 = engine.dScore(poses, sets, d_err, dpnp=J, quirk_transpose=quirk)
+    assert np.allclose(got2, got, rtol=1e-9, atol=1e-9 * np.abs(got).max())
+
+
+def test_dscore_accumulates(engine, orc, frame40):
+    fr = frame40
+    poses, sets = _setup(engine, orc, fr, 8, 2)
+    d_err = np.ones((8, 1600), np.float32)
+    g0 = engine.dScore(poses, sets, d_err)
+    g1 = engine.dScore(poses, sets, d_err, grad=g0.copy())
+    assert np.allclose(g1, 2 * g0, rtol=1e-6, atol=1e-9 * np.abs(g0).max())
+
+
+def test_dscore_parity_full_resolution(engine, orc, frame_full):
+    fr = frame_full
+    N = 40  # not a multiple of the hypothesis tile
+    poses, sets = _setup(engine, orc, fr, N, 9)
+    rng = np.random.default_rng(2)
+    P = fr["H"] * fr["W"]
+    d_err = (rng.normal(size=(N, P)) * 1e-3).astype(np.float32)
+    ref, _, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    got = engine.dScore(poses, sets, d_err)
+    emax, el2 = _rel(got, ref)
+    print("dScore 640x480: max-rel %.3e l2-rel %.3e" % (emax, el2))
+    assert emax <= 2e-3 and el2 <= 5e-4
+
+
+@pytest.mark.parametrize("H,W", [(37, 41), (5, 3)])
+def test_dscore_ragged(engine, orc, synth, H, W):
+    fr = synth.chess_like_frame(H, W, seed=17)
+    N = 5
+    engine.set_frame(fr["xyz"], fr["uv"], H, W, fr["cam"])
+    rng = np.random.default_rng(3)
+    sets = np.stack([rng.choice(H * W, 4, replace=False) for _ in range(N)]).astype(np.int32)
+    poses, _, ok, _ = orc.sample(N, 0, fr["xyz"], fr["uv"], H, W, fr["cam"], sets=sets, thr=1e9)
+    # dScore re-solves P3P itself and ignores the 4-point check; use unchecked P3P poses on both sides
+    poses = np.stack([orc.solve_p3p(fr["xyz"][s], fr["uv"][s], fr["cam"])[1] for s in sets])
+    d_err = rng.normal(size=(N, H * W)).astype(np.float32)
+    ref, _, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], H, W, fr["cam"])
+    got = engine.dScore(poses, sets, d_err)
+    emax, el2 = _rel(got, ref)
+    assert emax <= 2e-3 and el2 <= 1e-3
+
+
+def test_soft_score_backward(engine, orc, frame40):
+    fr = frame40
+    N = 48
+    poses, sets = _setup(engine, orc, fr, N, 12)
+    rng = np.random.default_rng(4)
+    g = rng.normal(size=N)
+    tau, beta = 10.0, 0.5
+    err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], 40, 40, fr["cam"]).astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-beta * (tau - err)))
+    dDiff = g[:, None] * (-beta) * s * (1 - s)
+    ref, _, _ = orc.dScore(sets, dDiff, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    got = engine.dSoftScore(poses, sets, g, tau=tau, beta=beta)
+    emax, el2 = _rel(got, ref)
+    print("soft score backward: max-rel %.3e l2-rel %.3e" % (emax, el2))
+    assert emax <= 2e-3 and el2 <= 5e-4
+
+
+def test_path1_and_softmax_backward(engine, orc, frame40):
+    fr = frame40
+    N = 64
+    poses, sets = _setup(engine, orc, fr, N, 14)
+    rng = np.random.default_rng(6)
+    v6 = rng.normal(size=6)
+    w = orc.softMax(rng.normal(size=N))
+    ref_grad, ref_g = orc.path1_pnp_and_softmax_bwd(v6, w, poses, sets, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    J = engine.dPNP(sets)
+    grad, g = engine.path1AndSoftmaxBackward(v6, w, poses, sets, J)
+    assert np.abs(g - ref_g).max() <= 1e-12 * max(1.0, np.abs(ref_g).max())
+    assert np.abs(grad - ref_grad).max() <= 1e-5 * max(1.0, np.abs(ref_grad).max())
+    assert abs(g.sum()) < 1e-12  # softmax gradients sum to zero
