@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] style)")
+    ap.add_argument("--k2-mode", choices=("both", "err", "soft"), default="both", help="K2 outputs: error images and/or soft-inlier sums")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +98,8 @@ def main():
         b = bufs[i % n_ctx]
         if not args.kernel_only:
             eng.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
-        eng.reproject(b["poses"], N=N, clamp=100.0, err=b["err"], soft=b["soft"], tau=10.0, beta=0.5)
+        eng.reproject(b["poses"], N=N, clamp=100.0, err=b["err"] if args.k2_mode != "soft" else None,
+                      soft=b["soft"] if args.k2_mode != "err" else None, tau=10.0, beta=0.5)
         if not args.kernel_only:
             eng.softMax(b["soft"], 0.1, b["poses"], N=N, out=(b["w"], b["ent"], b["avg"]))
 
@@ -143,7 +145,7 @@ def main():
         total_hyps = N * K * world
         value = total_hyps / elapsed
         k2_avg_s = (k2_ms / max(1, k2_n)) * 1e-3
-        abytes = algorithmic_bytes_k2(N, P, explicit_uv=False)
+        abytes = algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=args.k2_mode != "soft")
         achieved = abytes / k2_avg_s / 1e9 if k2_avg_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")

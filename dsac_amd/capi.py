@@ -10,6 +10,11 @@ import os
 
 import numpy as np
 
+try:  # torch bundles its own HIP runtime (same SONAME as /opt/rocm's); it must be the one the process loads
+    import torch  # noqa: F401  -- first, so that libdsac_hip.so binds to the runtime torch uses for device memory/streams
+except ImportError:  # pure C-ABI use without torch is fine: the library then binds to /opt/rocm/lib/libamdhip64.so
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdsac_hip.so")
 

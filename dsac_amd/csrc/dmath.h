@@ -342,10 +342,21 @@ DM_INLINE void align3(const double M[3][3], const double X[3][3], double R[9], d
 }
 
 // ------------------------------------------------------------------------------------------------
-// solvePnP(CV_P3P): 4 correspondences -> cv pose.  Returns false when there is no real solution.
-// X: 4 object points (float, mm), uv: 4 pixel positions (float).
+// solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
+// Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
+// (p3p) or by four neighbouring lanes in parallel (p3p_setup + p3p_eval_root, used by K1).
 // ------------------------------------------------------------------------------------------------
-DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, double cv6[6]) {
+struct P3PSetup {
+    double f[3][3];   // unit bearing vectors of points 0..2
+    double Xw[3][3];  // object points 0..2
+    double X3[3];     // 4th object point
+    double mu3, mv3;  // 4th image point (pixels, after the float round trip of undistortPoints)
+    double a, b, p, q, r, d2, inv_b0;
+    double roots[4];
+    int n;
+};
+
+DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K, P3PSetup& S) {
     // undistortPoints (zero distortion) rounds the normalised coordinates to float; the solver then maps
     // them back to pixels and normalises again in double.
     double mu[4], mv[4];
@@ -356,33 +367,32 @@ DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, doub
         mu[i] = (double)xn * K.fx + K.cx;
         mv[i] = (double)yn * K.fy + K.cy;
     }
+    S.mu3 = mu[3]; S.mv3 = mv[3];
     const double inv_fx = 1. / K.fx, inv_fy = 1. / K.fy, cx_fx = K.cx / K.fx, cy_fy = K.cy / K.fy;
-    double f[3][3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const double u = inv_fx * mu[i] - cx_fx, v = inv_fy * mv[i] - cy_fy;
         const double k = 1. / sqrt(u * u + v * v + 1);
-        f[i][0] = u * k; f[i][1] = v * k; f[i][2] = k;
+        S.f[i][0] = u * k; S.f[i][1] = v * k; S.f[i][2] = k;
     }
-    double Xw[3][3];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) Xw[i][j] = X[i][j];
-    const double X3x = X[3][0], X3y = X[3][1], X3z = X[3][2];
+        for (int j = 0; j < 3; j++) S.Xw[i][j] = X[i][j];
+    S.X3[0] = X[3][0]; S.X3[1] = X[3][1]; S.X3[2] = X[3][2];
 
     auto dist = [&](int a, int b) {
-        const double dx = Xw[a][0] - Xw[b][0], dy = Xw[a][1] - Xw[b][1], dz = Xw[a][2] - Xw[b][2];
+        const double dx = S.Xw[a][0] - S.Xw[b][0], dy = S.Xw[a][1] - S.Xw[b][1], dz = S.Xw[a][2] - S.Xw[b][2];
         return sqrt(dx * dx + dy * dy + dz * dz);
     };
-    auto dot = [&](int a, int b) { return f[a][0] * f[b][0] + f[a][1] * f[b][1] + f[a][2] * f[b][2]; };
+    auto dot = [&](int a, int b) { return S.f[a][0] * S.f[b][0] + S.f[a][1] * S.f[b][1] + S.f[a][2] * S.f[b][2]; };
     const double d0 = dist(1, 2), d1 = dist(0, 2), d2 = dist(0, 1);
     const double p = dot(1, 2) * 2, q = dot(0, 2) * 2, r = dot(0, 1) * 2;
-
     const double inv_d22 = 1. / (d2 * d2);
     const double a = inv_d22 * (d0 * d0), b = inv_d22 * (d1 * d1);
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
     const double pr = p * r, pqr = q * pr;
+    S.n = 0;
     if (p2 + q2 + r2 - pqr - 1 == 0) return false;
     const double ab = a * b, a_2 = 2 * a;
     const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
@@ -395,44 +405,57 @@ DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, doub
     const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
     const double b0 = b * temp * temp;
     if (b0 == 0) return false;
-    double roots[4];
-    const int n = roots4(A, B, C, D, E, roots);
-    if (n == 0) return false;
-    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q, inv_b0 = 1. / b0;
+    S.n = roots4(A, B, C, D, E, S.roots);
+    if (S.n == 0) return false;
+    S.a = a; S.b = b; S.p = p; S.q = q; S.r = r; S.d2 = d2; S.inv_b0 = 1. / b0;
+    return true;
+}
 
+// One quartic root x -> (R, T, squared reprojection error of the 4th point).  false: root rejected.
+DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double Rc[9], double Tc[3], double& reproj) {
+    if (!(x > 0)) return false;
+    const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    const double x2 = x * x;
+    const double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+                      (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+                        (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+                       (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+                        pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+                       2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+                       p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (!(b1 > 0)) return false;
+    const double y = S.inv_b0 * b1;
+    const double v = x2 + y * y - x * y * r;
+    if (!(v > 0)) return false;
+    const double Zl = S.d2 / sqrt(v);
+    const double L[3] = {x * Zl, y * Zl, Zl};
+    double M[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[k][j] = L[k] * S.f[k][j];
+    align3(M, S.Xw, Rc, Tc);
+    const double X3p = Rc[0] * S.X3[0] + Rc[1] * S.X3[1] + Rc[2] * S.X3[2] + Tc[0];
+    const double Y3p = Rc[3] * S.X3[0] + Rc[4] * S.X3[1] + Rc[5] * S.X3[2] + Tc[1];
+    const double Z3p = Rc[6] * S.X3[0] + Rc[7] * S.X3[1] + Rc[8] * S.X3[2] + Tc[2];
+    const double mu3p = K.cx + K.fx * X3p / Z3p, mv3p = K.cy + K.fy * Y3p / Z3p;
+    reproj = (mu3p - S.mu3) * (mu3p - S.mu3) + (mv3p - S.mv3) * (mv3p - S.mv3);
+    return true;
+}
+
+// All roots in sequence on one lane; the root whose pose re-projects the 4th point best wins (first on ties).
+DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, double cv6[6]) {
+    P3PSetup S;
+    if (!p3p_setup(X, uv, K, S)) return false;
     bool have = false;
     double best = 0, Rb[9], Tb[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (i >= n) continue;
-        const double x = roots[i];
-        if (!(x > 0)) continue;
-        const double x2 = x * x;
-        const double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
-                          (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
-                            (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
-                           (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
-                            pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
-                           2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
-                           p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
-        if (!(b1 > 0)) continue;
-        const double y = inv_b0 * b1;
-        const double v = x2 + y * y - x * y * r;
-        if (!(v > 0)) continue;
-        const double Zl = d2 / sqrt(v);
-        const double L[3] = {x * Zl, y * Zl, Zl};
-        double M[3][3];
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) M[k][j] = L[k] * f[k][j];
-        double Rc[9], Tc[3];
-        align3(M, Xw, Rc, Tc);
-        const double X3p = Rc[0] * X3x + Rc[1] * X3y + Rc[2] * X3z + Tc[0];
-        const double Y3p = Rc[3] * X3x + Rc[4] * X3y + Rc[5] * X3z + Tc[1];
-        const double Z3p = Rc[6] * X3x + Rc[7] * X3y + Rc[8] * X3z + Tc[2];
-        const double mu3p = K.cx + K.fx * X3p / Z3p, mv3p = K.cy + K.fy * Y3p / Z3p;
-        const double reproj = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+        if (i >= S.n) continue;
+        double Rc[9], Tc[3], reproj;
+        if (!p3p_eval_root(S, K, S.roots[i], Rc, Tc, reproj)) continue;
         if (!have || best > reproj) {
             have = true;
             best = reproj;

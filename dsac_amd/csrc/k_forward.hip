@@ -226,17 +226,22 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
 }
 
 // --------------------------------------------------------------------------------------------------
+// One wave per hypothesis, lanes stride over the pixel tiles (independent
+// loads in flight), fixed butterfly -> deterministic.
 __global__ __launch_bounds__(256) void k_reduce_soft(int N, int tiles, const float* __restrict__ part, double* __restrict__ soft) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (h >= N) return;
     double s = 0;
-    for (int t = 0; t < tiles; t++) s += (double)part[(size_t)t * N + h];
-    soft[h] = s;
+    for (int t = lane; t < tiles; t += 64) s += (double)part[(size_t)t * N + h];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) soft[h] = s;
 }
 
 hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce_soft, dim3((N + 255) / 256), dim3(256), 0, st, N, tiles, soft_part, soft);
+    hipLaunchKernelGGL(k_reduce_soft, dim3((N + 3) / 4), dim3(256), 0, st, N, tiles, soft_part, soft);
     return hipGetLastError();
 }
 

@@ -1,11 +1,11 @@
 // k_sample.hip -- K1 (minimal-set sampling + P3P) and K5 (dPNP) of the gfx950 DSAC engine.
 //
 // K1 replaces the rejection loop of processImage (core/cnn_softam.h:1010-1060).  The reference runs one
-// OpenMP thread per hypothesis and retries sequentially; here ONE WAVE owns a hypothesis and its 64 lanes
-// evaluate 64 consecutive attempts at once (attempt index = round*64 + lane, each with its own counter-
-// based draws).  A ballot picks the lowest accepted attempt, which is exactly the attempt the sequential
-// loop would have stopped at, so the result does not depend on the wave width or on scheduling.  P3P runs
-// in fp64 in registers (dmath.h).
+// OpenMP thread per hypothesis and retries sequentially; here ONE WAVE owns a hypothesis and evaluates 16
+// consecutive attempts at once, 4 lanes per attempt (one per quartic root of P3P), each attempt with its
+// own counter-based draws.  A ballot picks the lowest accepted attempt, which is exactly the attempt the
+// sequential loop would have stopped at, so the result does not depend on the wave width or on
+// scheduling.  P3P runs in fp64 in registers (dmath.h).
 //
 // K5 replaces dPNP (core/cnn_softam.h:101-146): one lane per (hypothesis, coordinate, +/-) P3P solve,
 // 24 lanes per hypothesis; central differences are formed after a wave-local exchange.
@@ -43,35 +43,82 @@ DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr
     return good;
 }
 
+// Draw the minimal set of attempt `attempt` (core/cnn_softam.h:1021-1039).  false: more than 32 candidate
+// draws were needed (degenerate tiny maps).
+DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32_t set4[4]) {
+    uint32_t k = 0;
+    int cnt = 0;
+    set4[0] = set4[1] = set4[2] = set4[3] = 0;
+    while (cnt < 4) {
+        if (k >= 64) return false;
+        const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
+        const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
+        const int idx = y * F.W + x;
+        const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
+        if (dup) continue;
+        if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
+        cnt++;
+    }
+    return true;
+}
+
+// One wave per hypothesis.  Lane l evaluates quartic root (l & 3) of attempt base + (l >> 2): 16 attempts
+// per round, the four candidate poses of an attempt side by side (their Jacobi eigen-solves, the long pole
+// of P3P, run in parallel instead of in sequence).
 __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok) {
     const int h = blockIdx.x;
     const int lane = threadIdx.x;
+    const int root = lane & 3;
     const uint64_t key = dm::hyp_key(seed, (uint32_t)h);
-    for (int base = 0; base < max_tries; base += 64) {
-        const uint32_t attempt = (uint32_t)(base + lane);
-        int32_t set4[4] = {0, 0, 0, 0};
-        bool good = (int)attempt < max_tries;
-        if (good) {
-            uint32_t k = 0;
-            int cnt = 0;
-            while (cnt < 4) {
-                if (k >= 64) { good = false; break; }
-                const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
-                const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
-                const int idx = y * F.W + x;
-                const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
-                if (dup) continue;
-                if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
-                cnt++;
+    const dm::Cam K = make_cam(F);
+    for (int base = 0; base < max_tries; base += 16) {
+        const uint32_t attempt = (uint32_t)(base + (lane >> 2));
+        int32_t set4[4];
+        bool live = (int)attempt < max_tries;
+        if (live) live = draw_set(F, key, attempt, set4);
+        float X[4][3], uv[4][2];
+        double Rc[9], Tc[3], reproj = 0;
+        bool cand = false;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+            dm::P3PSetup S;
+            if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
+                const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
+                cand = dm::p3p_eval_root(S, K, x, Rc, Tc, reproj);
             }
         }
+        // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
+        int win = -1;
+        double best = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ci = __shfl((int)cand, (lane & ~3) | i, 64) != 0;
+            const double ri = __shfl(reproj, (lane & ~3) | i, 64);
+            if (ci && (win < 0 || best > ri)) { win = i; best = ri; }
+        }
+        bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
-        if (good) good = solve_and_check(F, set4, thr_int, cv6);
+        if (live && win == root) {
+            dm::rodrigues_m2v(Rc, cv6);
+            cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
+            // 4-point re-projection check (core/cnn_softam.h:1046-1059), through Rodrigues(rvec) like projectPoints
+            double R[9];
+            dm::rodrigues_v2m<false>(cv6, R, nullptr);
+            good = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float u, v;
+                dm::project_f(R, cv6 + 3, K, X[j][0], X[j][1], X[j][2], u, v);
+                const float dx = uv[j][0] - u, dy = uv[j][1] - v;
+                good = good && (sqrt((double)dx * dx + (double)dy * dy) < (double)thr_int);
+            }
+        }
         const unsigned long long m = __ballot(good);
         if (m != 0ull) {
-            const int win = __ffsll((long long)m) - 1;
-            if (lane == win) {
+            const int w = __ffsll((long long)m) - 1;  // lowest lane = lowest attempt index
+            if (lane == w) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = cv6[k];
 #pragma unroll
@@ -81,23 +128,10 @@ __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F,
             return;
         }
     }
-    // no accepted attempt: zero pose, ok = 0; sets_out holds the last attempt's set (lane of attempt max_tries-1)
-    const int last = (max_tries - 1) & 63;
-    if (lane == last) {
-        // recompute the last attempt's set for reporting
-        int32_t set4[4] = {0, 0, 0, 0};
-        const uint32_t attempt = (uint32_t)(max_tries - 1);
-        uint32_t k = 0;
-        int cnt = 0;
-        while (cnt < 4 && k < 64) {
-            const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
-            const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
-            const int idx = y * F.W + x;
-            const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
-            if (dup) continue;
-            if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
-            cnt++;
-        }
+    // no accepted attempt: zero pose, ok = 0; sets_out reports the last attempt's set
+    if (lane == 0) {
+        int32_t set4[4];
+        draw_set(F, key, (uint32_t)(max_tries - 1), set4);
 #pragma unroll
         for (int kk = 0; kk < 6; kk++) poses[(size_t)h * 6 + kk] = 0.0;
 #pragma unroll

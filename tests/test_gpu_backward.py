@@ -65,12 +65,12 @@ def test_dscore_parity_full_resolution(engine, orc, frame_full):
 
 @pytest.mark.parametrize("H,W", [(37, 41), (5, 3)])
 def test_dscore_ragged(engine, orc, synth, H, W):
-    fr = synth.chess_like_frame(H, W, seed=17)
+    # clean frame (no outliers, 1 mm noise) so that any minimal set gives a sane pose on a tiny map
+    fr = synth.chess_like_frame(H, W, seed=17, noise_mm=1.0, outlier_frac=0.0)
     N = 5
     engine.set_frame(fr["xyz"], fr["uv"], H, W, fr["cam"])
     rng = np.random.default_rng(3)
     sets = np.stack([rng.choice(H * W, 4, replace=False) for _ in range(N)]).astype(np.int32)
-    poses, _, ok, _ = orc.sample(N, 0, fr["xyz"], fr["uv"], H, W, fr["cam"], sets=sets, thr=1e9)
     # dScore re-solves P3P itself and ignores the 4-point check; use unchecked P3P poses on both sides
     poses = np.stack([orc.solve_p3p(fr["xyz"][s], fr["uv"][s], fr["cam"])[1] for s in sets])
     d_err = rng.normal(size=(N, H * W)).astype(np.float32)
@@ -105,8 +105,8 @@ def test_path1_and_softmax_backward(engine, orc, frame40):
     v6 = rng.normal(size=6)
     w = orc.softMax(rng.normal(size=N))
     ref_grad, ref_g = orc.path1_pnp_and_softmax_bwd(v6, w, poses, sets, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
-    J = engine.dPNP(sets)
+    J = np.stack([orc.dPNP(fr["uv"][s], fr["xyz"][s], fr["cam"]) for s in sets])  # same dPNP on both sides
     grad, g = engine.path1AndSoftmaxBackward(v6, w, poses, sets, J)
     assert np.abs(g - ref_g).max() <= 1e-12 * max(1.0, np.abs(ref_g).max())
-    assert np.abs(grad - ref_grad).max() <= 1e-5 * max(1.0, np.abs(ref_grad).max())
+    assert np.abs(grad - ref_grad).max() <= 1e-10 * max(1.0, np.abs(ref_grad).max())
     assert abs(g.sum()) < 1e-12  # softmax gradients sum to zero
