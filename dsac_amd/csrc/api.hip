@@ -203,6 +203,10 @@ int dsac_create(dsac_ctx** out, int device) {
     c->own_stream = true;
     const char* v = getenv("DSAC_K2_VARIANT");
     if (v) c->reproject_variant = atoi(v);
+    const char* o = getenv("DSAC_K2_ORDER");
+    if (o) dk::reproject_set_order(atoi(o) != 0);
+    const char* kf = getenv("DSAC_K2_FLAGS");
+    if (kf) dk::reproject_set_flags(atoi(kf));
     *out = c;
     return DSAC_OK;
 }

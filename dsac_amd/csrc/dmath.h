@@ -1,5 +1,5 @@
 // dmath.h -- fp64 device math of the gfx950 DSAC engine: Rodrigues (both ways + derivative), pinhole
-// projection, minimal-set P3P (Gao's quartic + Horn's quaternion alignment), pose-convention flips.
+// projection, minimal-set P3P (Gao's quartic + triad alignment), pose-convention flips.
 //
 // Everything here runs on one lane in registers: all loops have compile-time bounds and every array
 // index is static after unrolling, so nothing lands in scratch because of dynamic indexing.
@@ -244,99 +244,43 @@ DM_INLINE int roots4(double a, double b, double c, double d, double e, double x[
 }
 
 // ------------------------------------------------------------------------------------------------
-// Horn's absolute orientation for 3 correspondences: largest eigenvector of the 4x4 N matrix by cyclic
-// Jacobi sweeps (the threshold schedule of the classic routine: 0.2*sum/16 for the first three sweeps).
+// Absolute orientation of the P3P triangle: M[k] (camera-frame points) = R * X[k] + T, k = 0..2.
+// OpenCV solves this with Horn's unit-quaternion least squares (a 4x4 Jacobi eigen-solve per root, the long
+// pole of P3P on one lane).  The camera-frame triangle is congruent to the object triangle by construction
+// (its side lengths come out of the P3P length solve), so the rotation is determined exactly by the two
+// orthonormal triads of the triangles and the least-squares machinery is not needed: R = Tc * Tw^T with
+// T* = [e1 e2 e3], e1 = (P1-P0)/|.|, e3 = e1 x (P2-P0)/|.|, e2 = e3 x e1 (Horn 1987, section 2.A).  It agrees
+// with the quaternion solution to rounding (the residual incongruence of the two triangles is ~1e-13).
 // ------------------------------------------------------------------------------------------------
-DM_INLINE void jrot(double& g_, double& h_, double s, double tau) {
-    const double g = g_, h = h_;
-    g_ = g - s * (h + g * tau);
-    h_ = h + s * (g - h * tau);
+DM_INLINE void triad(const double P[3][3], double E[9]) {  // E columns = e1, e2, e3 (row-major 3x3)
+    double a[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
+    const double b[3] = {P[2][0] - P[0][0], P[2][1] - P[0][1], P[2][2] - P[0][2]};
+    const double ia = 1.0 / sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    a[0] *= ia; a[1] *= ia; a[2] *= ia;
+    double n[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const double in = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    n[0] *= in; n[1] *= in; n[2] *= in;
+    const double m[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2], n[0] * a[1] - n[1] * a[0]};
+    E[0] = a[0]; E[1] = m[0]; E[2] = n[0];
+    E[3] = a[1]; E[4] = m[1]; E[5] = n[1];
+    E[6] = a[2]; E[7] = m[2]; E[8] = n[2];
 }
 
-DM_INLINE void jacobi4(double A[16], double D[4], double U[16]) {
-    double B[4], Z[4];
+// Ew = triad of the object triangle (hoisted: it is the same for all quartic roots)
+DM_INLINE void align3(const double M[3][3], const double X[3][3], const double Ew[9], double R[9], double T[3]) {
+    double Ec[9];
+    triad(M, Ec);
 #pragma unroll
-    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) { D[i] = B[i]; Z[i] = 0; }
-    for (int iter = 0; iter < 50; iter++) {
-        const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
-        if (sum == 0.0) return;
-        const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-#pragma unroll
-            for (int j = i + 1; j < 4; j++) {
-                const double Aij = A[4 * i + j];
-                const double eps_machine = 100.0 * fabs(Aij);
-                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) {
-                    A[4 * i + j] = 0.0;
-                } else if (fabs(Aij) > tresh) {
-                    double hh = D[j] - D[i], t;
-                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
-                    else {
-                        const double theta = 0.5 * hh / Aij;
-                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        if (theta < 0.0) t = -t;
-                    }
-                    hh = t * Aij;
-                    Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
-                    A[4 * i + j] = 0.0;
-                    const double c = 1.0 / sqrt(1 + t * t), s = t * c, tau = s / (1.0 + c);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k < i) jrot(A[k * 4 + i], A[k * 4 + j], s, tau);
-                        else if (k > i && k < j) jrot(A[i * 4 + k], A[k * 4 + j], s, tau);
-                        else if (k > j) jrot(A[i * 4 + k], A[j * 4 + k], s, tau);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) jrot(U[k * 4 + i], U[k * 4 + j], s, tau);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
-    }
-}
-
-// M[k] (camera-frame points) ~= R * X[k] + T  for k = 0..2
-DM_INLINE void align3(const double M[3][3], const double X[3][3], double R[9], double T[3]) {
+        for (int j = 0; j < 3; j++) R[i * 3 + j] = Ec[i * 3 + 0] * Ew[j * 3 + 0] + Ec[i * 3 + 1] * Ew[j * 3 + 1] + Ec[i * 3 + 2] * Ew[j * 3 + 2];
+    const double third = 1.0 / 3.0;
     double Cs[3], Ce[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        Ce[j] = (M[0][j] + M[1][j] + M[2][j]) / 3;
-        Cs[j] = (X[0][j] + X[1][j] + X[2][j]) / 3;
+        Ce[j] = (M[0][j] + M[1][j] + M[2][j]) * third;
+        Cs[j] = (X[0][j] + X[1][j] + X[2][j]) * third;
     }
-    double s[9];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) s[a * 3 + j] = (X[0][a] * M[0][j] + X[1][a] * M[1][j] + X[2][a] * M[2][j]) / 3 - Ce[j] * Cs[a];
-    double Q[16], ev[4], U[16];
-    Q[0] = s[0] + s[4] + s[8];
-    Q[5] = s[0] - s[4] - s[8];
-    Q[10] = s[4] - s[8] - s[0];
-    Q[15] = s[8] - s[0] - s[4];
-    Q[4] = Q[1] = s[5] - s[7];
-    Q[8] = Q[2] = s[6] - s[2];
-    Q[12] = Q[3] = s[1] - s[3];
-    Q[9] = Q[6] = s[3] + s[1];
-    Q[13] = Q[7] = s[6] + s[2];
-    Q[14] = Q[11] = s[7] + s[5];
-    jacobi4(Q, ev, U);
-    // eigenvector of the largest eigenvalue, first maximum wins
-    double evm = ev[0];
-    double q0 = U[0], q1 = U[4], q2 = U[8], q3 = U[12];
-#pragma unroll
-    for (int i = 1; i < 4; i++) {
-        if (ev[i] > evm) { evm = ev[i]; q0 = U[i]; q1 = U[4 + i]; q2 = U[8 + i]; q3 = U[12 + i]; }
-    }
-    const double q02 = q0 * q0, q12 = q1 * q1, q22 = q2 * q2, q32 = q3 * q3;
-    const double q0_1 = q0 * q1, q0_2 = q0 * q2, q0_3 = q0 * q3, q1_2 = q1 * q2, q1_3 = q1 * q3, q2_3 = q2 * q3;
-    R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q1_2 - q0_3); R[2] = 2. * (q1_3 + q0_2);
-    R[3] = 2. * (q1_2 + q0_3); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q2_3 - q0_1);
-    R[6] = 2. * (q1_3 - q0_2); R[7] = 2. * (q2_3 + q0_1); R[8] = q02 + q32 - q12 - q22;
 #pragma unroll
     for (int i = 0; i < 3; i++) T[i] = Ce[i] - (R[i * 3] * Cs[0] + R[i * 3 + 1] * Cs[1] + R[i * 3 + 2] * Cs[2]);
 }
@@ -353,6 +297,7 @@ struct P3PSetup {
     double mu3, mv3;  // 4th image point (pixels, after the float round trip of undistortPoints)
     double a, b, p, q, r, d2, inv_b0;
     double roots[4];
+    double Ew[9];     // orthonormal triad of the object triangle
     int n;
 };
 
@@ -380,6 +325,7 @@ DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K
 #pragma unroll
         for (int j = 0; j < 3; j++) S.Xw[i][j] = X[i][j];
     S.X3[0] = X[3][0]; S.X3[1] = X[3][1]; S.X3[2] = X[3][2];
+    triad(S.Xw, S.Ew);
 
     auto dist = [&](int a, int b) {
         const double dx = S.Xw[a][0] - S.Xw[b][0], dy = S.Xw[a][1] - S.Xw[b][1], dz = S.Xw[a][2] - S.Xw[b][2];
@@ -436,7 +382,7 @@ DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double R
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int j = 0; j < 3; j++) M[k][j] = L[k] * S.f[k][j];
-    align3(M, S.Xw, Rc, Tc);
+    align3(M, S.Xw, S.Ew, Rc, Tc);
     const double X3p = Rc[0] * S.X3[0] + Rc[1] * S.X3[1] + Rc[2] * S.X3[2] + Tc[0];
     const double Y3p = Rc[3] * S.X3[0] + Rc[4] * S.X3[1] + Rc[5] * S.X3[2] + Tc[1];
     const double Z3p = Rc[6] * S.X3[0] + Rc[7] * S.X3[1] + Rc[8] * S.X3[2] + Tc[2];

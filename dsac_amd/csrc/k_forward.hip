@@ -48,6 +48,12 @@ hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev&
 // --------------------------------------------------------------------------------------------------
 constexpr int K2_THREADS = 256;
 
+// block order of K2 (see the decode in the kernels); process-wide tuning knob
+static bool g_k2_pixel_minor = true;
+static int g_k2_flags = 0;
+void reproject_set_flags(int f) { g_k2_flags = f; }
+void reproject_set_order(bool pixel_minor) { g_k2_pixel_minor = pixel_minor; }
+
 DM_INLINE float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -72,17 +78,55 @@ DM_INLINE float soft_inlier(float e, float kA, float kB) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kA, e, kB)));
 }
 
+// Packed-fp32 forms: two pixels per VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  K2 is
+// VALU-issue bound once the stores stream (rocprof: SQ_ACTIVE_INST_VALU ~ all SIMD cycles), and a packed op
+// issues in the time of a scalar one, so the 9-FMA rigid transform and the residual arithmetic run at
+// half the issue cost; only rcp / sqrt / exp2 (transcendental pipe) and min stay per pixel.
+DM_INLINE f2 splat(float a) { return f2{a, a}; }
+DM_INLINE f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+DM_INLINE f2 residual2(const f4 r0, const f4 r1, const f4 r2, f2 X, f2 Y, f2 Z, f2 pu, f2 pv, float clampv) {
+    const f2 xc = pk_fma(splat(r0.x), X, pk_fma(splat(r0.y), Y, pk_fma(splat(r0.z), Z, splat(r0.w))));
+    const f2 yc = pk_fma(splat(r1.x), X, pk_fma(splat(r1.y), Y, pk_fma(splat(r1.z), Z, splat(r1.w))));
+    const f2 zc = pk_fma(splat(r2.x), X, pk_fma(splat(r2.y), Y, pk_fma(splat(r2.z), Z, splat(r2.w))));
+    f2 iz;
+    iz.x = (zc.x == 0.0f) ? 1.0f : __builtin_amdgcn_rcpf(zc.x);
+    iz.y = (zc.y == 0.0f) ? 1.0f : __builtin_amdgcn_rcpf(zc.y);
+    const f2 du = pk_fma(-xc, iz, pu);
+    const f2 dv = pk_fma(-yc, iz, pv);
+    const f2 d2 = pk_fma(dv, dv, du * du);
+    f2 e;
+    e.x = fminf(__builtin_amdgcn_sqrtf(d2.x), clampv);
+    e.y = fminf(__builtin_amdgcn_sqrtf(d2.y), clampv);
+    return e;
+}
+
+DM_INLINE f2 soft_inlier2(f2 e, float kA, float kB) {
+    const f2 t = pk_fma(splat(kA), e, splat(kB));
+    f2 ex;
+    ex.x = __builtin_amdgcn_exp2f(t.x);
+    ex.y = __builtin_amdgcn_exp2f(t.y);
+    const f2 d = ex + splat(1.0f);
+    f2 s;
+    s.x = __builtin_amdgcn_rcpf(d.x);
+    s.y = __builtin_amdgcn_rcpf(d.y);
+    return s;
+}
+
 template <int PX, int HT, bool ERR, bool SOFT, bool UV, bool SPOSE>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                           const float* __restrict__ uv, float* __restrict__ err,
                                                           float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
-                                                          float cy, float clampv, float kA, float kB) {
+                                                          float cy, float clampv, float kA, float kB, int kflags) {
     // XCD-aware decode: the 8 blocks of one dispatch round-robin group cover 8 different pixel tiles, and
     // successive groups walk the hypothesis tiles of those same pixel tiles.
     const int b = blockIdx.x;
     const int q = b >> 3;
-    const int ht = q % NT;
-    const int pt = (q / NT) * 8 + (b & 7);
+    // order: NT > 0 -> hypothesis tiles innermost (same pixel tile back to back);  NT < 0 -> pixel tiles
+    // innermost (the resident blocks write a contiguous band of error-image rows), |NT| hypothesis tiles.
+    int ht, pt;
+    if (NT > 0) { ht = q % NT; pt = (q / NT) * 8 + (b & 7); }
+    else { const int PTG = (PT + 7) >> 3; ht = q / PTG; pt = (q % PTG) * 8 + (b & 7); }
     if (pt >= PT) return;
     const int h0 = ht * HT;
     const int nh = min(HT, N - h0);
@@ -132,10 +176,10 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restric
     }
     if (!SPOSE) __syncthreads();
 
-    float acc[SOFT ? HT : 1];
     float* erow = ERR ? err + (size_t)h0 * P + p0 : nullptr;
+    const int wave = tid >> 6, lane = tid & 63;
 
-#pragma unroll(SOFT ? HT : 4)
+#pragma unroll 4
     for (int h = 0; h < HT; h++) {
         if (h < nh) {
             f4 r0, r1, r2;
@@ -147,34 +191,43 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restric
                 r0 = sp[0]; r1 = sp[1]; r2 = sp[2];
             }
             float e[PX];
+            if (PX % 2 == 0) {
 #pragma unroll
-            for (int k = 0; k < PX; k++) e[k] = residual(r0, r1, r2, X[k], Y[k], Z[k], pu[k], pv[k], clampv);
+                for (int k = 0; k < PX; k += 2) {
+                    const f2 e2 = residual2(r0, r1, r2, f2{X[k], X[k + 1]}, f2{Y[k], Y[k + 1]}, f2{Z[k], Z[k + 1]}, f2{pu[k], pu[k + 1]},
+                                            f2{pv[k], pv[k + 1]}, clampv);
+                    e[k] = e2.x; e[k + 1] = e2.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PX; k++) e[k] = residual(r0, r1, r2, X[k], Y[k], Z[k], pu[k], pv[k], clampv);
+            }
             if (ERR && valid) {
                 if (PX == 4) {
                     f4 o = {e[0], e[1], e[2], e[3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f4*>(erow + (size_t)h * P));
+                    if (kflags & 1) *reinterpret_cast<f4*>(erow + (size_t)h * P) = o; else __builtin_nontemporal_store(o, reinterpret_cast<f4*>(erow + (size_t)h * P));
                 } else {
                     __builtin_nontemporal_store(e[0], erow + (size_t)h * P);
                 }
             }
             if (SOFT) {
                 float s = 0.f;
+                if (PX % 2 == 0) {
+                    f2 s2 = splat(0.f);
 #pragma unroll
-                for (int k = 0; k < PX; k++) s += soft_inlier(e[k], kA, kB);
-                acc[h] = valid ? s : 0.f;
+                    for (int k = 0; k < PX; k += 2) s2 += soft_inlier2(f2{e[k], e[k + 1]}, kA, kB);
+                    s = s2.x + s2.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PX; k++) s += soft_inlier(e[k], kA, kB);
+                }
+                s = wave_sum(valid ? s : 0.f);
+                if (lane == 0) s_red[wave * HT + h] = s;
             }
-        } else if (SOFT) {
-            acc[h] = 0.f;
         }
     }
 
     if (SOFT) {
-        const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int h = 0; h < HT; h++) {
-            const float s = wave_sum(acc[h]);
-            if (lane == 0) s_red[wave * HT + h] = s;
-        }
         __syncthreads();
         if (tid < nh) {
             float s = 0.f;
@@ -185,6 +238,193 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restric
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// K2, matrix-core form.  The rigid transform of all pixels under all hypotheses is the product
+// [3N x 4] (rows R_i | t_i of every pose) x [4 x P] (X, Y, Z, 1 of every pixel) -- a GEMM with K = 4, which is
+// exactly one v_mfma_f32_16x16x4_f32 per 16 x 16 output tile (fp32 in, fp32 accumulate, bit-equal to an fmaf
+// chain).  rocprof showed the all-VALU kernel issue-bound on the vector ALUs (SQ_ACTIVE_INST_VALU ~ every
+// SIMD cycle) with HBM at ~63 %; moving the 9 FMAs per (hypothesis, pixel) to the matrix pipe, which runs
+// concurrently with the VALU, halves the VALU work per pair (rcp, 2 fma, mul, fma, sqrt, min remain).
+//
+// Tile layout per MFMA:  A[i][k]: i = 4*g + comp  (g = hypothesis within a group of 4, comp = x,y,z,pad)
+//                        B[k][j]: j = pixel column c, k = X,Y,Z,1
+//                        D: lane (g = lane/16, c = lane%16) receives rows 4g..4g+3 of column c
+// i.e. after one MFMA each lane holds (xc, yc, zc, -) of ONE (hypothesis, pixel) pair.  Four MFMAs with
+// column c -> pixel 4c + m (m = 0..3) give the lane 4 consecutive pixels of its hypothesis, which it
+// finishes on the VALU and stores as one 16-byte dwordx4 (16 lanes = 256 contiguous bytes per error-image row).
+// --------------------------------------------------------------------------------------------------
+DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true));  // row_half_mirror
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
+constexpr int KM_CH = 2;  // 64-pixel chunks per wave
+
+template <int HT, bool ERR, bool SOFT, bool UV>
+__global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __restrict__ staged, const float* __restrict__ xyz,
+                                                               const float* __restrict__ uv, float* __restrict__ err,
+                                                               float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
+                                                               float cy, float clampv, float kA, float kB, int kflags) {
+    static_assert(HT % 4 == 0, "hypothesis tile must be a multiple of 4");
+    const int b = blockIdx.x;
+    const int q = b >> 3;
+    // order: NT > 0 -> hypothesis tiles innermost (same pixel tile back to back);  NT < 0 -> pixel tiles
+    // innermost (the resident blocks write a contiguous band of error-image rows), |NT| hypothesis tiles.
+    int ht, pt;
+    if (NT > 0) { ht = q % NT; pt = (q / NT) * 8 + (b & 7); }
+    else { const int PTG = (PT + 7) >> 3; ht = q / PTG; pt = (q % PTG) * 8 + (b & 7); }
+    if (pt >= PT) return;
+    const int h0 = ht * HT;
+    const int nh = min(HT, N - h0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+
+    // A operands in MFMA lane order: s_A[gi*64 + l] = record[h0 + 4 gi + (l%16)/4][comp = (l%16)%4][k = l/16]
+    __shared__ float s_A[(HT / 4) * 64];
+    __shared__ float s_soft[SOFT ? (K2_THREADS / 64) * HT : 1];
+    for (int i = tid; i < (HT / 4) * 64; i += K2_THREADS) {
+        const int l = i & 63, gi = i >> 6;
+        const int row = l & 15, k = l >> 4;
+        const int hyp = 4 * gi + (row >> 2), comp = row & 3;
+        s_A[i] = (comp < 3 && hyp < nh) ? staged[(size_t)(h0 + hyp) * POSE_STRIDE + comp * 4 + k] : 0.0f;
+    }
+    __syncthreads();
+
+    float sacc[SOFT ? HT / 4 : 1];
+    if (SOFT) {
+#pragma unroll
+        for (int gi = 0; gi < HT / 4; gi++) sacc[gi] = 0.f;
+    }
+
+#pragma unroll 1
+    for (int ch = 0; ch < KM_CH; ch++) {
+        const int chunk0 = (pt * (K2_THREADS / 64) * KM_CH + wave * KM_CH + ch) * 64;
+        if (chunk0 >= P) break;
+        const int p0 = chunk0 + 4 * c;        // this lane's 4 consecutive pixels
+        const bool valid = p0 < P;            // P % 4 == 0
+        // B operands: lane (k = g, column c) supplies coordinate k of pixel 4c + m
+        float Bm[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int pc = min(p0 + m, P - 1);
+            Bm[m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
+        }
+        f2 pu[2], pv[2];
+        if (UV) {
+            if (valid) {
+                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0 * 2);
+                const f4 u0 = su[0], u1 = su[1];
+                pu[0] = f2{u0.x - cx, u0.z - cx}; pv[0] = f2{u0.y - cy, u0.w - cy};
+                pu[1] = f2{u1.x - cx, u1.z - cx}; pv[1] = f2{u1.y - cy, u1.w - cy};
+            } else { pu[0] = pu[1] = pv[0] = pv[1] = splat(0.f); }
+        } else {
+            float tu[4], tv[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int p = p0 + m;
+                const int y = p / W, x = p - y * W;
+                tu[m] = (float)x - cx; tv[m] = (float)y - cy;
+            }
+            pu[0] = f2{tu[0], tu[1]}; pu[1] = f2{tu[2], tu[3]};
+            pv[0] = f2{tv[0], tv[1]}; pv[1] = f2{tv[2], tv[3]};
+        }
+
+#pragma unroll
+        for (int gi = 0; gi < HT / 4; gi++) {
+            if (4 * gi >= nh) continue;  // wave-uniform
+            const float a = s_A[gi * 64 + lane];
+            const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[0], z4, 0, 0, 0);
+            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[1], z4, 0, 0, 0);
+            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[2], z4, 0, 0, 0);
+            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[3], z4, 0, 0, 0);
+            const int hyp = 4 * gi + g;
+            // finish on the VALU.  Scalar (unpacked) ops on purpose: the four results of a lane sit in four
+            // different MFMA destination quads, so packing them would cost more v_mov than it saves.
+            float iz0 = __builtin_amdgcn_rcpf(d0.z), iz1 = __builtin_amdgcn_rcpf(d1.z);
+            float iz2 = __builtin_amdgcn_rcpf(d2.z), iz3 = __builtin_amdgcn_rcpf(d3.z);
+            // projectPoints' "z = Z ? 1/Z : 1": one test for the 4 pixels, wave-uniform slow path (practically never)
+            const float zmin = fminf(fminf(fabsf(d0.z), fabsf(d1.z)), fminf(fabsf(d2.z), fabsf(d3.z)));
+            if (__builtin_expect(__any(zmin == 0.0f), 0)) {
+                iz0 = (d0.z == 0.0f) ? 1.0f : iz0; iz1 = (d1.z == 0.0f) ? 1.0f : iz1;
+                iz2 = (d2.z == 0.0f) ? 1.0f : iz2; iz3 = (d3.z == 0.0f) ? 1.0f : iz3;
+            }
+            float e0, e1, e2, e3;
+            {
+                const float du = fmaf(-d0.x, iz0, pu[0].x), dv = fmaf(-d0.y, iz0, pv[0].x);
+                e0 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+            }
+            {
+                const float du = fmaf(-d1.x, iz1, pu[0].y), dv = fmaf(-d1.y, iz1, pv[0].y);
+                e1 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+            }
+            {
+                const float du = fmaf(-d2.x, iz2, pu[1].x), dv = fmaf(-d2.y, iz2, pv[1].x);
+                e2 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+            }
+            {
+                const float du = fmaf(-d3.x, iz3, pu[1].y), dv = fmaf(-d3.y, iz3, pv[1].y);
+                e3 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+            }
+            const f2 e01 = {e0, e1}, e23 = {e2, e3};
+            if (ERR && valid && hyp < nh) {
+                const f4 o = {e0, e1, e2, e3};
+                if (kflags & 1) *reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0) = o; else __builtin_nontemporal_store(o, reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0));
+            }
+            if (SOFT) {
+                const f2 s2 = soft_inlier2(e01, kA, kB) + soft_inlier2(e23, kA, kB);
+                sacc[gi] += valid ? (s2.x + s2.y) : 0.f;
+            }
+        }
+    }
+
+    if (SOFT) {
+        // one 16-lane row reduction per hypothesis group for the whole block pass (not per chunk)
+#pragma unroll
+        for (int gi = 0; gi < HT / 4; gi++) {
+            const float s = row16_sum(sacc[gi]);
+            if (c == 0) s_soft[wave * HT + 4 * gi + g] = s;
+        }
+    }
+
+    if (SOFT) {
+        __syncthreads();
+        if (tid < nh) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < K2_THREADS / 64; w++) s += s_soft[w * HT + tid];
+            soft_part[(size_t)pt * N + h0 + tid] = s;
+        }
+    }
+}
+
+template <int HT>
+static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
+                                        float kB, float* soft_part, int* tiles_used) {
+    const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
+    const int PT = (F.P + tile - 1) / tile;
+    const int NTa = (N + HT - 1) / HT;
+    const int grid = ((PT + 7) / 8) * 8 * NTa;
+    const int NT = g_k2_pixel_minor ? -NTa : NTa;
+    if (tiles_used) *tiles_used = PT;
+    const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
+#define DSAC_K2M(E, S, U)                                                                                                               \
+    hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
+                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags)
+    if (ERR && SOFT) { if (UV) DSAC_K2M(true, true, true); else DSAC_K2M(true, true, false); }
+    else if (ERR) { if (UV) DSAC_K2M(true, false, true); else DSAC_K2M(true, false, false); }
+    else if (SOFT) { if (UV) DSAC_K2M(false, true, true); else DSAC_K2M(false, true, false); }
+#undef DSAC_K2M
+    return hipGetLastError();
+}
+
 int reproject_num_pixel_tiles(int P) { return (P + K2_THREADS - 1) / K2_THREADS; }  // the scalar path's (larger) count
 
 template <int PX, int HT, bool SPOSE>
@@ -192,12 +432,13 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
                                    float* soft_part) {
     const int tile = K2_THREADS * PX;
     const int PT = (F.P + tile - 1) / tile;
-    const int NT = (N + HT - 1) / HT;
-    const int grid = ((PT + 7) / 8) * 8 * NT;
+    const int NTa = (N + HT - 1) / HT;
+    const int grid = ((PT + 7) / 8) * 8 * NTa;
+    const int NT = g_k2_pixel_minor ? -NTa : NTa;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2(E, S, U)                                                                                                              \
     hipLaunchKernelGGL((k_reproject<PX, HT, E, S, U, SPOSE>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, \
-                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB)
+                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags)
     if (ERR && SOFT) { if (UV) DSAC_K2(true, true, true); else DSAC_K2(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2(true, false, true); else DSAC_K2(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2(false, true, true); else DSAC_K2(false, true, false); }
@@ -218,6 +459,9 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
     switch (variant) {
+        case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
+        case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
+        case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
         case 1: return launch_reproject<4, 32, true>(st, N, staged, F, clampv, err, kA, kB, soft_part);
         case 2: return launch_reproject<4, 16, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
         case 3: return launch_reproject<4, 64, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);

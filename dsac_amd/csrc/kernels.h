@@ -23,6 +23,8 @@ constexpr int POSE_STRIDE = 12;
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
 
 // K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
+void reproject_set_order(bool pixel_minor);  // block order knob (default: pixel tiles innermost)
+void reproject_set_flags(int flags);         // bit0: plain (cached) stores instead of non-temporal
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,

@@ -287,7 +287,7 @@ void d_loss_max(const double* est, const double* gt, double* J6) {
 
 // ---- core/cnn_softam.h:101-146  dPNP (4 points, CV_P3P) --------------------------------------------
 // objPts are floats and are perturbed *in float*, sequentially (+eps, -2eps, +eps), as in the reference.
-void d_pnp(const float* uv4, const float* X4_in, float eps, const Cam& K, double* J /*6x12*/) {
+__attribute__((noinline)) void d_pnp(const float* uv4, const float* X4_in, float eps, const Cam& K, double* J /*6x12*/) {
     float X4[12];
     std::memcpy(X4, X4_in, sizeof(X4));
     for (int i = 0; i < 4; i++)

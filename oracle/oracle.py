@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_FAST = None
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)
@@ -22,8 +23,9 @@ c_bp = C.POINTER(C.c_uint8)
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
+    so2 = os.path.join(_HERE, "liborc_fast.so")
     srcs = [os.path.join(_HERE, f) for f in ("dsac_oracle.cpp", "cvlike.h", "Makefile")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    if force or not os.path.exists(so) or not os.path.exists(so2) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return so
 
@@ -41,6 +43,19 @@ def lib():
         _LIB.orc_time_forward.restype = C.c_double
         _LIB.orc_num_threads.restype = C.c_int
     return _LIB
+
+
+def lib_fast():
+    """The same oracle built with the reference's flags (-Ofast); only for timing (bench.py cpu_baseline)."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        so = os.path.join(_HERE, "liborc_fast.so")
+        if not os.path.exists(so):
+            build()
+        _LIB_FAST = C.CDLL(so)
+        _LIB_FAST.orc_time_forward.restype = C.c_double
+        _LIB_FAST.orc_num_threads.restype = C.c_int
+    return _LIB_FAST
 
 
 def _d(a):
@@ -385,7 +400,8 @@ def time_forward(N, seed, xyz, uv, H, W, cam, thr=10.0, max_tries=1000000, tau=1
     uv, up = _f(np.asarray(uv).reshape(-1, 2))
     cam, cp = _cam(cam)
     w = np.zeros(N)
-    lib().orc_time_forward.argtypes = [C.c_int, C.c_uint64, c_fp, c_fp, C.c_int, C.c_int, c_dp, C.c_float, C.c_int, C.c_float, C.c_float,
-                                       C.c_double, C.c_int, c_dp]
-    sec = lib().orc_time_forward(N, seed, xp, up, H, W, cp, thr, max_tries, tau, beta, alpha, reps, w.ctypes.data_as(c_dp))
+    lf = lib_fast()
+    lf.orc_time_forward.argtypes = [C.c_int, C.c_uint64, c_fp, c_fp, C.c_int, C.c_int, c_dp, C.c_float, C.c_int, C.c_float, C.c_float,
+                                    C.c_double, C.c_int, c_dp]
+    sec = lf.orc_time_forward(N, seed, xp, up, H, W, cp, thr, max_tries, tau, beta, alpha, reps, w.ctypes.data_as(c_dp))
     return sec, w

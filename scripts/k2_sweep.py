@@ -23,8 +23,10 @@ for N in (256, 4096):
     print("fill N=%d: %.1f us  %.0f GB/s" % (N, ms * 1e3, 4.0 * N * P / ms / 1e6))
     del buf
 res = []
-for variant in (0, 1, 2, 3):
+for variant, order, kf in ((4, 0, 0), (4, 0, 1), (5, 0, 0), (0, 1, 0)):
     os.environ["DSAC_K2_VARIANT"] = str(variant)
+    os.environ["DSAC_K2_ORDER"] = str(order)
+    os.environ["DSAC_K2_FLAGS"] = str(kf)
     eng = dsac_amd.Engine(0)
     eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)
     eng.profile_enable(True)
@@ -42,7 +44,7 @@ for variant in (0, 1, 2, 3):
             ms, n = eng.profile_read(0)
             us = ms / n * 1e3
             ab = 12 * P + 48 * N + (4 * N * P if mode != "soft" else 0) + 4 * N
-            print("variant %d N=%4d %-4s: %8.1f us  %7.0f GB/s (alg)  %.2f Gpair/s" % (variant, N, mode, us, ab / us / 1e3, N * P / us / 1e3))
+            print("variant %d order %d flags %d N=%4d %-4s: %8.1f us  %7.0f GB/s (alg)  %.2f Gpair/s" % (variant, order, kf, N, mode, us, ab / us / 1e3, N * P / us / 1e3))
             res.append(dict(variant=variant, N=N, mode=mode, us=us, gbs=ab / us / 1e3))
         del err
     eng.close()
