@@ -401,7 +401,6 @@ int dsac_profile_read(dsac_ctx* c, int which, double* ms_total, int* launches, i
     return DSAC_OK;
 }
 
-// ---- not yet implemented (round-1 work in progress) --------------------------------------------------
 static int score_backward_common(dsac_ctx* c, const char* who, int N, const double* poses, const int32_t* sets, const float* d_err,
                                  const double* g, float clampv, float tau, float beta, const double* dpnp_or_null, unsigned flags,
                                  double* grad_xyz) {
@@ -461,13 +460,86 @@ int dsac_soft_score_backward(dsac_ctx* c, int N, const double* poses, const int3
     if (c && !g) return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_backward: g is NULL");
     return score_backward_common(c, "dsac_soft_score_backward", N, poses, sets, nullptr, g, clampv, tau, beta, dpnp_or_null, flags, grad_xyz);
 }
-int dsac_refine(dsac_ctx* c, int, const double*, const int32_t*, int, int, int, float, const int32_t*, const float*, double*, int32_t*, int32_t*) {
-    return fail(c, DSAC_ERR_INVALID, "dsac_refine: not implemented yet");
+int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                const int32_t* pert_px_c, const float* pert_value, double* out_poses, int32_t* inlier_map, int32_t* steps_done) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine: no frame set");
+    if (B < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: NULL argument or negative count");
+    if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
+    if ((pert_px_c != nullptr) != (pert_value != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_refine: pert_px_c and pert_value go together");
+    if (B == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double* d_init;
+    const int32_t *d_perm, *d_px;
+    const float* d_pv;
+    double* d_out;
+    int32_t *d_map, *d_sd;
+    ARG_TRY(in_arg(c, init_poses, (size_t)B * 6, &d_init));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, pert_px_c, (size_t)B * 2, &d_px));
+    ARG_TRY(in_arg(c, pert_value, (size_t)B, &d_pv));
+    ARG_TRY(out_arg(c, out_poses, (size_t)B * 6, &d_out));
+    ARG_TRY(out_arg(c, inlier_map, P, &d_map, /*preload=*/true));
+    ARG_TRY(out_arg(c, steps_done, (size_t)B, &d_sd));
+    HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd));
+    return end_call(c);
 }
-int dsac_refine_fd(dsac_ctx* c, const double*, const int32_t*, int, int, int, float, const int32_t*, float, float, float, double*, int32_t*, double*, int, int32_t*) {
-    return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: not implemented yet");
+
+int dsac_refine_fd(dsac_ctx* c, const double* init_pose, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                   const int32_t* inlier_map, float sub_sample, float eps_hyp, float eps_obj, double* J_hyp, int32_t* obj_pixels, double* J_obj,
+                   int cap, int32_t* n_obj) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd: no frame set");
+    if (!init_pose || !perm || !inlier_map || !J_hyp || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: NULL argument or negative count");
+    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: need 1 <= max_inl <= 256");
+    if (!(sub_sample > 0.f) || !(eps_hyp > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: sub_sample, eps_hyp, eps_obj must be > 0");
+    const int skip = (int)(1 / sub_sample);  // core/cnn_softam.h:871
+    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: sub_sample > 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double* d_init;
+    const int32_t *d_perm, *d_map;
+    double *d_Jh, *d_Jo;
+    int32_t *d_px, *d_n;
+    ARG_TRY(in_arg(c, init_pose, 6, &d_init));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, inlier_map, P, &d_map));
+    ARG_TRY(out_arg(c, J_hyp, 36, &d_Jh));
+    ARG_TRY(out_arg(c, obj_pixels, (size_t)cap, &d_px));
+    ARG_TRY(out_arg(c, J_obj, (size_t)cap * 18, &d_Jo));
+    ARG_TRY(out_arg(c, n_obj, 1, &d_n));
+    const size_t B = 12 + 6 * (size_t)cap;
+    DevBuf& rp = next_slot(c); HIP_TRY(c, rp.reserve(B * 6 * sizeof(double)));
+    DevBuf& rx = next_slot(c); HIP_TRY(c, rx.reserve(B * 2 * sizeof(int32_t)));
+    DevBuf& rv = next_slot(c); HIP_TRY(c, rv.reserve(B * sizeof(float)));
+    DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
+    DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap + 1) * sizeof(int32_t)));
+    int32_t* d_pxbuf = d_px ? d_px : px.as<int32_t>();
+    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_init, d_map, c->F, skip, eps_hyp, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n));
+    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
+    HIP_TRY(c, dk::refine_fd_finish(c->stream, ro.as<double>(), d_n, cap, skip, eps_hyp, eps_obj, d_Jh, d_Jo));
+    return end_call(c);
 }
-int dsac_loss(dsac_ctx* c, const double*, const double*, double*, double*) { return fail(c, DSAC_ERR_INVALID, "dsac_loss: not implemented yet"); }
+
+int dsac_loss(dsac_ctx* c, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_loss: ctx is NULL");
+    if (!est_cv6 || !gt_jp6 || (!out4 && !J6_or_null)) return fail(c, DSAC_ERR_INVALID, "dsac_loss: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const double *d_est, *d_gt;
+    double *d_out, *d_J;
+    ARG_TRY(in_arg(c, est_cv6, 6, &d_est));
+    ARG_TRY(in_arg(c, gt_jp6, 6, &d_gt));
+    ARG_TRY(out_arg(c, out4, 4, &d_out));
+    ARG_TRY(out_arg(c, J6_or_null, 6, &d_J));
+    HIP_TRY(c, dk::pose_loss(c->stream, d_est, d_gt, d_out, d_J));
+    return end_call(c);
+}
+
 int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                     const double* dpnp, double* grad_xyz, double* g) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: ctx is NULL");

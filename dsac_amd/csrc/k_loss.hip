@@ -1,0 +1,142 @@
+// k_loss.hip -- K7: pose loss max(rotation error [deg], translation error [cm]) and its analytic gradient.
+//
+// Replaces maxLoss (core/maxloss.h:69-79, with getInvHyp :39-61 and Hypothesis::calcAngularDistance,
+// core/Hypothesis.cpp:137-143) and dLossMax (core/maxloss.h:87-198).  One lane; kept on the device so that a
+// training step can chain loss -> refinement Jacobians -> score backward without a host round trip.
+#include "kernels.h"
+#include "dmath.h"
+
+namespace dk {
+
+DM_INLINE void inv3(const double A[9], double Ai[9]) {
+    const double d = dm::det3(A);
+    const double id = 1.0 / d;
+    Ai[0] = (A[4] * A[8] - A[5] * A[7]) * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = (A[5] * A[6] - A[3] * A[8]) * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = (A[3] * A[7] - A[4] * A[6]) * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+DM_INLINE void mul3(const double A[9], const double B[9], double C[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+__global__ __launch_bounds__(64) void k_pose_loss(const double* __restrict__ est_cv6, const double* __restrict__ gt_jp6,
+                                                  double* __restrict__ out4, double* __restrict__ J6) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double PI = 3.14159265358979323846;
+    double cv6[6], gt[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cv6[k] = est_cv6[k]; gt[k] = gt_jp6[k]; }
+    // estimate in the jp convention (cv2our), ground truth from its jp 6-vector (Hypothesis(std::vector<double>), Hypothesis.cpp:81-99)
+    double R1[9], t1[3], R2[9];
+    dm::cv2our(cv6, R1, t1);
+    const double glen = sqrt(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2]);
+    if (glen > 1e-5) dm::rodrigues_v2m<false>(gt, R2, nullptr);
+    else { R2[0] = 1; R2[1] = 0; R2[2] = 0; R2[3] = 0; R2[4] = 1; R2[5] = 0; R2[6] = 0; R2[7] = 0; R2[8] = 1; }
+    const double t2[3] = {gt[3], gt[4], gt[5]};
+    // getInvHyp: inverse of [R t; 0 1] = [R^-1, -R^-1 t]
+    double Ri1[9], Ri2[9], ti1[3], ti2[3];
+    inv3(R1, Ri1);
+    inv3(R2, Ri2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ti1[i] = -(Ri1[i * 3] * t1[0] + Ri1[i * 3 + 1] * t1[1] + Ri1[i * 3 + 2] * t1[2]);
+        ti2[i] = -(Ri2[i * 3] * t2[0] + Ri2[i * 3 + 1] * t2[1] + Ri2[i * 3 + 2] * t2[2]);
+    }
+    // invH1.calcAngularDistance(invH2): trace(invR1 * inv(invR2))
+    double Rii2[9], D[9];
+    inv3(Ri2, Rii2);
+    mul3(Ri1, Rii2, D);
+    double tr = D[0] + D[4] + D[8];
+    tr = fmin(3.0, fmax(-1.0, tr));
+    const double rotErr = 180 * acos((tr - 1.0) / 2.0) / PI;
+    const double dx = ti1[0] - ti2[0], dy = ti1[1] - ti2[1], dz = ti1[2] - ti2[2];
+    const double tErr = sqrt(dx * dx + dy * dy + dz * dz);
+    if (out4) {
+        out4[0] = fmin(fmax(rotErr, tErr / 10), 10000000.0);
+        out4[1] = rotErr;
+        out4[2] = tErr;
+        out4[3] = (rotErr < 5 && tErr < 50) ? 1.0 : 0.0;  // core/cnn_softam.h:1172-1173
+    }
+    if (!J6) return;
+
+    // ---- dLossMax(est jp 6-vector, gt jp 6-vector) ----
+    double est[6];
+    dm::rodrigues_m2v(R1, est);
+    est[3] = t1[0]; est[4] = t1[1]; est[5] = t1[2];
+    double rot1[9], rot2[9], dRod[27];
+    dm::rodrigues_v2m<true>(est, rot1, dRod);
+    dm::rodrigues_v2m<false>(gt, rot2, nullptr);
+    double J[6] = {0, 0, 0, 0, 0, 0};
+    // diffRot = rot1 * rot2^T
+    double trace = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) trace += rot1[i * 3 + k] * rot2[i * 3 + k];
+    trace = fmin(3.0, fmax(-1.0, trace));
+    const double rErr = 180 * acos((trace - 1.0) / 2.0) / PI;
+    double invT1[3], invT2[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {  // rot^T * (-t/10)
+        invT1[i] = rot1[0 * 3 + i] * (-est[3] / 10) + rot1[1 * 3 + i] * (-est[4] / 10) + rot1[2 * 3 + i] * (-est[5] / 10);
+        invT2[i] = rot2[0 * 3 + i] * (-gt[3] / 10) + rot2[1 * 3 + i] * (-gt[4] / 10) + rot2[2 * 3 + i] * (-gt[5] / 10);
+    }
+    const double d0 = invT1[0] - invT2[0], d1 = invT1[1] - invT2[1], d2 = invT1[2] - invT2[2];
+    const double tE = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const bool zero = (fmax(rErr, tE) > 10000000.0) || ((tE + rErr) < 0.00000001);
+    if (!zero) {
+        if (tE > rErr) {
+            const double dd[3] = {d0 / tE, d1 / tE, d2 / tE};
+            // J[3:6] = dd * (-invRot1),  invRot1 = rot1^T
+#pragma unroll
+            for (int c = 0; c < 3; c++) J[3 + c] = -(dd[0] * rot1[c * 3 + 0] + dd[1] * rot1[c * 3 + 1] + dd[2] * rot1[c * 3 + 2]);
+            // v9[r + 3c] = dd[r] * (-est[3+c]/10)    (core/maxloss.h:147-158)
+            double v9[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) v9[r + 3 * c] = dd[r] * (-est[3 + c] / 10);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s += v9[k] * dRod[i * 9 + k];
+                J[i] = s;
+            }
+        } else {
+            // v9 = dTrace * dRotDiff^T: v9[3b + r] = invRot2(r, b) = rot2(b, r)   (core/maxloss.h:170-188)
+            double v9[9];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int r = 0; r < 3; r++) v9[3 * b + r] = rot2[b * 3 + r];
+            const double scale = 180 / PI * -1 / sqrt(3 - trace * trace + 2 * trace);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s += v9[k] * dRod[i * 9 + k];
+                J[i] = scale * s;
+            }
+        }
+        bool nan = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) nan = nan || (J[i] != J[i]);
+        if (nan) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) J[i] = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) J6[i] = J[i];
+}
+
+hipError_t pose_loss(hipStream_t st, const double* est_cv6, const double* gt_jp6, double* out4, double* J6) {
+    hipLaunchKernelGGL(k_pose_loss, dim3(1), dim3(64), 0, st, est_cv6, gt_jp6, out4, J6);
+    return hipGetLastError();
+}
+
+}  // namespace dk

@@ -1,0 +1,365 @@
+// k_refine.hip -- K6: inlier refinement (Levenberg-Marquardt PnP) and its finite-difference replicas.
+//
+// Replaces the refinement loop of processImage (core/cnn_softam.h:1099-1154), the replay helper refine()
+// (:663-723) and the central-difference drivers dRefineHyp (:738-836) / dRefineObj (:853-923).
+//
+// Design: ONE WAVE PER REFINEMENT PROBLEM.  The reference recomputes a full error image before every
+// refinement step (getDiffMap, P residuals) although the walk along the pixel permutation stops as soon as
+// `max_inl` (100) inliers are found -- typically after a few hundred cells.  Here the wave evaluates the
+// residuals lazily, 64 permuted cells at a time (fp64, the arithmetic of getDiffMap), and compacts the
+// inliers in permutation order with ballot + popcount, so a refinement step touches O(max_inl) cells
+// instead of P.  The LM solve (CvLevMarq's state machine: Marquardt scaling 1+lambda, lambda0 = 1e-3,
+// x10 / /10, <= 20 iterations, eps = FLT_EPSILON on the relative parameter change) runs on the same wave:
+// lanes split the <= max_inl correspondences, J^T J / J^T e are reduced with a butterfly (bit-identical on
+// all lanes), and every lane solves the damped 6x6 system redundantly, which keeps control flow uniform.
+// The 12 + 6*n finite-difference replicas of dRefineHyp/dRefineObj are just more waves of the same kernel:
+// a replica is (start pose, optionally one replaced coordinate), so the whole Jacobian is one launch.
+#include "kernels.h"
+#include "dmath.h"
+
+namespace dk {
+
+constexpr int RF_MAX_INL = 256;  // LDS capacity for the collected correspondences
+
+DM_INLINE dm::Cam make_cam_r(const FrameDev& F) { return dm::Cam{(double)F.fx, (double)F.fy, (double)F.cx, (double)F.cy}; }
+
+DM_INLINE double wave_allsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Cholesky solve of the symmetric positive definite 6x6 system A x = b (A given by its upper triangle,
+// row-major 6x6).  OpenCV uses an SVD pseudo-inverse here; identical for full-rank normal equations.
+DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
+    double L[36];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            double s = A[j * 6 + i];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            if (i == j) {
+                ok = ok && (s > 0.0);
+                L[i * 6 + i] = sqrt(s);
+            } else {
+                L[i * 6 + j] = s / L[j * 6 + j];
+            }
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
+        y[i] = s / L[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
+        x[i] = s / L[i * 6 + i];
+    }
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = 0.0;
+    }
+    return ok;
+}
+
+// Residuals (and optionally the normal equations) of the n collected correspondences at pose `p`.
+// Returns the L2 norm of the 2n residuals; all lanes return the same bits.
+template <bool WITH_J>
+DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, const dm::Cam& K, const double p[6], double JtJ[21], double JtE[6]) {
+    const int lane = threadIdx.x & 63;
+    double R[9], dRdr[27];
+    dm::rodrigues_v2m<WITH_J>(p, R, dRdr);
+    double acc[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) acc[i] = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double Mx = s_X[i * 3], My = s_X[i * 3 + 1], Mz = s_X[i * 3 + 2];
+        const double Xc = R[0] * Mx + R[1] * My + R[2] * Mz + p[3];
+        const double Yc = R[3] * Mx + R[4] * My + R[5] * Mz + p[4];
+        const double Zc = R[6] * Mx + R[7] * My + R[8] * Mz + p[5];
+        const double z = (Zc != 0.0) ? 1. / Zc : 1.;
+        const double x = Xc * z, y = Yc * z;
+        const double eu = x * K.fx + K.cx - (double)s_uv[i * 2];
+        const double ev = y * K.fy + K.cy - (double)s_uv[i * 2 + 1];
+        acc[27] += eu * eu + ev * ev;
+        if (WITH_J) {
+            double Ju[6], Jv[6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double* dR = dRdr + j * 9;
+                const double dX = dR[0] * Mx + dR[1] * My + dR[2] * Mz;
+                const double dY = dR[3] * Mx + dR[4] * My + dR[5] * Mz;
+                const double dZ = dR[6] * Mx + dR[7] * My + dR[8] * Mz;
+                Ju[j] = K.fx * z * (dX - x * dZ);
+                Jv[j] = K.fy * z * (dY - y * dZ);
+            }
+            Ju[3] = K.fx * z; Ju[4] = 0; Ju[5] = -K.fx * x * z;
+            Jv[3] = 0; Jv[4] = K.fy * z; Jv[5] = -K.fy * y * z;
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                acc[21 + a] += Ju[a] * eu + Jv[a] * ev;
+#pragma unroll
+                for (int b2 = a; b2 < 6; b2++) { acc[q] += Ju[a] * Ju[b2] + Jv[a] * Jv[b2]; q++; }
+            }
+        }
+    }
+    const double e2 = wave_allsum(acc[27]);
+    if (WITH_J) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) JtJ[i] = wave_allsum(acc[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) JtE[i] = wave_allsum(acc[21 + i]);
+    }
+    return sqrt(e2);
+}
+
+DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10, const double prev[6], double param[6]) {
+    const double lambda = exp((double)lambdaLg10 * 2.302585092994046);  // exp(lambdaLg10 * log(10))
+    double A[36];
+    int q = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = a; b < 6; b++) { A[a * 6 + b] = JtJ[q]; A[b * 6 + a] = JtJ[q]; q++; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) A[i * 7] *= 1. + lambda;
+    double dx[6];
+    solve6_spd(A, JtE, dx);
+#pragma unroll
+    for (int i = 0; i < 6; i++) param[i] = prev[i] - dx[i];
+}
+
+// solvePnP(CV_ITERATIVE, useExtrinsicGuess = true) on the wave; pose is updated in place.
+DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, const dm::Cam& K, double pose[6]) {
+    double param[6], prev[6], JtJ[21], JtE[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) param[i] = pose[i];
+    int lambdaLg10 = -3, iters = 0;
+    double prevErrNorm = 1.7976931348623157e308, errNorm = 0;
+    double e_at_param = lm_eval<true>(n, s_X, s_uv, K, param, JtJ, JtE);
+    bool done = false;
+    for (int guard = 0; guard < 64 && !done; guard++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) prev[i] = param[i];
+        if (iters == 0) prevErrNorm = e_at_param;
+        lm_step(JtJ, JtE, lambdaLg10, prev, param);
+        for (int inner = 0; inner < 40; inner++) {
+            errNorm = lm_eval<false>(n, s_X, s_uv, K, param, nullptr, nullptr);
+            if (errNorm > prevErrNorm) {
+                if (++lambdaLg10 <= 16) { lm_step(JtJ, JtE, lambdaLg10, prev, param); continue; }
+            }
+            lambdaLg10 = max(lambdaLg10 - 1, -16);
+            double num = 0, den = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { num += (param[i] - prev[i]) * (param[i] - prev[i]); den += prev[i] * prev[i]; }
+            const double change = sqrt(num) / (sqrt(den) + 2.220446049250313e-16);
+            if (++iters >= 20 || change < 1.1920928955078125e-07) { done = true; break; }
+            prevErrNorm = errNorm;
+            e_at_param = lm_eval<true>(n, s_X, s_uv, K, param, JtJ, JtE);
+            break;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) pose[i] = param[i];
+}
+
+__global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict__ n_live, int live_base, int live_mul,
+                                               const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
+                                               int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
+                                               FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
+                                               int32_t* __restrict__ steps_done) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    if (n_live && b >= live_base + live_mul * n_live[0]) return;  // replica list shorter than the launch
+    const int lane = threadIdx.x;
+    __shared__ float s_X[RF_MAX_INL * 3];
+    __shared__ float s_uv[RF_MAX_INL * 2];
+    const dm::Cam K = make_cam_r(F);
+    double pose[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) pose[i] = init_poses[(size_t)b * 6 + i];
+    const int ppx = pert_px_c ? pert_px_c[2 * b] : -1;
+    const int pch = pert_px_c ? pert_px_c[2 * b + 1] : 0;
+    const float pval = pert_value ? pert_value[b] : 0.f;
+    const int P = F.P;
+    int done = 0;
+    for (int step = 0; step < steps; step++) {
+        double R[9];
+        dm::rodrigues_v2m<false>(pose, R, nullptr);
+        const int32_t* pidx = perm + (size_t)step * P;
+        int cnt = 0;
+        for (int base = 0; base < P && cnt < max_inl; base += 64) {
+            const int idx = base + lane;
+            const bool in = idx < P;
+            int p = in ? pidx[idx] : 0;
+            p = min(max(p, 0), P - 1);
+            float X = F.xyz[(size_t)p * 3], Y = F.xyz[(size_t)p * 3 + 1], Z = F.xyz[(size_t)p * 3 + 2];
+            if (p == ppx) { if (pch == 0) X = pval; else if (pch == 1) Y = pval; else Z = pval; }
+            float pu, pv;
+            if (F.uv) { pu = F.uv[(size_t)p * 2]; pv = F.uv[(size_t)p * 2 + 1]; }
+            else { const int y = p / F.W; pu = (float)(p - y * F.W); pv = (float)y; }
+            const float e = dm::residual_f(R, pose + 3, K, X, Y, Z, pu, pv, 100.0);
+            const bool inl = in && (e < thr);
+            const unsigned long long m = __ballot(inl);
+            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+            const bool take = inl && (cnt + prefix < max_inl);
+            if (take) {
+                const int slot = cnt + prefix;
+                s_X[slot * 3] = X; s_X[slot * 3 + 1] = Y; s_X[slot * 3 + 2] = Z;
+                s_uv[slot * 2] = pu; s_uv[slot * 2 + 1] = pv;
+                if (inlier_map && b == 0) atomicAdd(&inlier_map[p], 1);
+            }
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const int n = min(cnt, max_inl);
+        if (n < min_inl) break;  // abort for stability: too few inliers (core/cnn_softam.h:700, 1136)
+        double upd[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) upd[i] = pose[i];
+        lm_pnp(n, s_X, s_uv, K, upd);
+        bool nan = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
+        if (nan) break;
+#pragma unroll
+        for (int i = 0; i < 6; i++) pose[i] = upd[i];
+        done++;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) out_poses[(size_t)b * 6 + i] = pose[i];
+        if (steps_done) steps_done[b] = done;
+    }
+}
+
+hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                  const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
+                  int32_t* steps_done) {
+    if (B <= 0) return hipSuccess;
+    if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
+                       pert_value, F, out_poses, inlier_map, steps_done);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// Replica plan of dRefineHyp (12 replicas) + dRefineObj (6 per selected cell).  One wave scans inlier_map in
+// the reference's x-outer / y-inner order (core/cnn_softam.h:873-882) and keeps every skip-th inlier cell.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_refine_fd_plan(const double* __restrict__ init_pose, const int32_t* __restrict__ inlier_map, FrameDev F,
+                                                       int skip, float eps_hyp, float eps_obj, int cap, double* __restrict__ rep_poses,
+                                                       int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value,
+                                                       int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj) {
+    const int lane = threadIdx.x;
+    double init[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) init[i] = init_pose[i];
+    // dRefineHyp: replica 2i = +step on parameter i, 2i+1 = (+step) - 2 step  (double arithmetic, :758-772,798-812)
+    if (lane < 12) {
+        const int i = lane >> 1;
+        const double step = (i < 3) ? (double)eps_hyp : (double)(eps_hyp * 1000);
+        double pose[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose[k] = init[k];
+        double v = init[i] + step;
+        if (lane & 1) v -= 2 * step;
+#pragma unroll
+        for (int k = 0; k < 6; k++) rep_poses[(size_t)lane * 6 + k] = (k == i) ? v : pose[k];
+        rep_px_c[2 * lane] = -1; rep_px_c[2 * lane + 1] = 0; rep_value[lane] = 0.f;
+    }
+    // dRefineObj: column-major scan
+    const int P = F.P;
+    int inCount = 0, nsel = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int t = base + lane;  // index in x-outer / y-inner order: t = x * H + y
+        const bool in = t < P;
+        int p = 0;
+        bool inl = false;
+        if (in) { const int x = t / F.H, y = t - x * F.H; p = y * F.W + x; inl = inlier_map[p] != 0; }
+        const unsigned long long m = __ballot(inl);
+        const int myCount = inCount + __popcll(m & ((1ull << lane) - 1ull)) + 1;  // value of inCount after this cell
+        const bool sel = inl && (myCount % skip == 0);
+        const unsigned long long ms = __ballot(sel);
+        const int slot = nsel + __popcll(ms & ((1ull << lane) - 1ull));
+        if (sel && slot < cap) {
+            obj_pixels[slot] = p;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v0 = F.xyz[(size_t)p * 3 + c];
+                const float vf = v0 + eps_obj;
+                const float vb = vf - 2 * eps_obj;
+                const int r = 12 + slot * 6 + c * 2;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { rep_poses[(size_t)r * 6 + k] = init[k]; rep_poses[(size_t)(r + 1) * 6 + k] = init[k]; }
+                rep_px_c[2 * r] = p; rep_px_c[2 * r + 1] = c; rep_value[r] = vf;
+                rep_px_c[2 * (r + 1)] = p; rep_px_c[2 * (r + 1) + 1] = c; rep_value[r + 1] = vb;
+            }
+        }
+        inCount += __popcll(m);
+        nsel += __popcll(ms);
+    }
+    if (lane == 0) n_obj[0] = min(nsel, cap);
+}
+
+hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
+                          float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj) {
+    hipLaunchKernelGGL(k_refine_fd_plan, dim3(1), dim3(64), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c, rep_value,
+                       obj_pixels, n_obj);
+    return hipGetLastError();
+}
+
+// launches the replicas: grid = 12 + 6*cap waves, those beyond 12 + 6*n_obj exit immediately
+hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
+                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out) {
+    if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
+    const int B = 12 + 6 * cap;
+    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
+                       (int32_t*)nullptr, (int32_t*)nullptr);
+    return hipGetLastError();
+}
+
+// central differences of the jp 6-vectors (getRodVecAndTrans(Hypothesis(cv2our(.))), core/cnn_softam.h:721-722)
+__global__ __launch_bounds__(64) void k_refine_fd_finish(const double* __restrict__ rep_out, const int32_t* __restrict__ n_obj, int cap, int skip,
+                                                         float eps_hyp, float eps_obj, double* __restrict__ J_hyp, double* __restrict__ J_obj) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;  // replica pair index: 0..5 hyp, 6.. obj (3 per cell)
+    const int npairs = 6 + 3 * min(n_obj[0], cap);
+    if (pair >= npairs) return;
+    double f6[6], b6[6], cvf[6], cvb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cvf[k] = rep_out[(size_t)(2 * pair) * 6 + k]; cvb[k] = rep_out[(size_t)(2 * pair + 1) * 6 + k]; }
+    dm::cv_to_jp6(cvf, f6);
+    dm::cv_to_jp6(cvb, b6);
+    if (pair < 6) {
+        const int i = pair;
+#pragma unroll
+        for (int k = 0; k < 3; k++) J_hyp[k * 6 + i] = (f6[k] - b6[k]) / (double)(2 * eps_hyp);
+#pragma unroll
+        for (int k = 3; k < 6; k++) J_hyp[k * 6 + i] = (f6[k] - b6[k]) / (double)(2 * eps_hyp * 1000);
+    } else {
+        const int cell = (pair - 6) / 3, c = (pair - 6) % 3;
+#pragma unroll
+        for (int k = 0; k < 6; k++) J_obj[((size_t)cell * 6 + k) * 3 + c] = (f6[k] - b6[k]) / (double)(2 * eps_obj) * skip;
+    }
+}
+
+hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_hyp, float eps_obj,
+                            double* J_hyp, double* J_obj) {
+    const int pairs = 6 + 3 * cap;
+    hipLaunchKernelGGL(k_refine_fd_finish, dim3((pairs + 63) / 64), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_hyp, eps_obj, J_hyp, J_obj);
+    return hipGetLastError();
+}
+
+}  // namespace dk

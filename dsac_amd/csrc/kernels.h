@@ -66,6 +66,9 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,
                           int32_t* n_obj);
+// launches 12 + 6*cap replica waves; those beyond 12 + 6*n_obj[0] exit immediately
+hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
+                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out);
 hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_hyp, float eps_obj,
                             double* J_hyp, double* J_obj);
 

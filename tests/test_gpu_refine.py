@@ -1,0 +1,124 @@
+"""GPU parity of K6 (inlier refinement + finite-difference Jacobians) and K7 (pose loss) against the CPU oracle.
+
+Both sides run the same fp64 arithmetic (lazy getDiffMap residuals, CvLevMarq state machine); differences are
+libm-vs-ocml last bits and the 6x6 solve (Cholesky on the GPU, Gaussian elimination in the oracle).
+  refined poses : 1e-7 relative          inlier maps / step counts : identical
+  dRefineHyp/Obj: central differences divide LM outputs by 2e-3 / 4, so 1e-4 relative to the largest entry
+  loss, dLossMax: 1e-9
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _forward(engine, orc, synth, fr, N=256, seed=3):
+    engine.set_frame(fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    poses, sets, ok, _ = orc.sample(N, seed, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    w = orc.softMax(0.1 * orc.soft_inlier(err, 10.0, 0.5))
+    avg = orc.avg_pose(w, poses)
+    perm = synth.fast_permutations(fr["H"] * fr["W"], 8, seed=5489)
+    return avg, perm
+
+
+def test_refine_forward_reference_size(engine, orc, synth, frame40):
+    fr = frame40
+    avg, perm = _forward(engine, orc, synth, fr)
+    ref, imap_r, sd_r = orc.refine(avg, perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"], want_inlier_map=True)
+    got, sd, imap = engine.refine(avg, perm, want_inlier_map=True)
+    assert np.array_equal(sd, sd_r) and sd[0] == 8
+    assert np.array_equal(imap, imap_r)
+    assert np.allclose(got, ref, rtol=1e-7, atol=1e-9)
+    # the refined pose is close to the ground truth (sanity of the whole forward path)
+    Re, te = orc.cv2our(got[0])
+    Rg, tg = orc.cv2our(fr["gt_pose"])
+    rot, tr = orc.pose_errors(Re, te, Rg, tg)
+    assert rot < 1.0 and tr < 20.0
+
+
+def test_refine_full_resolution(engine, orc, synth, frame_full):
+    fr = frame_full
+    avg, perm = _forward(engine, orc, synth, fr, N=64)
+    ref, imap_r, sd_r = orc.refine(avg, perm, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"], want_inlier_map=True)
+    got, sd, imap = engine.refine(avg, perm, want_inlier_map=True)
+    assert np.array_equal(sd, sd_r)
+    assert np.array_equal(imap, imap_r)
+    assert np.allclose(got, ref, rtol=1e-7, atol=1e-9)
+
+
+def test_refine_replicas_and_perturbation(engine, orc, synth, frame40):
+    fr = frame40
+    avg, perm = _forward(engine, orc, synth, fr)
+    rng = np.random.default_rng(0)
+    B = 9
+    init = avg[None, :] + rng.normal(scale=[1e-3] * 3 + [1.0] * 3, size=(B, 6))
+    px = np.stack([rng.integers(-1, 1600, size=B), rng.integers(0, 3, size=B)], -1).astype(np.int32)
+    px[0, 0] = -1
+    val = (fr["xyz"][np.maximum(px[:, 0], 0), px[:, 1]] + rng.choice([-2.0, 2.0], size=B)).astype(np.float32)
+    ref, sd_r = orc.refine(init, perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"], pert_px_c=px, pert_value=val)
+    got, sd = engine.refine(init, perm, pert_px_c=px, pert_value=val)
+    assert np.array_equal(sd, sd_r)
+    assert np.allclose(got, ref, rtol=1e-7, atol=1e-9)
+
+
+def test_refine_too_few_inliers_and_short_perm(engine, orc, synth, frame40):
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    perm = synth.fast_permutations(1600, 3)
+    bad = np.array([0.5, -0.3, 0.2, 100.0, 50.0, 900.0])  # far from the truth: < 50 inliers -> loop stops, pose unchanged
+    got, sd, imap = engine.refine(bad, perm, want_inlier_map=True)
+    ref, imap_r, sd_r = orc.refine(bad, perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"], want_inlier_map=True)
+    assert sd[0] == sd_r[0] == 0
+    assert np.array_equal(got[0], bad)
+    assert np.array_equal(imap, imap_r)
+    # zero refinement steps requested
+    got, sd = engine.refine(bad, perm[:0].reshape(0, 1600))
+    assert np.array_equal(got[0], bad) and sd[0] == 0
+
+
+def test_drefine_parity(engine, orc, synth, frame40):
+    fr = frame40
+    avg, perm = _forward(engine, orc, synth, fr)
+    ref, imap, sd = orc.refine(avg, perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"], want_inlier_map=True)
+    Jh_r = orc.dRefineHyp(avg, perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    Jo_r = orc.dRefineObj(avg, perm, imap, fr["xyz"], fr["uv"], 40, 40, fr["cam"], sub_sample=0.01)
+    Jh, px, Jo = engine.dRefine(avg, perm, imap, sub_sample=0.01)
+    assert np.abs(Jh - Jh_r).max() <= 1e-4 * np.abs(Jh_r).max()
+    dense = np.zeros((6, 1600 * 3))
+    for i, p in enumerate(px):
+        dense[:, p * 3:p * 3 + 3] = Jo[i]
+    nz = np.flatnonzero(np.abs(Jo_r).sum(0))
+    assert len(px) == len(set(nz // 3)) and len(px) >= 1
+    assert np.abs(dense - Jo_r).max() <= 1e-4 * max(np.abs(Jo_r).max(), 1e-12)
+    # denser sub-sampling exercises more replicas
+    Jo_r2 = orc.dRefineObj(avg, perm, imap, fr["xyz"], fr["uv"], 40, 40, fr["cam"], sub_sample=0.1)
+    _, px2, Jo2 = engine.dRefine(avg, perm, imap, sub_sample=0.1)
+    dense2 = np.zeros((6, 1600 * 3))
+    for i, p in enumerate(px2):
+        dense2[:, p * 3:p * 3 + 3] = Jo2[i]
+    assert len(px2) > len(px)
+    assert np.abs(dense2 - Jo_r2).max() <= 1e-4 * max(np.abs(Jo_r2).max(), 1e-12)
+
+
+def test_loss_and_gradient(engine, orc, synth):
+    rng = np.random.default_rng(1)
+    gt_cv = np.array([0.2, -0.1, 0.05, 120.0, -340.0, 2100.0])
+    gt_jp = orc.cv_to_jp6(gt_cv)
+    Rg, tg = orc.cv2our(gt_cv)
+    cases = [gt_cv + np.array([0.05, 0.02, -0.03, 1.0, 2.0, -1.0]),      # rotation error dominates
+             gt_cv + np.array([1e-4, 0, 0, 80.0, -60.0, 150.0]),          # translation error dominates
+             gt_cv.copy(),                                                  # zero error -> zero gradient
+             gt_cv + rng.normal(scale=[0.3] * 3 + [500.0] * 3)]
+    for est in cases:
+        Re, te = orc.cv2our(est)
+        r = engine.maxLoss(est, gt_jp, want_grad=True)
+        rot, tr = orc.pose_errors(Rg, tg, Re, te)
+        # acos near 1 turns 1e-16 of round-off in the trace into ~1e-6 deg, hence the absolute floor
+        assert abs(r["loss"] - orc.maxLoss(Rg, tg, Re, te)) <= 1e-5 + 1e-9 * r["loss"]
+        assert abs(r["rotErr"] - rot) <= 1e-5 and abs(r["tErr"] - tr) <= 1e-7 * max(1.0, tr)
+        assert r["correct"] == (rot < 5 and tr < 50)
+        assert np.all(np.isfinite(r["grad"]))
+        if rot + tr > 1e-3:  # at exactly zero error the gradient is 0/0 on both sides
+            Jr = orc.dLossMax(orc.cv_to_jp6(est), gt_jp)
+            assert np.abs(r["grad"] - Jr).max() <= 1e-8 * max(1.0, np.abs(Jr).max())
