@@ -244,3 +244,56 @@ class Engine:
         check(self._ctx, lib.dsac_path1_and_softmax_backward(self._ctx, N, ptr(_np(v6, np.float64)), ptr(_np(w, np.float64)), ptr(_np(poses, np.float64)),
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
         return grad, g
+
+    # ---- pipelines (host-orchestrated mirrors of processImage and of the trainer's backward section) ---------
+    def processImage(self, N=256, seed=1305, perm=None, gt_jp6=None, thr=10.0, refSteps=8, inlierCount=100, minInliers=50, tau=10.0,
+                     beta=0.5, alpha=0.1, score_fn=None, keep_err=False, max_tries=1 << 20):
+        """Forward pass of processImage (cnn_softam.h:960-1179) on the frame set with set_frame: sample N
+        hypotheses, score them, soft-argmax, refine, evaluate.  Scores are alpha * soft-inlier counts unless
+        score_fn(err N x H x W float32) -> N float64 is given (the seam where the reference's score CNN sits,
+        cnn_softam.h:1072).  `perm` = refSteps x P pixel permutations (the reference's pixelIdxs)."""
+        poses, sets, ok = self.sample(N, seed=seed, thr=thr, max_tries=max_tries)
+        err = np.zeros((N, self.P), np.float32) if (keep_err or score_fn is not None) else None
+        soft = np.zeros(N)
+        self.reproject(poses, err=err, soft=soft, tau=tau, beta=beta)
+        if score_fn is not None:
+            scores, scale = np.ascontiguousarray(score_fn(err.reshape(N, self.H, self.W)), dtype=np.float64), 1.0
+        else:
+            scores, scale = soft, alpha
+        w, ent, avg = self.softMax(scores, scale, poses)
+        out = dict(hyps=poses, sampledPoints=sets, ok=ok, scores=scores, score_scale=scale, sfScores=w, sfEntropy=float(ent[0]), avgHyp=avg,
+                   diffMaps=err, soft=soft)
+        if perm is not None:
+            perm = np.ascontiguousarray(perm[:refSteps], dtype=np.int32)
+            ref, sd, imap = self.refine(avg, perm, max_inl=inlierCount, min_inl=minInliers, thr=float(int(thr)), want_inlier_map=True)
+            out.update(refAvgHyp=ref[0], refSteps=int(sd[0]), inlierMap=imap, pixelIdxs=perm)
+        else:
+            out.update(refAvgHyp=avg.copy(), refSteps=0, inlierMap=np.zeros(self.P, np.int32), pixelIdxs=None)
+        if gt_jp6 is not None:
+            out.update(self.maxLoss(out["refAvgHyp"], gt_jp6))
+        return out
+
+    def backward(self, fwd, gt_jp6, d_scores_fn=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, sub_sample=0.01,
+                 quirk_transpose=False):
+        """Backward section of the trainer (train_ransac_softam.cpp:288-394): dLoss/d(scene coordinates), P x 3.
+        Path I: dLossMax . (dRefineObj + dRefineHyp . sum_h w_h dPNP_h); path II: softmax backward -> score
+        gradients -> score backward.  With the soft-inlier score the last step is analytic; with a score CNN pass
+        d_scores_fn(g N float64) -> dLoss/d(err images) N x H x W float32 (its backward, cnn_softam.h:605-606)."""
+        grad = np.zeros((self.P, 3))
+        dL = self.dLossMax(fwd["refAvgHyp"], gt_jp6)
+        v6 = dL.copy()
+        if fwd["pixelIdxs"] is not None and fwd["refSteps"] > 0:
+            J_hyp, px, J_obj = self.dRefine(fwd["avgHyp"], fwd["pixelIdxs"], fwd["inlierMap"], max_inl=inlierCount, min_inl=minInliers,
+                                            thr=float(int(thr)), sub_sample=sub_sample)
+            for i, p in enumerate(px):
+                grad[p] += dL @ J_obj[i]
+            v6 = dL @ J_hyp
+        J = self.dPNP(fwd["sampledPoints"])
+        grad, g = self.path1AndSoftmaxBackward(v6, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], J, grad=grad)
+        if d_scores_fn is not None:
+            d_err = np.ascontiguousarray(d_scores_fn(g), dtype=np.float32).reshape(len(g), self.P)
+            grad = self.dScore(fwd["hyps"], fwd["sampledPoints"], d_err, dpnp=J, quirk_transpose=quirk_transpose, grad=grad)
+        else:
+            grad = self.dSoftScore(fwd["hyps"], fwd["sampledPoints"], g * fwd["score_scale"], tau=tau, beta=beta, dpnp=J,
+                                   quirk_transpose=quirk_transpose, grad=grad)
+        return dict(grad=grad, dLoss_dRef=dL, v6=v6, scoreOutputGradients=g, dpnp=J)

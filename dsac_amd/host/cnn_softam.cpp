@@ -1,0 +1,181 @@
+// cnn_softam.cpp -- see cnn_softam.h.  Marshals std::vector containers into the C ABI; no geometry on the CPU.
+#include "cnn_softam.h"
+
+#include <cmath>
+#include <random>
+
+namespace dsac {
+
+static std::vector<double> flatten(const std::vector<cv_trans_t>& h) {
+    std::vector<double> v(h.size() * 6);
+    for (size_t i = 0; i < h.size(); i++) {
+        const Pose6 p = pack(h[i]);
+        for (int k = 0; k < 6; k++) v[i * 6 + k] = p[k];
+    }
+    return v;
+}
+
+void Frame::check(int rc, const char* what) {
+    if (rc != DSAC_OK) throw Error(rc, std::string(what) + ": " + dsac_last_error(ctx_));
+}
+
+Frame::Frame(const float* estObj, const float* sampling, int H, int W, const Camera& cam, int device, bool quantiseInt16) : H_(H), W_(W) {
+    int rc = dsac_create(&ctx_, device);
+    if (rc != DSAC_OK) throw Error(rc, std::string("dsac_create: ") + dsac_last_error(nullptr));
+    rc = dsac_set_frame(ctx_, estObj, sampling, H, W, cam.fx, cam.fy, cam.cx, cam.cy, quantiseInt16 ? DSAC_FRAME_QUANTISE_INT16 : 0u);
+    if (rc != DSAC_OK) {
+        const std::string msg = dsac_last_error(ctx_);
+        dsac_destroy(ctx_);
+        ctx_ = nullptr;
+        throw Error(rc, "dsac_set_frame: " + msg);
+    }
+}
+
+Frame::~Frame() { dsac_destroy(ctx_); }
+
+std::vector<uint8_t> Frame::sampleHypotheses(int objHyps, uint64_t seed, int inlierThreshold2D, std::vector<cv_trans_t>& hyps,
+                                             std::vector<std::array<int32_t, 4>>& imgIdx, int maxTries) {
+    std::vector<double> poses((size_t)objHyps * 6);
+    std::vector<uint8_t> ok(objHyps);
+    imgIdx.assign(objHyps, {0, 0, 0, 0});
+    check(dsac_sample(ctx_, objHyps, seed, nullptr, (float)inlierThreshold2D, maxTries, poses.data(), &imgIdx[0][0], ok.data()), "dsac_sample");
+    hyps.resize(objHyps);
+    for (int h = 0; h < objHyps; h++) hyps[h] = unpack({poses[h * 6], poses[h * 6 + 1], poses[h * 6 + 2], poses[h * 6 + 3], poses[h * 6 + 4], poses[h * 6 + 5]});
+    return ok;
+}
+
+std::vector<float> Frame::getDiffMaps(const std::vector<cv_trans_t>& hyps) {
+    std::vector<float> err(hyps.size() * (size_t)H_ * W_);
+    const std::vector<double> p = flatten(hyps);
+    check(dsac_reproject(ctx_, (int)hyps.size(), p.data(), (float)CNN_OBJ_MAXINPUT, err.data(), 0.f, 0.f, nullptr), "dsac_reproject");
+    return err;
+}
+
+std::vector<float> Frame::getDiffMap(const cv_trans_t& hyp) { return getDiffMaps({hyp}); }
+
+std::vector<double> Frame::softInlierScores(const std::vector<cv_trans_t>& hyps, float tau, float beta) {
+    std::vector<double> s(hyps.size());
+    const std::vector<double> p = flatten(hyps);
+    check(dsac_reproject(ctx_, (int)hyps.size(), p.data(), (float)CNN_OBJ_MAXINPUT, nullptr, tau, beta, s.data()), "dsac_reproject");
+    return s;
+}
+
+std::vector<double> Frame::softArgMax(const std::vector<double>& scores, double scale, const std::vector<cv_trans_t>& hyps, double& sfEntropy,
+                                      cv_trans_t& avgHyp) {
+    std::vector<double> w(scores.size());
+    const std::vector<double> p = flatten(hyps);
+    double avg[6];
+    check(dsac_softmax(ctx_, (int)scores.size(), scores.data(), scale, w.data(), &sfEntropy, p.data(), avg), "dsac_softmax");
+    avgHyp = unpack({avg[0], avg[1], avg[2], avg[3], avg[4], avg[5]});
+    return w;
+}
+
+std::vector<double> Frame::dPNP(const std::vector<std::array<int32_t, 4>>& imgIdx, float eps) {
+    std::vector<double> J(imgIdx.size() * 72);
+    check(dsac_dpnp(ctx_, (int)imgIdx.size(), &imgIdx[0][0], eps, J.data()), "dsac_dpnp");
+    return J;
+}
+
+void Frame::dScore(const std::vector<cv_trans_t>& hyps, const std::vector<std::array<int32_t, 4>>& imgIdx, const std::vector<float>& dDiffMaps,
+                   std::vector<double>& jacobean, bool referenceIndexQuirk) {
+    jacobean.resize((size_t)H_ * W_ * 3, 0.0);
+    const std::vector<double> p = flatten(hyps);
+    check(dsac_score_backward(ctx_, (int)hyps.size(), p.data(), &imgIdx[0][0], dDiffMaps.data(), nullptr,
+                              referenceIndexQuirk ? DSAC_BWD_QUIRK_TRANSPOSE : 0u, jacobean.data()),
+          "dsac_score_backward");
+}
+
+cv_trans_t Frame::refine(int inlierCount, int refSteps, float inlierThreshold2D, const std::vector<int32_t>& pixelIdxs, const cv_trans_t& initHyp,
+                         std::vector<int32_t>* inlierMap, int* stepsDone) {
+    const Pose6 in = pack(initHyp);
+    double out[6];
+    int32_t sd = 0;
+    if (inlierMap) inlierMap->assign((size_t)H_ * W_, 0);
+    check(dsac_refine(ctx_, 1, in.data(), pixelIdxs.data(), refSteps, inlierCount, 50, inlierThreshold2D, nullptr, nullptr, out,
+                      inlierMap ? inlierMap->data() : nullptr, &sd),
+          "dsac_refine");
+    if (stepsDone) *stepsDone = sd;
+    return unpack({out[0], out[1], out[2], out[3], out[4], out[5]});
+}
+
+void Frame::dRefine(int inlierCount, int refSteps, float inlierThreshold2D, float subSampleFactor, const std::vector<int32_t>& pixelIdxs,
+                    const cv_trans_t& initHyp, const std::vector<int32_t>& inlierMap, std::array<double, 36>& dRefineHyp,
+                    std::vector<int32_t>& objPixels, std::vector<double>& dRefineObj) {
+    const Pose6 in = pack(initHyp);
+    const int cap = 4096;
+    objPixels.assign(cap, 0);
+    dRefineObj.assign((size_t)cap * 18, 0.0);
+    int32_t n = 0;
+    check(dsac_refine_fd(ctx_, in.data(), pixelIdxs.data(), refSteps, inlierCount, 50, inlierThreshold2D, inlierMap.data(), subSampleFactor, 0.001f,
+                         2.f, dRefineHyp.data(), objPixels.data(), dRefineObj.data(), cap, &n),
+          "dsac_refine_fd");
+    objPixels.resize(n);
+    dRefineObj.resize((size_t)n * 18);
+}
+
+double Frame::maxLoss(const Hypothesis& gt, const cv_trans_t& est, double* rotErr, double* tErr, bool* correct) {
+    const Pose6 e = pack(est);
+    const std::vector<double> g = gt.getRodVecAndTrans();
+    double out4[4];
+    check(dsac_loss(ctx_, e.data(), g.data(), out4, nullptr), "dsac_loss");
+    if (rotErr) *rotErr = out4[1];
+    if (tErr) *tErr = out4[2];
+    if (correct) *correct = out4[3] > 0.5;
+    return out4[0];
+}
+
+std::array<double, 6> Frame::dLossMax(const cv_trans_t& est, const Hypothesis& gt) {
+    const Pose6 e = pack(est);
+    const std::vector<double> g = gt.getRodVecAndTrans();
+    std::array<double, 6> J{};
+    double out4[4];
+    check(dsac_loss(ctx_, e.data(), g.data(), out4, J.data()), "dsac_loss");
+    return J;
+}
+
+ProcessImageResult Frame::processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
+                                       const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha) {
+    ProcessImageResult r;
+    sampleHypotheses(objHyps, seed, inlierThreshold2D, r.hyps, r.imgIdx);
+    const std::vector<double> scores = softInlierScores(r.hyps, tau, beta);  // the score-CNN seam of cnn_softam.h:1072
+    r.sfScores = softArgMax(scores, alpha, r.hyps, r.sfEntropy, r.avgHyp);
+    r.refAvgHyp = refine(inlierCount, refSteps, (float)inlierThreshold2D, pixelIdxs, r.avgHyp, &r.inlierMap, &r.refStepsDone);
+    r.loss = maxLoss(poseGT, r.refAvgHyp, &r.rotErr, &r.tErr, &r.correct);
+    return r;
+}
+
+std::vector<double> softMax(const std::vector<double>& scores) {
+    double m = 0;
+    for (size_t i = 0; i < scores.size(); i++)
+        if (i == 0 || scores[i] > m) m = scores[i];
+    std::vector<double> sf(scores.size());
+    double sum = 0;
+    for (size_t i = 0; i < scores.size(); i++) { sf[i] = std::exp(scores[i] - m); sum += sf[i]; }
+    for (double& v : sf) v /= sum;
+    return sf;
+}
+
+double entropy(const std::vector<double>& dist) {
+    double e = 0;
+    for (double d : dist)
+        if (d > 0) e -= d * std::log2(d);
+    return e;
+}
+
+std::vector<int32_t> refinePermutations(int P, int refSteps) {
+    std::mt19937 randG;  // default seed 5489, carried across steps
+    std::vector<int32_t> out((size_t)refSteps * P);
+    for (int s = 0; s < refSteps; s++) {
+        int32_t* a = out.data() + (size_t)s * P;
+        for (int i = 0; i < P; i++) a[i] = i;
+        for (int i = 1; i < P; i++) {  // libstdc++ 4.8 std::shuffle: swap i with uniform[0, i], rejection down-scaling
+            const uint32_t uerange = (uint32_t)i + 1, scaling = 0xFFFFFFFFu / uerange, past = uerange * scaling;
+            uint32_t rnd;
+            do rnd = (uint32_t)randG(); while (rnd >= past);
+            std::swap(a[i], a[rnd / scaling]);
+        }
+    }
+    return out;
+}
+
+}  // namespace dsac

@@ -1,0 +1,71 @@
+"""End-to-end parity: processImage forward + the trainer's backward section, GPU engine vs the same chain
+assembled from oracle functions (train_ransac_softam.cpp:288-394).  Tolerance: the chain multiplies several
+finite-difference Jacobians; the final gradient must agree to 1 % of its largest entry and 1 % in l2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_backward(orc, fr, fwd, gt_jp6, tau=10.0, beta=0.5):
+    H, W = fr["H"], fr["W"]
+    xyz, uv, cam = fr["xyz"], fr["uv"], fr["cam"]
+    poses, sets, w = fwd["hyps"], fwd["sampledPoints"], fwd["sfScores"]
+    dL = orc.dLossMax(orc.cv_to_jp6(fwd["refAvgHyp"]), gt_jp6)
+    Jo = orc.dRefineObj(fwd["avgHyp"], fwd["pixelIdxs"], fwd["inlierMap"], xyz, uv, H, W, cam)
+    Jh = orc.dRefineHyp(fwd["avgHyp"], fwd["pixelIdxs"], xyz, uv, H, W, cam)
+    grad = (dL @ Jo).reshape(H * W, 3)
+    v6 = dL @ Jh
+    grad, g = orc.path1_pnp_and_softmax_bwd(v6, w, poses, sets, xyz, uv, H, W, cam, grad=grad)
+    err = orc.get_diff_maps(poses, xyz, uv, H, W, cam).astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-beta * (tau - err)))
+    dDiff = (g * fwd["score_scale"])[:, None] * (-beta) * s * (1 - s)
+    grad, _, _ = orc.dScore(sets, dDiff, xyz, uv, H, W, cam, grad=grad)
+    return grad, dL, v6, g
+
+
+def test_process_image_and_backward_reference_size(engine, orc, synth, frame40):
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    perm = synth.fast_permutations(1600, 8)
+    gt_jp6 = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    fwd = engine.processImage(N=256, seed=1305, perm=perm, gt_jp6=gt_jp6)
+    assert fwd["ok"].all() and fwd["refSteps"] == 8
+    assert abs(fwd["sfScores"].sum() - 1) < 1e-12 and 0 < fwd["sfEntropy"] < 8
+    Re, te = orc.cv2our(fwd["refAvgHyp"])
+    Rg, tg = orc.cv2our(fr["gt_pose"])
+    rot, tr = orc.pose_errors(Re, te, Rg, tg)
+    assert rot < 1.0 and tr < 20.0  # the synthetic frame is solvable: refined pose within 1 deg / 2 cm of the truth
+    bwd = engine.backward(fwd, gt_jp6)
+    ref_grad, dL, v6, g = oracle_backward(orc, fr, fwd, gt_jp6)
+    assert np.abs(bwd["dLoss_dRef"] - dL).max() <= 1e-8 * max(1.0, np.abs(dL).max())
+    assert np.abs(bwd["v6"] - v6).max() <= 1e-3 * np.abs(v6).max()
+    assert np.abs(bwd["scoreOutputGradients"] - g).max() <= 1e-3 * np.abs(g).max()
+    emax = np.abs(bwd["grad"] - ref_grad).max() / np.abs(ref_grad).max()
+    el2 = np.linalg.norm(bwd["grad"] - ref_grad) / np.linalg.norm(ref_grad)
+    print("end-to-end gradient: max-rel %.3e l2-rel %.3e, nonzero rows %d" % (emax, el2, (np.abs(ref_grad).sum(1) > 0).sum()))
+    assert emax <= 1e-2 and el2 <= 1e-2
+
+
+def test_process_image_full_resolution_with_score_fn(engine, orc, synth, frame_full):
+    """640x480, the score taken from the error images through the score-CNN seam (here: a fixed linear 'CNN')."""
+    fr = frame_full
+    engine.set_frame(fr["xyz"], None, fr["H"], fr["W"], fr["cam"])
+    perm = synth.fast_permutations(fr["H"] * fr["W"], 8)
+    gt_jp6 = orc.cv_to_jp6(fr["gt_pose"])
+
+    def score_fn(err):  # higher score for smaller mean error
+        return -0.5 * err.reshape(err.shape[0], -1).mean(axis=1).astype(np.float64)
+
+    fwd = engine.processImage(N=64, seed=7, perm=perm, gt_jp6=gt_jp6, score_fn=score_fn)
+    ref_err = orc.get_diff_maps(fwd["hyps"], fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
+    wr = orc.softMax(score_fn(ref_err))
+    assert np.abs(fwd["sfScores"] - wr).max() <= 1e-4
+    assert fwd["rotErr"] < 1.0 and fwd["tErr"] < 20.0 and fwd["correct"]
+
+    def d_scores_fn(g):  # backward of the linear 'CNN': d score / d err = -0.5 / P
+        P = fr["H"] * fr["W"]
+        return np.broadcast_to((g * (-0.5 / P))[:, None], (len(g), P)).astype(np.float32)
+
+    bwd = engine.backward(fwd, gt_jp6, d_scores_fn=d_scores_fn)
+    assert np.isfinite(bwd["grad"]).all() and np.abs(bwd["grad"]).max() > 0
