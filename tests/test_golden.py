@@ -1,0 +1,66 @@
+"""Oracle (and, with -m gpu, the HIP engine) against the committed golden vectors of tests/golden/golden_v1.npz,
+which were produced by independent implementations (SciPy, torch autograd, numpy) -- see make_golden.py."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz"))
+CAM = (525.0, 525.0, 320.0, 240.0)
+
+
+def test_oracle_rodrigues(orc):
+    for r, R in zip(G["rodrigues_rvec"], G["rodrigues_R"]):
+        assert np.abs(orc.rodrigues_vec2mat(r) - R).max() < 1e-12
+
+
+def test_oracle_residuals(orc):
+    e = orc.get_diff_maps(G["res_pose"], G["res_X"], G["res_uv"], 1, 64, CAM)[0]
+    assert np.abs(e - G["res_err"]).max() < 2e-4  # projectPoints rounds the projection to float
+
+
+def test_oracle_projection_jacobians(orc):
+    for i in range(16):
+        JO = orc.dProjectdObj(G["jac_pt"][i], G["res_X"][i], G["jac_R"], G["jac_t"], CAM)
+        JH = orc.dProjectdHyp(G["jac_pt"][i], G["res_X"][i], G["jac_R"], G["jac_t"], CAM)
+        assert np.abs(JO - G["jac_dObj"][i]).max() < 1e-6 * max(1.0, np.abs(JO).max())
+        assert np.abs(JH - G["jac_dHyp"][i]).max() < 1e-6 * max(1.0, np.abs(JH).max())
+
+
+def test_oracle_lm_pnp(orc):
+    got, iters, err = orc.solve_pnp_iterative(G["pnp_X"], G["pnp_uv"], CAM, G["pnp_start"])
+    assert np.abs(got - G["pnp_opt"]).max() < 1e-3 * np.abs(G["pnp_opt"]).max()
+
+
+def test_oracle_softmax(orc):
+    assert np.abs(orc.softMax(G["sm_scores"]) - G["sm_w"]).max() < 1e-15
+    assert abs(orc.entropy(G["sm_w"]) - float(G["sm_entropy"])) < 1e-13
+
+
+def test_rng_stream_matches_the_spec(orc, synth):
+    """The first accepted minimal sets must be consistent with the golden integer draws: attempt a of hypothesis h
+    takes cells (x = draw 0, y = draw 1), (draw 2, draw 3), ... skipping duplicates."""
+    fr = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
+    poses, sets, ok, tries = orc.sample(4, 1305, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    for h in range(4):
+        a = tries[h] - 1
+        if a >= 3:
+            continue
+        d = G["rng_draws"][h, a]
+        cells = []
+        for k in range(0, 8, 2):
+            c = int(d[k + 1]) * 40 + int(d[k])
+            if c not in cells:
+                cells.append(c)
+        if len(cells) == 4:
+            assert list(sets[h]) == cells
+
+
+@pytest.mark.gpu
+def test_engine_against_golden(engine, synth):
+    engine.set_frame(G["res_X"], G["res_uv"], 1, 64, CAM)
+    e = engine.getDiffMap(G["res_pose"]).reshape(-1)
+    m = np.abs(G["res_err"] - 100.0) > 1e-3
+    assert np.abs(e - G["res_err"])[m].max() <= 1e-3
+    w, ent, _ = engine.softMax(G["sm_scores"])
+    assert np.abs(w - G["sm_w"]).max() < 1e-12 and abs(ent[0] - float(G["sm_entropy"])) < 1e-10
