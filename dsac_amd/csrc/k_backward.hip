@@ -25,11 +25,9 @@ namespace dk {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int K4_THREADS = 256;
-constexpr int K4_PX = 4;
 constexpr int K4_HT = 32;
 constexpr int BWD_REC = 12;  // floats per hypothesis: R'0|t'0, R'1|t'1, R'2|t'2
 
-int backward_num_pixel_tiles(int P) { return (P + K4_THREADS - 1) / K4_THREADS; }  // upper bound (scalar path)
 int backward_hyp_tile() { return K4_HT; }
 
 // --------------------------------------------------------------------------------------------------
@@ -65,19 +63,35 @@ hipError_t backward_prep(hipStream_t st, int N, const double* poses, const Frame
 }
 
 // --------------------------------------------------------------------------------------------------
-DM_INLINE float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Sum over the 64 lanes with DPP only (no LDS crossbar): 4 intra-row steps + row_bcast:15 / row_bcast:31.
+// The total is valid in lane 63.
+DM_INLINE float wave_sum_to_lane63(float v) {
+#define DSAC_DPP_ADD(ctrl, rmask)                                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    DSAC_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+    DSAC_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+    DSAC_DPP_ADD(0x141, 0xf);  // row_half_mirror
+    DSAC_DPP_ADD(0x140, 0xf);  // row_mirror        -> every lane of a row holds the row sum
+    DSAC_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    DSAC_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave sum
+#undef DSAC_DPP_ADD
     return v;
 }
 
+// K4 main pass.  A lane owns PXG groups of 4 consecutive pixels (group j at tile0 + j*1024 + 4*tid), so every
+// d_err / xyz / grad access is a coalesced dwordx4 and the per-hypothesis 12-value wave reduction is amortised
+// over 4*PXG pixels.  No barrier inside the hypothesis loop: every wave writes its own partial row.
+//   grad_part : [hyp tile][P*3]                 (register accumulation over the 32 hypotheses of the tile)
+//   G12_part  : [pixel tile * 4 + wave][N][12]  (sum over the wave's pixels)
 // SOFTMODE: w = g[h] * d soft / d err, soft = sigmoid(beta (tau - min(err, clamp)))
-template <int PX, bool SOFTMODE, bool UV>
+template <int PXG, bool VEC, bool SOFTMODE, bool UV>
 __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __restrict__ rec, const float* __restrict__ xyz,
                                                                const float* __restrict__ uv, const float* __restrict__ d_err,
                                                                const double* __restrict__ g, float* __restrict__ grad_part,
                                                                float* __restrict__ G12_part, int N, int P, int W, int PT, int NT,
                                                                float f, float cx, float cy, float clampv, float kA, float kB, float beta) {
+    constexpr int PXL = VEC ? 4 : 1;          // pixels per group
+    constexpr int NP = PXG * PXL;             // pixels per lane
     const int b = blockIdx.x;
     const int q = b >> 3;
     const int ht = q % NT;
@@ -89,158 +103,162 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
 
     __shared__ __attribute__((aligned(16))) float s_rec[K4_HT * BWD_REC];
     __shared__ float s_g[K4_HT];
-    __shared__ float s_red[(K4_THREADS / 64) * 12];
     for (int i = tid; i < nh * BWD_REC; i += K4_THREADS) s_rec[i] = rec[(size_t)h0 * BWD_REC + i];
     if (SOFTMODE && tid < nh) s_g[tid] = (float)g[h0 + tid];
 
-    const int p0 = (pt * K4_THREADS + tid) * PX;
-    const bool valid = p0 < P;
-    float X[PX], Y[PX], Z[PX], pu[PX], pv[PX];
-    if (PX == 4) {
-        if (valid) {
-            const f4* src = reinterpret_cast<const f4*>(xyz + (size_t)p0 * 3);
-            const f4 a = src[0], bb = src[1], c = src[2];
-            X[0] = a.x; Y[0] = a.y; Z[0] = a.z; X[1] = a.w; Y[1] = bb.x; Z[1] = bb.y;
-            X[2] = bb.z; Y[2] = bb.w; Z[2] = c.x; X[3] = c.y; Y[3] = c.z; Z[3] = c.w;
-            if (UV) {
-                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0 * 2);
-                const f4 u0 = su[0], u1 = su[1];
-                pu[0] = u0.x - cx; pv[0] = u0.y - cy; pu[1] = u0.z - cx; pv[1] = u0.w - cy;
-                pu[2] = u1.x - cx; pv[2] = u1.y - cy; pu[3] = u1.z - cx; pv[3] = u1.w - cy;
+    const int tile0 = pt * K4_THREADS * NP;
+    int pbase[PXG];
+    bool valid[PXG];
+    float X[NP], Y[NP], Z[NP], pu[NP], pv[NP];
+#pragma unroll
+    for (int j = 0; j < PXG; j++) {
+        pbase[j] = tile0 + j * K4_THREADS * PXL + tid * PXL;
+        valid[j] = pbase[j] < P;  // VEC is only used with P % 4 == 0
+        if (VEC) {
+            if (valid[j]) {
+                const f4* src = reinterpret_cast<const f4*>(xyz + (size_t)pbase[j] * 3);
+                const f4 a = src[0], bb = src[1], c = src[2];
+                X[j * 4 + 0] = a.x; Y[j * 4 + 0] = a.y; Z[j * 4 + 0] = a.z; X[j * 4 + 1] = a.w; Y[j * 4 + 1] = bb.x; Z[j * 4 + 1] = bb.y;
+                X[j * 4 + 2] = bb.z; Y[j * 4 + 2] = bb.w; Z[j * 4 + 2] = c.x; X[j * 4 + 3] = c.y; Y[j * 4 + 3] = c.z; Z[j * 4 + 3] = c.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) X[j * 4 + k] = Y[j * 4 + k] = Z[j * 4 + k] = 0.f;
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < PX; k++) { X[k] = Y[k] = Z[k] = 0.f; pu[k] = pv[k] = 0.f; }
+            if (valid[j]) { X[j] = xyz[(size_t)pbase[j] * 3]; Y[j] = xyz[(size_t)pbase[j] * 3 + 1]; Z[j] = xyz[(size_t)pbase[j] * 3 + 2]; }
+            else { X[j] = Y[j] = Z[j] = 0.f; }
         }
-    } else {
-        if (valid) {
-            X[0] = xyz[(size_t)p0 * 3]; Y[0] = xyz[(size_t)p0 * 3 + 1]; Z[0] = xyz[(size_t)p0 * 3 + 2];
-            if (UV) { pu[0] = uv[(size_t)p0 * 2] - cx; pv[0] = uv[(size_t)p0 * 2 + 1] - cy; }
-        } else { X[0] = Y[0] = Z[0] = 0.f; pu[0] = pv[0] = 0.f; }
-    }
-    if (!UV) {
 #pragma unroll
-        for (int k = 0; k < PX; k++) {
-            const int p = p0 + k;
-            const int y = p / W, x = p - y * W;
-            pu[k] = (float)x - cx;
-            pv[k] = (float)y - cy;
+        for (int k = 0; k < PXL; k++) {
+            const int p = pbase[j] + k;
+            if (UV) {
+                pu[j * PXL + k] = valid[j] ? uv[(size_t)p * 2] - cx : 0.f;
+                pv[j * PXL + k] = valid[j] ? uv[(size_t)p * 2 + 1] - cy : 0.f;
+            } else {
+                const int y = p / W, x = p - y * W;
+                pu[j * PXL + k] = (float)x - cx;
+                pv[j * PXL + k] = (float)y - cy;
+            }
         }
     }
     __syncthreads();
 
-    float gx[PX][3];
+    float gx[NP][3];
 #pragma unroll
-    for (int k = 0; k < PX; k++) gx[k][0] = gx[k][1] = gx[k][2] = 0.f;
+    for (int k = 0; k < NP; k++) gx[k][0] = gx[k][1] = gx[k][2] = 0.f;
 
+    float* gout = G12_part + ((size_t)(pt * (K4_THREADS / 64) + wave) * N + h0) * 12;
     for (int h = 0; h < nh; h++) {
         const f4* sp = reinterpret_cast<const f4*>(s_rec + h * BWD_REC);
         const f4 r0 = sp[0], r1 = sp[1], r2 = sp[2];
-        float wv[PX];
-        if (!SOFTMODE) {
-            if (valid) {
-                if (PX == 4) {
-                    const f4 d = __builtin_nontemporal_load(reinterpret_cast<const f4*>(d_err + (size_t)(h0 + h) * P + p0));
-                    wv[0] = d.x; wv[1] = d.y; wv[2] = d.z; wv[3] = d.w;
-                } else {
-                    wv[0] = __builtin_nontemporal_load(d_err + (size_t)(h0 + h) * P + p0);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PX; k++) wv[k] = 0.f;
-            }
-        }
         float G[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) G[i] = 0.f;
 #pragma unroll
-        for (int k = 0; k < PX; k++) {
-            const float ex = fmaf(r0.x, X[k], fmaf(r0.y, Y[k], fmaf(r0.z, Z[k], r0.w)));
-            const float ey = fmaf(r1.x, X[k], fmaf(r1.y, Y[k], fmaf(r1.z, Z[k], r1.w)));
-            const float ez = fmaf(r2.x, X[k], fmaf(r2.y, Y[k], fmaf(r2.z, Z[k], r2.w)));
-            const float iz = __builtin_amdgcn_rcpf(ez);
-            const float fz = f * iz;
-            const float du = fmaf(ex, fz, pu[k]);    // u - px,  px = -f ex/ez + cx
-            const float dv = fmaf(-ey, fz, pv[k]);   // v - py,  py =  f ey/ez + cy
-            const float err = __builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du));
-            // guards of the reference: |E.z| < 1e-8 -> 0 ; err > CNN_OBJ_MAXINPUT -> 0
-            const bool keep = valid && (fabsf(ez) >= 1e-8f) && !(err > clampv);
-            float w;
-            if (SOFTMODE) {
-                const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kA, fminf(err, clampv), kB)));
-                w = s_g[h] * (-beta) * s * (1.0f - s);
-            } else {
-                w = wv[k];
+        for (int j = 0; j < PXG; j++) {
+            float wv[PXL];
+            if (!SOFTMODE) {
+                if (valid[j]) {
+                    if (VEC) {
+                        const f4 d = __builtin_nontemporal_load(reinterpret_cast<const f4*>(d_err + (size_t)(h0 + h) * P + pbase[j]));
+                        wv[0] = d.x; wv[1 % PXL] = d.y; wv[2 % PXL] = d.z; wv[3 % PXL] = d.w;
+                    } else {
+                        wv[0] = __builtin_nontemporal_load(d_err + (size_t)(h0 + h) * P + pbase[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) wv[k] = 0.f;
+                }
             }
-            w = keep ? w : 0.f;
-            const float ie = __builtin_amdgcn_rcpf(err + 1e-8f);
-            const float a0 = -du * ie, a1 = -dv * ie;
-            const float c0 = -a0 * fz * w;
-            const float c1 = a1 * fz * w;
-            const float c2 = (a0 * ex - a1 * ey) * fz * iz * w;
-            // guard against inf * 0 when ez == 0 (w is already 0 there)
-            const float C0 = keep ? c0 : 0.f, C1 = keep ? c1 : 0.f, C2 = keep ? c2 : 0.f;
-            gx[k][0] = fmaf(r0.x, C0, fmaf(r1.x, C1, fmaf(r2.x, C2, gx[k][0])));
-            gx[k][1] = fmaf(r0.y, C0, fmaf(r1.y, C1, fmaf(r2.y, C2, gx[k][1])));
-            gx[k][2] = fmaf(r0.z, C0, fmaf(r1.z, C1, fmaf(r2.z, C2, gx[k][2])));
-            G[0] = fmaf(C0, X[k], G[0]); G[1] = fmaf(C0, Y[k], G[1]); G[2] = fmaf(C0, Z[k], G[2]);
-            G[3] = fmaf(C1, X[k], G[3]); G[4] = fmaf(C1, Y[k], G[4]); G[5] = fmaf(C1, Z[k], G[5]);
-            G[6] = fmaf(C2, X[k], G[6]); G[7] = fmaf(C2, Y[k], G[7]); G[8] = fmaf(C2, Z[k], G[8]);
-            G[9] += C0; G[10] += C1; G[11] += C2;
+#pragma unroll
+            for (int k = 0; k < PXL; k++) {
+                const int i = j * PXL + k;
+                const float ex = fmaf(r0.x, X[i], fmaf(r0.y, Y[i], fmaf(r0.z, Z[i], r0.w)));
+                const float ey = fmaf(r1.x, X[i], fmaf(r1.y, Y[i], fmaf(r1.z, Z[i], r1.w)));
+                const float ez = fmaf(r2.x, X[i], fmaf(r2.y, Y[i], fmaf(r2.z, Z[i], r2.w)));
+                const float iz = __builtin_amdgcn_rcpf(ez);
+                const float fz = f * iz;
+                const float du = fmaf(ex, fz, pu[i]);    // u - px,  px = -f ex/ez + cx
+                const float dv = fmaf(-ey, fz, pv[i]);   // v - py,  py =  f ey/ez + cy
+                const float err = __builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du));
+                // guards of the reference: |E.z| < 1e-8 -> 0 ; err > CNN_OBJ_MAXINPUT -> 0
+                const bool keep = valid[j] && (fabsf(ez) >= 1e-8f) && !(err > clampv);
+                float w;
+                if (SOFTMODE) {
+                    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kA, fminf(err, clampv), kB)));
+                    w = s_g[h] * (-beta) * s * (1.0f - s);
+                } else {
+                    w = wv[k];
+                }
+                const float ie = __builtin_amdgcn_rcpf(err + 1e-8f);
+                const float wfz = w * fz * ie;                    // w f / (E.z (err + eps))
+                // a = -(du, dv)/(err+eps);  c0 = -a0 f/E.z ; c1 = a1 f/E.z ; c2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w);
+                // the selects also kill the inf/NaN of E.z == 0
+                const float C0 = keep ? du * wfz : 0.f;
+                const float C1 = keep ? -dv * wfz : 0.f;
+                const float C2 = keep ? (dv * ey - du * ex) * wfz * iz : 0.f;
+                gx[i][0] = fmaf(r0.x, C0, fmaf(r1.x, C1, fmaf(r2.x, C2, gx[i][0])));
+                gx[i][1] = fmaf(r0.y, C0, fmaf(r1.y, C1, fmaf(r2.y, C2, gx[i][1])));
+                gx[i][2] = fmaf(r0.z, C0, fmaf(r1.z, C1, fmaf(r2.z, C2, gx[i][2])));
+                G[0] = fmaf(C0, X[i], G[0]); G[1] = fmaf(C0, Y[i], G[1]); G[2] = fmaf(C0, Z[i], G[2]);
+                G[3] = fmaf(C1, X[i], G[3]); G[4] = fmaf(C1, Y[i], G[4]); G[5] = fmaf(C1, Z[i], G[5]);
+                G[6] = fmaf(C2, X[i], G[6]); G[7] = fmaf(C2, Y[i], G[7]); G[8] = fmaf(C2, Z[i], G[8]);
+                G[9] += C0; G[10] += C1; G[11] += C2;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const float s = wave_sum_f(G[i]);
-            if (lane == 0) s_red[wave * 12 + i] = s;
+        for (int i = 0; i < 12; i++) G[i] = wave_sum_to_lane63(G[i]);
+        if (lane == 63) {
+            f4* o = reinterpret_cast<f4*>(gout + (size_t)h * 12);
+            o[0] = f4{G[0], G[1], G[2], G[3]};
+            o[1] = f4{G[4], G[5], G[6], G[7]};
+            o[2] = f4{G[8], G[9], G[10], G[11]};
         }
-        __syncthreads();
-        if (tid < 12) {
-            float s = 0.f;
-#pragma unroll
-            for (int wq = 0; wq < K4_THREADS / 64; wq++) s += s_red[wq * 12 + tid];
-            G12_part[((size_t)pt * N + h0 + h) * 12 + tid] = s;
-        }
-        __syncthreads();
     }
 
-    if (valid) {
-        float* dst = grad_part + (size_t)ht * P * 3 + (size_t)p0 * 3;
-        if (PX == 4) {
+#pragma unroll
+    for (int j = 0; j < PXG; j++) {
+        if (!valid[j]) continue;
+        float* dst = grad_part + (size_t)ht * P * 3 + (size_t)pbase[j] * 3;
+        if (VEC) {
             f4* d4 = reinterpret_cast<f4*>(dst);
-            d4[0] = f4{gx[0][0], gx[0][1], gx[0][2], gx[1][0]};
-            d4[1] = f4{gx[1][1], gx[1][2], gx[2][0], gx[2][1]};
-            d4[2] = f4{gx[2][2], gx[3][0], gx[3][1], gx[3][2]};
+            d4[0] = f4{gx[j * 4][0], gx[j * 4][1], gx[j * 4][2], gx[j * 4 + 1][0]};
+            d4[1] = f4{gx[j * 4 + 1][1], gx[j * 4 + 1][2], gx[j * 4 + 2][0], gx[j * 4 + 2][1]};
+            d4[2] = f4{gx[j * 4 + 2][2], gx[j * 4 + 3][0], gx[j * 4 + 3][1], gx[j * 4 + 3][2]};
         } else {
-            dst[0] = gx[0][0]; dst[1] = gx[0][1]; dst[2] = gx[0][2];
+            dst[0] = gx[j][0]; dst[1] = gx[j][1]; dst[2] = gx[j][2];
         }
     }
 }
 
+constexpr int K4_PXG = 2;  // 8 pixels per lane on the vector path
+
+int backward_num_partial_rows(int P) { return ((P + K4_THREADS - 1) / K4_THREADS) * (K4_THREADS / 64); }  // upper bound (scalar path)
+
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g, float clampv,
-                          float tau, float beta, float* grad_part, float* G12_part, int* pixel_tiles_used) {
-    if (pixel_tiles_used) *pixel_tiles_used = 0;
+                          float tau, float beta, float* grad_part, float* G12_part, int* partial_rows_used) {
+    if (partial_rows_used) *partial_rows_used = 0;
     if (N <= 0) return hipSuccess;
     const bool soft = d_err == nullptr;
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && ((reinterpret_cast<uintptr_t>(grad_part) & 15) == 0);
-    const int PX = vec ? 4 : 1;
-    const int tile = K4_THREADS * PX;
+                     ((reinterpret_cast<uintptr_t>(grad_part) & 15) == 0);
+    const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
     const int PT = (F.P + tile - 1) / tile;
     const int NT = (N + K4_HT - 1) / K4_HT;
     const int grid = ((PT + 7) / 8) * 8 * NT;
-    if (pixel_tiles_used) *pixel_tiles_used = PT;
+    if (partial_rows_used) *partial_rows_used = PT * (K4_THREADS / 64);
     const float LOG2E = 1.4426950408889634f;
     const float kA = beta * LOG2E, kB = -beta * tau * LOG2E;
     const bool UV = F.uv != nullptr;
-#define DSAC_K4(PXV, S, U)                                                                                                               \
-    hipLaunchKernelGGL((k_score_backward<PXV, S, U>), dim3(grid), dim3(K4_THREADS), 0, st, staged_bwd, F.xyz, F.uv, d_err, g, grad_part, \
+#define DSAC_K4(G_, V_, S_, U_)                                                                                                              \
+    hipLaunchKernelGGL((k_score_backward<G_, V_, S_, U_>), dim3(grid), dim3(K4_THREADS), 0, st, staged_bwd, F.xyz, F.uv, d_err, g, grad_part, \
                        G12_part, N, F.P, F.W, PT, NT, F.fx, F.cx, F.cy, clampv, kA, kB, beta)
     if (vec) {
-        if (soft) { if (UV) DSAC_K4(4, true, true); else DSAC_K4(4, true, false); }
-        else { if (UV) DSAC_K4(4, false, true); else DSAC_K4(4, false, false); }
+        if (soft) { if (UV) DSAC_K4(K4_PXG, true, true, true); else DSAC_K4(K4_PXG, true, true, false); }
+        else { if (UV) DSAC_K4(K4_PXG, true, false, true); else DSAC_K4(K4_PXG, true, false, false); }
     } else {
-        if (soft) { if (UV) DSAC_K4(1, true, true); else DSAC_K4(1, true, false); }
-        else { if (UV) DSAC_K4(1, false, true); else DSAC_K4(1, false, false); }
+        if (soft) { if (UV) DSAC_K4(1, false, true, true); else DSAC_K4(1, false, true, false); }
+        else { if (UV) DSAC_K4(1, false, false, true); else DSAC_K4(1, false, false, false); }
     }
 #undef DSAC_K4
     return hipGetLastError();

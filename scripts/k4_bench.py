@@ -1,0 +1,43 @@
+"""K4 (score backward) timing on the GPU with the engine's HIP-event hooks; algorithmic bytes per SURVEY 8(d)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import dsac_amd
+from dsac_amd import synth
+
+dev = torch.device("cuda:0")
+H, W = 480, 640
+P = H * W
+fr = synth.chess_like_frame(H, W, seed=1305)
+xyz = torch.from_numpy(fr["xyz"]).to(dev)
+eng = dsac_amd.Engine(0)
+eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)
+eng.profile_enable(True)
+res = []
+for N in (256, 1024):
+    poses = torch.zeros(N, 6, dtype=torch.float64, device=dev)
+    sets = torch.zeros(N, 4, dtype=torch.int32, device=dev)
+    ok = torch.zeros(N, dtype=torch.uint8, device=dev)
+    eng.sample(N, seed=7, out=(poses, sets, ok))
+    d_err = torch.randn(N, P, dtype=torch.float32, device=dev) * 1e-3
+    g = torch.randn(N, dtype=torch.float64, device=dev)
+    grad = torch.zeros(P, 3, dtype=torch.float64, device=dev)
+    dpnp = torch.zeros(N, 72, dtype=torch.float64, device=dev)
+    eng.dPNP(sets, out=dpnp)
+    for mode in ("d_err", "soft"):
+        def run():
+            if mode == "d_err":
+                eng.dScore(poses, sets, d_err, dpnp=dpnp, grad=grad)
+            else:
+                eng.dSoftScore(poses, sets, g, dpnp=dpnp, grad=grad)
+        for _ in range(3): run()
+        eng.synchronize(); eng.profile_read(1)
+        for _ in range(10): run()
+        eng.synchronize()
+        ms, n = eng.profile_read(1)
+        us = ms / n * 1e3
+        ab = (4 * N * P if mode == "d_err" else 0) + 12 * P + 48 * N + 48 * N + 12 * P
+        print("K4 N=%4d %-5s: %8.1f us  %7.0f GB/s (alg)  %.2f Gpair/s" % (N, mode, us, ab / us / 1e3, N * P / us / 1e3))
+        res.append(dict(N=N, mode=mode, us=us, gbs=ab / us / 1e3))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/k4_bench.json", "w"))
