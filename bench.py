@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "2")),
                     help="engine contexts (HIP streams) per GPU; frames are dealt round-robin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
