@@ -41,9 +41,16 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "2")),
-                    help="engine contexts (HIP streams) per GPU; frames are dealt round-robin")
+                    help="engine contexts (HIP streams) per GPU")
+    ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="pipeline",
+                    help="'pipeline' (default) = one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary "
+                         "stream under K2/K3 of frame i.  With 2 contexts: 'gated' = frames alternate between two contexts whose K2 launches are serialised by events "
+                         "(dsac_set_k2_events) so that K1/K3 of one frame overlap K2 of the other; 'stages' = stream A samples frame i+1 while stream B scores frame i (K2 launches never "
+                         "overlap each other); 'frames' = whole frames dealt round-robin to the streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--separate-calls", action="store_true", help="use dsac_sample / dsac_reproject / dsac_softmax instead of the fused call")
+    ap.add_argument("--event-stride", type=int, default=8, help="time every n-th K2 launch with HIP events (0 = none)")
     ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] style)")
     ap.add_argument("--k2-mode", choices=("both", "err", "soft"), default="both", help="K2 outputs: error images and/or soft-inlier sums")
     args = ap.parse_args()
@@ -58,14 +65,24 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     distributed = world > 1
+    backend = os.environ.get("DSAC_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only to exercise the N>1 path on one GPU
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if distributed and backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+    local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the tiny timing tensors are reduced
 
     N, H, W = args.hyps, args.height, args.width
     P = H * W
@@ -74,28 +91,80 @@ def main():
     # one frame per rank (seed 1305 + rank: the reference's ThreadRand seed), uploaded before timing
     fr = synth.chess_like_frame(H, W, seed=1305 + rank)
     xyz = torch.from_numpy(fr["xyz"]).to(dev)
-    n_ctx = max(1, args.streams)
+    pipelined = (args.overlap == "pipeline" and not args.kernel_only and args.k2_mode == "both" and not args.separate_calls)
+    n_ctx = 1 if pipelined else max(1, args.streams)
+    n_buf = 2 if pipelined else n_ctx
     engines, bufs = [], []
     for i in range(n_ctx):
         st = torch.cuda.Stream(device=dev)
         eng = dsac_amd.Engine(local_rank, stream=st)
         eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
-        eng.profile_enable(True)
+        eng.profile_enable(args.event_stride > 0, stride=max(1, args.event_stride))
         engines.append((eng, st))
+    for i in range(n_buf):
         bufs.append(dict(
             poses=torch.zeros(N, 6, dtype=torch.float64, device=dev), sets=torch.zeros(N, 4, dtype=torch.int32, device=dev),
             ok=torch.zeros(N, dtype=torch.uint8, device=dev), err=torch.empty(N, P, dtype=torch.float32, device=dev),
             soft=torch.zeros(N, dtype=torch.float64, device=dev), w=torch.zeros(N, dtype=torch.float64, device=dev),
             ent=torch.zeros(1, dtype=torch.float64, device=dev), avg=torch.zeros(6, dtype=torch.float64, device=dev)))
+    gated = (n_ctx == 2 and args.overlap == "gated")
+    if gated:
+        # K2 launches of the two contexts run back to back (never overlapping each other); K1 / K3 of one frame overlap K2 of the other
+        evs = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in evs:
+            e.record(torch.cuda.current_stream(dev))  # materialise the underlying hipEvent_t
+        torch.cuda.synchronize(dev)
+        engines[0][0].set_k2_events(wait_before=evs[1], record_after=evs[0])
+        engines[1][0].set_k2_events(wait_before=evs[0], record_after=evs[1])
     if args.kernel_only:
         rp = synth.random_poses(N, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])
         for b in bufs:
             b["poses"].copy_(torch.from_numpy(rp))
     torch.cuda.synchronize(dev)
 
+    staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
+    ev_sampled = [torch.cuda.Event() for _ in range(2)]
+    ev_scored = [None, None]
+
+    def step_staged(i):
+        # two-stage software pipeline over double-buffered pose sets: K1 of frame i+1 runs under K2/K3 of frame i
+        (engA, stA), (engB, stB) = engines
+        k = i & 1
+        b = bufs[k]
+        if ev_scored[k] is not None:
+            stA.wait_event(ev_scored[k])       # the scoring stage has finished reading this buffer
+        engA.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
+        ev_sampled[k].record(stA)
+        stB.wait_event(ev_sampled[k])
+        engB.reproject(b["poses"], N=N, clamp=100.0, err=b["err"], soft=b["soft"], tau=10.0, beta=0.5)
+        engB.softMax(b["soft"], 0.1, b["poses"], N=N, out=(b["w"], b["ent"], b["avg"]))
+        ev_scored[k] = torch.cuda.Event()
+        ev_scored[k].record(stB)
+
+    def seed_of(i):
+        return 1305 + 7919 * i + rank
+
+    def step_pipelined(i):
+        # software pipeline inside ONE context: K1 of frame i+1 (aux stream) under K2/K3 of frame i (main stream)
+        eng, _ = engines[0]
+        k = i & 1
+        nb = bufs[1 - k]
+        eng.sampleAhead(1 - k, N, seed_of(i + 1), nb["poses"], nb["sets"], nb["ok"], thr=10.0, max_tries=1 << 16)
+        b = bufs[k]
+        eng.scoreSampled(k, b["poses"], b["soft"], b["w"], ent=b["ent"], avg=b["avg"], err=err_shared, clamp=100.0, tau=10.0, beta=0.5, scale=0.1)
+
     def step(i):
+        if pipelined:
+            return step_pipelined(i)
+        if staged:
+            return step_staged(i)
         eng, _ = engines[i % n_ctx]
         b = bufs[i % n_ctx]
+        if not args.kernel_only and args.k2_mode == "both" and not args.separate_calls:
+            # one C-ABI call: K1 (+ staged pose records) -> K2 -> soft reduce -> K3
+            eng.scoreHypotheses(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
+                                err=b["err"], out=(b["poses"], b["sets"], b["ok"], b["soft"], b["w"], b["ent"], b["avg"]))
+            return
         if not args.kernel_only:
             eng.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
         eng.reproject(b["poses"], N=N, clamp=100.0, err=b["err"] if args.k2_mode != "soft" else None,
@@ -108,6 +177,9 @@ def main():
             eng.synchronize()
         torch.cuda.synchronize(dev)
 
+    if pipelined:
+        err_shared = bufs[0]["err"]  # the scoring stage is serial: one error-image buffer
+        engines[0][0].sampleAhead(0, N, seed_of(0), bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"], thr=10.0, max_tries=1 << 16)
     for i in range(Wm):
         step(i)
     sync_all()
@@ -134,10 +206,10 @@ def main():
     wsum = float(bufs[0]["w"].sum().item()) if not args.kernel_only else 1.0
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        kk = torch.tensor([k2_ms, float(k2_n)], dtype=torch.float64, device=dev)
+        kk = torch.tensor([k2_ms, float(k2_n)], dtype=torch.float64, device=cdev)
         dist.all_reduce(kk, op=dist.ReduceOp.SUM)
         k2_ms, k2_n = float(kk[0].item()), int(kk[1].item())
 
@@ -165,6 +237,8 @@ def main():
                                     % (N, W, H, "K2 only on random poses" if args.kernel_only else
                                        "K1 sample+P3P -> K2 reproject (error images + soft-inlier) -> K3 softmax")),
                        "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": 1, "streams_per_gpu": n_ctx,
+                       "overlap": ("in-context software pipeline: K1(i+1) || K2,K3(i)" if pipelined else "K2 launches serialised across 2 contexts, K1/K3 overlap them" if gated else "sampling stage || scoring stage" if staged
+                                   else ("frames round-robin" if n_ctx > 1 else "none")),
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
                        "accepted_fraction": ok_frac, "softmax_sum": wsum},
             "roofline": {"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

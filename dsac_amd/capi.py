@@ -33,8 +33,8 @@ DSAC_BWD_QUIRK_TRANSPOSE = 1
 # and the library against both)
 EXPORTS = [
     "dsac_version", "dsac_create", "dsac_destroy", "dsac_last_error", "dsac_set_stream", "dsac_get_stream", "dsac_synchronize",
-    "dsac_device_info", "dsac_set_frame", "dsac_sample", "dsac_reproject", "dsac_softmax", "dsac_dpnp", "dsac_score_backward",
-    "dsac_soft_score_backward", "dsac_refine", "dsac_refine_fd", "dsac_loss", "dsac_path1_and_softmax_backward", "dsac_profile_enable",
+    "dsac_device_info", "dsac_set_frame", "dsac_sample", "dsac_score_hypotheses", "dsac_sample_ahead", "dsac_score_sampled", "dsac_reproject", "dsac_softmax", "dsac_dpnp", "dsac_score_backward",
+    "dsac_soft_score_backward", "dsac_refine", "dsac_refine_fd", "dsac_loss", "dsac_path1_and_softmax_backward", "dsac_set_k2_events", "dsac_profile_enable",
     "dsac_profile_read",
 ]
 
@@ -67,6 +67,9 @@ def _load():
     lib.dsac_set_frame.argtypes = [vp, vp, vp, i32, i32, f32, f32, f32, f32, u32]
     lib.dsac_sample.argtypes = [vp, i32, u64, vp, f32, i32, vp, vp, vp]
     lib.dsac_reproject.argtypes = [vp, i32, vp, f32, vp, f32, f32, vp]
+    lib.dsac_sample_ahead.argtypes = [vp, i32, i32, u64, vp, f32, i32, vp, vp, vp]
+    lib.dsac_score_sampled.argtypes = [vp, i32, f32, f32, f32, f64, vp, vp, vp, vp, vp, vp]
+    lib.dsac_score_hypotheses.argtypes = [vp, i32, u64, vp, f32, i32, f32, f32, f32, f64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dsac_softmax.argtypes = [vp, i32, vp, f64, vp, vp, vp, vp]
     lib.dsac_dpnp.argtypes = [vp, i32, vp, f32, vp]
     lib.dsac_score_backward.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
@@ -75,6 +78,7 @@ def _load():
     lib.dsac_refine_fd.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, f32, f32, f32, vp, vp, vp, i32, vp]
     lib.dsac_loss.argtypes = [vp, vp, vp, vp, vp]
     lib.dsac_path1_and_softmax_backward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.dsac_set_k2_events.argtypes = [vp, vp, vp]
     lib.dsac_profile_enable.argtypes = [vp, i32]
     lib.dsac_profile_read.argtypes = [vp, i32, C.POINTER(f64), C.POINTER(i32), i32]
     return lib

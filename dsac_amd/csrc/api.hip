@@ -53,10 +53,19 @@ struct dsac_ctx {
     size_t slot_next = 0;
     struct Pending { void* host; const void* dev; size_t bytes; };
     std::vector<Pending> pending;
-    int reproject_variant = 0;
+    int reproject_variant = -1;  // auto
+    hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
+
+    // two-slot software pipeline (dsac_sample_ahead / dsac_score_sampled): K1 of frame i+1 on `aux` under K2/K3 of frame i
+    hipStream_t aux = nullptr;
+    DevBuf slot_staged[2];
+    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    bool slot_free_recorded[2] = {false, false};
+    int slot_N[2] = {0, 0};
 
     // measurement hooks: event pairs around the dominant kernels
     bool profiling = false;
+    int prof_stride = 1, prof_count[2] = {0, 0};  // record every prof_stride-th launch
     struct EvPair { hipEvent_t a, b; };
     std::vector<EvPair> ev[2];
     std::vector<EvPair> ev_free;
@@ -143,6 +152,7 @@ struct ProfScope {
     bool on = false;
     ProfScope(dsac_ctx* c_, int which_) : c(c_), which(which_) {
         if (!c->profiling) return;
+        if ((c->prof_count[which]++ % c->prof_stride) != 0) return;
         if (!c->ev_free.empty()) { p = c->ev_free.back(); c->ev_free.pop_back(); }
         else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
         on = hipEventRecord(p.a, c->stream) == hipSuccess;
@@ -219,6 +229,12 @@ void dsac_destroy(dsac_ctx* c) {
     c->staged.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
     c->grad_part.release(); c->g12_part.release(); c->g6.release();
     for (auto& s : c->slots) s.release();
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    for (int k = 0; k < 2; k++) {
+        c->slot_staged[k].release();
+        if (c->slot_ready[k]) (void)hipEventDestroy(c->slot_ready[k]);
+        if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
+    }
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -239,6 +255,7 @@ void* dsac_get_stream(dsac_ctx* c) { return c ? reinterpret_cast<void*>(c->strea
 
 int dsac_synchronize(dsac_ctx* c) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_synchronize: ctx is NULL");
+    if (c->aux) HIP_TRY(c, hipStreamSynchronize(c->aux));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DSAC_OK;
 }
@@ -334,10 +351,12 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
         d_part = c->soft_part.as<float>();
     }
     int used = 0;
+    if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, c->reproject_variant, &used));
     }
+    if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
     return end_call(c);
 }
@@ -360,6 +379,107 @@ int dsac_softmax(dsac_ctx* c, int N, const double* scores, double scale, double*
     return end_call(c);
 }
 
+int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
+                          float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
+                          double* w, double* entropy_or_null, double* avg6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_score_hypotheses: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_score_hypotheses: no frame set");
+    if (N <= 0 || !poses || !sets_out || !ok || !w) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: N > 0 and poses/sets_out/ok/w must be non-NULL");
+    if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: max_tries must be > 0");
+    if (!sets_or_null && c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: frame has fewer than 4 cells");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const int32_t* d_sets_in;
+    double *d_poses, *d_scores, *d_w, *d_ent, *d_avg;
+    int32_t* d_sets_out;
+    uint8_t* d_ok;
+    float* d_err;
+    ARG_TRY(in_arg(c, sets_or_null, (size_t)N * 4, &d_sets_in));
+    ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
+    ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
+    ARG_TRY(out_arg(c, err_or_null, (size_t)N * P, &d_err));
+    ARG_TRY(out_arg(c, scores_or_null, (size_t)N, &d_scores));
+    ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(out_arg(c, entropy_or_null, 1, &d_ent));
+    ARG_TRY(out_arg(c, avg6_or_null, 6, &d_avg));
+    if (!d_scores) {
+        DevBuf& s = next_slot(c);
+        HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
+        d_scores = s.as<double>();
+    }
+    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+    // K1 writes the poses AND their staged K2 records (no separate pose_prep launch)
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>()));
+    int used = 0;
+    if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
+    {
+        ProfScope ps(c, 0);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->reproject_variant, &used));
+    }
+    if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
+    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
+    HIP_TRY(c, dk::softmax(c->stream, N, d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg));
+    return end_call(c);
+}
+
+static int pipeline_init(dsac_ctx* c) {
+    if (c->aux) return DSAC_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ready[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
+    }
+    return DSAC_OK;
+}
+
+int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
+                      int32_t* sets_out, uint8_t* ok) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample_ahead: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample_ahead: no frame set");
+    if (slot < 0 || slot > 1 || N <= 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot in {0,1}, N > 0, non-NULL outputs");
+    if (!is_device_ptr(poses) || !is_device_ptr(sets_out) || !is_device_ptr(ok) || (sets_or_null && !is_device_ptr(sets_or_null)))
+        return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: the pipelined calls need device pointers");
+    if (!sets_or_null && (max_tries <= 0 || c->F.P < 4)) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: max_tries > 0 and >= 4 cells needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ARG_TRY(pipeline_init(c));
+    HIP_TRY(c, c->slot_staged[slot].reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    if (c->slot_free_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_free[slot], 0));  // the scorer is done with this slot
+    HIP_TRY(c, dk::sample(c->aux, N, seed, sets_or_null, c->F, (int)thr, max_tries, poses, sets_out, ok, c->slot_staged[slot].as<float>()));
+    HIP_TRY(c, hipEventRecord(c->slot_ready[slot], c->aux));
+    c->slot_N[slot] = N;
+    return DSAC_OK;
+}
+
+int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float beta, double scale, const double* poses, float* err_or_null,
+                       double* scores, double* w, double* entropy_or_null, double* avg6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_score_sampled: ctx is NULL");
+    if (slot < 0 || slot > 1 || !c->aux || c->slot_N[slot] <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: no dsac_sample_ahead on this slot");
+    if (!scores || !w || (avg6_or_null && !poses)) return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: scores/w (and poses with avg6) must be non-NULL");
+    if (!is_device_ptr(scores) || !is_device_ptr(w) || (err_or_null && !is_device_ptr(err_or_null)) || (poses && !is_device_ptr(poses)) ||
+        (entropy_or_null && !is_device_ptr(entropy_or_null)) || (avg6_or_null && !is_device_ptr(avg6_or_null)))
+        return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: the pipelined calls need device pointers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int N = c->slot_N[slot];
+    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_ready[slot], 0));  // normally long satisfied: K1 ran under the previous K2
+    int used = 0;
+    {
+        ProfScope ps(c, 0);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, c->soft_part.as<float>(),
+                                 c->reproject_variant, &used));
+    }
+    HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
+    c->slot_free_recorded[slot] = true;
+    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), scores));
+    HIP_TRY(c, dk::softmax(c->stream, N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null));
+    return DSAC_OK;
+}
+
 int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_dpnp: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_dpnp: no frame set");
@@ -375,9 +495,18 @@ int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     return end_call(c);
 }
 
+int dsac_set_k2_events(dsac_ctx* c, void* wait_before_or_null, void* record_after_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_k2_events: ctx is NULL");
+    c->k2_wait = reinterpret_cast<hipEvent_t>(wait_before_or_null);
+    c->k2_record = reinterpret_cast<hipEvent_t>(record_after_or_null);
+    return DSAC_OK;
+}
+
 int dsac_profile_enable(dsac_ctx* c, int on) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_profile_enable: ctx is NULL");
     c->profiling = on != 0;
+    c->prof_stride = on > 1 ? on : 1;  // on = n > 1: time every n-th launch only (event records are not free on the stream)
+    c->prof_count[0] = c->prof_count[1] = 0;
     return DSAC_OK;
 }
 

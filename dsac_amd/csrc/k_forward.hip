@@ -356,22 +356,27 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
                 iz0 = (d0.z == 0.0f) ? 1.0f : iz0; iz1 = (d1.z == 0.0f) ? 1.0f : iz1;
                 iz2 = (d2.z == 0.0f) ? 1.0f : iz2; iz3 = (d3.z == 0.0f) ? 1.0f : iz3;
             }
+            // (xc, yc) of one pixel are adjacent MFMA outputs -> one packed fma gives (du, dv), one packed mul their squares
             float e0, e1, e2, e3;
             {
-                const float du = fmaf(-d0.x, iz0, pu[0].x), dv = fmaf(-d0.y, iz0, pv[0].x);
-                e0 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+                const f2 d = pk_fma(-f2{d0.x, d0.y}, splat(iz0), f2{pu[0].x, pv[0].x});
+                const f2 q = d * d;
+                e0 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
             }
             {
-                const float du = fmaf(-d1.x, iz1, pu[0].y), dv = fmaf(-d1.y, iz1, pv[0].y);
-                e1 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+                const f2 d = pk_fma(-f2{d1.x, d1.y}, splat(iz1), f2{pu[0].y, pv[0].y});
+                const f2 q = d * d;
+                e1 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
             }
             {
-                const float du = fmaf(-d2.x, iz2, pu[1].x), dv = fmaf(-d2.y, iz2, pv[1].x);
-                e2 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+                const f2 d = pk_fma(-f2{d2.x, d2.y}, splat(iz2), f2{pu[1].x, pv[1].x});
+                const f2 q = d * d;
+                e2 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
             }
             {
-                const float du = fmaf(-d3.x, iz3, pu[1].y), dv = fmaf(-d3.y, iz3, pv[1].y);
-                e3 = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+                const f2 d = pk_fma(-f2{d3.x, d3.y}, splat(iz3), f2{pu[1].y, pv[1].y});
+                const f2 q = d * d;
+                e3 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
             }
             const f2 e01 = {e0, e1}, e23 = {e2, e3};
             if (ERR && valid && hyp < nh) {
@@ -446,7 +451,7 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
     return hipGetLastError();
 }
 
-// variant: 0 = LDS-staged poses, HT = 32 (default) ; 1 = scalar-load poses (SGPR operands), HT = 32 ;
+// variant: -1 = auto (default) ; 0 = VALU kernel, LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ;
 //          2 = LDS, HT = 16 ; 3 = LDS, HT = 64
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
                      float* soft_part, int variant, int* tiles_used) {
@@ -458,6 +463,18 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0);
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
+    if (variant < 0) {
+        // auto (measured on MI355X, profiles/r01_k2_variants.txt): with the fused soft-inlier sums the kernel is
+        // VALU-limited -> matrix-core form, HT = 32, pixel tiles innermost; error images only: store-limited ->
+        // the matrix-core form with HT = 64 / hypothesis tiles innermost for big launches, HT = 32 otherwise.
+        const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
+        const bool saved = g_k2_pixel_minor;
+        hipError_t e;
+        if (soft_part || !big) { g_k2_pixel_minor = true; e = launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
+        else { g_k2_pixel_minor = false; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
+        g_k2_pixel_minor = saved;
+        return e;
+    }
     switch (variant) {
         case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
         case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
@@ -495,55 +512,66 @@ hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part,
 // --------------------------------------------------------------------------------------------------
 constexpr int K3_THREADS = 256;
 
-template <typename Op>
-DM_INLINE double block_reduce(double v, double* s_buf, Op op) {
-    const int tid = threadIdx.x;
-    s_buf[tid] = v;
-    __syncthreads();
+DM_INLINE double wave_allmax_d(double v) {
 #pragma unroll
-    for (int o = K3_THREADS / 2; o > 0; o >>= 1) {
-        if (tid < o) s_buf[tid] = op(s_buf[tid], s_buf[tid + o]);
-        __syncthreads();
-    }
-    const double r = s_buf[0];
-    __syncthreads();
-    return r;
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+DM_INLINE double wave_allsum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
+// Two block-wide reductions in total: the maximum, then {sum e, sum e*log2 e, sum e*pose[0..5]} together.
+// With S = sum e:  w_i = e_i / S,  entropy = log2 S - (sum e log2 e)/S,  avg = (sum e pose)/S.
 __global__ __launch_bounds__(K3_THREADS) void k_softmax(int N, const double* __restrict__ scores, double scale, double* __restrict__ w,
                                                         double* __restrict__ entropy, const double* __restrict__ poses,
                                                         double* __restrict__ avg6) {
-    __shared__ double s_buf[K3_THREADS];
-    const int tid = threadIdx.x;
+    __shared__ double s_m[K3_THREADS / 64];
+    __shared__ double s_acc[K3_THREADS / 64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool want_avg = poses && avg6;
     double m = -1.7976931348623157e308;
     for (int i = tid; i < N; i += K3_THREADS) m = fmax(m, scale * scores[i]);
-    m = block_reduce(m, s_buf, [](double a, double b) { return fmax(a, b); });
-    double sum = 0;
-    for (int i = tid; i < N; i += K3_THREADS) {
-        const double e = exp(scale * scores[i] - m);
-        w[i] = e;
-        sum += e;
-    }
-    sum = block_reduce(sum, s_buf, [](double a, double b) { return a + b; });
-    double ent = 0, a[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < N; i += K3_THREADS) {
-        const double wi = w[i] / sum;
-        w[i] = wi;
-        if (wi > 0) ent -= wi * log2(wi);
-        if (poses && avg6) {
+    m = wave_allmax_d(m);
+    if (lane == 0) s_m[wave] = m;
+    __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 6; k++) a[k] += wi * poses[6 * (size_t)i + k];
+    for (int k = 0; k < K3_THREADS / 64; k++) m = fmax(m, s_m[k]);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < N; i += K3_THREADS) {
+        const double x = scale * scores[i] - m;
+        const double e = exp(x);
+        w[i] = e;
+        acc[0] += e;
+        acc[1] += e * (x * 1.4426950408889634);  // e * log2(e); exactly 0 when e underflows, like the reference's w > 0 test
+        if (want_avg) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc[2 + k] += e * poses[6 * (size_t)i + k];
         }
     }
-    if (entropy) {
-        ent = block_reduce(ent, s_buf, [](double x, double y) { return x + y; });
-        if (tid == 0) *entropy = ent;
-    }
-    if (poses && avg6) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const double s = block_reduce(a[k], s_buf, [](double x, double y) { return x + y; });
-            if (tid == 0) avg6[k] = s;
+    for (int k = 0; k < 8; k++) acc[k] = wave_allsum_d(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_acc[wave][k] = acc[k];
+    }
+    __syncthreads();
+    double tot[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        tot[k] = 0;
+#pragma unroll
+        for (int q = 0; q < K3_THREADS / 64; q++) tot[k] += s_acc[q][k];
+    }
+    const double S = tot[0];
+    for (int i = tid; i < N; i += K3_THREADS) w[i] = w[i] / S;
+    if (tid == 0) {
+        if (entropy) *entropy = log2(S) - tot[1] / S;
+        if (want_avg) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) avg6[k] = tot[2 + k] / S;
         }
     }
 }

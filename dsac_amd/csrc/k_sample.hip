@@ -43,6 +43,16 @@ DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr
     return good;
 }
 
+// Staged K2 record of a cv pose (same arithmetic as k_pose_prep in k_forward.hip: fp64 Rodrigues, intrinsics folded in).
+DM_INLINE void write_staged(const FrameDev& F, const double cv6[6], float* o) {
+    double R[9];
+    dm::rodrigues_v2m<false>(cv6, R, nullptr);
+    const double dfx = F.fx, dfy = F.fy;
+    o[0] = (float)(dfx * R[0]); o[1] = (float)(dfx * R[1]); o[2] = (float)(dfx * R[2]); o[3] = (float)(dfx * cv6[3]);
+    o[4] = (float)(dfy * R[3]); o[5] = (float)(dfy * R[4]); o[6] = (float)(dfy * R[5]); o[7] = (float)(dfy * cv6[4]);
+    o[8] = (float)R[6]; o[9] = (float)R[7]; o[10] = (float)R[8]; o[11] = (float)cv6[5];
+}
+
 // Draw the minimal set of attempt `attempt` (core/cnn_softam.h:1021-1039).  false: more than 32 candidate
 // draws were needed (degenerate tiny maps).
 DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32_t set4[4]) {
@@ -66,7 +76,7 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // per round, the four candidate poses of an attempt side by side (their Jacobi eigen-solves, the long pole
 // of P3P, run in parallel instead of in sequence).
 __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
-                                               int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok) {
+                                               int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged) {
     const int h = blockIdx.x;
     const int lane = threadIdx.x;
     const int root = lane & 3;
@@ -124,6 +134,7 @@ __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F,
 #pragma unroll
                 for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
                 ok[h] = 1;
+                if (staged) write_staged(F, cv6, staged + (size_t)h * POSE_STRIDE);
             }
             return;
         }
@@ -137,12 +148,14 @@ __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F,
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) sets_out[(size_t)h * 4 + kk] = set4[kk];
         ok[h] = 0;
+        if (staged) { const double z6[6] = {0, 0, 0, 0, 0, 0}; write_staged(F, z6, staged + (size_t)h * POSE_STRIDE); }
     }
 }
 
 // Given sets: one lane per hypothesis.
 __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restrict__ sets_in, FrameDev F, int thr_int,
-                                                  double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok) {
+                                                  double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok,
+                                                  float* __restrict__ staged) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= N) return;
     int32_t set4[4];
@@ -157,13 +170,17 @@ __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restri
         for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
     }
     ok[h] = good ? 1 : 0;
+    if (staged) {
+        if (!good) { cv6[0] = cv6[1] = cv6[2] = cv6[3] = cv6[4] = cv6[5] = 0.0; }
+        write_staged(F, cv6, staged + (size_t)h * POSE_STRIDE);
+    }
 }
 
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries, double* poses,
-                  int32_t* sets_out, uint8_t* ok) {
+                  int32_t* sets_out, uint8_t* ok, float* staged) {
     if (N <= 0) return hipSuccess;
-    if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok);
-    else hipLaunchKernelGGL(k_sample, dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok);
+    if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
+    else hipLaunchKernelGGL(k_sample, dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged);
     return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, do
 
 // ---- k_sample.hip ----------------------------------------------------------------------------------
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
-                  double* poses, int32_t* sets_out, uint8_t* ok);
+                  double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr);  // staged: K2 records (N x 12)
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
 
 // ---- k_backward.hip --------------------------------------------------------------------------------

@@ -82,8 +82,18 @@ class Engine:
         check(self._ctx, lib.dsac_device_info(self._ctx, C.byref(cus), C.byref(clk), C.byref(mem), name))
         return dict(cus=cus.value, clock_khz=clk.value, mem_bytes=mem.value, arch=name.value.decode())
 
-    def profile_enable(self, on=True):
-        check(self._ctx, lib.dsac_profile_enable(self._ctx, 1 if on else 0))
+    def set_k2_events(self, wait_before=None, record_after=None):
+        """Gate around the bandwidth-bound kernel (see dsac_set_k2_events).  Events: torch.cuda.Event or raw hipEvent_t."""
+        def addr(ev):
+            if ev is None:
+                return None
+            return getattr(ev, "cuda_event", ev)
+        self._k2_events = (wait_before, record_after)  # keep them alive
+        check(self._ctx, lib.dsac_set_k2_events(self._ctx, addr(wait_before), addr(record_after)))
+
+    def profile_enable(self, on=True, stride=1):
+        """Time the dominant kernels with HIP events; stride n > 1 times every n-th launch only."""
+        check(self._ctx, lib.dsac_profile_enable(self._ctx, (max(1, int(stride)) if on else 0)))
 
     def profile_read(self, which=0, reset=True):
         """(total ms, launches) of the dominant kernel measured with HIP events on this context's stream
@@ -135,6 +145,29 @@ class Engine:
         soft = np.zeros(poses.shape[0])
         self.reproject(poses, soft=soft, tau=tau, beta=beta, clamp=clamp)
         return soft
+
+    def scoreHypotheses(self, N, seed=1305, thr=10.0, max_tries=1 << 20, sets=None, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5, scale=0.1,
+                        err=None, out=None):
+        """K1 + K2 + K3 in one call (cnn_softam.h:1010-1094 with the soft-inlier score at the CNN seam).
+        out = (poses N x 6, sets N x 4, ok N, scores N, w N, entropy 1, avg6 6); returns it."""
+        if out is None:
+            out = (np.zeros((N, 6)), np.zeros((N, 4), np.int32), np.zeros(N, np.uint8), np.zeros(N), np.zeros(N), np.zeros(1), np.zeros(6))
+        poses, sets_out, ok, scores, w, ent, avg = out
+        sets = _np(sets, np.int32) if sets is not None else None
+        check(self._ctx, lib.dsac_score_hypotheses(self._ctx, int(N), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(sets), float(thr), int(max_tries),
+                                                   float(clamp), float(tau), float(beta), float(scale), ptr(poses), ptr(sets_out), ptr(ok),
+                                                   ptr(err), ptr(scores), ptr(w), ptr(ent), ptr(avg)))
+        return out
+
+    def sampleAhead(self, slot, N, seed, poses, sets_out, ok, thr=10.0, max_tries=1 << 20, sets=None):
+        """K1 for a later frame on the context's auxiliary stream (device buffers only), see dsac_sample_ahead."""
+        check(self._ctx, lib.dsac_sample_ahead(self._ctx, int(slot), int(N), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(sets), float(thr), int(max_tries),
+                                               ptr(poses), ptr(sets_out), ptr(ok)))
+
+    def scoreSampled(self, slot, poses, scores, w, ent=None, avg=None, err=None, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5, scale=0.1):
+        """K2 -> K3 for the hypotheses sampled into `slot` (device buffers only), see dsac_score_sampled."""
+        check(self._ctx, lib.dsac_score_sampled(self._ctx, int(slot), float(clamp), float(tau), float(beta), float(scale), ptr(poses), ptr(err),
+                                                ptr(scores), ptr(w), ptr(ent), ptr(avg)))
 
     # ---- K3 ---------------------------------------------------------------------------------------
     def softMax(self, scores, scale=1.0, poses=None, N=None, out=None):

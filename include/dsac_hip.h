@@ -113,6 +113,26 @@ int dsac_reproject(dsac_ctx* ctx, int N, const double* poses, float clamp, float
 int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, double* w, double* entropy_or_null,
                  const double* poses_or_null, double* avg6_or_null);
 
+/* ---- K1 + K2 + K3 in one call: the hypothesis-scoring half of processImage ------------------------ */
+/* Replaces core/cnn_softam.h:1010-1094 with the soft-inlier score in the place of the score CNN (:1072):
+ * sample N hypotheses (dsac_sample), reproject (dsac_reproject: error images optional, soft-inlier sums always),
+ * w = softmax(scale * soft), entropy, soft-argmax pose.  Same results as the three separate calls; the fused
+ * form saves the pose-staging launch and the host round trips.  scores_or_null receives the soft-inlier sums. */
+int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clamp, float tau,
+                          float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
+                          double* w, double* entropy_or_null, double* avg6_or_null);
+
+/* The same work as a two-slot software pipeline inside one context: dsac_sample_ahead(slot) enqueues K1 for a LATER
+ * frame on an auxiliary stream; dsac_score_sampled(slot) enqueues K2 -> K3 for that slot on the context's stream.
+ * Called as  ahead(0) ; { ahead(1-s) ; score(s) ; s = 1-s } ...  the latency-bound sampling of frame i+1 runs underneath
+ * the bandwidth-bound scoring of frame i and K2 launches follow each other back to back.  Device pointers only
+ * (the calls never block); poses/sets_out/ok of a slot must stay untouched until its score call has been issued,
+ * and dsac_synchronize waits for both streams. */
+int dsac_sample_ahead(dsac_ctx* ctx, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
+                      int32_t* sets_out, uint8_t* ok);
+int dsac_score_sampled(dsac_ctx* ctx, int slot, float clamp, float tau, float beta, double scale, const double* poses, float* err_or_null,
+                       double* scores, double* w, double* entropy_or_null, double* avg6_or_null);
+
 /* ---- K5: dPNP ------------------------------------------------------------------------------------ */
 /* Replaces dPNP core/cnn_softam.h:101-146 for the minimal (4-point, CV_P3P) case: central differences
  * (float eps, sequential float perturbation of the object points) of the jp 6-vector of the P3P pose.
@@ -165,6 +185,14 @@ int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double
  * g_j = w_j * (F_j - sum_h w_h F_h),  F_h = v6 . [rvec_h ; tvec_h / 1000]  (written O(N^2) in the reference). */
 int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                     const double* dpnp, double* grad_xyz, double* g);
+
+/* ---- stream scheduling ---------------------------------------------------------------------------------- */
+/* Optional gate around the one bandwidth-bound kernel (K2): before launching it the context's stream waits for
+ * `wait_before` (a hipEvent_t; a never-recorded event does not block), after it `record_after` is recorded.
+ * Two contexts working on alternate frames cross-wire their events so that their K2 launches run back to back
+ * -- never competing for HBM -- while the latency-bound kernels (K1 sampling, K3) of one frame fill the bubbles of
+ * the other.  NULL removes the gate. */
+int dsac_set_k2_events(dsac_ctx* ctx, void* wait_before_or_null, void* record_after_or_null);
 
 /* ---- measurement hooks (bench.py's roofline leg) ----------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded on the context's stream immediately around every launch of the

@@ -220,6 +220,56 @@ def test_device_pointers_through_torch(engine, orc, frame40):
     assert np.abs(avg.cpu().numpy() - orc.avg_pose(w_e2e, pr)).max() <= 1e-2 * np.abs(orc.avg_pose(w_e2e, pr)).max()
 
 
+def test_fused_score_hypotheses_equals_the_three_calls(engine, orc, frame40, frame_full):
+    for fr, N in ((frame40, 256), (frame_full, 96)):
+        _set(engine, fr)
+        P = fr["H"] * fr["W"]
+        poses, sets, ok = engine.sample(N, seed=77)
+        err = np.zeros((N, P), np.float32)
+        soft = np.zeros(N)
+        engine.reproject(poses, err=err, soft=soft)
+        w, ent, avg = engine.softMax(soft, 0.1, poses)
+        err2 = np.zeros((N, P), np.float32)
+        p2, s2, ok2, sc2, w2, ent2, avg2 = engine.scoreHypotheses(N, seed=77, scale=0.1, err=err2)
+        assert np.array_equal(p2, poses) and np.array_equal(s2, sets) and np.array_equal(ok2, ok)
+        assert np.array_equal(err2, err) and np.array_equal(sc2, soft)
+        assert np.array_equal(w2, w) and ent2[0] == ent[0] and np.array_equal(avg2, avg)
+        # without the error images (scores only) the weights are the same
+        out = engine.scoreHypotheses(N, seed=77, scale=0.1)
+        assert np.allclose(out[4], w, rtol=0, atol=1e-12)
+
+
+def test_in_context_pipeline_equals_the_fused_call(engine, frame40):
+    """dsac_sample_ahead / dsac_score_sampled (K1 of frame i+1 under K2/K3 of frame i) give the bits of dsac_score_hypotheses."""
+    import torch
+    fr = frame40
+    _set(engine, fr)
+    dev = torch.device("cuda:0")
+    N, P = 128, 1600
+    ref = [engine.scoreHypotheses(N, seed=500 + i, scale=0.1) for i in range(5)]
+    mk = lambda: dict(poses=torch.zeros(N, 6, dtype=torch.float64, device=dev), sets=torch.zeros(N, 4, dtype=torch.int32, device=dev),
+                      ok=torch.zeros(N, dtype=torch.uint8, device=dev), soft=torch.zeros(N, dtype=torch.float64, device=dev),
+                      w=torch.zeros(N, dtype=torch.float64, device=dev), ent=torch.zeros(1, dtype=torch.float64, device=dev),
+                      avg=torch.zeros(6, dtype=torch.float64, device=dev))
+    bufs = [mk(), mk()]
+    err = torch.zeros(N, P, dtype=torch.float32, device=dev)
+    engine.sampleAhead(0, N, 500, bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"])
+    for i in range(5):
+        k = i & 1
+        if i + 1 < 5:
+            nb = bufs[1 - k]
+            engine.sampleAhead(1 - k, N, 500 + i + 1, nb["poses"], nb["sets"], nb["ok"])
+        b = bufs[k]
+        engine.scoreSampled(k, b["poses"], b["soft"], b["w"], ent=b["ent"], avg=b["avg"], err=err, scale=0.1)
+        engine.synchronize()
+        p, s, ok, sc, w, ent, avg = ref[i]
+        assert np.array_equal(b["poses"].cpu().numpy(), p) and np.array_equal(b["sets"].cpu().numpy(), s)
+        assert np.array_equal(b["soft"].cpu().numpy(), sc) and np.array_equal(b["w"].cpu().numpy(), w)
+        assert b["ent"].item() == ent[0] and np.array_equal(b["avg"].cpu().numpy(), avg)
+    with pytest.raises(Exception):
+        engine.sampleAhead(0, N, 1, np.zeros((N, 6)), np.zeros((N, 4), np.int32), np.zeros(N, np.uint8))  # host pointers are rejected
+
+
 def test_quantise_flag(engine, orc, synth):
     fr = synth.chess_like_frame(40, 40, seed=4, quantise_int16=False)
     engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"], quantise_int16=True)
