@@ -265,7 +265,15 @@ DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, res
     return v;
 }
 
-constexpr int KM_CH = 2;  // 64-pixel chunks per wave
+constexpr int KM_CH = 2;  // 64-pixel chunks per wave, all held in registers
+
+// Finish one (hypothesis, pixel) pair from the MFMA outputs d = (xc, yc, zc, -): (xc, yc) are adjacent registers, so one
+// packed fma gives (du, dv) and one packed mul their squares.
+DM_INLINE float finish_pair(const f4 d, float iz, f2 ppix, float clampv) {
+    const f2 dd = pk_fma(-f2{d.x, d.y}, splat(iz), ppix);
+    const f2 q = dd * dd;
+    return fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
+}
 
 template <int HT, bool ERR, bool SOFT, bool UV>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __restrict__ staged, const float* __restrict__ xyz,
@@ -295,59 +303,57 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
         const int hyp = 4 * gi + (row >> 2), comp = row & 3;
         s_A[i] = (comp < 3 && hyp < nh) ? staged[(size_t)(h0 + hyp) * POSE_STRIDE + comp * 4 + k] : 0.0f;
     }
-    __syncthreads();
 
-    float sacc[SOFT ? HT / 4 : 1];
-    if (SOFT) {
+    // per-chunk operands: B (coordinate g of pixel 4c + m) and the lane's 4 pixel positions as (u - cx, v - cy) pairs
+    float Bm[KM_CH][4];
+    f2 ppix[KM_CH][4];
+    int p0[KM_CH];
+    bool valid[KM_CH];
 #pragma unroll
-        for (int gi = 0; gi < HT / 4; gi++) sacc[gi] = 0.f;
-    }
-
-#pragma unroll 1
     for (int ch = 0; ch < KM_CH; ch++) {
         const int chunk0 = (pt * (K2_THREADS / 64) * KM_CH + wave * KM_CH + ch) * 64;
-        if (chunk0 >= P) break;
-        const int p0 = chunk0 + 4 * c;        // this lane's 4 consecutive pixels
-        const bool valid = p0 < P;            // P % 4 == 0
-        // B operands: lane (k = g, column c) supplies coordinate k of pixel 4c + m
-        float Bm[4];
+        p0[ch] = chunk0 + 4 * c;       // this lane's 4 consecutive pixels
+        valid[ch] = p0[ch] < P;        // P % 4 == 0
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const int pc = min(p0 + m, P - 1);
-            Bm[m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
+            const int pc = min(p0[ch] + m, P - 1);
+            Bm[ch][m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
         }
-        f2 pu[2], pv[2];
         if (UV) {
-            if (valid) {
-                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0 * 2);
+            if (valid[ch]) {
+                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0[ch] * 2);
                 const f4 u0 = su[0], u1 = su[1];
-                pu[0] = f2{u0.x - cx, u0.z - cx}; pv[0] = f2{u0.y - cy, u0.w - cy};
-                pu[1] = f2{u1.x - cx, u1.z - cx}; pv[1] = f2{u1.y - cy, u1.w - cy};
-            } else { pu[0] = pu[1] = pv[0] = pv[1] = splat(0.f); }
+                ppix[ch][0] = f2{u0.x - cx, u0.y - cy}; ppix[ch][1] = f2{u0.z - cx, u0.w - cy};
+                ppix[ch][2] = f2{u1.x - cx, u1.y - cy}; ppix[ch][3] = f2{u1.z - cx, u1.w - cy};
+            } else {
+                ppix[ch][0] = ppix[ch][1] = ppix[ch][2] = ppix[ch][3] = splat(0.f);
+            }
         } else {
-            float tu[4], tv[4];
+            // implicit grid: one integer division per chunk, then walk (with row wrap)
+            int y = p0[ch] / W, x = p0[ch] - y * W;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const int p = p0 + m;
-                const int y = p / W, x = p - y * W;
-                tu[m] = (float)x - cx; tv[m] = (float)y - cy;
+                ppix[ch][m] = f2{(float)x - cx, (float)y - cy};
+                if (++x == W) { x = 0; y++; }
             }
-            pu[0] = f2{tu[0], tu[1]}; pu[1] = f2{tu[2], tu[3]};
-            pv[0] = f2{tv[0], tv[1]}; pv[1] = f2{tv[2], tv[3]};
         }
+    }
+    __syncthreads();
 
+#pragma unroll 2
+    for (int gi = 0; gi < HT / 4; gi++) {
+        if (4 * gi >= nh) break;
+        const float a = s_A[gi * 64 + lane];
+        const int hyp = 4 * gi + g;
+        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+        float ssum = 0.f;
 #pragma unroll
-        for (int gi = 0; gi < HT / 4; gi++) {
-            if (4 * gi >= nh) continue;  // wave-uniform
-            const float a = s_A[gi * 64 + lane];
-            const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[0], z4, 0, 0, 0);
-            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[1], z4, 0, 0, 0);
-            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[2], z4, 0, 0, 0);
-            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[3], z4, 0, 0, 0);
-            const int hyp = 4 * gi + g;
-            // finish on the VALU.  Scalar (unpacked) ops on purpose: the four results of a lane sit in four
-            // different MFMA destination quads, so packing them would cost more v_mov than it saves.
+        for (int ch = 0; ch < KM_CH; ch++) {
+            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][0], z4, 0, 0, 0);
+            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][1], z4, 0, 0, 0);
+            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][2], z4, 0, 0, 0);
+            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][3], z4, 0, 0, 0);
+            // finish on the VALU
             float iz0 = __builtin_amdgcn_rcpf(d0.z), iz1 = __builtin_amdgcn_rcpf(d1.z);
             float iz2 = __builtin_amdgcn_rcpf(d2.z), iz3 = __builtin_amdgcn_rcpf(d3.z);
             // projectPoints' "z = Z ? 1/Z : 1": one test for the 4 pixels, wave-uniform slow path (practically never)
@@ -356,46 +362,23 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
                 iz0 = (d0.z == 0.0f) ? 1.0f : iz0; iz1 = (d1.z == 0.0f) ? 1.0f : iz1;
                 iz2 = (d2.z == 0.0f) ? 1.0f : iz2; iz3 = (d3.z == 0.0f) ? 1.0f : iz3;
             }
-            // (xc, yc) of one pixel are adjacent MFMA outputs -> one packed fma gives (du, dv), one packed mul their squares
-            float e0, e1, e2, e3;
-            {
-                const f2 d = pk_fma(-f2{d0.x, d0.y}, splat(iz0), f2{pu[0].x, pv[0].x});
-                const f2 q = d * d;
-                e0 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
-            }
-            {
-                const f2 d = pk_fma(-f2{d1.x, d1.y}, splat(iz1), f2{pu[0].y, pv[0].y});
-                const f2 q = d * d;
-                e1 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
-            }
-            {
-                const f2 d = pk_fma(-f2{d2.x, d2.y}, splat(iz2), f2{pu[1].x, pv[1].x});
-                const f2 q = d * d;
-                e2 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
-            }
-            {
-                const f2 d = pk_fma(-f2{d3.x, d3.y}, splat(iz3), f2{pu[1].y, pv[1].y});
-                const f2 q = d * d;
-                e3 = fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
-            }
-            const f2 e01 = {e0, e1}, e23 = {e2, e3};
-            if (ERR && valid && hyp < nh) {
+            const float e0 = finish_pair(d0, iz0, ppix[ch][0], clampv);
+            const float e1 = finish_pair(d1, iz1, ppix[ch][1], clampv);
+            const float e2 = finish_pair(d2, iz2, ppix[ch][2], clampv);
+            const float e3 = finish_pair(d3, iz3, ppix[ch][3], clampv);
+            if (ERR && valid[ch] && hyp < nh) {
                 const f4 o = {e0, e1, e2, e3};
-                if (kflags & 1) *reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0) = o; else __builtin_nontemporal_store(o, reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0));
+                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0[ch]);
+                if (kflags & 1) *dst = o; else __builtin_nontemporal_store(o, dst);
             }
             if (SOFT) {
-                const f2 s2 = soft_inlier2(e01, kA, kB) + soft_inlier2(e23, kA, kB);
-                sacc[gi] += valid ? (s2.x + s2.y) : 0.f;
+                const f2 s2 = soft_inlier2(f2{e0, e1}, kA, kB) + soft_inlier2(f2{e2, e3}, kA, kB);
+                ssum += valid[ch] ? (s2.x + s2.y) : 0.f;
             }
         }
-    }
-
-    if (SOFT) {
-        // one 16-lane row reduction per hypothesis group for the whole block pass (not per chunk)
-#pragma unroll
-        for (int gi = 0; gi < HT / 4; gi++) {
-            const float s = row16_sum(sacc[gi]);
-            if (c == 0) s_soft[wave * HT + 4 * gi + g] = s;
+        if (SOFT) {
+            ssum = row16_sum(ssum);  // the 16 lanes of a row hold the same hypothesis
+            if (c == 0 && hyp < nh) s_soft[wave * HT + hyp] = ssum;  // written exactly once per (wave, hypothesis)
         }
     }
 
@@ -464,14 +447,14 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
     if (variant < 0) {
-        // auto (measured on MI355X, profiles/r01_k2_variants.txt): with the fused soft-inlier sums the kernel is
-        // VALU-limited -> matrix-core form, HT = 32, pixel tiles innermost; error images only: store-limited ->
-        // the matrix-core form with HT = 64 / hypothesis tiles innermost for big launches, HT = 32 otherwise.
+        // auto (measured on MI355X, profiles/r01_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited:
+        // matrix-core form (HT = 64), pixel tiles innermost except for very large launches.  Error images only: store-limited:
+        // the VALU kernel with pixel tiles innermost has the best store stream.
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
         const bool saved = g_k2_pixel_minor;
         hipError_t e;
-        if (soft_part || !big) { g_k2_pixel_minor = true; e = launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
-        else { g_k2_pixel_minor = false; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
+        if (soft_part) { g_k2_pixel_minor = !big; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
+        else { g_k2_pixel_minor = true; e = launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part); }
         g_k2_pixel_minor = saved;
         return e;
     }

@@ -44,13 +44,16 @@ DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr
 }
 
 // Staged K2 record of a cv pose (same arithmetic as k_pose_prep in k_forward.hip: fp64 Rodrigues, intrinsics folded in).
-DM_INLINE void write_staged(const FrameDev& F, const double cv6[6], float* o) {
-    double R[9];
-    dm::rodrigues_v2m<false>(cv6, R, nullptr);
+DM_INLINE void write_staged_R(const FrameDev& F, const double R[9], const double cv6[6], float* o) {
     const double dfx = F.fx, dfy = F.fy;
     o[0] = (float)(dfx * R[0]); o[1] = (float)(dfx * R[1]); o[2] = (float)(dfx * R[2]); o[3] = (float)(dfx * cv6[3]);
     o[4] = (float)(dfy * R[3]); o[5] = (float)(dfy * R[4]); o[6] = (float)(dfy * R[5]); o[7] = (float)(dfy * cv6[4]);
     o[8] = (float)R[6]; o[9] = (float)R[7]; o[10] = (float)R[8]; o[11] = (float)cv6[5];
+}
+DM_INLINE void write_staged(const FrameDev& F, const double cv6[6], float* o) {
+    double R[9];
+    dm::rodrigues_v2m<false>(cv6, R, nullptr);
+    write_staged_R(F, R, cv6, o);
 }
 
 // Draw the minimal set of attempt `attempt` (core/cnn_softam.h:1021-1039).  false: more than 32 candidate
@@ -110,11 +113,11 @@ __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F,
         }
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         if (live && win == root) {
             dm::rodrigues_m2v(Rc, cv6);
             cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
             // 4-point re-projection check (core/cnn_softam.h:1046-1059), through Rodrigues(rvec) like projectPoints
-            double R[9];
             dm::rodrigues_v2m<false>(cv6, R, nullptr);
             good = true;
 #pragma unroll
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F,
 #pragma unroll
                 for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
                 ok[h] = 1;
-                if (staged) write_staged(F, cv6, staged + (size_t)h * POSE_STRIDE);
+                if (staged) write_staged_R(F, R, cv6, staged + (size_t)h * POSE_STRIDE);
             }
             return;
         }

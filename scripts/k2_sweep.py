@@ -25,7 +25,7 @@ for N in (256, 4096):
 res = []
 import collections
 acc = collections.defaultdict(list)
-configs = ((0, 1, 0), (4, 0, 0), (6, 0, 0), (6, 1, 0), (5, 0, 0))
+configs = ((6, 1, 0), (4, 1, 0), (4, 0, 0), (0, 1, 0))
 for rep in range(3):
   for variant, order, kf in configs:
     os.environ["DSAC_K2_VARIANT"] = str(variant)

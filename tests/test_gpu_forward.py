@@ -105,12 +105,15 @@ def test_soft_inlier_scores(engine, orc, frame40, frame_full):
         ref = orc.soft_inlier(ref_err, 10.0, 0.5)
         got = engine.softInlierScores(poses, tau=10.0, beta=0.5)
         assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
-        # err + soft in one launch gives the same numbers as the separate launches
+        # err + soft in one launch agrees with the separate launches (the launcher may pick a different kernel form --
+        # matrix-core vs VALU fmaf chains round in a different order -- so not bit-for-bit)
         err = np.zeros((N, fr["H"] * fr["W"]), np.float32)
         soft = np.zeros(N)
         engine.reproject(poses, err=err, soft=soft)
-        assert np.array_equal(soft, got)
-        assert np.array_equal(err, engine.getDiffMap(poses).reshape(N, -1))
+        assert np.allclose(soft, got, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(got).max()))
+        sep = engine.getDiffMap(poses).reshape(N, -1)
+        mm = excl_clamp_edge(err, sep)
+        assert np.abs(err - sep)[mm].max() <= 5e-4
 
 
 def test_softmax_entropy_avg(engine, orc):
