@@ -42,9 +42,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "2")),
                     help="engine contexts (HIP streams) per GPU")
-    ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="pipeline",
-                    help="'pipeline' (default) = one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary "
-                         "stream under K2/K3 of frame i.  With 2 contexts: 'gated' = frames alternate between two contexts whose K2 launches are serialised by events "
+    ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="gated",
+                    help="'pipeline' = one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary "
+                         "stream under K2/K3 of frame i.  With 2 contexts: 'gated' (default) = frames alternate between two contexts whose K2 launches are serialised by events "
                          "(dsac_set_k2_events) so that K1/K3 of one frame overlap K2 of the other; 'stages' = stream A samples frame i+1 while stream B scores frame i (K2 launches never "
                          "overlap each other); 'frames' = whole frames dealt round-robin to the streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -57,10 +57,10 @@ struct dsac_ctx {
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
 
     // two-slot software pipeline (dsac_sample_ahead / dsac_score_sampled): K1 of frame i+1 on `aux` under K2/K3 of frame i
-    hipStream_t aux = nullptr;
-    DevBuf slot_staged[2];
-    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
-    bool slot_free_recorded[2] = {false, false};
+    hipStream_t aux = nullptr, aux2 = nullptr;  // aux: K1 of the next frame; aux2: K3 tail of the previous frame
+    DevBuf slot_staged[2], slot_soft_part[2];
+    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr}, slot_reduced[2] = {nullptr, nullptr};
+    bool slot_free_recorded[2] = {false, false}, slot_reduced_recorded[2] = {false, false};
     int slot_N[2] = {0, 0};
 
     // measurement hooks: event pairs around the dominant kernels
@@ -230,8 +230,11 @@ void dsac_destroy(dsac_ctx* c) {
     c->grad_part.release(); c->g12_part.release(); c->g6.release();
     for (auto& s : c->slots) s.release();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->aux2) { (void)hipStreamSynchronize(c->aux2); (void)hipStreamDestroy(c->aux2); }
     for (int k = 0; k < 2; k++) {
         c->slot_staged[k].release();
+        c->slot_soft_part[k].release();
+        if (c->slot_reduced[k]) (void)hipEventDestroy(c->slot_reduced[k]);
         if (c->slot_ready[k]) (void)hipEventDestroy(c->slot_ready[k]);
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
     }
@@ -256,6 +259,7 @@ void* dsac_get_stream(dsac_ctx* c) { return c ? reinterpret_cast<void*>(c->strea
 int dsac_synchronize(dsac_ctx* c) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_synchronize: ctx is NULL");
     if (c->aux) HIP_TRY(c, hipStreamSynchronize(c->aux));
+    if (c->aux2) HIP_TRY(c, hipStreamSynchronize(c->aux2));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DSAC_OK;
 }
@@ -429,9 +433,11 @@ int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets
 static int pipeline_init(dsac_ctx* c) {
     if (c->aux) return DSAC_OK;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ready[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->slot_reduced[k], hipEventDisableTiming));
     }
     return DSAC_OK;
 }
@@ -465,18 +471,24 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->slot_N[slot];
     const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
-    HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+    HIP_TRY(c, c->slot_soft_part[slot].reserve((size_t)tiles * N * sizeof(float)));
+    float* part = c->slot_soft_part[slot].as<float>();
+    // main stream: nothing but the bandwidth-bound kernel, back to back
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_ready[slot], 0));  // normally long satisfied: K1 ran under the previous K2
+    if (c->slot_reduced_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_reduced[slot], 0));  // partials of frame i-2 consumed
     int used = 0;
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, c->soft_part.as<float>(),
-                                 c->reproject_variant, &used));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, part, c->reproject_variant, &used));
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
     c->slot_free_recorded[slot] = true;
-    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), scores));
-    HIP_TRY(c, dk::softmax(c->stream, N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null));
+    // second auxiliary stream: the small latency-bound tail (partial sums -> scores -> softmax) runs under the next K2
+    HIP_TRY(c, hipStreamWaitEvent(c->aux2, c->slot_free[slot], 0));
+    HIP_TRY(c, dk::reduce_soft(c->aux2, N, used, part, scores));
+    HIP_TRY(c, hipEventRecord(c->slot_reduced[slot], c->aux2));
+    c->slot_reduced_recorded[slot] = true;
+    HIP_TRY(c, dk::softmax(c->aux2, N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null));
     return DSAC_OK;
 }
 

@@ -473,6 +473,7 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
 // One wave per hypothesis, lanes stride over the pixel tiles (independent
 // loads in flight), fixed butterfly -> deterministic.
 __global__ __launch_bounds__(256) void k_reduce_soft(int N, int tiles, const float* __restrict__ part, double* __restrict__ soft) {
+    __builtin_amdgcn_s_setprio(3);
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
@@ -511,6 +512,7 @@ DM_INLINE double wave_allsum_d(double v) {
 __global__ __launch_bounds__(K3_THREADS) void k_softmax(int N, const double* __restrict__ scores, double scale, double* __restrict__ w,
                                                         double* __restrict__ entropy, const double* __restrict__ poses,
                                                         double* __restrict__ avg6) {
+    __builtin_amdgcn_s_setprio(3);  // tiny latency-bound kernel, usually overlapped with a bandwidth-bound one
     __shared__ double s_m[K3_THREADS / 64];
     __shared__ double s_acc[K3_THREADS / 64][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

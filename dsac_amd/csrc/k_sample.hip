@@ -80,6 +80,9 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // of P3P, run in parallel instead of in sequence).
 __global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged) {
+    // latency-bound kernel that is meant to run underneath the bandwidth-bound K2 of another frame: raise the wave priority
+    // so that its (single) wave per SIMD wins issue arbitration against K2's many waves
+    __builtin_amdgcn_s_setprio(3);
     const int h = blockIdx.x;
     const int lane = threadIdx.x;
     const int root = lane & 3;

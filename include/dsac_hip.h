@@ -125,7 +125,9 @@ int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* se
 /* The same work as a two-slot software pipeline inside one context: dsac_sample_ahead(slot) enqueues K1 for a LATER
  * frame on an auxiliary stream; dsac_score_sampled(slot) enqueues K2 -> K3 for that slot on the context's stream.
  * Called as  ahead(0) ; { ahead(1-s) ; score(s) ; s = 1-s } ...  the latency-bound sampling of frame i+1 runs underneath
- * the bandwidth-bound scoring of frame i and K2 launches follow each other back to back.  Device pointers only
+ * the bandwidth-bound scoring of frame i, the small K3 tail of frame i runs under K2 of frame i+1, and K2 launches follow
+ * each other back to back on the context's stream.  The error images are complete in stream order; scores / w / entropy /
+ * avg6 are complete after dsac_synchronize (they are produced on the auxiliary stream).  Device pointers only
  * (the calls never block); poses/sets_out/ok of a slot must stay untouched until its score call has been issued,
  * and dsac_synchronize waits for both streams. */
 int dsac_sample_ahead(dsac_ctx* ctx, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,

@@ -5,10 +5,11 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; O=gpurun_out/r01; mkdir -p $O
 export TMPDIR=/tmp
 nproc > $O/nproc.txt
+echo "== bench 2 contexts, frames round-robin"; timeout 600 python bench.py --streams 2 --overlap frames --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_frames2.json | cut -c1-200
 echo "== bench (default)"; timeout 600 python bench.py 2>/dev/null | tail -1 | tee $O/bench_default.json | cut -c1-400
-echo "== bench (1 stream)"; timeout 600 python bench.py --streams 1 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_streams1.json | cut -c1-200
-echo "== bench K2 only, N=4096 (configs[2])"; for m in err both; do timeout 600 python bench.py --steps 30 --warmup 5 --hyps 4096 --kernel-only --no-cpu-baseline --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_4096_$m.json | cut -c1-120; done
-echo "== bench K2 only, N=256"; for m in err both; do timeout 600 python bench.py --steps 200 --warmup 20 --kernel-only --no-cpu-baseline --streams 1 --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_256_$m.json | cut -c1-120; done
+echo "== bench (no overlap)"; timeout 600 python bench.py --streams 1 --overlap frames --event-stride 1 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_streams1.json | cut -c1-200
+echo "== bench K2 only, N=4096 (configs[2])"; for m in err both; do timeout 600 python bench.py --steps 30 --warmup 5 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --event-stride 1 --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_4096_$m.json | cut -c1-120; done
+echo "== bench K2 only, N=256"; for m in err both; do timeout 600 python bench.py --steps 200 --warmup 20 --kernel-only --no-cpu-baseline --streams 1 --event-stride 1 --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_256_$m.json | cut -c1-120; done
 cd /tmp
 echo "== rocprofv3 kernel trace of the default bench"
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o k -- python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline > /tmp/kt.log 2>&1
@@ -31,9 +32,9 @@ for k, d in agg.items():
     print("%s | %s | n=%d | " % (tag, k, len(d["_dur_ns"])) + " | ".join("%s=%.6g" % (c, sum(v) / len(v)) for c, v in sorted(d.items())))
 PY
 }
-K2="python $REPO/bench.py --steps 12 --warmup 4 --kernel-only --no-cpu-baseline --streams 1 --k2-mode both"
-K2E="python $REPO/bench.py --steps 12 --warmup 4 --kernel-only --no-cpu-baseline --streams 1 --k2-mode err"
-K2B="python $REPO/bench.py --steps 6 --warmup 2 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --k2-mode both"
+K2="python $REPO/bench.py --steps 12 --warmup 4 --kernel-only --no-cpu-baseline --streams 1 --event-stride 0 --k2-mode both"
+K2E="python $REPO/bench.py --steps 12 --warmup 4 --kernel-only --no-cpu-baseline --streams 1 --event-stride 0 --k2-mode err"
+K2B="python $REPO/bench.py --steps 6 --warmup 2 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --event-stride 0 --k2-mode both"
 {
 pmc k2_256_both_write WRITE_SIZE -- $K2
 pmc k2_256_both_fetch FETCH_SIZE -- $K2
