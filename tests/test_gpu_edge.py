@@ -1,0 +1,131 @@
+"""Edge cases of the C ABI on the GPU: empty and degenerate inputs, NaNs, big and re-sized frames, several contexts."""
+import numpy as np
+import pytest
+
+import dsac_amd
+from conftest import excl_clamp_edge
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batches_are_no_ops(engine, frame40):
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    p, s, ok = engine.sample(0)
+    assert p.shape == (0, 6)
+    engine.reproject(np.zeros((0, 6)), N=0, err=np.zeros((0, 1600), np.float32))
+    assert engine.dPNP(np.zeros((0, 4), np.int32)).shape == (0, 6, 12)
+    g = engine.dScore(np.zeros((0, 6)), np.zeros((0, 4), np.int32), np.zeros((0, 1600), np.float32))
+    assert np.all(g == 0)
+    out, sd = engine.refine(np.zeros((0, 6)), np.zeros((1, 1600), np.int32))
+    assert out.shape == (0, 6)
+    with pytest.raises(dsac_amd.capi.DsacError):
+        engine.softMax(np.zeros(0))  # softmax of nothing is an error, like an empty std::vector in the reference would be UB
+
+
+def test_tiny_maps(engine, orc):
+    # fewer than 4 cells: sampling is impossible, reprojection still works
+    xyz = np.array([[0, 0, 1000], [10, 0, 1000], [0, 10, 1000]], np.float32)
+    uv = np.array([[320, 240], [330, 240], [320, 250]], np.float32)
+    engine.set_frame(xyz, uv, 1, 3, (525.0, 525.0, 320.0, 240.0))
+    with pytest.raises(dsac_amd.capi.DsacError):
+        engine.sample(4)
+    e = engine.getDiffMap(np.zeros((1, 6))).reshape(-1)
+    ref = orc.get_diff_maps(np.zeros(6), xyz, uv, 1, 3, (525.0, 525.0, 320.0, 240.0))[0]
+    assert np.abs(e - ref).max() <= 1e-3
+    # exactly 4 cells: every attempt uses all of them
+    fr4 = dict(xyz=np.array([[0, 0, 1000], [100, 0, 1100], [0, 100, 1200], [100, 100, 900]], np.float32),
+               uv=np.array([[320, 240], [367.7, 240], [320, 283.75], [378.3, 298.3]], np.float32))
+    engine.set_frame(fr4["xyz"], fr4["uv"], 2, 2, (525.0, 525.0, 320.0, 240.0))
+    p, s, ok = engine.sample(8, seed=1, max_tries=64)
+    pr, sr, okr, _ = orc.sample(8, 1, fr4["xyz"], fr4["uv"], 2, 2, (525.0, 525.0, 320.0, 240.0), max_tries=64)
+    assert np.array_equal(ok, okr)
+    assert all(sorted(x) == [0, 1, 2, 3] for x in s[ok.astype(bool)])
+
+
+def test_nan_and_inf_coordinates_do_not_poison_neighbours(engine, orc, frame40):
+    fr = dict(frame40)
+    xyz = fr["xyz"].copy()
+    xyz[5] = np.nan
+    xyz[77, 2] = np.inf
+    engine.set_frame(xyz, fr["uv"], 40, 40, fr["cam"])
+    poses, *_ = orc.sample(16, 3, frame40["xyz"], frame40["uv"], 40, 40, fr["cam"])
+    e = engine.getDiffMap(poses).reshape(16, -1)
+    ref = orc.get_diff_maps(poses, frame40["xyz"], fr["uv"], 40, 40, fr["cam"])
+    good = np.ones(1600, bool)
+    good[[5, 77]] = False
+    m = excl_clamp_edge(e[:, good], ref[:, good])
+    assert np.abs(e[:, good] - ref[:, good])[m].max() <= 1e-3
+    soft = engine.softInlierScores(poses)
+    assert np.all(np.isfinite(soft))  # NaN residuals clamp to 100 px (v_min_f32) and contribute ~0
+    # a NaN pose gives a finite (clamped) error image and never crashes
+    bad = poses.copy()
+    bad[0, 0] = np.nan
+    eb = engine.getDiffMap(bad).reshape(16, -1)
+    assert np.all(np.isfinite(eb[1:])) and np.array_equal(eb[1:], e[1:])
+
+
+def test_many_hypotheses_and_big_frame(engine, orc, synth):
+    fr = synth.chess_like_frame(40, 40, seed=5, quantise_int16=True)
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    N = 20000
+    poses, sets, ok = engine.sample(N, seed=11, max_tries=256)
+    assert ok.mean() > 0.99
+    soft = engine.softInlierScores(poses)
+    w, ent, avg = engine.softMax(soft, 0.1, poses)
+    assert abs(w.sum() - 1) < 1e-9 and np.all(np.isfinite(avg))
+    idx = np.random.default_rng(0).choice(N, 32, replace=False)
+    ref = orc.soft_inlier(orc.get_diff_maps(poses[idx], fr["xyz"], fr["uv"], 40, 40, fr["cam"]), 10.0, 0.5)
+    assert np.abs(soft[idx] - ref).max() <= 1e-4 * max(1.0, ref.max())
+    # full-HD map (P = 2 073 600): a few hypotheses, checked on a random subset of cells
+    big = synth.chess_like_frame(1080, 1920, seed=9, cam=(1400.0, 1400.0, 960.0, 540.0))
+    uvb = np.stack(np.meshgrid(np.arange(1920, dtype=np.float32), np.arange(1080, dtype=np.float32)), -1).reshape(-1, 2)
+    engine.set_frame(big["xyz"], None, 1080, 1920, big["cam"])
+    p3 = np.stack([big["gt_pose"], big["gt_pose"] + [0.01, 0, 0, 5, 0, 0], np.zeros(6)])
+    e = engine.getDiffMap(p3).reshape(3, -1)
+    cells = np.random.default_rng(1).choice(1080 * 1920, 5000, replace=False)
+    ref = orc.get_diff_maps(p3, big["xyz"][cells], uvb[cells], 1, 5000, big["cam"])
+    m = excl_clamp_edge(e[:, cells], ref)
+    assert np.abs(e[:, cells] - ref)[m].max() <= 2e-3  # larger focal length and coordinates: fp32 projection error grows with f
+
+
+def test_frames_can_be_replaced_and_contexts_are_independent(orc, synth):
+    a = synth.chess_like_frame(40, 40, seed=1)
+    b = synth.chess_like_frame(24, 56, seed=2)
+    with dsac_amd.Engine(0) as e1, dsac_amd.Engine(0) as e2:
+        e1.set_frame(a["xyz"], a["uv"], 40, 40, a["cam"])
+        e2.set_frame(b["xyz"], b["uv"], 24, 56, b["cam"])
+        pa, sa, oka = e1.sample(64, seed=3)
+        pb, sb, okb = e2.sample(64, seed=3)
+        assert np.array_equal(sa, orc.sample(64, 3, a["xyz"], a["uv"], 40, 40, a["cam"])[1])
+        assert np.array_equal(sb, orc.sample(64, 3, b["xyz"], b["uv"], 24, 56, b["cam"])[1])
+        # swap the frames: contexts regrow their scratch and carry no state from the previous frame
+        e1.set_frame(b["xyz"], b["uv"], 24, 56, b["cam"])
+        e2.set_frame(a["xyz"], a["uv"], 40, 40, a["cam"])
+        assert np.array_equal(e1.sample(64, seed=3)[1], sb)
+        assert np.array_equal(e2.sample(64, seed=3)[1], sa)
+        ea = e2.getDiffMap(pa).reshape(64, -1)
+        ref = orc.get_diff_maps(pa, a["xyz"], a["uv"], 40, 40, a["cam"])
+        m = excl_clamp_edge(ea, ref)
+        assert np.abs(ea - ref)[m].max() <= 1e-3
+
+
+def test_bad_arguments_are_rejected(engine, frame40):
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    C = dsac_amd.capi
+    for call in (lambda: engine.sample(4, max_tries=0),
+                 lambda: engine.refine(np.zeros(6), np.zeros((1, 1600), np.int32), max_inl=1000),
+                 lambda: engine.dPNP(np.zeros((2, 4), np.int32), eps=0.0),
+                 lambda: engine.dRefine(np.zeros(6), np.zeros((1, 1600), np.int32), np.zeros(1600, np.int32), sub_sample=0.0)):
+        with pytest.raises(C.DsacError) as ei:
+            call()
+        assert ei.value.code == C.DSAC_ERR_INVALID
+    # quirk transpose needs a square map
+    engine.set_frame(np.zeros((6, 3), np.float32), None, 2, 3, fr["cam"])
+    with pytest.raises(C.DsacError):
+        engine.dScore(np.zeros((1, 6)), np.zeros((1, 4), np.int32), np.zeros((1, 6), np.float32), quirk_transpose=True)
+    # out-of-range set indices are clamped, never fault
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    p, s, ok = engine.sample(2, sets=np.array([[0, 1, 2, 10 ** 6], [-5, 3, 4, 5]], np.int32))
+    assert p.shape == (2, 6)
