@@ -23,6 +23,7 @@
 namespace dk {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int K4_THREADS = 256;
 constexpr int K4_HT = 32;
@@ -63,18 +64,44 @@ hipError_t backward_prep(hipStream_t st, int N, const double* poses, const Frame
 }
 
 // --------------------------------------------------------------------------------------------------
-// Sum over the 64 lanes with DPP only (no LDS crossbar): 4 intra-row steps + row_bcast:15 / row_bcast:31.
-// The total is valid in lane 63.
-DM_INLINE float wave_sum_to_lane63(float v) {
-#define DSAC_DPP_ADD(ctrl, rmask)                                                                                          \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
-    DSAC_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
-    DSAC_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
-    DSAC_DPP_ADD(0x141, 0xf);  // row_half_mirror
-    DSAC_DPP_ADD(0x140, 0xf);  // row_mirror        -> every lane of a row holds the row sum
-    DSAC_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-    DSAC_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave sum
-#undef DSAC_DPP_ADD
+// Transpose-reduce of 12 per-lane values over the 64 lanes of a wave (26 + 9 VALU ops instead of 12 x 6 DPP steps
+// with their adds): every step halves both the number of live values per lane and the number of lanes left to sum.
+//   v_permlane32_swap / v_permlane16_swap (gfx950): swap(x, y) exchanges the upper half (odd 16-rows) of x with the
+//   lower half (even rows) of y, so x + y afterwards holds "value x summed over both halves" in the lower lanes and
+//   "value y summed" in the upper ones.  Inside a 16-row the same idea runs on quad_perm DPP moves with per-lane selects,
+//   then two row rotations finish the sum over lane bits 2 and 3.
+// Lane L returns the wave total of value index
+//   6*(L>>5) + 3*((L>>4)&1) + {0 if L&3==0, 1 if L&3==2, 2 if L&3==1}      (lanes with L&3 == 3 hold nothing)
+// (scripts/micro/wave_sum12.hip checks this mapping on the device.)
+DM_INLINE void lane_swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+DM_INLINE void lane_swap16(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+template <int CTRL, int BANK>
+DM_INLINE float dpp_merge(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, 0xf, BANK, false));
+}
+DM_INLINE float wave_sum12(float (&a)[12], int lane) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) { lane_swap32(a[k], a[6 + k]); a[k] += a[6 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { lane_swap16(a[k], a[3 + k]); a[k] += a[3 + k]; }
+    const bool odd = lane & 1, b1 = lane & 2;
+    // lane ^ 1: even lanes keep (a0, a1), odd lanes keep (a2, -); each lane sends what its partner keeps
+    const float s0 = (odd ? a[2] : a[0]) + dpp_merge<0xB1, 0xf>(0.f, odd ? a[0] : a[2]);
+    const float s1 = (odd ? 0.f : a[1]) + dpp_merge<0xB1, 0xf>(0.f, odd ? a[1] : 0.f);
+    // lane ^ 2: bit1 = 0 keeps s0, bit1 = 1 keeps s1
+    float v = (b1 ? s1 : s0) + dpp_merge<0x4E, 0xf>(0.f, b1 ? s0 : s1);
+    v += dpp_merge<0x124, 0xf>(0.f, v);  // row_ror:4
+    v += dpp_merge<0x128, 0xf>(0.f, v);  // row_ror:8
     return v;
 }
 
@@ -109,7 +136,8 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     const int tile0 = pt * K4_THREADS * NP;
     int pbase[PXG];
     bool valid[PXG];
-    float X[NP], Y[NP], Z[NP], pu[NP], pv[NP];
+    // per pixel: (X, Y) and (Z, 1) as register pairs (operands of v_pk_fma_f32), (u - cx, v - cy) as a pair
+    f2 xy[NP], zw[NP], ppix[NP];
 #pragma unroll
     for (int j = 0; j < PXG; j++) {
         pbase[j] = tile0 + j * K4_THREADS * PXL + tid * PXL;
@@ -118,42 +146,51 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
             if (valid[j]) {
                 const f4* src = reinterpret_cast<const f4*>(xyz + (size_t)pbase[j] * 3);
                 const f4 a = src[0], bb = src[1], c = src[2];
-                X[j * 4 + 0] = a.x; Y[j * 4 + 0] = a.y; Z[j * 4 + 0] = a.z; X[j * 4 + 1] = a.w; Y[j * 4 + 1] = bb.x; Z[j * 4 + 1] = bb.y;
-                X[j * 4 + 2] = bb.z; Y[j * 4 + 2] = bb.w; Z[j * 4 + 2] = c.x; X[j * 4 + 3] = c.y; Y[j * 4 + 3] = c.z; Z[j * 4 + 3] = c.w;
+                xy[j * 4 + 0] = f2{a.x, a.y};   zw[j * 4 + 0] = f2{a.z, 1.f};
+                xy[j * 4 + 1] = f2{a.w, bb.x};  zw[j * 4 + 1] = f2{bb.y, 1.f};
+                xy[j * 4 + 2] = f2{bb.z, bb.w}; zw[j * 4 + 2] = f2{c.x, 1.f};
+                xy[j * 4 + 3] = f2{c.y, c.z};   zw[j * 4 + 3] = f2{c.w, 1.f};
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) X[j * 4 + k] = Y[j * 4 + k] = Z[j * 4 + k] = 0.f;
+                for (int k = 0; k < 4; k++) { xy[j * 4 + k] = f2{0.f, 0.f}; zw[j * 4 + k] = f2{0.f, 1.f}; }
             }
         } else {
-            if (valid[j]) { X[j] = xyz[(size_t)pbase[j] * 3]; Y[j] = xyz[(size_t)pbase[j] * 3 + 1]; Z[j] = xyz[(size_t)pbase[j] * 3 + 2]; }
-            else { X[j] = Y[j] = Z[j] = 0.f; }
+            if (valid[j]) { xy[j] = f2{xyz[(size_t)pbase[j] * 3], xyz[(size_t)pbase[j] * 3 + 1]}; zw[j] = f2{xyz[(size_t)pbase[j] * 3 + 2], 1.f}; }
+            else { xy[j] = f2{0.f, 0.f}; zw[j] = f2{0.f, 1.f}; }
         }
+        if (UV) {
 #pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const int p = pbase[j] + k;
-            if (UV) {
-                pu[j * PXL + k] = valid[j] ? uv[(size_t)p * 2] - cx : 0.f;
-                pv[j * PXL + k] = valid[j] ? uv[(size_t)p * 2 + 1] - cy : 0.f;
-            } else {
-                const int y = p / W, x = p - y * W;
-                pu[j * PXL + k] = (float)x - cx;
-                pv[j * PXL + k] = (float)y - cy;
+            for (int k = 0; k < PXL; k++) {
+                const int p = pbase[j] + k;
+                ppix[j * PXL + k] = valid[j] ? f2{uv[(size_t)p * 2] - cx, uv[(size_t)p * 2 + 1] - cy} : f2{0.f, 0.f};
+            }
+        } else {
+            int y = pbase[j] / W, x = pbase[j] - y * W;  // one division per group, then walk with row wrap
+#pragma unroll
+            for (int k = 0; k < PXL; k++) {
+                ppix[j * PXL + k] = f2{(float)x - cx, (float)y - cy};
+                if (++x == W) { x = 0; y++; }
             }
         }
     }
     __syncthreads();
 
-    float gx[NP][3];
+    f2 gxy[NP];
+    float gz[NP];
 #pragma unroll
-    for (int k = 0; k < NP; k++) gx[k][0] = gx[k][1] = gx[k][2] = 0.f;
+    for (int k = 0; k < NP; k++) { gxy[k] = f2{0.f, 0.f}; gz[k] = 0.f; }
 
     float* gout = G12_part + ((size_t)(pt * (K4_THREADS / 64) + wave) * N + h0) * 12;
+    // which of the 12 per-hypothesis sums this lane holds after wave_sum12 (-1: none)
+    const int gslot = ((lane & 12) == 0 && (lane & 3) != 3) ? 6 * (lane >> 5) + 3 * ((lane >> 4) & 1) + ((lane & 3) == 0 ? 0 : (lane & 3) == 2 ? 1 : 2) : -1;
     for (int h = 0; h < nh; h++) {
         const f4* sp = reinterpret_cast<const f4*>(s_rec + h * BWD_REC);
         const f4 r0 = sp[0], r1 = sp[1], r2 = sp[2];
-        float G[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) G[i] = 0.f;
+        // column pairs of R' = rows 0,1 of each column: (R'00, R'10), (R'01, R'11), (R'02, R'12), (t'0, t'1)
+        const f2 c0 = {r0.x, r1.x}, c1 = {r0.y, r1.y}, c2 = {r0.z, r1.z}, c3 = {r0.w, r1.w};
+        const f2 r0xy = {r0.x, r0.y}, r1xy = {r1.x, r1.y}, r2xy = {r2.x, r2.y};
+        // G pairs: Ga[i] = C_i * (X, Y)  ;  Gb[i] = C_i * (Z, 1)
+        f2 Ga[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}}, Gb[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < PXG; j++) {
             float wv[PXL];
@@ -173,47 +210,42 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
                 const int i = j * PXL + k;
-                const float ex = fmaf(r0.x, X[i], fmaf(r0.y, Y[i], fmaf(r0.z, Z[i], r0.w)));
-                const float ey = fmaf(r1.x, X[i], fmaf(r1.y, Y[i], fmaf(r1.z, Z[i], r1.w)));
-                const float ez = fmaf(r2.x, X[i], fmaf(r2.y, Y[i], fmaf(r2.z, Z[i], r2.w)));
-                const float iz = __builtin_amdgcn_rcpf(ez);
+                const float Xi = xy[i].x, Yi = xy[i].y, Zi = zw[i].x;
+                // (E.x, E.y) as one packed chain, E.z scalar
+                const f2 exy = __builtin_elementwise_fma(c0, f2{Xi, Xi}, __builtin_elementwise_fma(c1, f2{Yi, Yi}, __builtin_elementwise_fma(c2, f2{Zi, Zi}, c3)));
+                const float ez = fmaf(r2.x, Xi, fmaf(r2.y, Yi, fmaf(r2.z, Zi, r2.w)));
+                // guard |E.z| < 1e-8 -> 0 (cnn_softam.h:416,476): a zero reciprocal keeps everything below finite
+                const float iz = (fabsf(ez) >= 1e-8f) ? __builtin_amdgcn_rcpf(ez) : 0.f;
                 const float fz = f * iz;
-                const float du = fmaf(ex, fz, pu[i]);    // u - px,  px = -f ex/ez + cx
-                const float dv = fmaf(-ey, fz, pv[i]);   // v - py,  py =  f ey/ez + cy
-                const float err = __builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du));
-                // guards of the reference: |E.z| < 1e-8 -> 0 ; err > CNN_OBJ_MAXINPUT -> 0
-                const bool keep = valid[j] && (fabsf(ez) >= 1e-8f) && !(err > clampv);
+                // (u - px, v - py) with px = -f E.x/E.z + cx, py = f E.y/E.z + cy
+                const f2 d = __builtin_elementwise_fma(exy, f2{fz, -fz}, ppix[i]);
+                const f2 dq = d * d;
+                const float err = __builtin_amdgcn_sqrtf(dq.x + dq.y);
                 float w;
                 if (SOFTMODE) {
-                    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kA, fminf(err, clampv), kB)));
-                    w = s_g[h] * (-beta) * s * (1.0f - s);
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(kA, fminf(err, clampv), kB)));
+                    w = s_g[h] * (-beta) * sg * (1.0f - sg);
                 } else {
                     w = wv[k];
                 }
+                // guards: invalid lane, E.z ~ 0 (iz == 0), err > CNN_OBJ_MAXINPUT -> zero contribution
+                const bool keep = valid[j] && (iz != 0.f) && !(err > clampv);
                 const float ie = __builtin_amdgcn_rcpf(err + 1e-8f);
-                const float wfz = w * fz * ie;                    // w f / (E.z (err + eps))
-                // a = -(du, dv)/(err+eps);  c0 = -a0 f/E.z ; c1 = a1 f/E.z ; c2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w);
-                // the selects also kill the inf/NaN of E.z == 0
-                const float C0 = keep ? du * wfz : 0.f;
-                const float C1 = keep ? -dv * wfz : 0.f;
-                const float C2 = keep ? (dv * ey - du * ex) * wfz * iz : 0.f;
-                gx[i][0] = fmaf(r0.x, C0, fmaf(r1.x, C1, fmaf(r2.x, C2, gx[i][0])));
-                gx[i][1] = fmaf(r0.y, C0, fmaf(r1.y, C1, fmaf(r2.y, C2, gx[i][1])));
-                gx[i][2] = fmaf(r0.z, C0, fmaf(r1.z, C1, fmaf(r2.z, C2, gx[i][2])));
-                G[0] = fmaf(C0, X[i], G[0]); G[1] = fmaf(C0, Y[i], G[1]); G[2] = fmaf(C0, Z[i], G[2]);
-                G[3] = fmaf(C1, X[i], G[3]); G[4] = fmaf(C1, Y[i], G[4]); G[5] = fmaf(C1, Z[i], G[5]);
-                G[6] = fmaf(C2, X[i], G[6]); G[7] = fmaf(C2, Y[i], G[7]); G[8] = fmaf(C2, Z[i], G[8]);
-                G[9] += C0; G[10] += C1; G[11] += C2;
+                const float wfz = keep ? w * fz * ie : 0.f;       // w f / (E.z (err + eps))
+                // a = -(du, dv)/(err+eps);  c0 = -a0 f/E.z ; c1 = a1 f/E.z ; c2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
+                const f2 C01 = d * f2{wfz, -wfz};
+                const f2 de = d * exy;                            // (du E.x, dv E.y)
+                const float C2 = (de.y - de.x) * (wfz * iz);
+                gxy[i] = __builtin_elementwise_fma(r0xy, f2{C01.x, C01.x}, __builtin_elementwise_fma(r1xy, f2{C01.y, C01.y}, __builtin_elementwise_fma(r2xy, f2{C2, C2}, gxy[i])));
+                gz[i] = fmaf(r0.z, C01.x, fmaf(r1.z, C01.y, fmaf(r2.z, C2, gz[i])));
+                Ga[0] = __builtin_elementwise_fma(f2{C01.x, C01.x}, xy[i], Ga[0]); Gb[0] = __builtin_elementwise_fma(f2{C01.x, C01.x}, zw[i], Gb[0]);
+                Ga[1] = __builtin_elementwise_fma(f2{C01.y, C01.y}, xy[i], Ga[1]); Gb[1] = __builtin_elementwise_fma(f2{C01.y, C01.y}, zw[i], Gb[1]);
+                Ga[2] = __builtin_elementwise_fma(f2{C2, C2}, xy[i], Ga[2]);       Gb[2] = __builtin_elementwise_fma(f2{C2, C2}, zw[i], Gb[2]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < 12; i++) G[i] = wave_sum_to_lane63(G[i]);
-        if (lane == 63) {
-            f4* o = reinterpret_cast<f4*>(gout + (size_t)h * 12);
-            o[0] = f4{G[0], G[1], G[2], G[3]};
-            o[1] = f4{G[4], G[5], G[6], G[7]};
-            o[2] = f4{G[8], G[9], G[10], G[11]};
-        }
+        float G[12] = {Ga[0].x, Ga[0].y, Gb[0].x, Ga[1].x, Ga[1].y, Gb[1].x, Ga[2].x, Ga[2].y, Gb[2].x, Gb[0].y, Gb[1].y, Gb[2].y};
+        const float tot = wave_sum12(G, lane);
+        if (gslot >= 0) gout[(size_t)h * 12 + gslot] = tot;
     }
 
 #pragma unroll
@@ -222,11 +254,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
         float* dst = grad_part + (size_t)ht * P * 3 + (size_t)pbase[j] * 3;
         if (VEC) {
             f4* d4 = reinterpret_cast<f4*>(dst);
-            d4[0] = f4{gx[j * 4][0], gx[j * 4][1], gx[j * 4][2], gx[j * 4 + 1][0]};
-            d4[1] = f4{gx[j * 4 + 1][1], gx[j * 4 + 1][2], gx[j * 4 + 2][0], gx[j * 4 + 2][1]};
-            d4[2] = f4{gx[j * 4 + 2][2], gx[j * 4 + 3][0], gx[j * 4 + 3][1], gx[j * 4 + 3][2]};
+            d4[0] = f4{gxy[j * 4].x, gxy[j * 4].y, gz[j * 4], gxy[j * 4 + 1].x};
+            d4[1] = f4{gxy[j * 4 + 1].y, gz[j * 4 + 1], gxy[j * 4 + 2].x, gxy[j * 4 + 2].y};
+            d4[2] = f4{gz[j * 4 + 2], gxy[j * 4 + 3].x, gxy[j * 4 + 3].y, gz[j * 4 + 3]};
         } else {
-            dst[0] = gx[j][0]; dst[1] = gx[j][1]; dst[2] = gx[j][2];
+            dst[0] = gxy[j].x; dst[1] = gxy[j].y; dst[2] = gz[j];
         }
     }
 }
