@@ -146,7 +146,7 @@ void d_project_d_obj(const float* pt, const float* obj, const double* R, const d
 // ---- core/cnn_softam.h:464-528  dProjectdHyp -------------------------------------------------------
 // NB the reference re-orthonormalises `rot` in place through Rodrigues(rot)->rod->rot (quirk 7); the
 // Jacobian dRdH is that of the re-derived Rodrigues vector.
-void d_project_d_hyp(const float* pt, const float* obj, const double* R, const double* t, const Cam& K, double* J6) {
+void d_project_d_hyp(const float* pt, const float* obj, const double* R, const double* t, const Cam& K, double* J6, double* R_writeback = nullptr) {
     double f = K.fx, ppx = K.cx, ppy = K.cy;
     for (int i = 0; i < 6; i++) J6[i] = 0;
     double ox = obj[0], oy = obj[1], oz = obj[2];
@@ -171,6 +171,7 @@ void d_project_d_hyp(const float* pt, const float* obj, const double* R, const d
     double rod[3], Rre[9], dRdH[27];
     cvl::rodrigues_mat2vec(R, rod);
     cvl::rodrigues_vec2mat(rod, Rre, dRdH);  // 3x9, used transposed (9x3)
+    if (R_writeback) std::memcpy(R_writeback, Rre, sizeof(Rre));  // quirk 7: cnn_softam.h:508 writes through `const cv::Mat& rot`
     double dNdR[9];
     for (int k = 0; k < 9; k++) dNdR[k] = dNdP[0] * dPdR[0][k] + dNdP[1] * dPdR[1][k];
     for (int i = 0; i < 3; i++) {
@@ -626,7 +627,9 @@ void orc_dRefineObj(const double* init_cv6, const int32_t* perm, int refSteps, i
 // hyps are re-derived from the minimal sets exactly as dScore does (:583-602).  Also returns the
 // per-hypothesis 1x6 pose gradient G6 (N x 6) and support gradient S (N x 12) for inspection.
 void orc_dScore(int N, const int32_t* sets, const double* dDiff, const float* xyz, const float* uv, int H, int W, const double* cam,
-                int quirk_transpose, double* grad /*P x 3, += */, double* G6_out, double* S_out) {
+                int quirks /*bit0: transposed columns (quirk 1); bit1: rotation written back per pixel (quirk 7)*/, double* grad /*P x 3, += */,
+                double* G6_out, double* S_out) {
+    const bool quirk_transpose = quirks & 1, quirk_writeback = quirks & 2;
     Frame F{xyz, uv, H, W, Cam{cam[0], cam[1], cam[2], cam[3]}};
     const int P = H * W;
     std::vector<std::vector<double>> jac(N);
@@ -652,7 +655,7 @@ void orc_dScore(int N, const int32_t* sets, const double* dDiff, const float* xy
                 double w = dDiff[(size_t)h * P + p];
                 double dPdO[3], dPdH[6];
                 d_project_d_obj(uv + 2 * (size_t)p, xyz + 3 * (size_t)p, R, t, F.K, dPdO);
-                d_project_d_hyp(uv + 2 * (size_t)p, xyz + 3 * (size_t)p, R, t, F.K, dPdH);
+                d_project_d_hyp(uv + 2 * (size_t)p, xyz + 3 * (size_t)p, R, t, F.K, dPdH, quirk_writeback ? R : nullptr);
                 int col = quirk_transpose ? (x * W * 3 + y * 3) : (p * 3);
                 for (int c = 0; c < 3; c++) J[col + c] = w * dPdO[c];  // copyTo (overwrite)
                 for (int k = 0; k < 6; k++) G6[k] += w * dPdH[k];

@@ -363,7 +363,7 @@ def dRefineObj(init_cv6, perm, inlier_map, xyz, uv, H, W, cam, inlier_count=100,
     return J
 
 
-def dScore(sets, dDiff, xyz, uv, H, W, cam, quirk_transpose=False, grad=None):
+def dScore(sets, dDiff, xyz, uv, H, W, cam, quirk_transpose=False, grad=None, quirk_rot_writeback=False):
     sets, sp = _i(np.asarray(sets).reshape(-1, 4))
     N = sets.shape[0]
     dDiff, dp = _d(np.asarray(dDiff).reshape(N, H * W))
@@ -374,7 +374,7 @@ def dScore(sets, dDiff, xyz, uv, H, W, cam, quirk_transpose=False, grad=None):
         grad = np.zeros((H * W, 3))
     G6 = np.zeros((N, 6))
     S = np.zeros((N, 12))
-    lib().orc_dScore(N, sp, dp, xp, up, H, W, cp, int(bool(quirk_transpose)), grad.ctypes.data_as(c_dp), G6.ctypes.data_as(c_dp),
+    lib().orc_dScore(N, sp, dp, xp, up, H, W, cp, int(bool(quirk_transpose)) | (2 if quirk_rot_writeback else 0), grad.ctypes.data_as(c_dp), G6.ctypes.data_as(c_dp),
                      S.ctypes.data_as(c_dp))
     return grad, G6, S
 

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_frame_v1.npz from the REAL reference (oracle/_ref/libdsac_ref.so = /root/reference/core
+compiled where it lies against OpenCV / Lua stand-ins, see oracle/refbuild/).  Needs /root/reference, so it runs in
+the build container only; the fixture it writes travels to the GPU box.
+
+One synthetic 7-Scenes-like frame goes through the reference's processImage (40x40 stochastic sub-sampling, 64
+hypotheses by P3P, soft-inlier score in place of the score CNN, soft-argmax, 8 refinement steps, loss) and through
+the backward section of its training loop (train_ransac_softam.cpp:288-394).  Stored: every input the product needs
+to replay the frame (scene coordinates, sampling grid, the reference's own minimal sets and shuffles, ground truth)
+and every output to compare against.  Run:  python tests/golden/make_golden_ref.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from dsac_amd import synth  # noqa: E402
+from oracle import reference as ref  # noqa: E402
+
+TAU, BETA, ALPHA = 10.0, 0.5, 0.1
+N = 64
+SUB_SAMPLE = 0.05
+
+
+def main():
+    assert os.path.isdir("/root/reference/core"), "the reference sources are needed to generate this fixture"
+    ref.build()
+    ref.lib()
+    ref.set_score_model(TAU, BETA, ALPHA)
+    fr = synth.chess_like_frame(40, 40, seed=20260925, quantise_int16=True)
+    # ground truth a little off the pose the scene was rendered with, so that loss and gradient are not zero
+    gt_cv = fr["gt_pose"] + np.array([0.012, -0.02, 0.008, 6.0, -9.0, 14.0])
+    gt_jp6 = ref.cv_to_jp6(gt_cv)
+    r = ref.processImage(1305, fr["xyz"], gt_jp6, hyps=N, backward=True, sub_sample=SUB_SAMPLE)
+    out = dict(cam=ref.cam(), tau=TAU, beta=BETA, alpha=ALPHA, sub_sample=SUB_SAMPLE, gt_jp6=gt_jp6, thr=10, inlier_count=100, ref_steps=8)
+    for k in ("hyps", "sampledPoints", "sfScores", "avgHyp", "refAvgHyp", "sampling", "estObj", "inlierMap", "pixelIdxs", "dLoss_dObj"):
+        out[k] = r[k]
+    for k in ("loss", "sfEntropy", "tErr", "rotErr", "correct"):
+        out[k] = np.asarray(r[k])
+    # the reference's error images for the first 8 hypotheses and for the averaged / refined pose
+    uvi = r["sampling"]
+    out["diffMaps8"] = np.stack([ref.getDiffMap(r["hyps"][h], r["estObj"], uvi, 40, 40) for h in range(8)])
+    out["diffMap_avg"] = ref.getDiffMap(r["avgHyp"], r["estObj"], uvi, 40, 40)
+    out["diffMap_ref"] = ref.getDiffMap(r["refAvgHyp"], r["estObj"], uvi, 40, 40)
+    # per-function vectors: dPNP of the first 8 sets, dLossMax, dRefineHyp, refined pose as the reference returns it (jp)
+    sets = r["sampledPoints"][:, :, 1] * 40 + r["sampledPoints"][:, :, 0]
+    uvf = uvi.astype(np.float32)
+    out["dPNP8"] = np.stack([ref.dPNP(uvf[sets[h]], r["estObj"][sets[h]]) for h in range(8)])
+    out["refAvgHyp_jp6"] = ref.cv_to_jp6(r["refAvgHyp"])
+    out["dLossMax"] = ref.dLossMax(out["refAvgHyp_jp6"], gt_jp6)
+    out["dRefineHyp"] = ref.dRefineHyp(r["avgHyp"], r["pixelIdxs"], r["estObj"], uvi, 40, 40)
+    # dScore on an explicit gradient image (what a score CNN's backward would hand over), first 8 hypotheses
+    rng = np.random.default_rng(7)
+    natural = rng.normal(size=(8, 40, 40)) * 1e-2
+    out["dScore_ddiff_natural"] = natural
+    out["dScore_jac_sum"] = ref.dScore(r["sampledPoints"][:8], r["estObj"], uvi, ddiff=natural.reshape(8, -1)).sum(0).reshape(1600, 3)
+    path = os.path.join(HERE, "ref_frame_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| loss %.4f rotErr %.4f tErr %.3f entropy %.4f" %
+          (r["loss"], r["rotErr"], r["tErr"], r["sfEntropy"]))
+
+
+if __name__ == "__main__":
+    main()
