@@ -48,6 +48,7 @@ struct dsac_ctx {
 
     // scratch, one buffer per role so that calls can be chained without aliasing
     DevBuf staged, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
+    int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
     // staging for host-pointer arguments: slots are bump-allocated per call
     std::vector<DevBuf> slots;
     size_t slot_next = 0;
@@ -587,6 +588,20 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     }
     HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), NT, c->g12_part.as<float>(), PT, c->dRdH.as<double>(), d_dpnp,
                                          d_sets, flags, d_grad, c->g6.as<double>()));
+    c->g6_n = N;
+    return end_call(c);
+}
+
+int dsac_last_pose_gradients(dsac_ctx* c, int N, double* G6) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_last_pose_gradients: ctx is NULL");
+    if (N < 0 || !G6) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: NULL argument or negative count");
+    if (N > c->g6_n) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: %d requested, the last score-backward call had %d", N, c->g6_n);
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    double* d_out;
+    ARG_TRY(out_arg(c, G6, (size_t)N * 6, &d_out));
+    HIP_TRY(c, hipMemcpyAsync(d_out, c->g6.p, (size_t)N * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return end_call(c);
 }
 

@@ -286,6 +286,111 @@ DM_INLINE void align3(const double M[3][3], const double X[3][3], const double E
 }
 
 // ------------------------------------------------------------------------------------------------
+// Horn's absolute orientation for 3 correspondences, the way OpenCV's P3P does it: largest eigenvector of the 4x4
+// N matrix by cyclic Jacobi sweeps (threshold schedule of the classic routine: 0.2*sum/16 for the first three
+// sweeps).  Used where parity with OpenCV's rounding matters more than speed: K5 (dPNP) takes central differences
+// of this pose with a 0.1 mm step, and on near-degenerate minimal sets the two alignment methods distribute the
+// residual incongruence of the triangles differently, which the 1/(2 eps) then amplifies.
+// ------------------------------------------------------------------------------------------------
+DM_INLINE void jrot(double& g_, double& h_, double s, double tau) {
+    const double g = g_, h = h_;
+    g_ = g - s * (h + g * tau);
+    h_ = h + s * (g - h * tau);
+}
+
+DM_INLINE void jacobi4(double A[16], double D[4], double U[16]) {
+    double B[4], Z[4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    B[0] = A[0]; B[1] = A[5]; B[2] = A[10]; B[3] = A[15];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { D[i] = B[i]; Z[i] = 0; }
+    for (int iter = 0; iter < 50; iter++) {
+        const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+        if (sum == 0.0) return;
+        const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = i + 1; j < 4; j++) {
+                const double Aij = A[4 * i + j];
+                const double eps_machine = 100.0 * fabs(Aij);
+                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) {
+                    A[4 * i + j] = 0.0;
+                } else if (fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+                    else {
+                        const double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh; Z[j] += hh; D[i] -= hh; D[j] += hh;
+                    A[4 * i + j] = 0.0;
+                    const double c = 1.0 / sqrt(1 + t * t), s = t * c, tau = s / (1.0 + c);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < i) jrot(A[k * 4 + i], A[k * 4 + j], s, tau);
+                        else if (k > i && k < j) jrot(A[i * 4 + k], A[k * 4 + j], s, tau);
+                        else if (k > j) jrot(A[i * 4 + k], A[j * 4 + k], s, tau);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) jrot(U[k * 4 + i], U[k * 4 + j], s, tau);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { B[i] += Z[i]; D[i] = B[i]; Z[i] = 0; }
+    }
+}
+
+// M[k] (camera-frame points) ~= R * X[k] + T  for k = 0..2
+DM_INLINE void align3_horn(const double M[3][3], const double X[3][3], double R[9], double T[3]) {
+    double Cs[3], Ce[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Ce[j] = (M[0][j] + M[1][j] + M[2][j]) / 3;
+        Cs[j] = (X[0][j] + X[1][j] + X[2][j]) / 3;
+    }
+    double s[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[a * 3 + j] = (X[0][a] * M[0][j] + X[1][a] * M[1][j] + X[2][a] * M[2][j]) / 3 - Ce[j] * Cs[a];
+    double Q[16], ev[4], U[16];
+    Q[0] = s[0] + s[4] + s[8];
+    Q[5] = s[0] - s[4] - s[8];
+    Q[10] = s[4] - s[8] - s[0];
+    Q[15] = s[8] - s[0] - s[4];
+    Q[4] = Q[1] = s[5] - s[7];
+    Q[8] = Q[2] = s[6] - s[2];
+    Q[12] = Q[3] = s[1] - s[3];
+    Q[9] = Q[6] = s[3] + s[1];
+    Q[13] = Q[7] = s[6] + s[2];
+    Q[14] = Q[11] = s[7] + s[5];
+    jacobi4(Q, ev, U);
+    // eigenvector of the largest eigenvalue, first maximum wins
+    double evm = ev[0];
+    double q0 = U[0], q1 = U[4], q2 = U[8], q3 = U[12];
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        if (ev[i] > evm) { evm = ev[i]; q0 = U[i]; q1 = U[4 + i]; q2 = U[8 + i]; q3 = U[12 + i]; }
+    }
+    const double q02 = q0 * q0, q12 = q1 * q1, q22 = q2 * q2, q32 = q3 * q3;
+    const double q0_1 = q0 * q1, q0_2 = q0 * q2, q0_3 = q0 * q3, q1_2 = q1 * q2, q1_3 = q1 * q3, q2_3 = q2 * q3;
+    R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q1_2 - q0_3); R[2] = 2. * (q1_3 + q0_2);
+    R[3] = 2. * (q1_2 + q0_3); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q2_3 - q0_1);
+    R[6] = 2. * (q1_3 - q0_2); R[7] = 2. * (q2_3 + q0_1); R[8] = q02 + q32 - q12 - q22;
+#pragma unroll
+    for (int i = 0; i < 3; i++) T[i] = Ce[i] - (R[i * 3] * Cs[0] + R[i * 3 + 1] * Cs[1] + R[i * 3 + 2] * Cs[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
+// Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
+
+// ------------------------------------------------------------------------------------------------
 // solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
 // Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
 // (p3p) or by four neighbouring lanes in parallel (p3p_setup + p3p_eval_root, used by K1).
@@ -358,6 +463,7 @@ DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K
 }
 
 // One quartic root x -> (R, T, squared reprojection error of the 4th point).  false: root rejected.
+template <bool HORN = false>
 DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double Rc[9], double Tc[3], double& reproj) {
     if (!(x > 0)) return false;
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
@@ -382,7 +488,8 @@ DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double R
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int j = 0; j < 3; j++) M[k][j] = L[k] * S.f[k][j];
-    align3(M, S.Xw, S.Ew, Rc, Tc);
+    if (HORN) align3_horn(M, S.Xw, Rc, Tc);
+    else align3(M, S.Xw, S.Ew, Rc, Tc);
     const double X3p = Rc[0] * S.X3[0] + Rc[1] * S.X3[1] + Rc[2] * S.X3[2] + Tc[0];
     const double Y3p = Rc[3] * S.X3[0] + Rc[4] * S.X3[1] + Rc[5] * S.X3[2] + Tc[1];
     const double Z3p = Rc[6] * S.X3[0] + Rc[7] * S.X3[1] + Rc[8] * S.X3[2] + Tc[2];
@@ -392,6 +499,7 @@ DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double R
 }
 
 // All roots in sequence on one lane; the root whose pose re-projects the 4th point best wins (first on ties).
+template <bool HORN = false>
 DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, double cv6[6]) {
     P3PSetup S;
     if (!p3p_setup(X, uv, K, S)) return false;
@@ -401,7 +509,7 @@ DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, doub
     for (int i = 0; i < 4; i++) {
         if (i >= S.n) continue;
         double Rc[9], Tc[3], reproj;
-        if (!p3p_eval_root(S, K, S.roots[i], Rc, Tc, reproj)) continue;
+        if (!p3p_eval_root<HORN>(S, K, S.roots[i], Rc, Tc, reproj)) continue;
         if (!have || best > reproj) {
             have = true;
             best = reproj;

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void k_dpnp(int N, const int32_t* __restrict__ 
             else if (cc == c) { v += eps; if (l & 1) v -= 2 * eps; }
         }
         double cv6[6];
-        if (!dm::p3p(X, uv, make_cam(F), cv6)) {
+        if (!dm::p3p<true>(X, uv, make_cam(F), cv6)) {  // Horn alignment as in OpenCV: the difference quotient amplifies the method's rounding
 #pragma unroll
             for (int k = 0; k < 6; k++) cv6[k] = 0;  // safeSolvePnP's zero pose
         }

@@ -219,6 +219,12 @@ class Engine:
                                                       ptr(_np(dpnp, np.float64) if dpnp is not None else None), flags, ptr(grad)))
         return grad
 
+    def lastPoseGradients(self, N):
+        """N x 6 pose gradients (sum of d_err * dProjectdHyp, cnn_softam.h:631-632) of the last dScore / dSoftScore call."""
+        G6 = np.zeros((int(N), 6))
+        check(self._ctx, lib.dsac_last_pose_gradients(self._ctx, int(N), ptr(G6)))
+        return G6
+
     # ---- K6 ---------------------------------------------------------------------------------------
     def refine(self, init_poses, perm, max_inl=100, min_inl=50, thr=10.0, pert_px_c=None, pert_value=None, want_inlier_map=False):
         """refine() (cnn_softam.h:663-723) for B start poses / replicas; with want_inlier_map the forward

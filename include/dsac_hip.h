@@ -154,6 +154,11 @@ int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t
 int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
                              float beta, const double* dpnp_or_null, unsigned flags, double* grad_xyz);
 
+/* The per-hypothesis 1 x 6 pose gradients of the most recent dsac_score_backward / dsac_soft_score_backward call on
+ * this context: G6[h] = sum over cells of d_err[h][p] * dProjectdHyp(p) (the accumulation of core/cnn_softam.h:631-632
+ * before its product with dPNP; columns = jp Rodrigues vector, translation in mm).  N must not exceed that call's N. */
+int dsac_last_pose_gradients(dsac_ctx* ctx, int N, double* G6);
+
 /* ---- K6: inlier refinement (LM-PnP) and its finite-difference Jacobians -------------------------- */
 /* Replaces the refinement loop of processImage core/cnn_softam.h:1099-1154 (B = 1, fills inlier_map) and
  * the replay helper refine() :663-723 (B replicas).  perm is steps x H*W pixel indices (the reference's

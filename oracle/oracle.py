@@ -3,7 +3,8 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing
 under dsac_amd/ does (tests/test_boundary.py::test_product_never_imports_oracle enforces it).
 
-PARITY UNPINNED -- see the header of oracle/dsac_oracle.cpp.
+Pinned against the real reference sources (oracle/reference.py, tests/test_reference_pinning.py) for the reference's own
+functions; the OpenCV internals in cvlike.h are PARITY UNPINNED -- see the header of oracle/dsac_oracle.cpp.
 """
 import ctypes as C
 import os

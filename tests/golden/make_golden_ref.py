@@ -56,6 +56,12 @@ def main():
     # dScore on an explicit gradient image (what a score CNN's backward would hand over), first 8 hypotheses
     rng = np.random.default_rng(7)
     natural = rng.normal(size=(8, 40, 40)) * 1e-2
+    # No weight on a hypothesis' own four points: their residual is zero by construction, so d|r|/dr there is a unit
+    # vector of round-off (0/0 guarded by EPS, cnn_softam.h:430,490) in the reference and in anything compared with it.
+    # The reference reads the image back transposed (lua_calls.h:329-335): cell (y, x) takes natural[x, y].
+    for h in range(8):
+        for (x, y) in r["sampledPoints"][h]:
+            natural[h, x, y] = 0.0
     out["dScore_ddiff_natural"] = natural
     out["dScore_jac_sum"] = ref.dScore(r["sampledPoints"][:8], r["estObj"], uvi, ddiff=natural.reshape(8, -1)).sum(0).reshape(1600, 3)
     path = os.path.join(HERE, "ref_frame_v1.npz")

@@ -1,0 +1,113 @@
+"""HIP engine (through the C ABI) against tests/golden/ref_frame_v1.npz -- outputs of the REAL reference sources
+(compiled against OpenCV / Lua stand-ins, see oracle/refbuild/ and tests/golden/make_golden_ref.py) for one
+synthetic frame: processImage forward, per-function Jacobians and the training loop's backward section.
+The engine replays the frame from the reference's own draws (sampling grid, minimal sets, shuffles).
+
+Tolerances (fp32 projection in K2/K4, fp64 elsewhere; see tests/test_gpu_forward.py for the P3P note):
+  error images 1e-3 px (clamp edge excluded) | softmax weights 2e-4 abs | averaged pose 1e-4 rad / 0.05 mm |
+  refined pose 1e-5 rel | loss 1e-4 | dScore / end-to-end gradient 2 % of the largest entry and 2 % in l2
+  (central differences of P3P amplify last-bit differences; the reference's own rotation drift, quirk 7, is not
+  reproduced by the product and moves ill-conditioned hypotheses in the 4th digit).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import excl_clamp_edge
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_frame_v1.npz")
+H = W = 40
+
+
+@pytest.fixture(scope="module")
+def g():
+    d = dict(np.load(G))
+    d["uv"] = d["sampling"].astype(np.float32)
+    d["sets"] = (d["sampledPoints"][:, :, 1] * W + d["sampledPoints"][:, :, 0]).astype(np.int32)
+    return d
+
+
+@pytest.fixture()
+def eng(engine, g):
+    engine.set_frame(g["estObj"], g["uv"], H, W, tuple(g["cam"]))
+    return engine
+
+
+def pose_delta(a, b):
+    from dsac_amd.synth import rodrigues
+    D = rodrigues(a[:3]) @ rodrigues(b[:3]).T
+    return np.degrees(np.arccos(np.clip((np.trace(D) - 1) / 2, -1, 1))), np.linalg.norm(a[3:] - b[3:]) / max(np.linalg.norm(b[3:]), 1e-9)
+
+
+def test_hypotheses_from_the_references_minimal_sets(eng, g):
+    poses, sets, ok = eng.sample(64, sets=g["sets"], thr=float(g["thr"]))
+    assert ok.all() and np.array_equal(sets, g["sets"])  # every set the reference accepted is accepted
+    d = np.array([pose_delta(a, b) for a, b in zip(poses, g["hyps"])])
+    tight = (d[:, 0] <= 1e-5) & (d[:, 1] <= 1e-6)
+    assert tight.mean() >= 0.95 and ((d[:, 0] <= 0.1) & (d[:, 1] <= 5e-3)).mean() >= 0.99, (tight.mean(), d.max(0))
+
+
+def test_error_images_scores_and_soft_argmax(eng, g):
+    err = eng.getDiffMap(g["hyps"]).reshape(64, H, W)
+    m = excl_clamp_edge(err[:8], g["diffMaps8"])
+    assert np.abs(err[:8] - g["diffMaps8"])[m].max() <= 1e-3
+    a = eng.getDiffMap(g["avgHyp"][None]).reshape(H, W)
+    assert np.abs(a - g["diffMap_avg"])[excl_clamp_edge(a, g["diffMap_avg"])].max() <= 1e-3
+    soft = np.zeros(64)
+    eng.reproject(g["hyps"], soft=soft, tau=float(g["tau"]), beta=float(g["beta"]))
+    w, ent, avg = eng.softMax(soft, float(g["alpha"]), g["hyps"])
+    assert np.abs(w - g["sfScores"]).max() <= 2e-4
+    assert abs(ent[0] - float(g["sfEntropy"])) <= 2e-3
+    assert np.abs(avg[:3] - g["avgHyp"][:3]).max() <= 1e-4 and np.abs(avg[3:] - g["avgHyp"][3:]).max() <= 5e-2
+    # the fused call (K1 -> K2 -> K3) on the reference's sets gives the same distribution
+    out = eng.scoreHypotheses(64, sets=g["sets"], thr=float(g["thr"]), tau=float(g["tau"]), beta=float(g["beta"]), scale=float(g["alpha"]))
+    assert np.abs(out[4] - g["sfScores"]).max() <= 2e-4
+
+
+def test_refinement_and_loss(eng, g):
+    got, sd, imap = eng.refine(g["avgHyp"], g["pixelIdxs"], max_inl=int(g["inlier_count"]), thr=float(g["thr"]), want_inlier_map=True)
+    assert sd[0] == int(g["ref_steps"]) and np.array_equal(imap, g["inlierMap"])
+    assert np.allclose(got[0], g["refAvgHyp"], rtol=1e-5, atol=1e-7)
+    L = eng.maxLoss(g["refAvgHyp"], g["gt_jp6"], want_grad=True)
+    assert abs(L["loss"] - float(g["loss"])) <= 1e-4 * max(1, float(g["loss"]))
+    assert abs(L["rotErr"] - float(g["rotErr"])) <= 1e-4 and abs(L["tErr"] - float(g["tErr"])) <= 1e-3
+    assert bool(L["correct"]) == bool(g["correct"])
+    assert np.abs(L["grad"] - g["dLossMax"]).max() <= 1e-6 * np.abs(g["dLossMax"]).max()
+
+
+def test_jacobians(eng, g):
+    J = eng.dPNP(g["sets"][:8])
+    rel = np.array([np.abs(J[h] - g["dPNP8"][h]).max() / max(1.0, np.abs(g["dPNP8"][h]).max()) for h in range(8)])
+    assert np.median(rel) <= 1e-5 and rel.max() <= 5e-2, rel
+    J_hyp, px, J_obj = eng.dRefine(g["avgHyp"], g["pixelIdxs"], g["inlierMap"], max_inl=int(g["inlier_count"]), thr=float(g["thr"]),
+                                   sub_sample=float(g["sub_sample"]))
+    assert np.abs(J_hyp - g["dRefineHyp"]).max() <= 1e-6 + 1e-3 * np.abs(g["dRefineHyp"]).max()
+    # dScore on an explicit gradient image, read back transposed and written to transposed columns as the reference does
+    as_read = np.ascontiguousarray(g["dScore_ddiff_natural"].transpose(0, 2, 1)).reshape(8, -1).astype(np.float32)
+    grad = eng.dScore(g["hyps"][:8], g["sets"][:8], as_read, quirk_transpose=True)
+    want = g["dScore_jac_sum"]
+    assert np.abs(grad - want).max() <= 2e-2 * np.abs(want).max()
+    assert np.linalg.norm(grad - want) <= 2e-2 * np.linalg.norm(want)
+
+
+def test_training_backward_end_to_end(eng, g):
+    tau, beta, alpha = float(g["tau"]), float(g["beta"]), float(g["alpha"])
+    fwd = dict(hyps=g["hyps"], sampledPoints=g["sets"], sfScores=g["sfScores"], avgHyp=g["avgHyp"], refAvgHyp=g["refAvgHyp"],
+               pixelIdxs=g["pixelIdxs"], inlierMap=g["inlierMap"], refSteps=int(g["ref_steps"]), score_scale=alpha)
+    err = eng.getDiffMap(g["hyps"]).reshape(64, H, W).astype(np.float64)
+
+    def d_scores_fn(gs):  # backward of the stand-in score CNN, handed over the way the reference reads it (transposed)
+        s = 1 / (1 + np.exp(-beta * (tau - err)))
+        natural = gs[:, None, None] * alpha * (-beta) * s * (1 - s)
+        return np.ascontiguousarray(natural.transpose(0, 2, 1))
+
+    bwd = eng.backward(fwd, g["gt_jp6"], d_scores_fn=d_scores_fn, thr=float(g["thr"]), inlierCount=int(g["inlier_count"]), tau=tau, beta=beta,
+                       sub_sample=float(g["sub_sample"]), quirk_transpose=True)
+    want = g["dLoss_dObj"]
+    emax = np.abs(bwd["grad"] - want).max() / np.abs(want).max()
+    el2 = np.linalg.norm(bwd["grad"] - want) / np.linalg.norm(want)
+    print("end-to-end gradient vs the reference: max-rel %.3e l2-rel %.3e" % (emax, el2))
+    assert emax <= 2e-2 and el2 <= 2e-2
