@@ -40,6 +40,26 @@ def test_dscore_parity_reference_size(engine, orc, frame40, quirk):
     assert np.allclose(got2, got, rtol=1e-9, atol=1e-9 * np.abs(got).max())
 
 
+def test_pose_gradients_of_the_last_call(engine, orc, frame40):
+    """dsac_last_pose_gradients: the 1 x 6 sums of d_err * dProjectdHyp (cnn_softam.h:631-632) before dPNP.  No weight on a
+    hypothesis' own four cells: their residual is exactly zero and d|r|/dr there is a unit vector of round-off on every
+    implementation (the EPS guard of cnn_softam.h:490)."""
+    fr = frame40
+    N = 48
+    poses, sets = _setup(engine, orc, fr, N, 11)
+    rng = np.random.default_rng(3)
+    d_err = rng.normal(size=(N, 1600)).astype(np.float32)
+    d_err[np.arange(N)[:, None], sets] = 0
+    _, G6, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    engine.dScore(poses, sets, d_err)
+    got = engine.lastPoseGradients(N)
+    rel = np.abs(got - G6).max(1) / np.abs(G6).max(1)
+    print("pose gradients: median rel %.2e max rel %.2e" % (np.median(rel), rel.max()))
+    assert np.median(rel) <= 1e-4 and rel.max() <= 1e-3  # measured 2e-6 / 6e-6
+    with pytest.raises(Exception):
+        engine.lastPoseGradients(N + 1)  # more than the last call produced
+
+
 def test_dscore_accumulates(engine, orc, frame40):
     fr = frame40
     poses, sets = _setup(engine, orc, fr, 8, 2)
