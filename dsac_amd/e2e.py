@@ -1,0 +1,148 @@
+"""The two CNN seams of the soft-argmax pipeline and one end-to-end training step around the HIP engine.
+
+SURVEY.md 8(f) rank 2 and 8(d) config 5.  In the reference both CNNs sit behind the Lua C API (core/lua_calls.h): the
+N x 40 x 40 error images are pushed to Lua number by number (lua_calls.h:89-105), the score gradients come back the same
+way, transposed (lua_calls.h:329-335), and the scene-coordinate gradient is handed to a second Lua state
+(train_ransac_softam.cpp:396-412).  Here the seams are device pointers:
+
+    CoordNet (PyTorch-ROCm)  ->  xyz  H*W x 3 f32 on the GPU   --borrowed by dsac_set_frame, no copy-->
+    K1 sample, K2 error images written straight into a torch tensor  ->  ScoreNet consumes them in place  ->  K3
+    ... K6 refine, K7 loss, backward K7/K6/K5 ...  ->  g (N)  ->  ScoreNet.backward gives dErr (n, y, x) in place  ->
+    K4 dsac_score_backward  ->  dLoss/dXYZ  ->  CoordNet.backward  ->  RCCL all-reduce of both nets' gradients.
+
+The networks are the reference's architectures (core/lua/train_obj.lua:57-89, core/lua/train_score.lua:55-88) with
+random weights: PyTorch is plumbing here (device memory, autograd of the CNNs, torch.distributed), the geometry between
+the seams is the engine.  Hyper-parameters follow core/lua/train_{obj,score}_softam.lua (means 127 / 45, gradient clamp
+0.1, SGD momentum 0.9, learning rates 1e-5 / 1e-7).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as ddist
+from .engine import Engine
+
+CNN_OBJ_PATCHSIZE = 40  # core/lua_calls.h:33
+CNN_RGB_PATCHSIZE = 42  # core/lua_calls.h:30
+OBJ_MEAN, SCORE_MEAN, CLAMP_E2E = 127.0, 45.0, 0.1  # train_obj_softam.lua:17,14 ; train_score_softam.lua:6,13
+
+
+def _conv(cin, cout, stride, pad):
+    return [nn.Conv2d(cin, cout, 3, stride, pad), nn.ReLU(inplace=True)]
+
+
+class CoordNet(nn.Module):
+    """Scene-coordinate regressor, 3 x 42 x 42 RGB patch -> 3 coordinates in metres (core/lua/train_obj.lua:57-89)."""
+
+    def __init__(self):
+        super().__init__()
+        L = _conv(3, 64, 1, 0) + _conv(64, 64, 2, 1) + _conv(64, 128, 1, 1) + _conv(128, 128, 2, 1) + _conv(128, 256, 1, 1) + \
+            _conv(256, 256, 1, 1) + _conv(256, 256, 2, 1) + _conv(256, 512, 1, 1) + _conv(512, 512, 1, 1) + _conv(512, 512, 2, 0)
+        self.features = nn.Sequential(*L)
+        self.head = nn.Sequential(nn.Linear(2 * 2 * 512, 4096), nn.ReLU(inplace=True), nn.Linear(4096, 4096), nn.ReLU(inplace=True), nn.Linear(4096, 3))
+
+    def forward(self, patches):  # B x 3 x 42 x 42, 0..255
+        return self.head(self.features(patches - OBJ_MEAN).flatten(1))
+
+
+class ScoreNet(nn.Module):
+    """Hypothesis score regressor, 1 x 40 x 40 error image -> score (core/lua/train_score.lua:55-88)."""
+
+    def __init__(self):
+        super().__init__()
+        L = _conv(1, 32, 1, 1) + _conv(32, 32, 2, 1) + _conv(32, 64, 1, 1) + _conv(64, 64, 2, 1) + _conv(64, 128, 1, 1) + _conv(128, 128, 2, 1) + \
+            _conv(128, 256, 1, 1) + _conv(256, 256, 2, 0) + _conv(256, 512, 1, 1) + _conv(512, 512, 2, 1)
+        self.features = nn.Sequential(*L)
+        self.head = nn.Sequential(nn.Linear(512, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1))
+
+    def forward(self, err):  # N x 1 x 40 x 40 reprojection errors in px, clamped to 100
+        return self.head(self.features(err - SCORE_MEAN).flatten(1)).squeeze(1)
+
+
+class TrainStep:
+    """One update of both CNNs from one frame per rank (train_ransac_softam.cpp:225-430), the geometry on the engine.
+
+    The engine runs on torch's current stream, so K1..K7 and the CNN kernels are ordered without events; the frame, the
+    hypotheses, the error images and their gradients never leave the GPU.  The few 6-vectors and the 6 x 6 / 6 x 12
+    Jacobians of the refinement stage go through the host (they are inputs of host-side control flow anyway)."""
+
+    def __init__(self, device=0, hyps=256, ref_steps=8, inlier_count=100, thr=10.0, sub_sample=0.01, cam=(525.0, 525.0, 320.0, 240.0),
+                 coord_net=None, score_net=None, lr_obj=1e-5, lr_score=1e-7, momentum=0.9):
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.N, self.ref_steps, self.inlier_count, self.thr, self.sub_sample, self.cam = hyps, ref_steps, inlier_count, thr, sub_sample, cam
+        self.coord_net = (coord_net or CoordNet()).to(self.dev)
+        self.score_net = (score_net or ScoreNet()).to(self.dev)
+        self.opt_obj = torch.optim.SGD(self.coord_net.parameters(), lr=lr_obj, momentum=momentum)
+        self.opt_score = torch.optim.SGD(self.score_net.parameters(), lr=lr_score, momentum=momentum)
+        self.engine = Engine(device, stream=torch.cuda.current_stream(self.dev))
+        S, N = CNN_OBJ_PATCHSIZE, hyps
+        self.poses = torch.zeros(N, 6, dtype=torch.float64, device=self.dev)
+        self.sets = torch.zeros(N, 4, dtype=torch.int32, device=self.dev)
+        self.ok = torch.zeros(N, dtype=torch.uint8, device=self.dev)
+        self.err = torch.zeros(N, 1, S, S, dtype=torch.float32, device=self.dev)
+        self.w = torch.zeros(N, dtype=torch.float64, device=self.dev)
+        self.ent = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.avg = torch.zeros(6, dtype=torch.float64, device=self.dev)
+        self.grad_xyz = torch.zeros(S * S, 3, dtype=torch.float64, device=self.dev)
+
+    def params(self):
+        return list(self.coord_net.parameters()) + list(self.score_net.parameters())
+
+    def forward_backward(self, patches, sampling_uv, gt_jp6, perm, seed=1305, quirk_transpose=False, xyz_offset_mm=None):
+        """patches: 1600 x 3 x 42 x 42 (device, 0..255); sampling_uv: 1600 x 2 f32 pixel positions (device);
+        gt_jp6: ground-truth pose (jp rodrigues vector | translation mm); perm: ref_steps x 1600 int32 (host).
+        xyz_offset_mm (1600 x 3, device): added to the CNN output -- with random weights and synthetic patches the CNN
+        predicts ~0, the offset then carries a synthetic scene so that the geometry has something to solve.
+        Leaves parameter gradients in .grad and returns a dict of scalars / small arrays for logging."""
+        eng, N, S = self.engine, self.N, CNN_OBJ_PATCHSIZE
+        # ---- CNN 1: scene coordinates (metres -> mm, cnn_softam.h:265) -------------------------------------------------
+        pred_m = self.coord_net(patches)
+        xyz = pred_m.detach() * 1000.0
+        if xyz_offset_mm is not None:
+            xyz = xyz + xyz_offset_mm
+        xyz = xyz.float().contiguous()
+        eng.set_frame(xyz, sampling_uv, S, S, self.cam, borrow=True)
+        # ---- K1, K2: hypotheses and their error images, written into the tensor the score CNN reads ---------------------
+        eng.sample(N, seed=seed, thr=self.thr, out=(self.poses, self.sets, self.ok))
+        eng.reproject(self.poses, N=N, err=self.err)
+        err = self.err.detach().requires_grad_(True)  # same storage: the score CNN reads what K2 wrote
+        scores = self.score_net(err)
+        # ---- K3: softmax, entropy, soft-argmax pose ------------------------------------------------------------------
+        eng.softMax(scores.detach().double().contiguous(), 1.0, self.poses, N=N, out=(self.w, self.ent, self.avg))
+        avg = self.avg.cpu().numpy()
+        # ---- K6, K7 forward --------------------------------------------------------------------------------------------
+        ref, sd, imap = eng.refine(avg, perm, max_inl=self.inlier_count, thr=float(int(self.thr)), want_inlier_map=True)
+        L = eng.maxLoss(ref[0], gt_jp6, want_grad=True)
+        # ---- backward, path I (train_ransac_softam.cpp:294-353) -------------------------------------------------------
+        dL = L["grad"]
+        self.grad_xyz.zero_()
+        v6 = dL
+        if sd[0] > 0:
+            J_hyp, px, J_obj = eng.dRefine(avg, perm, imap, max_inl=self.inlier_count, thr=float(int(self.thr)), sub_sample=self.sub_sample)
+            if len(px):
+                rows = torch.as_tensor(np.einsum("k,ikc->ic", dL, J_obj), device=self.dev)
+                self.grad_xyz.index_add_(0, torch.as_tensor(px, device=self.dev, dtype=torch.long), rows)
+            v6 = dL @ J_hyp
+        dpnp = torch.zeros(N, 6, 12, dtype=torch.float64, device=self.dev)
+        eng.dPNP(self.sets, out=dpnp)
+        g = torch.zeros(N, dtype=torch.float64, device=self.dev)
+        eng.path1AndSoftmaxBackward(np.ascontiguousarray(v6), self.w, self.poses, self.sets, dpnp, grad=self.grad_xyz, out_g=g)
+        # ---- backward, path II: score CNN (gradient clamp of train_score_softam.lua:97), then K4 -----------------------
+        scores.backward(gradient=g.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
+        d_err = err.grad.reshape(N, S * S).contiguous()  # (n, y, x): already the layout K4 reads
+        eng.dScore(self.poses, self.sets, d_err, dpnp=dpnp, quirk_transpose=quirk_transpose, grad=self.grad_xyz)
+        # ---- CNN 1 backward (gradient clamp of train_obj_softam.lua:105) ---------------------------------------------
+        pred_m.backward(gradient=self.grad_xyz.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
+        return dict(loss=L["loss"], rotErr=L["rotErr"], tErr=L["tErr"], entropy=float(self.ent.item()), ref_steps=int(sd[0]),
+                    accepted=int(self.ok.sum().item()), refAvgHyp=ref[0], avgHyp=avg)
+
+    def step(self, *a, **kw):
+        """forward_backward + gradient all-reduce over the ranks (RCCL on GPUs, a few flat buckets) + SGD update."""
+        self.opt_obj.zero_grad(set_to_none=False)
+        self.opt_score.zero_grad(set_to_none=False)
+        out = self.forward_backward(*a, **kw)
+        out["collectives"] = ddist.all_reduce_gradients([p.grad for p in self.params() if p.grad is not None])
+        self.opt_obj.step()
+        self.opt_score.step()
+        return out

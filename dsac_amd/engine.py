@@ -274,12 +274,12 @@ class Engine:
     def dLossMax(self, est_cv6, gt_jp6):
         return self.maxLoss(est_cv6, gt_jp6, want_grad=True)["grad"]
 
-    def path1AndSoftmaxBackward(self, v6, w, poses, sets, dpnp, grad=None):
-        """train_ransac_softam.cpp:344-376.  Returns (grad, g)."""
+    def path1AndSoftmaxBackward(self, v6, w, poses, sets, dpnp, grad=None, out_g=None):
+        """train_ransac_softam.cpp:344-376.  Returns (grad, g); out_g = preallocated N float64 (host or device)."""
         N = int(np.asarray(w).shape[0]) if isinstance(w, np.ndarray) else int(w.shape[0])
         if grad is None:
             grad = np.zeros((self.P, 3))
-        g = np.zeros(N)
+        g = out_g if out_g is not None else np.zeros(N)
         check(self._ctx, lib.dsac_path1_and_softmax_backward(self._ctx, N, ptr(_np(v6, np.float64)), ptr(_np(w, np.float64)), ptr(_np(poses, np.float64)),
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
         return grad, g

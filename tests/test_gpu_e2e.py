@@ -1,0 +1,97 @@
+"""The CNN seams and the end-to-end training step (dsac_amd/e2e.py): the error
+images are consumed where K2 wrote them, the score CNN's input gradient goes straight into K4, and the scene-coordinate
+gradient that reaches CNN 1 equals the one assembled by Engine.backward from the same pieces."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S = 40
+
+
+class TableNet:
+    """Stand-in for CNN 1 in the tests: the 'prediction' is a trainable table (metres), so the geometry is non-trivial."""
+
+    def __new__(cls, xyz_m):
+        import torch
+
+        class _T(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.table = torch.nn.Parameter(torch.as_tensor(xyz_m, dtype=torch.float32))
+
+            def forward(self, patches):
+                return self.table + 0.0 * patches.mean()
+        return _T()
+
+
+@pytest.fixture()
+def setup(synth, frame40, orc):
+    import torch
+    from dsac_amd import e2e
+    fr = frame40
+    torch.manual_seed(0)
+    ts = e2e.TrainStep(0, hyps=64, sub_sample=0.05, coord_net=TableNet(fr["xyz"] / 1000.0))
+    dev = ts.dev
+    patches = torch.rand(S * S, 3, 42, 42, device=dev) * 255
+    uv = torch.as_tensor(fr["uv"], device=dev)
+    perm = synth.fast_permutations(S * S, 8)
+    gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    yield ts, fr, patches, uv, perm, gt
+    ts.engine.close()
+
+
+def test_seams_zero_copy_and_gradient_assembly(setup, orc):
+    import torch
+    ts, fr, patches, uv, perm, gt = setup
+    out = ts.forward_backward(patches, uv, gt, perm, seed=1305)
+    torch.cuda.synchronize()
+    assert out["accepted"] == 64 and out["ref_steps"] == 8 and np.isfinite(out["loss"])
+    # K2 wrote the tensor the score CNN read: same numbers as a separate getDiffMap of the same poses
+    poses = ts.poses.cpu().numpy()
+    err = ts.engine.getDiffMap(poses).reshape(64, 1, S, S)
+    assert np.array_equal(ts.err.cpu().numpy(), err)
+    # the gradient handed to CNN 1 = Engine.backward on the same forward state with the score CNN's autograd as d_scores_fn
+    fwd = dict(hyps=poses, sampledPoints=ts.sets.cpu().numpy(), sfScores=ts.w.cpu().numpy(), avgHyp=out["avgHyp"], refAvgHyp=out["refAvgHyp"],
+               pixelIdxs=perm, inlierMap=ts.engine.refine(out["avgHyp"], perm, thr=10.0, want_inlier_map=True)[2], refSteps=8, score_scale=1.0)
+
+    def d_scores_fn(g):
+        e = torch.as_tensor(err, device=ts.dev).requires_grad_(True)
+        ts.score_net(e).backward(gradient=torch.as_tensor(g, device=ts.dev).float().clamp_(-0.1, 0.1))
+        return e.grad.reshape(64, S, S).cpu().numpy()
+
+    bwd = ts.engine.backward(fwd, gt, d_scores_fn=d_scores_fn, sub_sample=0.05)
+    got = ts.grad_xyz.cpu().numpy()
+    assert np.abs(got).max() > 0
+    assert np.abs(got - bwd["grad"]).max() <= 1e-6 * np.abs(bwd["grad"]).max()
+    # ... and it arrived at the parameters of both networks
+    gt_tab = ts.coord_net.table.grad.cpu().numpy()
+    assert np.allclose(gt_tab, np.clip(got, -0.1, 0.1).astype(np.float32), rtol=1e-6, atol=1e-12)
+    gs = [p.grad for p in ts.score_net.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in gs) and any(float(g.abs().max()) > 0 for g in gs)
+
+
+def test_step_with_the_reference_architectures(synth, frame40, orc):
+    """CoordNet / ScoreNet (reference architectures, random weights) around the engine: one SGD step runs, every
+    parameter receives a finite gradient, the weights move."""
+    import torch
+    from dsac_amd import e2e
+    fr = frame40
+    torch.manual_seed(1)
+    ts = e2e.TrainStep(0, hyps=32, sub_sample=0.05)
+    assert abs(sum(p.numel() for p in ts.coord_net.parameters()) - 32.8e6) < 0.1e6  # 32.8 M + 6.3 M parameters
+    assert abs(sum(p.numel() for p in ts.score_net.parameters()) - 6.3e6) < 0.1e6
+    dev = ts.dev
+    patches = torch.rand(S * S, 3, 42, 42, device=dev) * 255
+    uv = torch.as_tensor(fr["uv"], device=dev)
+    off = torch.as_tensor(fr["xyz"], device=dev)
+    perm = synth.fast_permutations(S * S, 8)
+    gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    before = [p.detach().clone() for p in ts.params()]
+    out = ts.step(patches, uv, gt, perm, seed=7, xyz_offset_mm=off)
+    torch.cuda.synchronize()
+    assert out["collectives"] == 0 and np.isfinite(out["loss"]) and out["accepted"] == 32
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ts.params())
+    moved = sum(int((a != b).any()) for a, b in zip(before, ts.params()))
+    assert moved > 0
+    ts.engine.close()
