@@ -10,6 +10,7 @@
 // K5 replaces dPNP (core/cnn_softam.h:101-146): one lane per (hypothesis, coordinate, +/-) P3P solve,
 // 24 lanes per hypothesis; central differences are formed after a wave-local exchange.
 #include "kernels.h"
+#include <cstdlib>
 #include "dmath.h"
 
 namespace dk {
@@ -78,13 +79,20 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // One wave per hypothesis.  Lane l evaluates quartic root (l & 3) of attempt base + (l >> 2): 16 attempts
 // per round, the four candidate poses of an attempt side by side (their Jacobi eigen-solves, the long pole
 // of P3P, run in parallel instead of in sequence).
-__global__ __launch_bounds__(64) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
-                                               int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged) {
-    // latency-bound kernel that is meant to run underneath the bandwidth-bound K2 of another frame: raise the wave priority
-    // so that its (single) wave per SIMD wins issue arbitration against K2's many waves
-    __builtin_amdgcn_s_setprio(3);
-    const int h = blockIdx.x;
-    const int lane = threadIdx.x;
+// WPB waves (hypotheses) per workgroup.  The kernel is meant to run underneath the bandwidth-bound K2 of another frame; a
+// K1 wave holds 278 registers (occupancy 1), so wherever it lands it takes more than half of that SIMD's register file
+// away from K2's waves.  Measured on MI355X (scripts/gpu_k1_layout.sh, default bench): 1 wave/workgroup (every CU gets one)
+// 91.3 us/step, 4 waves (one CU in four, all four SIMDs) 90.3, 8 waves (2 per SIMD, 100 B scratch) 94.6, 16 waves (128
+// VGPRs, 580 B scratch per lane) 125.  Raised wave priority is worth ~1 us.
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
+                                                     int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio) {
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const int h = blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (h >= N) return;
+    const int lane = threadIdx.x & 63;
     const int root = lane & 3;
     const uint64_t key = dm::hyp_key(seed, (uint32_t)h);
     const dm::Cam K = make_cam(F);
@@ -186,7 +194,18 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
                   int32_t* sets_out, uint8_t* ok, float* staged) {
     if (N <= 0) return hipSuccess;
     if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
-    else hipLaunchKernelGGL(k_sample, dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged);
+    else {
+        static int wpb = -1, prio = 0;
+        if (wpb < 0) {  // knobs for experiments: DSAC_K1_WPB in {1, 4, 8, 16}, DSAC_K1_PRIO in 0..3
+            const char* e = getenv("DSAC_K1_WPB");
+            wpb = e ? atoi(e) : 4;
+            const char* q = getenv("DSAC_K1_PRIO");
+            prio = q ? atoi(q) : 3;
+        }
+#define DSAC_K1(W) hipLaunchKernelGGL(k_sample<W>, dim3((N + W - 1) / W), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio)
+        if (wpb >= 16) DSAC_K1(16); else if (wpb >= 8) DSAC_K1(8); else if (wpb >= 4) DSAC_K1(4); else DSAC_K1(1);
+#undef DSAC_K1
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,7 @@
+#!/bin/bash
+# K2 'both' variants under SUSTAINED back-to-back launches (clocks settle lower than in isolated runs)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+for v in -1 0 4 6 5; do for o in 0 1; do
+  r=$(DSAC_K2_VARIANT=$v DSAC_K2_ORDER=$o timeout 300 python bench.py --steps 400 --warmup 50 --kernel-only --no-cpu-baseline --streams 1 --event-stride 1 --k2-mode both 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f us/step  frac %.3f' % (d['ms_per_step']*1e3, d['roofline']['frac']))")
+  echo "variant $v order $o both sustained: $r"
+done; done | tee gpurun_out/k2_sustained.txt
