@@ -692,7 +692,86 @@ int dsac_loss(dsac_ctx* c, const double* est_cv6, const double* gt_jp6, double* 
     ARG_TRY(in_arg(c, gt_jp6, 6, &d_gt));
     ARG_TRY(out_arg(c, out4, 4, &d_out));
     ARG_TRY(out_arg(c, J6_or_null, 6, &d_J));
-    HIP_TRY(c, dk::pose_loss(c->stream, d_est, d_gt, d_out, d_J));
+    HIP_TRY(c, dk::pose_loss(c->stream, 1, d_est, d_gt, d_out, d_J));
+    return end_call(c);
+}
+
+int dsac_loss_batch(dsac_ctx* c, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_loss_batch: ctx is NULL");
+    if (B < 0 || !est_cv6 || !gt_jp6 || (!out4 && !J6_or_null)) return fail(c, DSAC_ERR_INVALID, "dsac_loss_batch: NULL argument or negative count");
+    if (B == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const double *d_est, *d_gt;
+    double *d_out, *d_J;
+    ARG_TRY(in_arg(c, est_cv6, (size_t)B * 6, &d_est));
+    ARG_TRY(in_arg(c, gt_jp6, 6, &d_gt));
+    ARG_TRY(out_arg(c, out4, (size_t)B * 4, &d_out));
+    ARG_TRY(out_arg(c, J6_or_null, (size_t)B * 6, &d_J));
+    HIP_TRY(c, dk::pose_loss(c->stream, B, d_est, d_gt, d_out, d_J));
+    return end_call(c);
+}
+
+int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                    const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_all: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_all: no frame set");
+    if (N < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: NULL argument or negative count");
+    if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double* d_init;
+    const int32_t *d_perm, *d_sets;
+    double* d_out;
+    int32_t *d_maps, *d_sd;
+    ARG_TRY(in_arg(c, init_poses, (size_t)N * 6, &d_init));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, sets_or_null, (size_t)N * 4, &d_sets));
+    ARG_TRY(out_arg(c, out_poses, (size_t)N * 6, &d_out));
+    ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)N * P, &d_maps, /*preload=*/false));
+    ARG_TRY(out_arg(c, steps_done_or_null, (size_t)N, &d_sd));
+    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)N * P * sizeof(int32_t), c->stream));
+    HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0));
+    if (d_maps && d_sets) HIP_TRY(c, dk::zero_set_cells(c->stream, N, d_sets, (int)P, d_maps));
+    return end_call(c);
+}
+
+int dsac_refine_fd_set(dsac_ctx* c, const int32_t* set4, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                       const int32_t* inlier_map, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                       int32_t* n_obj) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd_set: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd_set: no frame set");
+    if (!set4 || !perm || !inlier_map || !J_set || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: NULL argument or negative count");
+    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: need 1 <= max_inl <= 256");
+    if (!(sub_sample > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: sub_sample and eps_obj must be > 0");
+    const int skip = (int)(1 / sub_sample);  // core/cnn.h:933
+    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: sub_sample > 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const int32_t *d_set, *d_perm, *d_map;
+    double *d_Js, *d_Jo;
+    int32_t *d_px, *d_n;
+    ARG_TRY(in_arg(c, set4, 4, &d_set));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, inlier_map, P, &d_map));
+    ARG_TRY(out_arg(c, J_set, 54, &d_Js));
+    ARG_TRY(out_arg(c, obj_pixels, (size_t)cap, &d_px));
+    ARG_TRY(out_arg(c, J_obj, (size_t)cap * 18, &d_Jo));
+    ARG_TRY(out_arg(c, n_obj, 1, &d_n));
+    const size_t B = 18 + 6 * (size_t)cap;
+    DevBuf& rp = next_slot(c); HIP_TRY(c, rp.reserve(B * 6 * sizeof(double)));
+    DevBuf& rx = next_slot(c); HIP_TRY(c, rx.reserve(B * 2 * sizeof(int32_t)));
+    DevBuf& rv = next_slot(c); HIP_TRY(c, rv.reserve(B * sizeof(float)));
+    DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
+    DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap + 1) * sizeof(int32_t)));
+    int32_t* d_pxbuf = d_px ? d_px : px.as<int32_t>();
+    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_set, d_map, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n));
+    HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
+    HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo));
     return end_call(c);
 }
 

@@ -22,9 +22,15 @@ DM_INLINE void mul3(const double A[9], const double B[9], double C[9]) {
         for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
 
-__global__ __launch_bounds__(64) void k_pose_loss(const double* __restrict__ est_cv6, const double* __restrict__ gt_jp6,
-                                                  double* __restrict__ out4, double* __restrict__ J6) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// One lane per estimate (B = 1: maxLoss / dLossMax of the soft-argmax pipeline; B = N: the per-hypothesis losses of
+// expectedMaxLoss, core/cnn.h:137-150, and the per-hypothesis dLossMax of core/train_ransac.cpp:345-349).
+__global__ __launch_bounds__(64) void k_pose_loss(int B, const double* __restrict__ est_all, const double* __restrict__ gt_jp6,
+                                                  double* __restrict__ out4_all, double* __restrict__ J6_all) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const double* est_cv6 = est_all + (size_t)b * 6;
+    double* out4 = out4_all ? out4_all + (size_t)b * 4 : nullptr;
+    double* J6 = J6_all ? J6_all + (size_t)b * 6 : nullptr;
     const double PI = 3.14159265358979323846;
     double cv6[6], gt[6];
 #pragma unroll
@@ -134,8 +140,9 @@ __global__ __launch_bounds__(64) void k_pose_loss(const double* __restrict__ est
     for (int i = 0; i < 6; i++) J6[i] = J[i];
 }
 
-hipError_t pose_loss(hipStream_t st, const double* est_cv6, const double* gt_jp6, double* out4, double* J6) {
-    hipLaunchKernelGGL(k_pose_loss, dim3(1), dim3(64), 0, st, est_cv6, gt_jp6, out4, J6);
+hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pose_loss, dim3((B + 63) / 64), dim3(64), 0, st, B, est_cv6, gt_jp6, out4, J6);
     return hipGetLastError();
 }
 

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
-                                               int32_t* __restrict__ steps_done) {
+                                               int32_t* __restrict__ steps_done, int map_stride) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (n_live && b >= live_base + live_mul * n_live[0]) return;  // replica list shorter than the launch
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                 const int slot = cnt + prefix;
                 s_X[slot * 3] = X; s_X[slot * 3 + 1] = Y; s_X[slot * 3 + 2] = Z;
                 s_uv[slot * 2] = pu; s_uv[slot * 2 + 1] = pv;
-                if (inlier_map && b == 0) atomicAdd(&inlier_map[p], 1);
+                if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
             }
             cnt += __popcll(m);
         }
@@ -247,11 +247,24 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
 
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done) {
+                  int32_t* steps_done, int map_stride) {
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done);
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride);
+    return hipGetLastError();
+}
+
+__global__ void k_zero_set_cells(int N, const int32_t* __restrict__ sets, int P, int32_t* __restrict__ maps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 4) return;
+    const int h = i >> 2;
+    const int p = sets[i];
+    if (p >= 0 && p < P) maps[(size_t)h * P + p] = 0;
+}
+hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_set_cells, dim3((N * 4 + 255) / 256), dim3(256), 0, st, N, sets, P, inlier_maps);
     return hipGetLastError();
 }
 
@@ -327,7 +340,125 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     const int B = 12 + 6 * cap;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// DSAC variant (core/cnn.h:854-990 dRefine): the refinement restarts from P3P of the minimal set (cnn.h:797-800), so the
+// first three set points are perturbed too (the 4th only disambiguates: "gradient is anyway zero", :872).  Replicas
+// 0..17 = (point pt, channel c, +/-), then 6 per selected inlier cell exactly as in dRefineObj.  The start pose of every
+// replica is P3P of the set read from the replica's perturbed map -- for the inlier replicas that is the unperturbed
+// hypothesis, because processImage removes the set's own cells from the inlier map (:1208-1214).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_refine_fd_plan_set(const int32_t* __restrict__ set4, const int32_t* __restrict__ inlier_map, FrameDev F, int skip,
+                                                           float eps_obj, int cap, int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value,
+                                                           int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj) {
+    const int lane = threadIdx.x;
+    const int P = F.P;
+    if (lane < 18) {
+        const int pt = lane / 6, c = (lane % 6) >> 1;
+        const int p = min(max(set4[pt], 0), P - 1);
+        const float v0 = F.xyz[(size_t)p * 3 + c];
+        const float vf = v0 + eps_obj;
+        rep_px_c[2 * lane] = p; rep_px_c[2 * lane + 1] = c;
+        rep_value[lane] = (lane & 1) ? vf - 2 * eps_obj : vf;
+    }
+    int inCount = 0, nsel = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int t = base + lane;  // x-outer / y-inner order: t = x * H + y  (cnn.h:935-945)
+        const bool in = t < P;
+        int p = 0;
+        bool inl = false;
+        if (in) { const int x = t / F.H, y = t - x * F.H; p = y * F.W + x; inl = inlier_map[p] != 0; }
+        const unsigned long long m = __ballot(inl);
+        const int myCount = inCount + __popcll(m & ((1ull << lane) - 1ull)) + 1;
+        const bool sel = inl && (myCount % skip == 0);
+        const unsigned long long ms = __ballot(sel);
+        const int slot = nsel + __popcll(ms & ((1ull << lane) - 1ull));
+        if (sel && slot < cap) {
+            obj_pixels[slot] = p;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v0 = F.xyz[(size_t)p * 3 + c];
+                const float vf = v0 + eps_obj;
+                const int r = 18 + slot * 6 + c * 2;
+                rep_px_c[2 * r] = p; rep_px_c[2 * r + 1] = c; rep_value[r] = vf;
+                rep_px_c[2 * (r + 1)] = p; rep_px_c[2 * (r + 1) + 1] = c; rep_value[r + 1] = vf - 2 * eps_obj;
+            }
+        }
+        inCount += __popcll(m);
+        nsel += __popcll(ms);
+    }
+    if (lane == 0) n_obj[0] = min(nsel, cap);
+}
+
+// start pose of replica r: P3P (Horn alignment, as OpenCV) of the set read through the replica's perturbation
+__global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4,
+                                                           const int32_t* __restrict__ rep_px_c, const float* __restrict__ rep_value, FrameDev F,
+                                                           double* __restrict__ rep_poses) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= 18 + 6 * min(n_obj[0], cap)) return;
+    const int ppx = rep_px_c[2 * r], pch = rep_px_c[2 * r + 1];
+    const float pval = rep_value[r];
+    float X[4][3], uv[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = min(max(set4[j], 0), F.P - 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) X[j][c] = (p == ppx && c == pch) ? pval : F.xyz[(size_t)p * 3 + c];
+        if (F.uv) { uv[j][0] = F.uv[(size_t)p * 2]; uv[j][1] = F.uv[(size_t)p * 2 + 1]; }
+        else { const int y = p / F.W; uv[j][0] = (float)(p - y * F.W); uv[j][1] = (float)y; }
+    }
+    double cv6[6];
+    if (!dm::p3p<true>(X, uv, make_cam_r(F), cv6)) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cv6[k] = 0;  // safeSolvePnP's zero pose
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) rep_poses[(size_t)r * 6 + k] = cv6[k];
+}
+
+hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj) {
+    hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1), dim3(64), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
+    const int R = 18 + 6 * cap;
+    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 63) / 64), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
+    return hipGetLastError();
+}
+
+hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out) {
+    if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
+    const int B = 18 + 6 * cap;
+    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void k_refine_fd_finish_set(const double* __restrict__ rep_out, const int32_t* __restrict__ n_obj, int cap, int skip,
+                                                             float eps_obj, double* __restrict__ J_set, double* __restrict__ J_obj) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;  // 0..8: set point pt = pair / 3, channel pair % 3; then 3 per cell
+    const int npairs = 9 + 3 * min(n_obj[0], cap);
+    if (pair >= npairs) return;
+    double f6[6], b6[6], cvf[6], cvb[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cvf[k] = rep_out[(size_t)(2 * pair) * 6 + k]; cvb[k] = rep_out[(size_t)(2 * pair + 1) * 6 + k]; }
+    dm::cv_to_jp6(cvf, f6);
+    dm::cv_to_jp6(cvb, b6);
+    if (pair < 9) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) J_set[k * 9 + pair] = (f6[k] - b6[k]) / (double)(2 * eps_obj);  // no skip factor (cnn.h:923)
+    } else {
+        const int cell = (pair - 9) / 3, c = (pair - 9) % 3;
+#pragma unroll
+        for (int k = 0; k < 6; k++) J_obj[((size_t)cell * 6 + k) * 3 + c] = (f6[k] - b6[k]) / (double)(2 * eps_obj) * skip;
+    }
+}
+
+hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set, double* J_obj) {
+    const int pairs = 9 + 3 * cap;
+    hipLaunchKernelGGL(k_refine_fd_finish_set, dim3((pairs + 63) / 64), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_obj, J_set, J_obj);
     return hipGetLastError();
 }
 

@@ -59,9 +59,20 @@ hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6
                                   const double* dpnp, double* grad_xyz, double* g);
 
 // ---- k_refine.hip ----------------------------------------------------------------------------------
+// inlier_map: map_stride == 0 -> H*W counters of problem 0 only; map_stride == H*W -> one map per problem
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done);
+                  int32_t* steps_done, int map_stride = 0);
+// inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)
+hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps);
+// DSAC-variant replica plan (core/cnn.h:854-990 dRefine): 18 replicas perturb the first three points of the minimal set,
+// 6 per selected inlier cell follow; every replica's start pose is P3P of the set read from the perturbed map.
+hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj);
+hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out);
+hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set /*6 x 9*/,
+                                double* J_obj);
 // builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,
@@ -73,6 +84,6 @@ hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t
                             double* J_hyp, double* J_obj);
 
 // ---- k_loss.hip ------------------------------------------------------------------------------------
-hipError_t pose_loss(hipStream_t st, const double* est_cv6, const double* gt_jp6, double* out4, double* J6);
+hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6 /*B x 6*/, const double* gt_jp6, double* out4 /*B x 4*/, double* J6 /*B x 6*/);
 
 }  // namespace dk

@@ -284,6 +284,106 @@ class Engine:
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
         return grad, g
 
+    # ---- DSAC variant (core/cnn.h) ------------------------------------------------------------------------
+    def refineAll(self, init_poses, perm, sets=None, max_inl=100, min_inl=50, thr=10.0, want_inlier_maps=False):
+        """All N hypotheses refined as one batch (processImage of core/cnn.h:1155-1215).  Returns (poses N x 6 [cv], steps_done N
+        [, inlier_maps N x P with the minimal sets' own cells cleared when `sets` is given])."""
+        init = _np(np.asarray(init_poses, dtype=np.float64).reshape(-1, 6), np.float64)
+        N = int(init.shape[0])
+        perm = _np(np.asarray(perm).reshape(-1, self.P), np.int32)
+        out = np.zeros((N, 6))
+        sd = np.zeros(N, np.int32)
+        maps = np.zeros((N, self.P), np.int32) if want_inlier_maps else None
+        check(self._ctx, lib.dsac_refine_all(self._ctx, N, ptr(init), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl), float(thr),
+                                             ptr(_np(sets, np.int32)) if sets is not None else None, ptr(out), ptr(maps), ptr(sd)))
+        return (out, sd, maps) if want_inlier_maps else (out, sd)
+
+    def dRefineSet(self, set4, perm, inlier_map, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01, eps_obj=2.0, cap=4096):
+        """dRefine of the DSAC variant (core/cnn.h:854-990) for one hypothesis given by its minimal set.
+        Returns (J_set 6 x 9 [columns pt*3 + c, pt < 3], obj_pixels n, J_obj n x 6 x 3)."""
+        set4 = _np(np.asarray(set4).reshape(4), np.int32)
+        perm = _np(np.asarray(perm).reshape(-1, self.P), np.int32)
+        im = _np(np.asarray(inlier_map).reshape(self.P), np.int32)
+        cap = int(min(cap, max(1, int((im != 0).sum()))))
+        J_set = np.zeros((6, 9))
+        px = np.zeros(cap, np.int32)
+        J_obj = np.zeros((cap, 6, 3))
+        n = np.zeros(1, np.int32)
+        check(self._ctx, lib.dsac_refine_fd_set(self._ctx, ptr(set4), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl), float(thr), ptr(im),
+                                                float(sub_sample), float(eps_obj), ptr(J_set), ptr(px), ptr(J_obj), cap, ptr(n)))
+        k = int(n[0])
+        return J_set, px[:k], J_obj[:k]
+
+    def maxLossBatch(self, est_cv6, gt_jp6, want_grad=False):
+        """maxLoss [+ dLossMax] of B estimates against one ground truth (losses of expectedMaxLoss, core/cnn.h:137-150)."""
+        est = np.ascontiguousarray(np.asarray(est_cv6, dtype=np.float64).reshape(-1, 6))
+        gt = np.ascontiguousarray(np.asarray(gt_jp6, dtype=np.float64).reshape(6))
+        B = est.shape[0]
+        out4 = np.zeros((B, 4))
+        J = np.zeros((B, 6)) if want_grad else None
+        check(self._ctx, lib.dsac_loss_batch(self._ctx, B, ptr(est), ptr(gt), ptr(out4), ptr(J)))
+        r = dict(loss=out4[:, 0].copy(), rotErr=out4[:, 1].copy(), tErr=out4[:, 2].copy(), correct=out4[:, 3] > 0.5)
+        if want_grad:
+            r["grad"] = J
+        return r
+
+    @staticmethod
+    def draw(probs, u=None, eps=1e-8):
+        """draw (core/cnn.h:102-127): entry of the discrete distribution hit by u * sum (u uniform in [0,1), supplied by the caller),
+        entries below EPS skipped; u = None -> the most probable entry (randomDraw = false)."""
+        probs = np.asarray(probs, dtype=np.float64)
+        keep = np.flatnonzero(probs >= eps)
+        if u is None:
+            return int(keep[np.argmax(probs[keep])])
+        cum = np.cumsum(probs[keep])
+        return int(keep[min(np.searchsorted(cum, u * cum[-1], side="right"), len(keep) - 1)])
+
+    def processImageDSAC(self, N=256, seed=1305, perm=None, gt_jp6=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, alpha=0.1,
+                         score_fn=None, draw_u=None, sets=None, max_tries=1 << 20):
+        """Forward pass of the DSAC variant's processImage (core/cnn.h:1000-1240): N hypotheses, scores (soft-inlier count or
+        score_fn on the error images), softmax, probabilistic selection, refinement of ALL hypotheses, expected loss."""
+        poses, sets_out, ok = self.sample(N, seed=seed, thr=thr, max_tries=max_tries, sets=sets)
+        err = np.zeros((N, self.P), np.float32) if score_fn is not None else None
+        soft = np.zeros(N)
+        self.reproject(poses, err=err, soft=soft, tau=tau, beta=beta)
+        scores, scale = (np.ascontiguousarray(score_fn(err.reshape(N, self.H, self.W)), dtype=np.float64), 1.0) if score_fn is not None else (soft, alpha)
+        w, ent, _ = self.softMax(scores, scale)
+        hyp_idx = self.draw(w, draw_u)
+        ref, sd, maps = self.refineAll(poses, perm, sets=sets_out, max_inl=inlierCount, min_inl=minInliers, thr=float(int(thr)), want_inlier_maps=True)
+        out = dict(hyps=poses, sampledPoints=sets_out, ok=ok, scores=scores, score_scale=scale, sfScores=w, sfEntropy=float(ent[0]), hypIdx=hyp_idx,
+                   refHyps=ref, refSteps=sd, inlierMaps=maps, pixelIdxs=np.ascontiguousarray(perm, dtype=np.int32), diffMaps=err)
+        if gt_jp6 is not None:
+            L = self.maxLossBatch(ref, gt_jp6)
+            out.update(losses=L["loss"], expectedLoss=float(np.dot(w, L["loss"])), rotErr=float(L["rotErr"][hyp_idx]), tErr=float(L["tErr"][hyp_idx]),
+                       correct=bool(L["correct"][hyp_idx]))
+        return out
+
+    def backwardDSAC(self, fwd, gt_jp6, d_scores_fn=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, sub_sample=0.01, min_prob=1e-4):
+        """Backward section of the DSAC trainer (core/train_ransac.cpp:303-399): dE[loss]/d(scene coordinates), P x 3.
+        Path I: sum_h w_h dLossMax(ref_h) . dRefine_h (hypotheses with w_h <= 1e-4 skipped, :318); path II: dSMScore (core/cnn.h:
+        726-768), whose result the reference re-orders to row-major, i.e. no index quirk here."""
+        w, sets, ref = fwd["sfScores"], fwd["sampledPoints"], fwd["refHyps"]
+        N = len(w)
+        grad = np.zeros((self.P, 3))
+        dL = self.maxLossBatch(ref, gt_jp6, want_grad=True)["grad"]
+        for h in range(N):
+            if not w[h] > min_prob:
+                continue
+            J_set, px, J_obj = self.dRefineSet(sets[h], fwd["pixelIdxs"], fwd["inlierMaps"][h], max_inl=inlierCount, min_inl=minInliers,
+                                               thr=float(int(thr)), sub_sample=sub_sample)
+            for pt in range(3):
+                grad[sets[h][pt]] += w[h] * (dL[h] @ J_set[:, pt * 3:pt * 3 + 3])
+            if len(px):
+                np.add.at(grad, px, w[h] * np.einsum("k,ikc->ic", dL[h], J_obj))
+        losses = fwd["losses"]
+        g = w * (losses - np.dot(w, losses))  # core/cnn.h:737-742
+        if d_scores_fn is not None:
+            d_err = np.ascontiguousarray(d_scores_fn(g), dtype=np.float32).reshape(N, self.P)
+            grad = self.dScore(fwd["hyps"], sets, d_err, grad=grad)
+        else:
+            grad = self.dSoftScore(fwd["hyps"], sets, g * fwd["score_scale"], tau=tau, beta=beta, grad=grad)
+        return dict(grad=grad, dLoss_dRef=dL, scoreOutputGradients=g)
+
     # ---- pipelines (host-orchestrated mirrors of processImage and of the trainer's backward section) ---------
     def processImage(self, N=256, seed=1305, perm=None, gt_jp6=None, thr=10.0, refSteps=8, inlierCount=100, minInliers=50, tau=10.0,
                      beta=0.5, alpha=0.1, score_fn=None, keep_err=False, max_tries=1 << 20):

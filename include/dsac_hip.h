@@ -178,6 +178,24 @@ int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_t* perm, 
                    const int32_t* inlier_map, float sub_sample, float eps_hyp, float eps_obj, double* J_hyp, int32_t* obj_pixels,
                    double* J_obj, int cap, int32_t* n_obj);
 
+/* ---- DSAC variant (core/cnn.h, the probabilistic-selection twin of the soft-argmax path) ------------------------ */
+/* All N hypotheses refined as one batch: the per-hypothesis loop of processImage core/cnn.h:1155-1215.  perm is the
+ * shared steps x H*W permutation (every hypothesis re-seeds the same default std::mt19937, :1169).  inlier_maps
+ * (N x H*W int32, zeroed here) receives one hit-count map per hypothesis; with sets (N x 4) the cells of each
+ * hypothesis' own minimal set are cleared afterwards (:1208-1214). */
+int dsac_refine_all(dsac_ctx* ctx, int N, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                    const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null);
+/* Replaces dRefine core/cnn.h:854-990 for ONE hypothesis given by its minimal set: the refinement restarts from P3P of
+ * the set (:797-800), so besides dRefineObj's inlier cells the first three set points are perturbed as well
+ * (+-eps_obj = 2.f on the map and on the P3P input alike).  J_set is 6 x 9 (columns pt*3 + c, pt < 3), J_obj / obj_pixels /
+ * n_obj as in dsac_refine_fd (scaled by skip; J_set is not, :923). */
+int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                       const int32_t* inlier_map, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                       int32_t* n_obj);
+/* maxLoss / dLossMax for B estimates against one ground truth: the losses[] of expectedMaxLoss core/cnn.h:137-150 and
+ * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
+int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+
 /* ---- K7: pose loss ---------------------------------------------------------------------------------- */
 /* Replaces maxLoss core/maxloss.h:69-79 (+ getInvHyp :39-61, Hypothesis::calcAngularDistance
  * Hypothesis.cpp:137-143) and dLossMax :87-198.  est is a cv pose (converted with cv2our, types.h:186-214,

@@ -624,6 +624,65 @@ void orc_dRefineObj(const double* init_cv6, const int32_t* perm, int refSteps, i
     }
 }
 
+// ---- core/cnn.h:786-852 refine (DSAC variant) and :854-990 dRefine --------------------------------------------------
+// The DSAC variant's refine() restarts from P3P of the minimal set (cnn.h:797-800) instead of taking a pose, so its
+// finite differences also perturb the first three set points -- on the map (localEstObj) and on the P3P input (objPts)
+// alike (:875-880) -- before the inlier cells of dRefineObj's scheme (:930-986).  Column index y*W*3 + x*3 + c.
+static void refine_from_set(const Frame& F, const int32_t* set4, const int32_t* perm, int refSteps, int inlierCount, int minInliers, float thr,
+                            int pert_px, int pert_c, float pert_value, double* out_cv6) {
+    float X4[12], uv4[8];
+    for (int j = 0; j < 4; j++) {
+        const int p = set4[j];
+        for (int c = 0; c < 3; c++) X4[j * 3 + c] = (p == pert_px && c == pert_c) ? pert_value : F.xyz[(size_t)p * 3 + c];
+        uv4[2 * j] = F.uv[2 * (size_t)p]; uv4[2 * j + 1] = F.uv[2 * (size_t)p + 1];
+    }
+    double init[6];
+    safe_p3p(X4, uv4, F.K, init);
+    refine_cv(F, perm, refSteps, inlierCount, minInliers, thr, init, pert_px, pert_c, pert_value, out_cv6, nullptr);
+}
+
+void orc_refine_from_set(const int32_t* set4, const int32_t* perm, int refSteps, int inlierCount, int minInliers, float thr, const float* xyz,
+                         const float* uv, int H, int W, const double* cam, double* out_cv6) {
+    Frame F{xyz, uv, H, W, Cam{cam[0], cam[1], cam[2], cam[3]}};
+    refine_from_set(F, set4, perm, refSteps, inlierCount, minInliers, thr, -1, 0, 0.f, out_cv6);
+}
+
+void orc_dRefineDSAC(const int32_t* set4, const int32_t* perm, int refSteps, int inlierCount, int minInliers, float thr, float subSampleFactor,
+                     const int32_t* inlier_map, const float* xyz, const float* uv, int H, int W, const double* cam, float eps,
+                     double* J /*6 x 3P, zero-filled here*/) {
+    Frame F{xyz, uv, H, W, Cam{cam[0], cam[1], cam[2], cam[3]}};
+    const size_t P = (size_t)H * W;
+    std::fill(J, J + 6 * 3 * P, 0.0);
+    struct Job { int p, c; double scale; };
+    std::vector<Job> jobs;
+    for (int pt = 0; pt < 3; pt++)  // "skip last point, because gradient is anyway zero" (cnn.h:872)
+        for (int c = 0; c < 3; c++) jobs.push_back({set4[pt], c, 1.0});
+    const int skip = (int)(1 / subSampleFactor);
+    int inCount = 0;
+    for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+            if (inlier_map[y * W + x] == 0) continue;
+            inCount++;
+            if (inCount % skip != 0) continue;
+            for (int c = 0; c < 3; c++) jobs.push_back({y * W + x, c, (double)skip});
+        }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < (int)jobs.size(); i++) {
+        const Job& jb = jobs[i];
+        const float v0 = F.xyz[(size_t)jb.p * 3 + jb.c];
+        const float vf = v0 + eps;
+        const float vb = vf - 2 * eps;
+        double o[6], f6[6], b6[6];
+        refine_from_set(F, set4, perm, refSteps, inlierCount, minInliers, thr, jb.p, jb.c, vf, o);
+        cv_to_jp6(o, f6);
+        refine_from_set(F, set4, perm, refSteps, inlierCount, minInliers, thr, jb.p, jb.c, vb, o);
+        cv_to_jp6(o, b6);
+        // a set point that is also a selected inlier cell would be written twice in the reference (second write wins, with
+        // the skip factor); processImage clears the set's cells from the inlier map, so that does not happen
+        for (int k = 0; k < 6; k++) J[k * 3 * P + (size_t)jb.p * 3 + jb.c] = (f6[k] - b6[k]) / (2 * eps) * jb.scale;
+    }
+}
+
 // ---- core/cnn_softam.h:609-645  dScore, part (iii) --------------------------------------------------
 // Given the gradient of the loss w.r.t. each error image (dDiff, N x P doubles, (y,x) row-major) this
 // accumulates sum_h J_h into grad (P x 3, row-major y*W+x unless quirk_transpose).

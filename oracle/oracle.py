@@ -364,6 +364,33 @@ def dRefineObj(init_cv6, perm, inlier_map, xyz, uv, H, W, cam, inlier_count=100,
     return J
 
 
+def refine_from_set(set4, perm, xyz, uv, H, W, cam, inlier_count=100, min_inliers=50, thr=10.0):
+    """DSAC variant's refine (core/cnn.h:786-852): P3P of the minimal set, then the same inlier / LM loop.  Returns the cv pose."""
+    set4, sp = _i(np.asarray(set4).reshape(4))
+    perm, pp = _i(np.asarray(perm).reshape(-1, H * W))
+    xyz, xp = _f(np.asarray(xyz).reshape(-1, 3))
+    uv, up = _f(np.asarray(uv).reshape(-1, 2))
+    cam, cp = _cam(cam)
+    out = np.zeros(6)
+    lib().orc_refine_from_set.argtypes = [c_ip, c_ip, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp, C.c_int, C.c_int, c_dp, c_dp]
+    lib().orc_refine_from_set(sp, pp, perm.shape[0], inlier_count, min_inliers, thr, xp, up, H, W, cp, out.ctypes.data_as(c_dp))
+    return out
+
+
+def dRefineDSAC(set4, perm, inlier_map, xyz, uv, H, W, cam, inlier_count=100, min_inliers=50, thr=10.0, sub_sample=0.01, eps=2.0):
+    """DSAC variant's dRefine (core/cnn.h:854-990): 6 x 3P, columns y*W*3 + x*3 + c."""
+    set4, sp = _i(np.asarray(set4).reshape(4))
+    perm, pp = _i(np.asarray(perm).reshape(-1, H * W))
+    im, ip = _i(np.asarray(inlier_map).reshape(H * W))
+    xyz, xp = _f(np.asarray(xyz).reshape(-1, 3))
+    uv, up = _f(np.asarray(uv).reshape(-1, 2))
+    cam, cp = _cam(cam)
+    J = np.zeros((6, 3 * H * W))
+    lib().orc_dRefineDSAC.argtypes = [c_ip, c_ip, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_ip, c_fp, c_fp, C.c_int, C.c_int, c_dp, C.c_float, c_dp]
+    lib().orc_dRefineDSAC(sp, pp, perm.shape[0], inlier_count, min_inliers, thr, sub_sample, ip, xp, up, H, W, cp, eps, J.ctypes.data_as(c_dp))
+    return J
+
+
 def dScore(sets, dDiff, xyz, uv, H, W, cam, quirk_transpose=False, grad=None, quirk_rot_writeback=False):
     sets, sp = _i(np.asarray(sets).reshape(-1, 4))
     N = sets.shape[0]

@@ -1,0 +1,89 @@
+"""GPU parity of the DSAC-variant rows (core/cnn.h, core/train_ransac.cpp): refinement of all N
+hypotheses with per-hypothesis inlier maps, per-hypothesis losses / expected loss, dRefine with minimal-set perturbation,
+dSMScore and the trainer's backward section -- HIP engine through the C ABI against the oracle restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+H = W = 40
+
+
+@pytest.fixture()
+def fwd_state(engine, orc, synth, frame40):
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], H, W, fr["cam"])
+    perm = synth.fast_permutations(H * W, 8)
+    gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    fwd = engine.processImageDSAC(N=48, seed=77, perm=perm, gt_jp6=gt, draw_u=0.37)
+    return fr, perm, gt, fwd
+
+
+def test_refine_all_losses_and_selection(engine, orc, fwd_state):
+    fr, perm, gt, fwd = fwd_state
+    N = 48
+    assert fwd["ok"].all() and abs(fwd["sfScores"].sum() - 1) < 1e-12
+    Rg = orc.rodrigues_vec2mat(gt[:3])
+    losses = np.zeros(N)
+    for h in range(N):
+        ref, imap, sd = orc.refine(fwd["hyps"][h][None], perm, fr["xyz"], fr["uv"], H, W, fr["cam"], want_inlier_map=True)
+        imap[fwd["sampledPoints"][h]] = 0  # core/cnn.h:1208-1214
+        assert sd[0] == fwd["refSteps"][h]
+        assert np.array_equal(imap, fwd["inlierMaps"][h])
+        assert np.allclose(fwd["refHyps"][h], ref[0], rtol=1e-6, atol=1e-8)
+        Re, te = orc.cv2our(ref[0])
+        losses[h] = orc.maxLoss(Rg, gt[3:], Re, te)
+    assert np.allclose(fwd["losses"], losses, rtol=1e-6, atol=1e-7)
+    assert abs(fwd["expectedLoss"] - np.dot(fwd["sfScores"], losses)) <= 1e-6 * max(1, fwd["expectedLoss"])
+    # selection: the reference's cumulative-map draw for a given uniform number; arg-max when randomDraw is off
+    cum = np.cumsum(fwd["sfScores"])
+    assert fwd["hypIdx"] == int(np.searchsorted(cum, 0.37 * cum[-1], side="right"))
+    assert engine.draw(fwd["sfScores"]) == int(np.argmax(fwd["sfScores"]))
+    # batched dLossMax = per-pose dLossMax
+    g = engine.maxLossBatch(fwd["refHyps"], gt, want_grad=True)["grad"]
+    for h in (0, 7, 31):
+        assert np.allclose(g[h], orc.dLossMax(orc.cv_to_jp6(fwd["refHyps"][h]), gt), rtol=1e-6, atol=1e-9)
+
+
+def test_drefine_with_minimal_set_perturbation(engine, orc, fwd_state):
+    fr, perm, gt, fwd = fwd_state
+    order = np.argsort(-fwd["sfScores"])[:3]
+    for h in order:
+        set4, imap = fwd["sampledPoints"][h], fwd["inlierMaps"][h]
+        J_set, px, J_obj = engine.dRefineSet(set4, perm, imap, sub_sample=0.05)
+        Jr = orc.dRefineDSAC(set4, perm, imap, fr["xyz"], fr["uv"], H, W, fr["cam"], sub_sample=0.05)
+        got = np.zeros_like(Jr)
+        for pt in range(3):
+            got[:, set4[pt] * 3:set4[pt] * 3 + 3] = J_set[:, pt * 3:pt * 3 + 3]
+        for i, p in enumerate(px):
+            got[:, p * 3:p * 3 + 3] = J_obj[i]
+        assert (np.abs(Jr).sum(0) > 0).sum() >= 9 and len(px) > 0
+        scale = np.abs(Jr).max()
+        assert np.abs(got - Jr).max() <= 2e-3 * scale, (h, np.abs(got - Jr).max(), scale)
+        # the refinement restarted from the set reproduces the forward refinement of that hypothesis
+        assert np.allclose(orc.refine_from_set(set4, perm, fr["xyz"], fr["uv"], H, W, fr["cam"]), fwd["refHyps"][h], rtol=1e-6, atol=1e-8)
+
+
+def test_training_backward_of_the_dsac_variant(engine, orc, fwd_state):
+    fr, perm, gt, fwd = fwd_state
+    tau, beta = 10.0, 0.5
+    bwd = engine.backwardDSAC(fwd, gt, sub_sample=0.05)
+    # the same chain from oracle pieces (core/train_ransac.cpp:303-373)
+    w, sets = fwd["sfScores"], fwd["sampledPoints"]
+    N = len(w)
+    grad = np.zeros((H * W, 3))
+    for h in range(N):
+        if not w[h] > 1e-4:
+            continue
+        dL = orc.dLossMax(orc.cv_to_jp6(fwd["refHyps"][h]), gt)
+        J = orc.dRefineDSAC(sets[h], perm, fwd["inlierMaps"][h], fr["xyz"], fr["uv"], H, W, fr["cam"], sub_sample=0.05)
+        grad += w[h] * (dL @ J).reshape(H * W, 3)
+    g = w * (fwd["losses"] - np.dot(w, fwd["losses"]))
+    assert np.allclose(bwd["scoreOutputGradients"], g, rtol=1e-9, atol=1e-12)
+    err = orc.get_diff_maps(fwd["hyps"], fr["xyz"], fr["uv"], H, W, fr["cam"]).astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-beta * (tau - err)))
+    dDiff = (g * fwd["score_scale"])[:, None] * (-beta) * s * (1 - s)
+    grad, _, _ = orc.dScore(sets, dDiff, fr["xyz"], fr["uv"], H, W, fr["cam"], grad=grad)  # dSMScore re-orders to row-major: no quirk
+    emax = np.abs(bwd["grad"] - grad).max() / np.abs(grad).max()
+    el2 = np.linalg.norm(bwd["grad"] - grad) / np.linalg.norm(grad)
+    print("DSAC-variant end-to-end gradient: max-rel %.3e l2-rel %.3e" % (emax, el2))
+    assert emax <= 1e-2 and el2 <= 1e-2
