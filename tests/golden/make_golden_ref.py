@@ -69,6 +69,24 @@ def main():
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| loss %.4f rotErr %.4f tErr %.3f entropy %.4f" %
           (r["loss"], r["rotErr"], r["tErr"], r["sfEntropy"]))
 
+    # ---- the DSAC (probabilistic selection) variant, core/cnn.h + the backward section of core/train_ransac.cpp ----------
+    from oracle import reference_dsac as refd
+    refd.lib(random_draw=False)
+    refd.set_score_model(TAU, BETA, ALPHA)
+    d = refd.processImage(1305, fr["xyz"], gt_jp6, hyps=32, backward=True, sub_sample=SUB_SAMPLE)
+    o2 = dict(cam=ref.cam(), tau=TAU, beta=BETA, alpha=ALPHA, sub_sample=SUB_SAMPLE, gt_jp6=gt_jp6, thr=10, inlier_count=100, ref_steps=8)
+    for k in ("hyps", "refHyps", "sampledPoints", "sfScores", "losses", "sampling", "estObj", "inlierMaps", "pixelIdxs", "dLoss_dObj"):
+        o2[k] = d[k]
+    for k in ("expectedLoss", "sfEntropy", "tErr", "rotErr", "correct", "hypIdx"):
+        o2[k] = np.asarray(d[k])
+    best = int(np.argmax(d["sfScores"]))
+    sets = d["sampledPoints"][:, :, 1] * 40 + d["sampledPoints"][:, :, 0]
+    o2["dRefine_best"] = refd.dRefine(sets[best], d["pixelIdxs"], d["inlierMaps"][best], d["estObj"], d["sampling"], 40, 40, sub_sample=SUB_SAMPLE)
+    path = os.path.join(HERE, "refd_frame_v1.npz")
+    np.savez_compressed(path, **o2)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| expected loss %.4f hypIdx %d entropy %.4f" %
+          (d["expectedLoss"], d["hypIdx"], d["sfEntropy"]))
+
 
 if __name__ == "__main__":
     main()
