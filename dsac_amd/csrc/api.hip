@@ -696,6 +696,26 @@ int dsac_loss(dsac_ctx* c, const double* est_cv6, const double* gt_jp6, double* 
     return end_call(c);
 }
 
+int dsac_gather_patches(dsac_ctx* c, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches, int32_t* skipped_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_gather_patches: ctx is NULL");
+    if (!bgr || !sampling_xy || !patches || H <= 0 || W <= 0 || n < 0 || patch <= 0 || (patch & 1))
+        return fail(c, DSAC_ERR_INVALID, "dsac_gather_patches: NULL argument, empty image or odd/non-positive patch size");
+    if (n == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const uint8_t* d_img;
+    const int32_t* d_xy;
+    float* d_out;
+    int32_t* d_skip;
+    ARG_TRY(in_arg(c, bgr, (size_t)H * W * 3, &d_img));
+    ARG_TRY(in_arg(c, sampling_xy, (size_t)n * 2, &d_xy));
+    ARG_TRY(out_arg(c, patches, (size_t)n * 3 * patch * patch, &d_out));
+    ARG_TRY(out_arg(c, skipped_or_null, 1, &d_skip));
+    if (d_skip) HIP_TRY(c, hipMemsetAsync(d_skip, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, dk::gather_patches(c->stream, d_img, H, W, d_xy, n, patch, d_out, d_skip));
+    return end_call(c);
+}
+
 int dsac_loss_batch(dsac_ctx* c, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_loss_batch: ctx is NULL");
     if (B < 0 || !est_cv6 || !gt_jp6 || (!out4 && !J6_or_null)) return fail(c, DSAC_ERR_INVALID, "dsac_loss_batch: NULL argument or negative count");

@@ -86,4 +86,8 @@ hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t
 // ---- k_loss.hip ------------------------------------------------------------------------------------
 hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6 /*B x 6*/, const double* gt_jp6, double* out4 /*B x 4*/, double* J6 /*B x 6*/);
 
+// ---- k_patches.hip ---------------------------------------------------------------------------------
+// n patches of 3 x patch x patch floats (patch, channel, row, column) around sampling_xy[i] = (x, y) of an H x W x 3 BGR image
+hipError_t gather_patches(hipStream_t st, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* out, int32_t* skipped);
+
 }  // namespace dk

@@ -27,6 +27,44 @@ CNN_RGB_PATCHSIZE = 42  # core/lua_calls.h:30
 OBJ_MEAN, SCORE_MEAN, CLAMP_E2E = 127.0, 45.0, 0.1  # train_obj_softam.lua:17,14 ; train_score_softam.lua:6,13
 
 
+def stochastic_sub_sample(width=640, height=480, target=CNN_OBJ_PATCHSIZE, patch=CNN_RGB_PATCHSIZE, seed=1305):
+    """stochasticSubSample (core/cnn_softam.h:283-309): one random pixel per cell of a target x target partition of the frame
+    interior.  Returns target*target x 2 int32 (x, y), row-major over the sub-sampled grid (cell (sampleY, sampleX)).
+
+    Bit-exact with the reference's generator: ThreadRand thread 0 is std::mt19937(seed) (thread_rand.cpp:40-57, default seed
+    1305), drand is std::uniform_real_distribution<double>, i.e. libstdc++'s generate_canonical: two 32-bit draws,
+    (a + b * 2^32) / 2^64, scaled to [min, max); the float loop variables and the int() truncation are the reference's."""
+    from numpy.random import MT19937
+    bg = MT19937()
+    bg._legacy_seeding(int(seed))
+
+    def drand(lo, hi):
+        a, b = (int(v) for v in bg.random_raw(2))
+        r = (a + b * 4294967296.0) / 18446744073709551616.0
+        if r >= 1.0:
+            r = np.nextafter(1.0, 0.0)
+        return r * (float(hi) - float(lo)) + float(lo)
+
+    f32 = np.float32
+    out = np.zeros((target, target, 2), np.int32)
+    x_stride = f32(width - patch) / f32(target)
+    y_stride = f32(height - patch) / f32(target)
+    half = patch // 2
+    sx, min_x, x = 0, f32(half), f32(x_stride + f32(half))
+    while x <= width - half + 1:
+        sy, min_y, y = 0, f32(half), f32(y_stride + f32(half))
+        while y <= height - half + 1:
+            cur_x = int(drand(min_x, x))
+            cur_y = int(drand(min_y, y))
+            if sx < target and sy < target:
+                out[sy, sx] = (cur_x, cur_y)
+            sy += 1
+            min_y, y = y, f32(y + y_stride)
+        sx += 1
+        min_x, x = x, f32(x + x_stride)
+    return out.reshape(target * target, 2)
+
+
 def _conv(cin, cout, stride, pad):
     return [nn.Conv2d(cin, cout, 3, stride, pad), nn.ReLU(inplace=True)]
 

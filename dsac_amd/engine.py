@@ -284,6 +284,21 @@ class Engine:
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
         return grad, g
 
+    # ---- producer side ------------------------------------------------------------------------------------------
+    def gatherPatches(self, bgr, sampling_xy, patch=42, out=None):
+        """Patch assembly of getCoordImg (cnn_softam.h:224-254): bgr H x W x 3 uint8, sampling_xy n x 2 int32 (x, y) ->
+        n x 3 x patch x patch float32 (the layout pushMaps hands to the scene-coordinate CNN).  Returns (patches, skipped)."""
+        H, W = int(bgr.shape[0]), int(bgr.shape[1])
+        if isinstance(bgr, np.ndarray):
+            bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        xy = _np(sampling_xy, np.int32)
+        n = int(xy.shape[0])
+        if out is None:
+            out = np.zeros((n, 3, patch, patch), np.float32)
+        skipped = np.zeros(1, np.int32)
+        check(self._ctx, lib.dsac_gather_patches(self._ctx, ptr(bgr), H, W, ptr(xy), n, int(patch), ptr(out), ptr(skipped)))
+        return out, int(skipped[0])
+
     # ---- DSAC variant (core/cnn.h) ------------------------------------------------------------------------
     def refineAll(self, init_poses, perm, sets=None, max_inl=100, min_inl=50, thr=10.0, want_inlier_maps=False):
         """All N hypotheses refined as one batch (processImage of core/cnn.h:1155-1215).  Returns (poses N x 6 [cv], steps_done N

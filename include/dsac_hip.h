@@ -196,6 +196,14 @@ int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_t* perm, 
  * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
 int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
 
+/* ---- producer side: patch gather for the scene-coordinate CNN ----------------------------------------------------- */
+/* Replaces the patch assembly of getCoordImg core/cnn_softam.h:224-254 in the table layout of pushMaps core/lua_calls.h:63-80:
+ * patches[i][c][y][x] = (float) bgr[(sy + y) * W + (sx + x)][c] with (sx, sy) = sampling_xy[i] - patch/2.  bgr is the H x W x 3
+ * uint8 image (jp::img_bgr_t), sampling_xy n x (x, y) int32 (the reference's `sampling`), patch = CNN_RGB_PATCHSIZE (42).
+ * A window that leaves the image (the reference skips such patches, :235-239) is written as zeros and counted in *skipped. */
+int dsac_gather_patches(dsac_ctx* ctx, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches,
+                        int32_t* skipped_or_null);
+
 /* ---- K7: pose loss ---------------------------------------------------------------------------------- */
 /* Replaces maxLoss core/maxloss.h:69-79 (+ getInvHyp :39-61, Hypothesis::calcAngularDistance
  * Hypothesis.cpp:137-143) and dLossMax :87-198.  est is a cv pose (converted with cv2our, types.h:186-214,

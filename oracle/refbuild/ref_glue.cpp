@@ -149,6 +149,30 @@ void ref_dScore(int N, const int32_t* points, const double* ddiff_or_null, const
     for (int h = 0; h < N; h++) put_mat(J[h], jac + (size_t)h * S * S * 3);
 }
 
+// ---- producer side: stochasticSubSample (cnn_softam.h:283-309) and the patch assembly of getCoordImg (:224-254) ------------
+// sampling_xy: 1600 x (x, y); patches: n x 3 x 42 x 42 floats in the order pushMaps would hand them to Lua (lua_calls.h:63-80).
+// Returns the number of patches (border positions are skipped by the reference).
+int ref_subsample_and_patches(unsigned seed, const unsigned char* bgr, int32_t* sampling_xy, float* patches) {
+    const int S = CNN_OBJ_PATCHSIZE, PS = CNN_RGB_PATCHSIZE;
+    GlobalProperties* gp = GlobalProperties::getInstance();
+    const int saved_threads = omp_get_max_threads();
+    omp_set_num_threads(1);
+    ThreadRand::forceInit(seed);
+    jp::img_bgr_t img(gp->dP.imageHeight, gp->dP.imageWidth);
+    for (int y = 0; y < img.rows; y++) for (int x = 0; x < img.cols; x++)
+        img(y, x) = jp::bgr_t(bgr[((size_t)y * img.cols + x) * 3], bgr[((size_t)y * img.cols + x) * 3 + 1], bgr[((size_t)y * img.cols + x) * 3 + 2]);
+    cv::Mat_<cv::Point2i> sampling = stochasticSubSample(img, S, PS);
+    for (int y = 0; y < S; y++) for (int x = 0; x < S; x++) { sampling_xy[2 * (y * S + x)] = sampling(y, x).x; sampling_xy[2 * (y * S + x) + 1] = sampling(y, x).y; }
+    g_pred_m.assign((size_t)S * S * 3, 0.f);
+    std::vector<cv::Mat_<cv::Vec3f>> pv;
+    getCoordImg(img, sampling, PS, pv, coord_state());
+    for (size_t n = 0; n < pv.size(); n++)
+        for (int c = 0; c < 3; c++) for (int y = 0; y < PS; y++) for (int x = 0; x < PS; x++)
+            patches[((n * 3 + c) * PS + y) * PS + x] = pv[n](y, x)[c];
+    omp_set_num_threads(saved_threads);
+    return (int)pv.size();
+}
+
 double ref_maxLoss(const double* R1, const double* t1, const double* R2, const double* t2) {
     return maxLoss(Hypothesis(make_R(R1), cv::Point3d(t1[0], t1[1], t1[2])), Hypothesis(make_R(R2), cv::Point3d(t2[0], t2[1], t2[2])));
 }

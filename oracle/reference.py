@@ -187,6 +187,17 @@ def dScore(points_xy, xyz, uv, ddiff=None, g=None):
     return jac
 
 
+def subsample_and_patches(seed, bgr):
+    """stochasticSubSample + the patch assembly of getCoordImg on a 480 x 640 x 3 uint8 image.
+    Returns (sampling 1600 x 2 [x, y], patches n x 3 x 42 x 42 float32)."""
+    img = np.ascontiguousarray(bgr, dtype=np.uint8)
+    assert img.shape == (480, 640, 3)
+    xy = np.zeros((S * S, 2), np.int32)
+    patches = np.zeros((S * S, 3, 42, 42), np.float32)
+    n = lib().ref_subsample_and_patches(C.c_uint(seed), img.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(xy, c_ip), _p(patches, c_fp))
+    return xy, patches[:n]
+
+
 def maxLoss(R1, t1, R2, t2):
     R1 = _d(R1); t1 = _d(t1); R2 = _d(R2); t2 = _d(t2)
     return float(lib().ref_maxLoss(_p(R1, c_dp), _p(t1, c_dp), _p(R2, c_dp), _p(t2, c_dp)))

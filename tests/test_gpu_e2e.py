@@ -95,3 +95,24 @@ def test_step_with_the_reference_architectures(synth, frame40, orc):
     moved = sum(int((a != b).any()) for a, b in zip(before, ts.params()))
     assert moved > 0
     ts.engine.close()
+
+
+def test_patch_gather_matches_the_reference_layout(engine):
+    """dsac_gather_patches vs numpy slicing (the layout is pinned against the reference's getCoordImg in tests/test_producer_cpu.py);
+    host and device buffers, and a window that leaves the image."""
+    import torch
+    from dsac_amd.e2e import stochastic_sub_sample
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    xy = stochastic_sub_sample(640, 480, seed=1305)
+    want = np.stack([img[y - 21:y + 21, x - 21:x + 21].transpose(2, 0, 1).astype(np.float32) for x, y in xy])
+    got, skipped = engine.gatherPatches(img, xy)
+    assert skipped == 0 and np.array_equal(got, want)
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(1600, 3, 42, 42, device=dev)
+    engine.gatherPatches(torch.as_tensor(img, device=dev), torch.as_tensor(xy, device=dev), out=out)
+    engine.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    xy2 = xy[:4].copy(); xy2[1] = (5, 100); xy2[3] = (630, 470)
+    got2, skipped2 = engine.gatherPatches(img, xy2)
+    assert skipped2 == 2 and not got2[1].any() and not got2[3].any() and np.array_equal(got2[0], want[0]) and np.array_equal(got2[2], want[2])
