@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <random>
 
-#include "cnn_softam.h"
+#include "cnn.h"
 
 int main() {
     using namespace dsac;
@@ -45,7 +45,18 @@ int main() {
         std::printf("dScore: |grad| = %.6g\n", std::sqrt(n));
         const std::array<double, 6> dL = frame.dLossMax(r.refAvgHyp, poseGT);
         std::printf("dLossMax: %.4g %.4g %.4g %.4g %.4g %.4g\n", dL[0], dL[1], dL[2], dL[3], dL[4], dL[5]);
-        return (r.correct && r.refStepsDone == 8 && n > 0) ? 0 : 2;
+        // the DSAC (probabilistic selection) variant on the same frame: all hypotheses refined, expected loss, dRefine of the winner
+        DsacFrame dframe(xyz.data(), uv.data(), H, W, cam);
+        ProcessImageDsacResult d = dframe.processImage(poseGT, 64, 1305, 10, 100, 8, perms);
+        std::array<double, 54> Jset{};
+        std::vector<int32_t> px;
+        std::vector<double> Jobj;
+        dframe.dRefine(100, 8, 0.05f, 10.f, perms, d.imgIdx[d.hypIdx], d.inlierMaps.data() + (size_t)d.hypIdx * H * W, Jset, px, Jobj);
+        double ns = 0;
+        for (double v : Jset) ns += v * v;
+        std::printf("DSAC variant: hypIdx %d (p = %.3f), expected loss %.4f, winner rot %.4f deg / trans %.3f mm, |dRefine_set| = %.4g, %zu inlier cells\n",
+                    d.hypIdx, d.sfScores[d.hypIdx], d.expectedLoss, d.rotErr, d.tErr, std::sqrt(ns), px.size());
+        return (r.correct && r.refStepsDone == 8 && n > 0 && d.correct && ns > 0 && d.expectedLoss > 0) ? 0 : 2;
     } catch (const Error& e) {
         std::printf("dsac error %d: %s\n", e.code, e.what());
         return 1;
