@@ -43,10 +43,11 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "2")),
                     help="engine contexts (HIP streams) per GPU")
     ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="gated",
-                    help="'pipeline' = one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary "
-                         "stream under K2/K3 of frame i.  With 2 contexts: 'gated' (default) = frames alternate between two contexts whose K2 launches are serialised by events "
-                         "(dsac_set_k2_events) so that K1/K3 of one frame overlap K2 of the other; 'stages' = stream A samples frame i+1 while stream B scores frame i (K2 launches never "
-                         "overlap each other); 'frames' = whole frames dealt round-robin to the streams")
+                    help="With 2 contexts: 'gated' (default) = frames alternate between two contexts whose K2 launches are serialised by events (dsac_set_k2_events): K1/K3 of "
+                         "one frame run under K2 of the other and K2 runs alone.  'frames' = the same without the serialisation: two K2 launches may share the GPU -- 5-10 %% "
+                         "more throughput on some boxes, but each K2 launch then takes ~25 %% longer, which lowers roofline.frac (profiles/r01_streams_modes.txt).  'pipeline' = "
+                         "one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary stream under K2/K3 of frame i.  'stages' = stream A "
+                         "samples frame i+1 while stream B scores frame i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--separate-calls", action="store_true", help="use dsac_sample / dsac_reproject / dsac_softmax instead of the fused call")

@@ -265,7 +265,7 @@ DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, res
     return v;
 }
 
-constexpr int KM_CH = 2;  // 64-pixel chunks per wave, all held in registers
+constexpr int KM_CH_DEFAULT = 2;  // 64-pixel chunks per wave, all held in registers (template parameter KM_CH)
 
 // Finish one (hypothesis, pixel) pair from the MFMA outputs d = (xc, yc, zc, -): (xc, yc) are adjacent registers, so one
 // packed fma gives (du, dv) and one packed mul their squares.
@@ -275,7 +275,7 @@ DM_INLINE float finish_pair(const f4 d, float iz, f2 ppix, float clampv) {
     return fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
 }
 
-template <int HT, bool ERR, bool SOFT, bool UV>
+template <int HT, bool ERR, bool SOFT, bool UV, int KM_CH>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                                const float* __restrict__ uv, float* __restrict__ err,
                                                                float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
     }
 }
 
-template <int HT>
+template <int HT, int KM_CH = KM_CH_DEFAULT>
 static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
                                         float kB, float* soft_part, int* tiles_used) {
     const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
@@ -404,7 +404,7 @@ static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* stag
     if (tiles_used) *tiles_used = PT;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2M(E, S, U)                                                                                                               \
-    hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
+    hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
                        F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags)
     if (ERR && SOFT) { if (UV) DSAC_K2M(true, true, true); else DSAC_K2M(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2M(true, false, true); else DSAC_K2M(true, false, false); }
@@ -462,6 +462,9 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
         case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
         case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
+        case 7: return launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
+        case 8: return launch_reproject_mfma<64, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
+        case 9: return launch_reproject_mfma<32, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
         case 1: return launch_reproject<4, 32, true>(st, N, staged, F, clampv, err, kA, kB, soft_part);
         case 2: return launch_reproject<4, 16, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
         case 3: return launch_reproject<4, 64, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);

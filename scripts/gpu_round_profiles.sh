@@ -5,7 +5,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; O=gpurun_out/r01; mkdir -p $O
 export TMPDIR=/tmp
 nproc > $O/nproc.txt
-echo "== bench 2 contexts, frames round-robin"; timeout 600 python bench.py --streams 2 --overlap frames --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_frames2.json | cut -c1-200
+echo "== bench 2 contexts, frames round-robin (K2 launches may overlap)"; timeout 600 python bench.py --streams 2 --overlap frames --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_frames2.json | cut -c1-200
 echo "== bench in-context pipeline"; timeout 600 python bench.py --streams 1 --overlap pipeline --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_pipeline.json | cut -c1-200
 echo "== bench (default)"; timeout 600 python bench.py 2>/dev/null | tail -1 | tee $O/bench_default.json | cut -c1-400
 echo "== bench (no overlap)"; timeout 600 python bench.py --streams 1 --overlap frames --event-stride 1 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_streams1.json | cut -c1-200
