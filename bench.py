@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "1")),
                     help="engine contexts (HIP streams) per GPU")
     ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="gated",
                     help="With 2 contexts: 'gated' (default) = frames alternate between two contexts whose K2 launches are serialised by events (dsac_set_k2_events): K1/K3 of "
@@ -48,6 +48,9 @@ def main():
                          "more throughput on some boxes, but each K2 launch then takes ~25 %% longer, which lowers roofline.frac (profiles/r01_streams_modes.txt).  'pipeline' = "
                          "one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary stream under K2/K3 of frame i.  'stages' = stream A "
                          "samples frame i+1 while stream B scores frame i")
+    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSAC_BENCH_FRAMES", "8")),
+                    help="independent 640x480 frames (each with --hyps hypotheses) batched into one step: dsac_set_frames / dsac_score_hypotheses_frames carry "
+                         "them through K1, K2, K3 in three launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--separate-calls", action="store_true", help="use dsac_sample / dsac_reproject / dsac_softmax instead of the fused call")
@@ -89,9 +92,18 @@ def main():
     P = H * W
     K, Wm = args.steps, args.warmup
 
-    # one frame per rank (seed 1305 + rank: the reference's ThreadRand seed), uploaded before timing
+    # one frame per rank (seed 1305 + rank: the reference's ThreadRand seed), uploaded before timing; with --frames-per-step B a batch of
+    # B different frames per rank
+    B = max(1, args.frames_per_step)
+    batched = B > 1
+    if batched and (args.kernel_only or args.separate_calls or args.k2_mode != "both" or args.overlap in ("pipeline", "stages") or N % 128 != 0):
+        B, batched = 1, False  # those modes time single frames (K2-only runs, the in-context pipeline, odd hypothesis counts)
     fr = synth.chess_like_frame(H, W, seed=1305 + rank)
-    xyz = torch.from_numpy(fr["xyz"]).to(dev)
+    if batched:
+        frs = [fr] + [synth.chess_like_frame(H, W, seed=1305 + world * 1000 + rank * B + f) for f in range(1, B)]
+        xyz = torch.from_numpy(np.ascontiguousarray(np.stack([f_["xyz"] for f_ in frs]))).to(dev)
+    else:
+        xyz = torch.from_numpy(fr["xyz"]).to(dev)
     pipelined = (args.overlap == "pipeline" and not args.kernel_only and args.k2_mode == "both" and not args.separate_calls)
     n_ctx = 1 if pipelined else max(1, args.streams)
     n_buf = 2 if pipelined else n_ctx
@@ -99,15 +111,19 @@ def main():
     for i in range(n_ctx):
         st = torch.cuda.Stream(device=dev)
         eng = dsac_amd.Engine(local_rank, stream=st)
-        eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
+        if batched:
+            eng.set_frames(xyz, None, H, W, fr["cam"], borrow=True)
+        else:
+            eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
         eng.profile_enable(args.event_stride > 0, stride=max(1, args.event_stride))
         engines.append((eng, st))
+    NB = N * B  # hypotheses per step and context
     for i in range(n_buf):
         bufs.append(dict(
-            poses=torch.zeros(N, 6, dtype=torch.float64, device=dev), sets=torch.zeros(N, 4, dtype=torch.int32, device=dev),
-            ok=torch.zeros(N, dtype=torch.uint8, device=dev), err=torch.empty(N, P, dtype=torch.float32, device=dev),
-            soft=torch.zeros(N, dtype=torch.float64, device=dev), w=torch.zeros(N, dtype=torch.float64, device=dev),
-            ent=torch.zeros(1, dtype=torch.float64, device=dev), avg=torch.zeros(6, dtype=torch.float64, device=dev)))
+            poses=torch.zeros(NB, 6, dtype=torch.float64, device=dev), sets=torch.zeros(NB, 4, dtype=torch.int32, device=dev),
+            ok=torch.zeros(NB, dtype=torch.uint8, device=dev), err=torch.empty(NB, P, dtype=torch.float32, device=dev),
+            soft=torch.zeros(NB, dtype=torch.float64, device=dev), w=torch.zeros(NB, dtype=torch.float64, device=dev),
+            ent=torch.zeros(B, dtype=torch.float64, device=dev), avg=torch.zeros(B, 6, dtype=torch.float64, device=dev)))
     gated = (n_ctx == 2 and args.overlap == "gated")
     if gated:
         # K2 launches of the two contexts run back to back (never overlapping each other); K1 / K3 of one frame overlap K2 of the other
@@ -161,6 +177,11 @@ def main():
             return step_staged(i)
         eng, _ = engines[i % n_ctx]
         b = bufs[i % n_ctx]
+        if batched:
+            # three launches for B frames: K1 over B*N waves, K2 over B*N error images, K3 with one workgroup per frame
+            eng.scoreHypothesesFrames(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
+                                      err=b["err"], out=(b["poses"], b["sets"], b["ok"], b["soft"], b["w"], b["ent"], b["avg"]))
+            return
         if not args.kernel_only and args.k2_mode == "both" and not args.separate_calls:
             # one C-ABI call: K1 (+ staged pose records) -> K2 -> soft reduce -> K3
             eng.scoreHypotheses(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
@@ -204,7 +225,7 @@ def main():
         k2_ms += ms
         k2_n += n
     ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
-    wsum = float(bufs[0]["w"].sum().item()) if not args.kernel_only else 1.0
+    wsum = float(bufs[0]["w"][:N].sum().item()) if not args.kernel_only else 1.0
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -215,17 +236,17 @@ def main():
         k2_ms, k2_n = float(kk[0].item()), int(kk[1].item())
 
     if rank == 0:
-        total_hyps = N * K * world
+        total_hyps = N * B * K * world
         value = total_hyps / elapsed
         k2_avg_s = (k2_ms / max(1, k2_n)) * 1e-3
-        abytes = algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=args.k2_mode != "soft")
+        abytes = B * algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=args.k2_mode != "soft")  # one launch carries B frames
         achieved = abytes / k2_avg_s / 1e9 if k2_avg_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("N") == N and tj.get("P") == P:
+                if tj.get("N") == N * B and tj.get("P") == P and tj.get("frames", 1) == B:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -234,10 +255,10 @@ def main():
             "value": value, "unit": "hyp/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: 'chess'-like single frame, %d hypotheses, %dx%d coord map, %s"
-                                    % (N, W, H, "K2 only on random poses" if args.kernel_only else
+            "config": {"workload": ("BASELINE.json configs[1]: 'chess'-like frame, %d hypotheses, %dx%d coord map%s, %s"
+                                    % (N, W, H, (" x %d independent frames per step (one launch each for K1, K2, K3)" % B) if batched else " (single frame per step)", "K2 only on random poses" if args.kernel_only else
                                        "K1 sample+P3P -> K2 reproject (error images + soft-inlier) -> K3 softmax")),
-                       "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": 1, "streams_per_gpu": n_ctx,
+                       "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": B, "streams_per_gpu": n_ctx,
                        "overlap": ("in-context software pipeline: K1(i+1) || K2,K3(i)" if pipelined else "K2 launches serialised across 2 contexts, K1/K3 overlap them" if gated else "sampling stage || scoring stage" if staged
                                    else ("frames round-robin" if n_ctx > 1 else "none")),
                        "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,

@@ -274,13 +274,16 @@ int dsac_device_info(dsac_ctx* c, int* cus, int* clock_khz, uint64_t* mem_bytes,
     return DSAC_OK;
 }
 
-int dsac_set_frame(dsac_ctx* c, const float* xyz, const float* uv, int H, int W, float fx, float fy, float cx, float cy, unsigned flags) {
+static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const float* uv, bool uv_per_frame, int H, int W, float fx, float fy, float cx,
+                             float cy, unsigned flags) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_frame: ctx is NULL");
-    if (!xyz || H <= 0 || W <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: need xyz and H, W > 0 (got H=%d W=%d)", H, W);
-    if ((long long)H * W > (1ll << 28)) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: H*W too large");
+    if (!xyz || H <= 0 || W <= 0 || frames <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: need xyz, frames > 0 and H, W > 0 (got H=%d W=%d)", H, W);
+    if ((long long)H * W * frames > (1ll << 30)) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: frames*H*W too large");
     if (!(fx != 0.f) || !(fy != 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: zero focal length");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t P = (size_t)H * W;
+    const size_t P1 = (size_t)H * W;
+    const size_t P = P1 * (size_t)frames;              // cells to copy for xyz
+    const size_t Puv = uv_per_frame ? P : P1;
     const bool borrow = (flags & DSAC_FRAME_BORROW) != 0;
     if (borrow) {
         if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
@@ -292,8 +295,8 @@ int dsac_set_frame(dsac_ctx* c, const float* xyz, const float* uv, int H, int W,
         HIP_TRY(c, hipMemcpyAsync(c->frame_xyz.p, xyz, P * 3 * sizeof(float), hipMemcpyDefault, c->stream));
         c->F.xyz = c->frame_xyz.as<float>();
         if (uv) {
-            HIP_TRY(c, c->frame_uv.reserve(P * 2 * sizeof(float)));
-            HIP_TRY(c, hipMemcpyAsync(c->frame_uv.p, uv, P * 2 * sizeof(float), hipMemcpyDefault, c->stream));
+            HIP_TRY(c, c->frame_uv.reserve(Puv * 2 * sizeof(float)));
+            HIP_TRY(c, hipMemcpyAsync(c->frame_uv.p, uv, Puv * 2 * sizeof(float), hipMemcpyDefault, c->stream));
             c->F.uv = c->frame_uv.as<float>();
         } else {
             c->F.uv = nullptr;
@@ -305,16 +308,29 @@ int dsac_set_frame(dsac_ctx* c, const float* xyz, const float* uv, int H, int W,
         }
         if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) HIP_TRY(c, hipStreamSynchronize(c->stream));  // host source may be freed after return
     }
-    c->F.H = H; c->F.W = W; c->F.P = (int)P;
+    c->F.H = H; c->F.W = W; c->F.P = (int)P1;
     c->F.fx = fx; c->F.fy = fy; c->F.cx = cx; c->F.cy = cy;
+    c->F.frames = frames;
+    c->F.xyz_stride = (long long)P1 * 3;
+    c->F.uv_stride = (uv && uv_per_frame) ? (long long)P1 * 2 : 0;
     c->have_frame = true;
     return DSAC_OK;
+}
+
+int dsac_set_frame(dsac_ctx* c, const float* xyz, const float* uv, int H, int W, float fx, float fy, float cx, float cy, unsigned flags) {
+    return set_frames_common(c, 1, xyz, uv, false, H, W, fx, fy, cx, cy, flags);
+}
+
+int dsac_set_frames(dsac_ctx* c, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy, float cx,
+                    float cy, unsigned flags) {
+    return set_frames_common(c, frames, xyz, uv_or_null, uv_per_frame != 0, H, W, fx, fy, cx, cy, flags);
 }
 
 int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses, int32_t* sets_out,
                 uint8_t* ok) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_sample: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (N < 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample: N >= 0 and poses/sets_out/ok must be non-NULL");
     if (N == 0) return DSAC_OK;
     if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_sample: max_tries must be > 0");
@@ -336,6 +352,7 @@ int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, 
 int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float* err_or_null, float tau, float beta, double* soft_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_reproject: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_reproject: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_reproject: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (N < 0 || !poses) return fail(c, DSAC_ERR_INVALID, "dsac_reproject: N >= 0 and poses must be non-NULL");
     if (N == 0 || (!err_or_null && !soft_or_null)) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -384,12 +401,13 @@ int dsac_softmax(dsac_ctx* c, int N, const double* scores, double scale, double*
     return end_call(c);
 }
 
-int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
-                          float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
-                          double* w, double* entropy_or_null, double* avg6_or_null) {
+static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
+                                   float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
+                                   double* w, double* entropy_or_null, double* avg6_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_score_hypotheses: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_score_hypotheses: no frame set");
     if (N <= 0 || !poses || !sets_out || !ok || !w) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: N > 0 and poses/sets_out/ok/w must be non-NULL");
+    const int frames = Nf > 0 ? N / Nf : 1;
     if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: max_tries must be > 0");
     if (!sets_or_null && c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: frame has fewer than 4 cells");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -407,8 +425,8 @@ int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets
     ARG_TRY(out_arg(c, err_or_null, (size_t)N * P, &d_err));
     ARG_TRY(out_arg(c, scores_or_null, (size_t)N, &d_scores));
     ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
-    ARG_TRY(out_arg(c, entropy_or_null, 1, &d_ent));
-    ARG_TRY(out_arg(c, avg6_or_null, 6, &d_avg));
+    ARG_TRY(out_arg(c, entropy_or_null, (size_t)frames, &d_ent));
+    ARG_TRY(out_arg(c, avg6_or_null, (size_t)frames * 6, &d_avg));
     if (!d_scores) {
         DevBuf& s = next_slot(c);
         HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
@@ -418,17 +436,37 @@ int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
     HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
     // K1 writes the poses AND their staged K2 records (no separate pose_prep launch)
-    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>()));
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>(), Nf));
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->reproject_variant, &used));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->reproject_variant, &used, Nf));
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
-    HIP_TRY(c, dk::softmax(c->stream, N, d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg));
+    HIP_TRY(c, dk::softmax(c->stream, Nf > 0 ? Nf : N, d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg, frames));
     return end_call(c);
+}
+
+int dsac_score_hypotheses(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
+                          float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
+                          double* w, double* entropy_or_null, double* avg6_or_null) {
+    if (c && c->have_frame && c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: a frame batch is set (use dsac_score_hypotheses_frames)");
+    return score_hypotheses_common(c, N, 0, seed, sets_or_null, thr, max_tries, clampv, tau, beta, scale, poses, sets_out, ok, err_or_null, scores_or_null, w,
+                                   entropy_or_null, avg6_or_null);
+}
+
+int dsac_score_hypotheses_frames(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clampv, float tau, float beta, double scale,
+                                 double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null, double* w,
+                                 double* entropy_or_null, double* avg6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_score_hypotheses_frames: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_score_hypotheses_frames: no frame set");
+    if (hyps_per_frame <= 0 || hyps_per_frame % 128 != 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses_frames: hyps_per_frame must be a positive multiple of 128 (got %d)", hyps_per_frame);
+    if ((long long)hyps_per_frame * c->F.frames > (1ll << 24)) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses_frames: too many hypotheses");
+    return score_hypotheses_common(c, hyps_per_frame * c->F.frames, hyps_per_frame, seed, nullptr, thr, max_tries, clampv, tau, beta, scale, poses, sets_out, ok,
+                                   err_or_null, scores_or_null, w, entropy_or_null, avg6_or_null);
 }
 
 static int pipeline_init(dsac_ctx* c) {
@@ -447,6 +485,7 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
                       int32_t* sets_out, uint8_t* ok) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample_ahead: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample_ahead: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (slot < 0 || slot > 1 || N <= 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot in {0,1}, N > 0, non-NULL outputs");
     if (!is_device_ptr(poses) || !is_device_ptr(sets_out) || !is_device_ptr(ok) || (sets_or_null && !is_device_ptr(sets_or_null)))
         return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: the pipelined calls need device pointers");
@@ -496,6 +535,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
 int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_dpnp: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_dpnp: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (N < 0 || !sets || !J || !(eps > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: need sets, J and eps > 0");
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -620,6 +660,7 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
                 const int32_t* pert_px_c, const float* pert_value, double* out_poses, int32_t* inlier_map, int32_t* steps_done) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (B < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
     if ((pert_px_c != nullptr) != (pert_value != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_refine: pert_px_c and pert_value go together");
@@ -648,6 +689,7 @@ int dsac_refine_fd(dsac_ctx* c, const double* init_pose, const int32_t* perm, in
                    int cap, int32_t* n_obj) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (!init_pose || !perm || !inlier_map || !J_hyp || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
         return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: need 1 <= max_inl <= 256");
@@ -736,6 +778,7 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
                     const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_all: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_all: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (N < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
     if (N == 0) return DSAC_OK;
@@ -763,6 +806,7 @@ int dsac_refine_fd_set(dsac_ctx* c, const int32_t* set4, const int32_t* perm, in
                        int32_t* n_obj) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd_set: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd_set: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (!set4 || !perm || !inlier_map || !J_set || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
         return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: need 1 <= max_inl <= 256");
@@ -799,6 +843,7 @@ int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const 
                                     const double* dpnp, double* grad_xyz, double* g) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_path1_and_softmax_backward: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (N <= 0 || !v6 || !w || !poses || !g) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: NULL argument");
     if ((grad_xyz != nullptr) != (dpnp != nullptr) || (grad_xyz && !sets))
         return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: grad_xyz, dpnp and sets go together");

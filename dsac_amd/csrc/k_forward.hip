@@ -117,7 +117,8 @@ template <int PX, int HT, bool ERR, bool SOFT, bool UV, bool SPOSE>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                           const float* __restrict__ uv, float* __restrict__ err,
                                                           float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
-                                                          float cy, float clampv, float kA, float kB, int kflags) {
+                                                          float cy, float clampv, float kA, float kB, int kflags, int Nf, long long xyz_stride,
+                                                          long long uv_stride) {
     // XCD-aware decode: the 8 blocks of one dispatch round-robin group cover 8 different pixel tiles, and
     // successive groups walk the hypothesis tiles of those same pixel tiles.
     const int b = blockIdx.x;
@@ -131,6 +132,11 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restric
     const int h0 = ht * HT;
     const int nh = min(HT, N - h0);
     const int tid = threadIdx.x;
+    {   // frame batch: all hypotheses of this tile score the same frame (Nf is a multiple of HT)
+        const int frame = h0 / Nf;
+        xyz += (long long)frame * xyz_stride;
+        if (UV) uv += (long long)frame * uv_stride;
+    }
 
     __shared__ __attribute__((aligned(16))) float s_pose[HT * POSE_STRIDE];
     __shared__ float s_red[SOFT ? (K2_THREADS / 64) * HT : 1];
@@ -279,7 +285,8 @@ template <int HT, bool ERR, bool SOFT, bool UV, int KM_CH>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                                const float* __restrict__ uv, float* __restrict__ err,
                                                                float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
-                                                               float cy, float clampv, float kA, float kB, int kflags) {
+                                                               float cy, float clampv, float kA, float kB, int kflags, int Nf,
+                                                               long long xyz_stride, long long uv_stride) {
     static_assert(HT % 4 == 0, "hypothesis tile must be a multiple of 4");
     const int b = blockIdx.x;
     const int q = b >> 3;
@@ -293,6 +300,11 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
     const int nh = min(HT, N - h0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
+    {   // frame batch: all hypotheses of this tile score the same frame (Nf is a multiple of HT)
+        const int frame = h0 / Nf;
+        xyz += (long long)frame * xyz_stride;
+        if (UV) uv += (long long)frame * uv_stride;
+    }
 
     // A operands in MFMA lane order: s_A[gi*64 + l] = record[h0 + 4 gi + (l%16)/4][comp = (l%16)%4][k = l/16]
     __shared__ float s_A[(HT / 4) * 64];
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
 
 template <int HT, int KM_CH = KM_CH_DEFAULT>
 static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
-                                        float kB, float* soft_part, int* tiles_used) {
+                                        float kB, float* soft_part, int* tiles_used, int Nf) {
     const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
@@ -405,7 +417,7 @@ static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* stag
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2M(E, S, U)                                                                                                               \
     hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
-                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags)
+                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2M(true, true, true); else DSAC_K2M(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2M(true, false, true); else DSAC_K2M(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2M(false, true, true); else DSAC_K2M(false, true, false); }
@@ -417,7 +429,7 @@ int reproject_num_pixel_tiles(int P) { return (P + K2_THREADS - 1) / K2_THREADS;
 
 template <int PX, int HT, bool SPOSE>
 static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
-                                   float* soft_part) {
+                                   float* soft_part, int Nf) {
     const int tile = K2_THREADS * PX;
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
@@ -426,7 +438,7 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2(E, S, U)                                                                                                              \
     hipLaunchKernelGGL((k_reproject<PX, HT, E, S, U, SPOSE>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, \
-                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags)
+                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2(true, true, true); else DSAC_K2(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2(true, false, true); else DSAC_K2(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2(false, true, true); else DSAC_K2(false, true, false); }
@@ -437,15 +449,17 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
 // variant: -1 = auto (default) ; 0 = VALU kernel, LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ;
 //          2 = LDS, HT = 16 ; 3 = LDS, HT = 64
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
-                     float* soft_part, int variant, int* tiles_used) {
+                     float* soft_part, int variant, int* tiles_used, int Nf) {
     if (tiles_used) *tiles_used = 0;
     if (N <= 0 || F.P <= 0 || (!err && !soft_part)) return hipSuccess;
+    if (Nf <= 0 || F.frames <= 1) Nf = N > 0 ? ((N + 127) / 128) * 128 : 128;  // one frame: every tile maps to frame 0
+    else if (Nf % 128 != 0) return hipErrorInvalidValue;                      // tiles (<= 128 hypotheses) must not straddle frames
     const float LOG2E = 1.4426950408889634f;
     const float kA = beta * LOG2E, kB = -beta * tau * LOG2E;
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0);
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
-    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
+    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
     if (variant < 0) {
         // auto (measured on MI355X, profiles/r01_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited:
         // matrix-core form (HT = 64), pixel tiles innermost except for very large launches.  Error images only: store-limited:
@@ -453,22 +467,22 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
         const bool saved = g_k2_pixel_minor;
         hipError_t e;
-        if (soft_part) { g_k2_pixel_minor = !big; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used); }
-        else { g_k2_pixel_minor = true; e = launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part); }
+        if (soft_part) { g_k2_pixel_minor = !big; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf); }
+        else { g_k2_pixel_minor = true; e = launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf); }
         g_k2_pixel_minor = saved;
         return e;
     }
     switch (variant) {
-        case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 7: return launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 8: return launch_reproject_mfma<64, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 9: return launch_reproject_mfma<32, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used);
-        case 1: return launch_reproject<4, 32, true>(st, N, staged, F, clampv, err, kA, kB, soft_part);
-        case 2: return launch_reproject<4, 16, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
-        case 3: return launch_reproject<4, 64, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
-        default: return launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part);
+        case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 7: return launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 8: return launch_reproject_mfma<64, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 9: return launch_reproject_mfma<32, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 1: return launch_reproject<4, 32, true>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 2: return launch_reproject<4, 16, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 3: return launch_reproject<4, 64, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        default: return launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
     }
 }
 
@@ -516,6 +530,13 @@ __global__ __launch_bounds__(K3_THREADS) void k_softmax(int N, const double* __r
                                                         double* __restrict__ entropy, const double* __restrict__ poses,
                                                         double* __restrict__ avg6) {
     __builtin_amdgcn_s_setprio(3);  // tiny latency-bound kernel, usually overlapped with a bandwidth-bound one
+    {   // frame batch: workgroup f owns the N scores of frame f
+        const size_t f = blockIdx.x;
+        scores += f * N; w += f * N;
+        if (entropy) entropy += f;
+        if (poses) poses += f * N * 6;
+        if (avg6) avg6 += f * 6;
+    }
     __shared__ double s_m[K3_THREADS / 64];
     __shared__ double s_acc[K3_THREADS / 64][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -564,9 +585,10 @@ __global__ __launch_bounds__(K3_THREADS) void k_softmax(int N, const double* __r
     }
 }
 
-hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6) {
-    if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_softmax, dim3(1), dim3(K3_THREADS), 0, st, N, scores, scale, w, entropy, poses, avg6);
+hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6,
+                   int frames) {
+    if (N <= 0 || frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_softmax, dim3(frames), dim3(K3_THREADS), 0, st, N, scores, scale, w, entropy, poses, avg6);
     return hipGetLastError();
 }
 

@@ -86,7 +86,8 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // VGPRs, 580 B scratch per lane) 125.  Raised wave priority is worth ~1 us.
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
-                                                     int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio) {
+                                                     int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
+                                                     int Nf) {
     if (prio >= 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
     if (h >= N) return;
     const int lane = threadIdx.x & 63;
     const int root = lane & 3;
-    const uint64_t key = dm::hyp_key(seed, (uint32_t)h);
+    const int frame = h / Nf;  // Nf == N for a single frame
+    F.xyz += (long long)frame * F.xyz_stride;
+    if (F.uv) F.uv += (long long)frame * F.uv_stride;
+    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
     const dm::Cam K = make_cam(F);
     for (int base = 0; base < max_tries; base += 16) {
         const uint32_t attempt = (uint32_t)(base + (lane >> 2));
@@ -191,8 +195,9 @@ __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restri
 }
 
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries, double* poses,
-                  int32_t* sets_out, uint8_t* ok, float* staged) {
+                  int32_t* sets_out, uint8_t* ok, float* staged, int Nf) {
     if (N <= 0) return hipSuccess;
+    if (sets_in && Nf > 0 && F.frames > 1) return hipErrorInvalidValue;  // given sets are evaluated on one frame only
     if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
     else {
         static int wpb = -1, prio = 0;
@@ -202,7 +207,7 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
             const char* q = getenv("DSAC_K1_PRIO");
             prio = q ? atoi(q) : 3;
         }
-#define DSAC_K1(W) hipLaunchKernelGGL(k_sample<W>, dim3((N + W - 1) / W), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio)
+#define DSAC_K1(W) hipLaunchKernelGGL(k_sample<W>, dim3((N + W - 1) / W), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
         if (wpb >= 16) DSAC_K1(16); else if (wpb >= 8) DSAC_K1(8); else if (wpb >= 4) DSAC_K1(4); else DSAC_K1(1);
 #undef DSAC_K1
     }

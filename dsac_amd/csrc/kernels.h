@@ -12,6 +12,10 @@ struct FrameDev {
     const float* uv;   // P x 2 or nullptr (implicit grid u = x, v = y)
     int H, W, P;
     float fx, fy, cx, cy;
+    // frame batch (dsac_set_frames): `frames` maps of the same geometry back to back, frame f at xyz + f * xyz_stride
+    // (floats); uv is shared (uv_stride == 0) or per frame.  Only K1 (random sampling), K2 and K3 look at frames > 0.
+    int frames = 1;
+    long long xyz_stride = 0, uv_stride = 0;
 };
 
 // Staged pose record used by K2, 12 floats (48 B, three float4 rows) per hypothesis:
@@ -27,17 +31,22 @@ void reproject_set_order(bool pixel_minor);  // block order knob (default: pixel
 void reproject_set_flags(int flags);         // bit0: plain (cached) stores instead of non-temporal
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
+// Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of 64 then); 0 = one frame.
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
-                     float* soft_part, int variant, int* tiles_used);
+                     float* soft_part, int variant, int* tiles_used, int Nf = 0);
 // soft[h] = sum over pixel tiles of soft_part[tile][h]   (double, deterministic)
 hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft);
 
 // K3.
-hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6);
+// frames > 1: one independent softmax per consecutive group of N scores (outputs entropy[frames], avg6[frames][6])
+hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6,
+                   int frames = 1);
 
 // ---- k_sample.hip ----------------------------------------------------------------------------------
+// Nf > 0 (frame batch): hypothesis h belongs to frame h / Nf and draws from the stream of (seed + frame, h % Nf), i.e. exactly
+// what a single-frame call with seed + frame would draw.
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
-                  double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr);  // staged: K2 records (N x 12)
+                  double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr, int Nf = 0);  // staged: K2 records (N x 12)
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
 
 // ---- k_backward.hip --------------------------------------------------------------------------------

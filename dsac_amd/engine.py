@@ -110,8 +110,34 @@ class Engine:
         flags = (capi.DSAC_FRAME_QUANTISE_INT16 if quantise_int16 else 0) | (capi.DSAC_FRAME_BORROW if borrow else 0)
         fx, fy, cx, cy = [float(c) for c in cam]
         check(self._ctx, lib.dsac_set_frame(self._ctx, ptr(xyz), ptr(uv), int(H), int(W), fx, fy, cx, cy, flags))
-        self.H, self.W, self.P = int(H), int(W), int(H) * int(W)
+        self.H, self.W, self.P, self.frames = int(H), int(W), int(H) * int(W), 1
         self._keep = (xyz, uv) if borrow else None
+
+    def set_frames(self, xyz, uv=None, H=None, W=None, cam=(525.0, 525.0, 320.0, 240.0), uv_per_frame=False, borrow=False):
+        """A batch of frames of the same geometry: xyz F x H*W x 3 float32 (contiguous), uv shared (H*W x 2), per frame (F x H*W x 2)
+        or None.  Only scoreHypothesesFrames works on a batch."""
+        xyz = _np(xyz, np.float32)
+        F = int(xyz.shape[0])
+        uv = _np(uv, np.float32) if uv is not None else None
+        fx, fy, cx, cy = [float(c) for c in cam]
+        check(self._ctx, lib.dsac_set_frames(self._ctx, F, ptr(xyz), ptr(uv), 1 if uv_per_frame else 0, int(H), int(W), fx, fy, cx, cy,
+                                             capi.DSAC_FRAME_BORROW if borrow else 0))
+        self.H, self.W, self.P, self.frames = int(H), int(W), int(H) * int(W), F
+        self._keep = (xyz, uv) if borrow else None
+
+    def scoreHypothesesFrames(self, hyps_per_frame, seed=1305, thr=10.0, max_tries=1 << 20, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5, scale=0.1,
+                              err=None, out=None):
+        """K1 + K2 + K3 for every frame of the batch in three launches; frame f uses the random stream of seed + f.
+        out = (poses F*N x 6, sets F*N x 4, ok F*N, scores F*N, w F*N, entropy F, avg6 F x 6); returns it."""
+        F, N = self.frames, int(hyps_per_frame)
+        if out is None:
+            out = (np.zeros((F * N, 6)), np.zeros((F * N, 4), np.int32), np.zeros(F * N, np.uint8), np.zeros(F * N), np.zeros(F * N), np.zeros(F),
+                   np.zeros((F, 6)))
+        poses, sets_out, ok, scores, w, ent, avg = out
+        check(self._ctx, lib.dsac_score_hypotheses_frames(self._ctx, N, int(seed) & 0xFFFFFFFFFFFFFFFF, float(thr), int(max_tries), float(clamp), float(tau),
+                                                          float(beta), float(scale), ptr(poses), ptr(sets_out), ptr(ok), ptr(err), ptr(scores), ptr(w),
+                                                          ptr(ent), ptr(avg)))
+        return out
 
     # ---- K1 ---------------------------------------------------------------------------------------
     def sample(self, N, seed=1305, thr=10.0, max_tries=1 << 20, sets=None, out=None):

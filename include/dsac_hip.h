@@ -89,6 +89,20 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
 int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int H, int W, float fx, float fy, float cx, float cy,
                    unsigned flags);
 
+/* Frame batch: `frames` coordinate maps of the same H x W and camera, stored back to back (frame f at xyz + f*H*W*3); uv is one
+ * shared H*W x 2 table (uv_per_frame = 0), one table per frame (uv_per_frame = 1) or NULL (implicit grid).  Independent frames
+ * are the unit the path shards over (core/test_ransac_softam.cpp:97-230); batching them lets one launch carry several frames.
+ * Only dsac_score_hypotheses_frames accepts a batch; every other call reports DSAC_ERR_INVALID while one is set. */
+int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
+                    float cx, float cy, unsigned flags);
+/* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).
+ * Frame f draws from the stream of seed + f, so the result equals `frames` single-frame calls with seeds seed, seed + 1, ...
+ * hyps_per_frame must be a multiple of 128.  Outputs are frame-major: poses / sets_out / ok / scores / w [frames][hyps_per_frame],
+ * err [frames*hyps_per_frame][H*W], entropy [frames], avg6 [frames][6]. */
+int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta,
+                                 double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null, double* w,
+                                 double* entropy_or_null, double* avg6_or_null);
+
 /* ---- K1: minimal-set sampling + P3P ------------------------------------------------------------ */
 /* Replaces the sampling loop of processImage, core/cnn_softam.h:1010-1060 (irand x4, alreadyChosen,
  * safeSolvePnP(CV_P3P) :1042, projectPoints :1046, 4-point re-projection check :1050-1059 with the

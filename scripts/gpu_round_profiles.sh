@@ -5,10 +5,12 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; O=gpurun_out/r01; mkdir -p $O
 export TMPDIR=/tmp
 nproc > $O/nproc.txt
-echo "== bench 2 contexts, frames round-robin (K2 launches may overlap)"; timeout 600 python bench.py --streams 2 --overlap frames --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_frames2.json | cut -c1-200
-echo "== bench in-context pipeline"; timeout 600 python bench.py --streams 1 --overlap pipeline --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_pipeline.json | cut -c1-200
+echo "== bench 2 contexts, frames round-robin (K2 launches may overlap)"; timeout 600 python bench.py --frames-per-step 1 --streams 2 --overlap frames --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_frames2.json | cut -c1-200
+echo "== bench in-context pipeline"; timeout 600 python bench.py --frames-per-step 1 --streams 1 --overlap pipeline --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_pipeline.json | cut -c1-200
 echo "== bench (default)"; timeout 600 python bench.py 2>/dev/null | tail -1 | tee $O/bench_default.json | cut -c1-400
-echo "== bench (no overlap)"; timeout 600 python bench.py --streams 1 --overlap frames --event-stride 1 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_streams1.json | cut -c1-200
+echo "== bench single frame per step, 2 contexts gated"; timeout 600 python bench.py --frames-per-step 1 --streams 2 --overlap gated --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_single_gated2.json | cut -c1-200
+echo "== bench 8 frames per step, 2 contexts gated"; timeout 600 python bench.py --frames-per-step 8 --streams 2 --overlap gated --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_batch8_gated2.json | cut -c1-200
+echo "== bench single frame per step, no overlap"; timeout 600 python bench.py --frames-per-step 1 --streams 1 --overlap frames --event-stride 1 --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/bench_streams1.json | cut -c1-200
 echo "== bench K2 only, N=4096 (configs[2])"; for m in err both; do timeout 600 python bench.py --steps 30 --warmup 5 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --event-stride 1 --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_4096_$m.json | cut -c1-120; done
 echo "== bench K2 only, N=256"; for m in err both; do timeout 600 python bench.py --steps 200 --warmup 20 --kernel-only --no-cpu-baseline --streams 1 --event-stride 1 --k2-mode $m 2>/dev/null | tail -1 | tee $O/bench_k2only_256_$m.json | cut -c1-120; done
 cd /tmp
@@ -45,6 +47,9 @@ pmc k2_4096_both_write WRITE_SIZE -- $K2B
 pmc k2_4096_both_fetch FETCH_SIZE -- $K2B
 pmc k2_256_both_sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY -- $K2
 pmc k2_256_both_clk GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -- $K2
+K2F="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --event-stride 0"
+pmc k2_batch8_write WRITE_SIZE -- $K2F
+pmc k2_batch8_fetch FETCH_SIZE -- $K2F
 pmc k4_write WRITE_SIZE -- python $REPO/scripts/k4_bench.py
 pmc k4_fetch FETCH_SIZE -- python $REPO/scripts/k4_bench.py
 pmc k4_sq SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -- python $REPO/scripts/k4_bench.py

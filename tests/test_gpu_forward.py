@@ -293,3 +293,35 @@ def test_error_behaviour(engine):
     with pytest.raises(dsac_amd.capi.DsacError):
         e2.set_frame(np.zeros((4, 3), np.float32), None, 0, 4)
     e2.close()
+
+
+def test_frame_batch_equals_single_frame_calls(engine, orc, synth):
+    """dsac_set_frames + dsac_score_hypotheses_frames: F independent frames in three launches give exactly what F single-frame calls
+    with seeds seed, seed + 1, ... give (same minimal sets, poses, error images, weights, soft-argmax poses)."""
+    H, W, F, N = 48, 64, 3, 128
+    frames = [synth.chess_like_frame(H, W, seed=100 + f) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv = frames[0]["uv"]
+    engine.set_frames(xyz, uv, H, W, frames[0]["cam"])
+    err = np.zeros((F * N, H * W), np.float32)
+    poses, sets, ok, scores, w, ent, avg = engine.scoreHypothesesFrames(N, seed=31, err=err)
+    with pytest.raises(Exception):
+        engine.sample(8)  # single-frame calls refuse a batch
+    for f in range(F):
+        engine.set_frame(xyz[f], uv, H, W, frames[0]["cam"])
+        e1 = np.zeros((N, H * W), np.float32)
+        p1, s1, o1, sc1, w1, en1, a1 = engine.scoreHypotheses(N, seed=31 + f, err=e1)
+        sl = slice(f * N, (f + 1) * N)
+        assert np.array_equal(sets[sl], s1) and np.array_equal(ok[sl], o1)
+        assert np.array_equal(poses[sl], p1)
+        assert np.array_equal(err[sl], e1)
+        assert np.allclose(scores[sl], sc1, rtol=1e-12) and np.allclose(w[sl], w1, rtol=1e-9, atol=1e-15)
+        assert abs(ent[f] - en1[0]) <= 1e-9 and np.allclose(avg[f], a1, rtol=1e-9, atol=1e-12)
+    # per-frame uv tables
+    uvs = np.ascontiguousarray(np.stack([uv + np.float32(f) for f in range(F)]))
+    engine.set_frames(xyz, uvs, H, W, frames[0]["cam"], uv_per_frame=True)
+    p2 = engine.scoreHypothesesFrames(N, seed=31)[0]
+    engine.set_frame(xyz[2], uvs[2], H, W, frames[0]["cam"])
+    assert np.array_equal(p2[2 * N:], engine.scoreHypotheses(N, seed=33)[0])
+    with pytest.raises(Exception):
+        engine.set_frames(xyz, uv, H, W, frames[0]["cam"]); engine.scoreHypothesesFrames(100)  # not a multiple of 128
