@@ -84,26 +84,38 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // away from K2's waves.  Measured on MI355X (scripts/gpu_k1_layout.sh, default bench): 1 wave/workgroup (every CU gets one)
 // 91.3 us/step, 4 waves (one CU in four, all four SIMDs) 90.3, 8 waves (2 per SIMD, 100 B scratch) 94.6, 16 waves (128
 // VGPRs, 580 B scratch per lane) 125.  Raised wave priority is worth ~1 us.
-template <int WPB>
+// HPW hypotheses per wave: each hypothesis owns 64/HPW lanes = 16/HPW attempts per round (4 root lanes each).  Attempts are
+// consumed in index order and the lowest accepted index wins, so the result does not depend on HPW (the GPU tests pass with
+// DSAC_K1_HPW=2 and 4).  The idea was that the instruction stream of a round costs the same whether 4 or 64 lanes are live;
+// measured (scripts/k1_bench.py, 640x480 synthetic frame): N=2048 takes 65 us with HPW=1, 91 us with 2, 183 us with 4 -- a
+// hypothesis needs ~20 attempts here (4 noisy inliers rarely re-project the 4th point within 10 px), so the 16 attempt lanes
+// of HPW=1 are busy and fewer lanes per hypothesis only serialise.  HPW=1 stays the default; the knob is for easy frames.
+template <int WPB, int HPW>
 __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                      int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
                                                      int Nf) {
     if (prio >= 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    const int h = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (h >= N) return;
+    constexpr int LPH = 64 / HPW;        // lanes per hypothesis
+    constexpr int APR = LPH / 4;         // attempts per round and hypothesis
     const int lane = threadIdx.x & 63;
+    const int sub = lane / LPH, sl = lane % LPH;
+    const int h = (blockIdx.x * WPB + (threadIdx.x >> 6)) * HPW + sub;
+    const unsigned long long submask = (HPW == 1) ? ~0ull : (((1ull << LPH) - 1ull) << (sub * LPH));
+    bool done = h >= N;                  // uniform over the lanes of a hypothesis
+    const int hc = done ? 0 : h;
     const int root = lane & 3;
-    const int frame = h / Nf;  // Nf == N for a single frame
+    const int frame = hc / Nf;           // Nf == N for a single frame
     F.xyz += (long long)frame * F.xyz_stride;
     if (F.uv) F.uv += (long long)frame * F.uv_stride;
-    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(hc - frame * Nf));
     const dm::Cam K = make_cam(F);
-    for (int base = 0; base < max_tries; base += 16) {
-        const uint32_t attempt = (uint32_t)(base + (lane >> 2));
+    for (int base = 0; base < max_tries; base += APR) {
+        if (__ballot(!done) == 0ull) return;
+        const uint32_t attempt = (uint32_t)(base + (sl >> 2));
         int32_t set4[4];
-        bool live = (int)attempt < max_tries;
+        bool live = !done && (int)attempt < max_tries;
         if (live) live = draw_set(F, key, attempt, set4);
         float X[4][3], uv[4][2];
         double Rc[9], Tc[3], reproj = 0;
@@ -143,9 +155,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
                 good = good && (sqrt((double)dx * dx + (double)dy * dy) < (double)thr_int);
             }
         }
-        const unsigned long long m = __ballot(good);
+        const unsigned long long m = __ballot(good) & submask;
         if (m != 0ull) {
-            const int w = __ffsll((long long)m) - 1;  // lowest lane = lowest attempt index
+            const int w = __ffsll((long long)m) - 1;  // lowest lane of this hypothesis = lowest attempt index
             if (lane == w) {
 #pragma unroll
                 for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = cv6[k];
@@ -154,11 +166,11 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
                 ok[h] = 1;
                 if (staged) write_staged_R(F, R, cv6, staged + (size_t)h * POSE_STRIDE);
             }
-            return;
+            done = true;
         }
     }
     // no accepted attempt: zero pose, ok = 0; sets_out reports the last attempt's set
-    if (lane == 0) {
+    if (!done && sl == 0) {
         int32_t set4[4];
         draw_set(F, key, (uint32_t)(max_tries - 1), set4);
 #pragma unroll
@@ -200,15 +212,20 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
     if (sets_in && Nf > 0 && F.frames > 1) return hipErrorInvalidValue;  // given sets are evaluated on one frame only
     if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
     else {
-        static int wpb = -1, prio = 0;
-        if (wpb < 0) {  // knobs for experiments: DSAC_K1_WPB in {1, 4, 8, 16}, DSAC_K1_PRIO in 0..3
+        static int wpb = -1, prio = 0, hpw = 0;
+        if (wpb < 0) {  // knobs for experiments: DSAC_K1_WPB in {1, 4, 8}, DSAC_K1_PRIO in 0..3, DSAC_K1_HPW in {1, 2, 4}
             const char* e = getenv("DSAC_K1_WPB");
             wpb = e ? atoi(e) : 4;
             const char* q = getenv("DSAC_K1_PRIO");
             prio = q ? atoi(q) : 3;
+            const char* g = getenv("DSAC_K1_HPW");
+            hpw = g ? atoi(g) : 0;
         }
-#define DSAC_K1(W) hipLaunchKernelGGL(k_sample<W>, dim3((N + W - 1) / W), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
-        if (wpb >= 16) DSAC_K1(16); else if (wpb >= 8) DSAC_K1(8); else if (wpb >= 4) DSAC_K1(4); else DSAC_K1(1);
+        const int H2 = hpw > 0 ? hpw : 1;  // see the measurement in the kernel's comment
+#define DSAC_K1(W, G) hipLaunchKernelGGL((k_sample<W, G>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
+        if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4); else DSAC_K1(1, 4); }
+        else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2); else if (wpb >= 4) DSAC_K1(4, 2); else DSAC_K1(1, 2); }
+        else { if (wpb >= 8) DSAC_K1(8, 1); else if (wpb >= 4) DSAC_K1(4, 1); else DSAC_K1(1, 1); }
 #undef DSAC_K1
     }
     return hipGetLastError();
