@@ -141,7 +141,13 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (live && win == root) {
+        // Early rejection: `reproj` is the squared re-projection error (px^2, fp64) of the 4th point under (Rc, Tc); the check
+        // below re-derives the rotation through the Rodrigues vector and rounds the projections to float, which moves that
+        // error by < 1e-3 px.  An attempt whose 4th point misses the threshold by more than 0.01 px can therefore not pass, and
+        // a round in which no lane can pass (the common case: ~20 attempts per accepted set) skips the Rodrigues round trip and
+        // the four projections altogether.
+        const double thr_hi = (double)thr_int + 0.01;
+        if (live && win == root && !(reproj > thr_hi * thr_hi)) {
             dm::rodrigues_m2v(Rc, cv6);
             cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
             // 4-point re-projection check (core/cnn_softam.h:1046-1059), through Rodrigues(rvec) like projectPoints
