@@ -325,3 +325,38 @@ def test_frame_batch_equals_single_frame_calls(engine, orc, synth):
     assert np.array_equal(p2[2 * N:], engine.scoreHypotheses(N, seed=33)[0])
     with pytest.raises(Exception):
         engine.set_frames(xyz, uv, H, W, frames[0]["cam"]); engine.scoreHypothesesFrames(100)  # not a multiple of 128
+
+
+def test_frame_batch_at_baseline_size(engine, synth):
+    """BASELINE.json configs[1] size (640x480, 256 hypotheses), two frames in one batch, everything kept on the GPU: the batched
+    launch reproduces the two single-frame launches bit for bit (error images compared by equality and by a checksum of row sums)."""
+    import torch
+    H, W, F, N = 480, 640, 2, 256
+    dev = torch.device("cuda", 0)
+    frames = [synth.chess_like_frame(H, W, seed=1305 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    P = H * W
+
+    def bufs(n, nf):
+        return dict(poses=torch.zeros(n, 6, dtype=torch.float64, device=dev), sets=torch.zeros(n, 4, dtype=torch.int32, device=dev),
+                    ok=torch.zeros(n, dtype=torch.uint8, device=dev), err=torch.empty(n, P, dtype=torch.float32, device=dev),
+                    sc=torch.zeros(n, dtype=torch.float64, device=dev), w=torch.zeros(n, dtype=torch.float64, device=dev),
+                    ent=torch.zeros(nf, dtype=torch.float64, device=dev), avg=torch.zeros(nf, 6, dtype=torch.float64, device=dev))
+
+    b = bufs(F * N, F)
+    engine.set_frames(xyz, None, H, W, frames[0]["cam"], borrow=True)
+    engine.scoreHypothesesFrames(N, seed=77, err=b["err"], out=(b["poses"], b["sets"], b["ok"], b["sc"], b["w"], b["ent"], b["avg"]))
+    engine.synchronize()
+    assert int(b["ok"].sum().item()) == F * N
+    assert float(b["err"].max().item()) <= 100.0 and float(b["err"].min().item()) >= 0.0
+    for f in range(F):
+        s = bufs(N, 1)
+        engine.set_frame(xyz[f], None, H, W, frames[0]["cam"], borrow=True)
+        engine.scoreHypotheses(N, seed=77 + f, err=s["err"], out=(s["poses"], s["sets"], s["ok"], s["sc"], s["w"], s["ent"], s["avg"][0]))
+        engine.synchronize()
+        sl = slice(f * N, (f + 1) * N)
+        assert torch.equal(b["sets"][sl], s["sets"]) and torch.equal(b["poses"][sl], s["poses"])
+        assert torch.equal(b["err"][sl], s["err"])
+        assert torch.equal(b["err"][sl].double().sum(1), s["err"].double().sum(1))
+        assert torch.allclose(b["w"][sl], s["w"], rtol=1e-9, atol=1e-15) and abs(float(b["w"][sl].sum().item()) - 1.0) < 1e-12
+        assert torch.allclose(b["avg"][f], s["avg"][0], rtol=1e-9, atol=1e-12)
