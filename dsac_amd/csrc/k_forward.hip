@@ -467,7 +467,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
         const bool saved = g_k2_pixel_minor;
         hipError_t e;
-        if (soft_part) { g_k2_pixel_minor = !big; e = launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf); }
+        if (soft_part) {
+            // big launches (> 1.5 GB of error images: N = 4096, or a batch of frames): 1024 pixels per workgroup (4 chunks per wave, 92
+            // VGPRs) is 2 % faster than 512 (profiles/r01_k2_batch_variants.txt, r01_k2_big_variants.txt); small ones keep 512
+            g_k2_pixel_minor = true;
+            e = big ? launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf)
+                    : launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        }
         else { g_k2_pixel_minor = true; e = launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf); }
         g_k2_pixel_minor = saved;
         return e;
