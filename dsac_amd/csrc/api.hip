@@ -738,6 +738,45 @@ int dsac_loss(dsac_ctx* c, const double* est_cv6, const double* gt_jp6, double* 
     return end_call(c);
 }
 
+int dsac_refine_fd_sets(dsac_ctx* c, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                        const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                        int32_t* n_obj) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd_sets: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd_sets: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    if (M < 0 || !sets || !perm || !inlier_maps || !J_set || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: NULL argument or negative count");
+    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: need 1 <= max_inl <= 256");
+    if (!(sub_sample > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: sub_sample and eps_obj must be > 0");
+    const int skip = (int)(1 / sub_sample);  // core/cnn.h:933
+    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: sub_sample > 1");
+    if (M == 0) return DSAC_OK;
+    const size_t R = 18 + 6 * (size_t)cap, B = R * (size_t)M;
+    if (B > (1u << 26)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: M * (18 + 6*cap) = %zu replicas is too many", B);
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const int32_t *d_sets, *d_perm, *d_maps;
+    double *d_Js, *d_Jo;
+    int32_t *d_px, *d_n;
+    ARG_TRY(in_arg(c, sets, (size_t)M * 4, &d_sets));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, inlier_maps, (size_t)M * P, &d_maps));
+    ARG_TRY(out_arg(c, J_set, (size_t)M * 54, &d_Js));
+    ARG_TRY(out_arg(c, obj_pixels, (size_t)M * cap, &d_px));
+    ARG_TRY(out_arg(c, J_obj, (size_t)M * cap * 18, &d_Jo));
+    ARG_TRY(out_arg(c, n_obj, (size_t)M, &d_n));
+    DevBuf& rp = next_slot(c); HIP_TRY(c, rp.reserve(B * 6 * sizeof(double)));
+    DevBuf& rx = next_slot(c); HIP_TRY(c, rx.reserve(B * 2 * sizeof(int32_t)));
+    DevBuf& rv = next_slot(c); HIP_TRY(c, rv.reserve(B * sizeof(float)));
+    DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
+    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_sets, d_maps, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_px, d_n, M));
+    HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F,
+                                     ro.as<double>(), M));
+    HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo, M));
+    return end_call(c);
+}
+
 int dsac_gather_patches(dsac_ctx* c, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches, int32_t* skipped_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_gather_patches: ctx is NULL");
     if (!bgr || !sampling_xy || !patches || H <= 0 || W <= 0 || n < 0 || patch <= 0 || (patch & 1))

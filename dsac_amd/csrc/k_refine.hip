@@ -177,10 +177,14 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
-                                               int32_t* __restrict__ steps_done, int map_stride) {
+                                               int32_t* __restrict__ steps_done, int map_stride, int group) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    if (n_live && b >= live_base + live_mul * n_live[0]) return;  // replica list shorter than the launch
+    // replica lists shorter than the launch: `group` replicas per list (0: one list), list m holds live_base + live_mul * n_live[m]
+    if (n_live) {
+        const int m = group > 0 ? b / group : 0, local = group > 0 ? b - m * group : b;
+        if (local >= live_base + live_mul * n_live[m]) return;
+    }
     const int lane = threadIdx.x;
     __shared__ float s_X[RF_MAX_INL * 3];
     __shared__ float s_uv[RF_MAX_INL * 2];
@@ -251,7 +255,7 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done, map_stride);
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0);
     return hipGetLastError();
 }
 
@@ -340,7 +344,7 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     const int B = 12 + 6 * cap;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr, 0);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0);
     return hipGetLastError();
 }
 
@@ -356,6 +360,10 @@ __global__ __launch_bounds__(64) void k_refine_fd_plan_set(const int32_t* __rest
                                                            int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj) {
     const int lane = threadIdx.x;
     const int P = F.P;
+    {   // hypothesis m of a batch (blockIdx.y): its set, inlier map and slice of the replica arrays (18 + 6*cap replicas each)
+        const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
+        set4 += 4 * m; inlier_map += m * P; rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
+    }
     if (lane < 18) {
         const int pt = lane / 6, c = (lane % 6) >> 1;
         const int p = min(max(set4[pt], 0), P - 1);
@@ -397,6 +405,10 @@ __global__ __launch_bounds__(64) void k_refine_fd_plan_set(const int32_t* __rest
 __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4,
                                                            const int32_t* __restrict__ rep_px_c, const float* __restrict__ rep_value, FrameDev F,
                                                            double* __restrict__ rep_poses) {
+    {
+        const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
+        set4 += 4 * m; rep_px_c += m * R * 2; rep_value += m * R; rep_poses += m * R * 6; n_obj += m;
+    }
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= 18 + 6 * min(n_obj[0], cap)) return;
     const int ppx = rep_px_c[2 * r], pch = rep_px_c[2 * r + 1];
@@ -420,24 +432,32 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
 }
 
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
-                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj) {
-    hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1), dim3(64), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(64), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
     const int R = 18 + 6 * cap;
-    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 63) / 64), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
+    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 63) / 64, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
     return hipGetLastError();
 }
 
 hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out) {
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M) {
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
-    const int B = 18 + 6 * cap;
-    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr, 0);
+    if (M <= 0) return hipSuccess;
+    const int R = 18 + 6 * cap;
+    const long long B = (long long)R * M;
+    if (B > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_refine, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
+                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(64) void k_refine_fd_finish_set(const double* __restrict__ rep_out, const int32_t* __restrict__ n_obj, int cap, int skip,
                                                              float eps_obj, double* __restrict__ J_set, double* __restrict__ J_obj) {
+    {
+        const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
+        rep_out += m * R * 6; n_obj += m; J_set += m * 54; J_obj += m * (size_t)cap * 18;
+    }
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;  // 0..8: set point pt = pair / 3, channel pair % 3; then 3 per cell
     const int npairs = 9 + 3 * min(n_obj[0], cap);
     if (pair >= npairs) return;
@@ -456,9 +476,11 @@ __global__ __launch_bounds__(64) void k_refine_fd_finish_set(const double* __res
     }
 }
 
-hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set, double* J_obj) {
+hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set, double* J_obj,
+                                int M) {
+    if (M <= 0) return hipSuccess;
     const int pairs = 9 + 3 * cap;
-    hipLaunchKernelGGL(k_refine_fd_finish_set, dim3((pairs + 63) / 64), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_obj, J_set, J_obj);
+    hipLaunchKernelGGL(k_refine_fd_finish_set, dim3((pairs + 63) / 64, M), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_obj, J_set, J_obj);
     return hipGetLastError();
 }
 

@@ -77,11 +77,12 @@ hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int
 // DSAC-variant replica plan (core/cnn.h:854-990 dRefine): 18 replicas perturb the first three points of the minimal set,
 // 6 per selected inlier cell follow; every replica's start pose is P3P of the set read from the perturbed map.
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
-                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj);
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M = 1);
+// M hypotheses at once (sets M x 4, inlier maps M x H*W, 18 + 6*cap replicas each): one launch of M * (18 + 6*cap) waves
 hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out);
-hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set /*6 x 9*/,
-                                double* J_obj);
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M = 1);
+hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set /*M x 6 x 9*/,
+                                double* J_obj, int M = 1);
 // builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,

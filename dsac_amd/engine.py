@@ -355,6 +355,24 @@ class Engine:
         k = int(n[0])
         return J_set, px[:k], J_obj[:k]
 
+    def dRefineSets(self, sets, perm, inlier_maps, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01, eps_obj=2.0, cap=None):
+        """dRefineSet for M hypotheses in one batched launch (the hypothesis loop of core/train_ransac.cpp:314-339).
+        Returns (J_set M x 6 x 9, n_obj M, obj_pixels M x cap, J_obj M x cap x 6 x 3); only the first n_obj[m] cells of hypothesis m count."""
+        sets = _np(np.asarray(sets).reshape(-1, 4), np.int32)
+        M = int(sets.shape[0])
+        perm = _np(np.asarray(perm).reshape(-1, self.P), np.int32)
+        maps = _np(np.asarray(inlier_maps).reshape(M, self.P), np.int32)
+        skip = max(1, int(1 / np.float32(sub_sample)))
+        if cap is None:
+            cap = max(1, int((maps != 0).sum(1).max()) // skip) if M else 1
+        J_set = np.zeros((M, 6, 9))
+        px = np.zeros((M, cap), np.int32)
+        J_obj = np.zeros((M, cap, 6, 3))
+        n = np.zeros(M, np.int32)
+        check(self._ctx, lib.dsac_refine_fd_sets(self._ctx, M, ptr(sets), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl), float(thr), ptr(maps),
+                                                 float(sub_sample), float(eps_obj), ptr(J_set), ptr(px), ptr(J_obj), int(cap), ptr(n)))
+        return J_set, n, px, J_obj
+
     def maxLossBatch(self, est_cv6, gt_jp6, want_grad=False):
         """maxLoss [+ dLossMax] of B estimates against one ground truth (losses of expectedMaxLoss, core/cnn.h:137-150)."""
         est = np.ascontiguousarray(np.asarray(est_cv6, dtype=np.float64).reshape(-1, 6))
@@ -407,15 +425,16 @@ class Engine:
         N = len(w)
         grad = np.zeros((self.P, 3))
         dL = self.maxLossBatch(ref, gt_jp6, want_grad=True)["grad"]
-        for h in range(N):
-            if not w[h] > min_prob:
-                continue
-            J_set, px, J_obj = self.dRefineSet(sets[h], fwd["pixelIdxs"], fwd["inlierMaps"][h], max_inl=inlierCount, min_inl=minInliers,
-                                               thr=float(int(thr)), sub_sample=sub_sample)
-            for pt in range(3):
-                grad[sets[h][pt]] += w[h] * (dL[h] @ J_set[:, pt * 3:pt * 3 + 3])
-            if len(px):
-                np.add.at(grad, px, w[h] * np.einsum("k,ikc->ic", dL[h], J_obj))
+        sel = np.flatnonzero(w > min_prob)
+        if len(sel):  # one batched launch for all hypotheses that carry weight (train_ransac.cpp:318)
+            J_set, n_obj, px, J_obj = self.dRefineSets(sets[sel], fwd["pixelIdxs"], fwd["inlierMaps"][sel], max_inl=inlierCount, min_inl=minInliers,
+                                                       thr=float(int(thr)), sub_sample=sub_sample)
+            for i, h in enumerate(sel):
+                for pt in range(3):
+                    grad[sets[h][pt]] += w[h] * (dL[h] @ J_set[i][:, pt * 3:pt * 3 + 3])
+                k = int(n_obj[i])
+                if k:
+                    np.add.at(grad, px[i][:k], w[h] * np.einsum("k,ikc->ic", dL[h], J_obj[i][:k]))
         losses = fwd["losses"]
         g = w * (losses - np.dot(w, losses))  # core/cnn.h:737-742
         if d_scores_fn is not None:

@@ -206,6 +206,12 @@ int dsac_refine_all(dsac_ctx* ctx, int N, const double* init_poses, const int32_
 int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                        const int32_t* inlier_map, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
                        int32_t* n_obj);
+/* dsac_refine_fd_set for M hypotheses in ONE batch of M * (18 + 6*cap) refinement problems -- the loop over hypotheses of
+ * core/train_ransac.cpp:314-339 (the reference runs it under OpenMP).  sets M x 4, inlier_maps M x H*W; outputs J_set M x 6 x 9,
+ * obj_pixels M x cap, J_obj M x cap x 6 x 3, n_obj M (entries beyond n_obj[m] are untouched). */
+int dsac_refine_fd_sets(dsac_ctx* ctx, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                        const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                        int32_t* n_obj);
 /* maxLoss / dLossMax for B estimates against one ground truth: the losses[] of expectedMaxLoss core/cnn.h:137-150 and
  * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
 int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);

@@ -87,3 +87,21 @@ def test_training_backward_of_the_dsac_variant(engine, orc, fwd_state):
     el2 = np.linalg.norm(bwd["grad"] - grad) / np.linalg.norm(grad)
     print("DSAC-variant end-to-end gradient: max-rel %.3e l2-rel %.3e" % (emax, el2))
     assert emax <= 1e-2 and el2 <= 1e-2
+
+
+def test_batched_drefine_equals_per_hypothesis_calls(engine, fwd_state):
+    """dsac_refine_fd_sets (all weighted hypotheses in one launch of M * (18 + 6 cap) waves) = M calls of dsac_refine_fd_set."""
+    fr, perm, gt, fwd = fwd_state
+    sel = np.argsort(-fwd["sfScores"])[:6]
+    J_set, n_obj, px, J_obj = engine.dRefineSets(fwd["sampledPoints"][sel], perm, fwd["inlierMaps"][sel], sub_sample=0.05)
+    assert n_obj.max() > 0
+    for i, h in enumerate(sel):
+        Js, p1, Jo = engine.dRefineSet(fwd["sampledPoints"][h], perm, fwd["inlierMaps"][h], sub_sample=0.05)
+        k = int(n_obj[i])
+        assert k == len(p1) and np.array_equal(px[i][:k], p1)
+        assert np.array_equal(J_set[i], Js) and np.array_equal(J_obj[i][:k], Jo)
+    # empty batch and a batch whose maps hold no inlier cells
+    z = engine.dRefineSets(fwd["sampledPoints"][:0], perm, fwd["inlierMaps"][:0])
+    assert z[0].shape == (0, 6, 9)
+    J0, n0, _, _ = engine.dRefineSets(fwd["sampledPoints"][:2], perm, np.zeros_like(fwd["inlierMaps"][:2]), sub_sample=0.05)
+    assert not n0.any() and J0.shape == (2, 6, 9)
