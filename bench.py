@@ -96,7 +96,7 @@ def main():
     # B different frames per rank
     B = max(1, args.frames_per_step)
     batched = B > 1
-    if batched and (args.kernel_only or args.separate_calls or args.k2_mode != "both" or args.overlap in ("pipeline", "stages") or N % 128 != 0):
+    if batched and (args.kernel_only or args.separate_calls or args.k2_mode != "both" or args.overlap == "stages" or N % 128 != 0):
         B, batched = 1, False  # those modes time single frames (K2-only runs, the in-context pipeline, odd hypothesis counts)
     fr = synth.chess_like_frame(H, W, seed=1305 + rank)
     if batched:
@@ -166,7 +166,7 @@ def main():
         eng, _ = engines[0]
         k = i & 1
         nb = bufs[1 - k]
-        eng.sampleAhead(1 - k, N, seed_of(i + 1), nb["poses"], nb["sets"], nb["ok"], thr=10.0, max_tries=1 << 16)
+        eng.sampleAhead(1 - k, NB, seed_of(i + 1), nb["poses"], nb["sets"], nb["ok"], thr=10.0, max_tries=1 << 16)
         b = bufs[k]
         eng.scoreSampled(k, b["poses"], b["soft"], b["w"], ent=b["ent"], avg=b["avg"], err=err_shared, clamp=100.0, tau=10.0, beta=0.5, scale=0.1)
 
@@ -201,7 +201,7 @@ def main():
 
     if pipelined:
         err_shared = bufs[0]["err"]  # the scoring stage is serial: one error-image buffer
-        engines[0][0].sampleAhead(0, N, seed_of(0), bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"], thr=10.0, max_tries=1 << 16)
+        engines[0][0].sampleAhead(0, NB, seed_of(0), bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"], thr=10.0, max_tries=1 << 16)
     for i in range(Wm):
         step(i)
     sync_all()

@@ -485,8 +485,13 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
                       int32_t* sets_out, uint8_t* ok) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample_ahead: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample_ahead: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
     if (slot < 0 || slot > 1 || N <= 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot in {0,1}, N > 0, non-NULL outputs");
+    int Nf = 0;  // frame batch: N = frames x hypotheses per frame, frame f draws from the stream of seed + f
+    if (c->F.frames > 1) {
+        if (sets_or_null || N % c->F.frames != 0 || (N / c->F.frames) % 128 != 0)
+            return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: with a frame batch N must be frames x (a multiple of 128) and the sets are drawn here");
+        Nf = N / c->F.frames;
+    }
     if (!is_device_ptr(poses) || !is_device_ptr(sets_out) || !is_device_ptr(ok) || (sets_or_null && !is_device_ptr(sets_or_null)))
         return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: the pipelined calls need device pointers");
     if (!sets_or_null && (max_tries <= 0 || c->F.P < 4)) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: max_tries > 0 and >= 4 cells needed");
@@ -494,7 +499,7 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
     ARG_TRY(pipeline_init(c));
     HIP_TRY(c, c->slot_staged[slot].reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
     if (c->slot_free_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_free[slot], 0));  // the scorer is done with this slot
-    HIP_TRY(c, dk::sample(c->aux, N, seed, sets_or_null, c->F, (int)thr, max_tries, poses, sets_out, ok, c->slot_staged[slot].as<float>()));
+    HIP_TRY(c, dk::sample(c->aux, N, seed, sets_or_null, c->F, (int)thr, max_tries, poses, sets_out, ok, c->slot_staged[slot].as<float>(), Nf));
     HIP_TRY(c, hipEventRecord(c->slot_ready[slot], c->aux));
     c->slot_N[slot] = N;
     return DSAC_OK;
@@ -510,6 +515,8 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
         return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: the pipelined calls need device pointers");
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->slot_N[slot];
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    const int Nf = frames > 1 ? N / frames : 0;
     const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
     HIP_TRY(c, c->slot_soft_part[slot].reserve((size_t)tiles * N * sizeof(float)));
     float* part = c->slot_soft_part[slot].as<float>();
@@ -519,7 +526,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     int used = 0;
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, part, c->reproject_variant, &used));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, part, c->reproject_variant, &used, Nf));
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
     c->slot_free_recorded[slot] = true;
@@ -528,7 +535,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     HIP_TRY(c, dk::reduce_soft(c->aux2, N, used, part, scores));
     HIP_TRY(c, hipEventRecord(c->slot_reduced[slot], c->aux2));
     c->slot_reduced_recorded[slot] = true;
-    HIP_TRY(c, dk::softmax(c->aux2, N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null));
+    HIP_TRY(c, dk::softmax(c->aux2, frames > 1 ? Nf : N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null, frames));
     return DSAC_OK;
 }
 

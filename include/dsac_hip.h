@@ -92,7 +92,8 @@ int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int
 /* Frame batch: `frames` coordinate maps of the same H x W and camera, stored back to back (frame f at xyz + f*H*W*3); uv is one
  * shared H*W x 2 table (uv_per_frame = 0), one table per frame (uv_per_frame = 1) or NULL (implicit grid).  Independent frames
  * are the unit the path shards over (core/test_ransac_softam.cpp:97-230); batching them lets one launch carry several frames.
- * Only dsac_score_hypotheses_frames accepts a batch; every other call reports DSAC_ERR_INVALID while one is set. */
+ * Only dsac_score_hypotheses_frames and the pipelined pair dsac_sample_ahead / dsac_score_sampled (N = frames x hypotheses per frame,
+ * outputs frame-major) accept a batch; every other call reports DSAC_ERR_INVALID while one is set. */
 int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
                     float cx, float cy, unsigned flags);
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).

@@ -360,3 +360,26 @@ def test_frame_batch_at_baseline_size(engine, synth):
         assert torch.equal(b["err"][sl].double().sum(1), s["err"].double().sum(1))
         assert torch.allclose(b["w"][sl], s["w"], rtol=1e-9, atol=1e-15) and abs(float(b["w"][sl].sum().item()) - 1.0) < 1e-12
         assert torch.allclose(b["avg"][f], s["avg"][0], rtol=1e-9, atol=1e-12)
+
+
+def test_pipelined_calls_on_a_frame_batch(engine, synth):
+    """dsac_sample_ahead / dsac_score_sampled on a frame batch give what dsac_score_hypotheses_frames gives."""
+    import torch
+    H, W, F, N = 48, 64, 2, 128
+    dev = torch.device("cuda", 0)
+    frames = [synth.chess_like_frame(H, W, seed=300 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    uv = torch.from_numpy(frames[0]["uv"]).to(dev)
+    engine.set_frames(xyz, uv, H, W, frames[0]["cam"], borrow=True)
+    ref = engine.scoreHypothesesFrames(N, seed=5)
+    poses = torch.zeros(F * N, 6, dtype=torch.float64, device=dev); sets = torch.zeros(F * N, 4, dtype=torch.int32, device=dev)
+    ok = torch.zeros(F * N, dtype=torch.uint8, device=dev); sc = torch.zeros(F * N, dtype=torch.float64, device=dev)
+    w = torch.zeros(F * N, dtype=torch.float64, device=dev); ent = torch.zeros(F, dtype=torch.float64, device=dev)
+    avg = torch.zeros(F, 6, dtype=torch.float64, device=dev)
+    engine.sampleAhead(0, F * N, 5, poses, sets, ok)
+    engine.scoreSampled(0, poses, sc, w, ent=ent, avg=avg)
+    engine.synchronize()
+    assert np.array_equal(sets.cpu().numpy(), ref[1]) and np.array_equal(poses.cpu().numpy(), ref[0])
+    assert np.allclose(w.cpu().numpy(), ref[4], rtol=1e-12, atol=0) and np.allclose(ent.cpu().numpy(), ref[5]) and np.allclose(avg.cpu().numpy(), ref[6])
+    with pytest.raises(Exception):
+        engine.sampleAhead(0, F * N + 1, 5, poses, sets, ok)  # not frames x (a multiple of 128)
