@@ -482,6 +482,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
         case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
         case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 10: return launch_reproject<4, 1, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 11: return launch_reproject<4, 2, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 12: return launch_reproject<4, 4, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 13: return launch_reproject<4, 8, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 14: return (Nf % 256) ? hipErrorInvalidValue : launch_reproject_mfma<256, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 15: return (Nf % 256) ? hipErrorInvalidValue : launch_reproject_mfma<256, 2>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+        case 16: return launch_reproject_mfma<128, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
         case 7: return launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
         case 8: return launch_reproject_mfma<64, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
         case 9: return launch_reproject_mfma<32, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);

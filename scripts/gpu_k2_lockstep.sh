@@ -1,0 +1,10 @@
+#!/bin/bash
+# K2 with all hypotheses of a frame looped inside the workgroup (workgroups sweep the rows of the error images in lock-step)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
+fmt='import sys,json; d=json.loads(sys.stdin.read()); print("%.1f us/frame  %.3f Mhyp/s  frac %.3f  K2 %.1f us" % (d["ms_per_step"]*1e3/d["config"]["frames_per_step"], d["value"]/1e6, d["roofline"]["frac"], d["roofline"]["avg_launch_us"]))'
+for v in -1 14 15 16 5; do for o in 0 1; do
+  r=$(DSAC_K2_VARIANT=$v DSAC_K2_ORDER=$o timeout 300 python bench.py --steps 60 --warmup 8 --no-cpu-baseline --event-stride 1 2>/dev/null | tail -1 | python -c "$fmt")
+  echo "batch 8, variant $v order $o: $r"
+  r=$(DSAC_K2_VARIANT=$v DSAC_K2_ORDER=$o timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --event-stride 1 --frames-per-step 1 --kernel-only --k2-mode both 2>/dev/null | tail -1 | python -c "$fmt")
+  echo "K2 only N=256, variant $v order $o: $r"
+done; done | tee gpurun_out/k2_lockstep.txt
