@@ -186,9 +186,13 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     for (int h = 0; h < nh; h++) {
         const f4* sp = reinterpret_cast<const f4*>(s_rec + h * BWD_REC);
         const f4 r0 = sp[0], r1 = sp[1], r2 = sp[2];
-        // column pairs of R' = rows 0,1 of each column: (R'00, R'10), (R'01, R'11), (R'02, R'12), (t'0, t'1)
-        const f2 c0 = {r0.x, r1.x}, c1 = {r0.y, r1.y}, c2 = {r0.z, r1.z}, c3 = {r0.w, r1.w};
-        const f2 r0xy = {r0.x, r0.y}, r1xy = {r1.x, r1.y}, r2xy = {r2.x, r2.y};
+        // Sign bookkeeping is folded into per-hypothesis constants so that the pixel loop has no negations (on packed operands they
+        // cost register moves): the y row of R' is negated in the column pairs, which yields (E.x, -E.y) and with it (du, dv) and
+        // (C0, -C1, -C2) directly; the accumulators that receive -C1 / -C2 use negated constants (gx) or are negated once per
+        // hypothesis (G).
+        const f2 c0 = {r0.x, -r1.x}, c1 = {r0.y, -r1.y}, c2 = {r0.z, -r1.z}, c3 = {r0.w, -r1.w};
+        const f2 r0xy = {r0.x, r0.y}, nr1xy = {-r1.x, -r1.y}, nr2xy = {-r2.x, -r2.y};
+        const float nr1z = -r1.z, nr2z = -r2.z;
         // G pairs: Ga[i] = C_i * (X, Y)  ;  Gb[i] = C_i * (Z, 1)
         f2 Ga[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}}, Gb[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
@@ -211,14 +215,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
             for (int k = 0; k < PXL; k++) {
                 const int i = j * PXL + k;
                 const float Xi = xy[i].x, Yi = xy[i].y, Zi = zw[i].x;
-                // (E.x, E.y) as one packed chain, E.z scalar
+                // (E.x, -E.y) as one packed chain, E.z scalar
                 const f2 exy = __builtin_elementwise_fma(c0, f2{Xi, Xi}, __builtin_elementwise_fma(c1, f2{Yi, Yi}, __builtin_elementwise_fma(c2, f2{Zi, Zi}, c3)));
                 const float ez = fmaf(r2.x, Xi, fmaf(r2.y, Yi, fmaf(r2.z, Zi, r2.w)));
                 // guard |E.z| < 1e-8 -> 0 (cnn_softam.h:416,476): a zero reciprocal keeps everything below finite
                 const float iz = (fabsf(ez) >= 1e-8f) ? __builtin_amdgcn_rcpf(ez) : 0.f;
                 const float fz = f * iz;
                 // (u - px, v - py) with px = -f E.x/E.z + cx, py = f E.y/E.z + cy
-                const f2 d = __builtin_elementwise_fma(exy, f2{fz, -fz}, ppix[i]);
+                const f2 d = __builtin_elementwise_fma(exy, f2{fz, fz}, ppix[i]);   // exy = (E.x, -E.y)
                 const f2 dq = d * d;
                 const float err = __builtin_amdgcn_sqrtf(dq.x + dq.y);
                 float w;
@@ -232,18 +236,18 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
                 const bool keep = valid[j] && (iz != 0.f) && !(err > clampv);
                 const float ie = __builtin_amdgcn_rcpf(err + 1e-8f);
                 const float wfz = keep ? w * fz * ie : 0.f;       // w f / (E.z (err + eps))
-                // a = -(du, dv)/(err+eps);  c0 = -a0 f/E.z ; c1 = a1 f/E.z ; c2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
-                const f2 C01 = d * f2{wfz, -wfz};
-                const f2 de = d * exy;                            // (du E.x, dv E.y)
-                const float C2 = (de.y - de.x) * (wfz * iz);
-                gxy[i] = __builtin_elementwise_fma(r0xy, f2{C01.x, C01.x}, __builtin_elementwise_fma(r1xy, f2{C01.y, C01.y}, __builtin_elementwise_fma(r2xy, f2{C2, C2}, gxy[i])));
-                gz[i] = fmaf(r0.z, C01.x, fmaf(r1.z, C01.y, fmaf(r2.z, C2, gz[i])));
-                Ga[0] = __builtin_elementwise_fma(f2{C01.x, C01.x}, xy[i], Ga[0]); Gb[0] = __builtin_elementwise_fma(f2{C01.x, C01.x}, zw[i], Gb[0]);
-                Ga[1] = __builtin_elementwise_fma(f2{C01.y, C01.y}, xy[i], Ga[1]); Gb[1] = __builtin_elementwise_fma(f2{C01.y, C01.y}, zw[i], Gb[1]);
-                Ga[2] = __builtin_elementwise_fma(f2{C2, C2}, xy[i], Ga[2]);       Gb[2] = __builtin_elementwise_fma(f2{C2, C2}, zw[i], Gb[2]);
+                // a = -(du, dv)/(err+eps);  C0 = -a0 f/E.z ; C1 = a1 f/E.z ; C2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
+                const f2 Cn = d * f2{wfz, wfz};                   // (C0, -C1)
+                const f2 de = d * exy;                            // (du E.x, -dv E.y)
+                const float nC2 = (de.x + de.y) * (wfz * iz);     // -C2
+                gxy[i] = __builtin_elementwise_fma(r0xy, f2{Cn.x, Cn.x}, __builtin_elementwise_fma(nr1xy, f2{Cn.y, Cn.y}, __builtin_elementwise_fma(nr2xy, f2{nC2, nC2}, gxy[i])));
+                gz[i] = fmaf(r0.z, Cn.x, fmaf(nr1z, Cn.y, fmaf(nr2z, nC2, gz[i])));
+                Ga[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, xy[i], Ga[0]); Gb[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, zw[i], Gb[0]);
+                Ga[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, xy[i], Ga[1]); Gb[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, zw[i], Gb[1]);   // -C1 sums
+                Ga[2] = __builtin_elementwise_fma(f2{nC2, nC2}, xy[i], Ga[2]);   Gb[2] = __builtin_elementwise_fma(f2{nC2, nC2}, zw[i], Gb[2]);     // -C2 sums
             }
         }
-        float G[12] = {Ga[0].x, Ga[0].y, Gb[0].x, Ga[1].x, Ga[1].y, Gb[1].x, Ga[2].x, Ga[2].y, Gb[2].x, Gb[0].y, Gb[1].y, Gb[2].y};
+        float G[12] = {Ga[0].x, Ga[0].y, Gb[0].x, -Ga[1].x, -Ga[1].y, -Gb[1].x, -Ga[2].x, -Ga[2].y, -Gb[2].x, Gb[0].y, -Gb[1].y, -Gb[2].y};
         const float tot = wave_sum12(G, lane);
         if (gslot >= 0) gout[(size_t)h * 12 + gslot] = tot;
     }
