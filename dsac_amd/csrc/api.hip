@@ -618,7 +618,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>()));
         d_dpnp = s.as<double>();
     }
-    const int HT = dk::backward_hyp_tile();
+    const int HT = dk::backward_hyp_tile(N, c->F.P);
     const int NT = (N + HT - 1) / HT;
     const int PTmax = dk::backward_num_partial_rows(c->F.P);
     HIP_TRY(c, c->bwd_staged.reserve((size_t)N * 12 * sizeof(float)));
@@ -631,7 +631,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     {
         ProfScope ps(c, 1);
         HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
-                                      c->g12_part.as<float>(), &PT));
+                                      c->g12_part.as<float>(), &PT, HT));
     }
     HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), NT, c->g12_part.as<float>(), PT, c->dRdH.as<double>(), d_dpnp,
                                          d_sets, flags, d_grad, c->g6.as<double>()));

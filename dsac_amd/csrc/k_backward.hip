@@ -26,10 +26,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int K4_THREADS = 256;
-constexpr int K4_HT = 32;
+constexpr int K4_PXG = 2;     // 8 pixels per lane on the vector path
+constexpr int K4_PXG_C = K4_PXG;
+constexpr int K4_HT_MAX = 128;  // LDS capacity for the hypothesis records of a tile; the tile size itself is chosen per launch
 constexpr int BWD_REC = 12;  // floats per hypothesis: R'0|t'0, R'1|t'1, R'2|t'2
 
-int backward_hyp_tile() { return K4_HT; }
+
 
 // --------------------------------------------------------------------------------------------------
 // per hypothesis: jp pose (cv2our), its float record, and dR'/drod (3x9) for the finish kernel
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
                                                                const float* __restrict__ uv, const float* __restrict__ d_err,
                                                                const double* __restrict__ g, float* __restrict__ grad_part,
                                                                float* __restrict__ G12_part, int N, int P, int W, int PT, int NT,
-                                                               float f, float cx, float cy, float clampv, float kA, float kB, float beta) {
+                                                               float f, float cx, float cy, float clampv, float kA, float kB, float beta, int HT) {
     constexpr int PXL = VEC ? 4 : 1;          // pixels per group
     constexpr int NP = PXG * PXL;             // pixels per lane
     const int b = blockIdx.x;
@@ -124,14 +126,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     const int ht = q % NT;
     const int pt = (q / NT) * 8 + (b & 7);
     if (pt >= PT) return;
-    const int h0 = ht * K4_HT;
-    const int nh = min(K4_HT, N - h0);
+    const int h0 = ht * HT;
+    const int nh = min(HT, N - h0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    __shared__ __attribute__((aligned(16))) float s_rec[K4_HT * BWD_REC];
-    __shared__ float s_g[K4_HT];
+    __shared__ __attribute__((aligned(16))) float s_rec[K4_HT_MAX * BWD_REC];
+    __shared__ float s_g[K4_HT_MAX];
     for (int i = tid; i < nh * BWD_REC; i += K4_THREADS) s_rec[i] = rec[(size_t)h0 * BWD_REC + i];
-    if (SOFTMODE && tid < nh) s_g[tid] = (float)g[h0 + tid];
+    if (SOFTMODE && tid < nh) s_g[tid] = (float)g[h0 + tid];  // nh <= K4_HT_MAX <= K4_THREADS
 
     const int tile0 = pt * K4_THREADS * NP;
     int pbase[PXG];
@@ -267,20 +269,29 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     }
 }
 
-constexpr int K4_PXG = 2;  // 8 pixels per lane on the vector path
+
+// Hypothesis tile of a launch (a kernel argument, <= K4_HT_MAX).  32 everywhere: a round-counting model (workgroups / (2 per CU),
+// cost ~ rounds x HT) suggested 86 for N = 256 on a 640 x 480 map (450 workgroups in one round instead of 1200 in 2.34) and 103 for
+// N = 1024; measured, 86 gains 3 % at N = 256 (175 -> 169 us) and 103 loses 5 % at N = 1024 (575 -> 602 us) -- workgroups do not
+// run in lock-step rounds, and long tiles have the longer tail.
+int backward_hyp_tile(int N, int P) {
+    (void)N; (void)P;
+    return 32;
+}
 
 int backward_num_partial_rows(int P) { return ((P + K4_THREADS - 1) / K4_THREADS) * (K4_THREADS / 64); }  // upper bound (scalar path)
 
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g, float clampv,
-                          float tau, float beta, float* grad_part, float* G12_part, int* partial_rows_used) {
+                          float tau, float beta, float* grad_part, float* G12_part, int* partial_rows_used, int HT) {
     if (partial_rows_used) *partial_rows_used = 0;
     if (N <= 0) return hipSuccess;
+    if (HT < 1 || HT > K4_HT_MAX) return hipErrorInvalidValue;
     const bool soft = d_err == nullptr;
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(grad_part) & 15) == 0);
     const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
     const int PT = (F.P + tile - 1) / tile;
-    const int NT = (N + K4_HT - 1) / K4_HT;
+    const int NT = (N + HT - 1) / HT;
     const int grid = ((PT + 7) / 8) * 8 * NT;
     if (partial_rows_used) *partial_rows_used = PT * (K4_THREADS / 64);
     const float LOG2E = 1.4426950408889634f;
@@ -288,7 +299,7 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
     const bool UV = F.uv != nullptr;
 #define DSAC_K4(G_, V_, S_, U_)                                                                                                              \
     hipLaunchKernelGGL((k_score_backward<G_, V_, S_, U_>), dim3(grid), dim3(K4_THREADS), 0, st, staged_bwd, F.xyz, F.uv, d_err, g, grad_part, \
-                       G12_part, N, F.P, F.W, PT, NT, F.fx, F.cx, F.cy, clampv, kA, kB, beta)
+                       G12_part, N, F.P, F.W, PT, NT, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT)
     if (vec) {
         if (soft) { if (UV) DSAC_K4(K4_PXG, true, true, true); else DSAC_K4(K4_PXG, true, true, false); }
         else { if (UV) DSAC_K4(K4_PXG, true, false, true); else DSAC_K4(K4_PXG, true, false, false); }

@@ -53,12 +53,12 @@ hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, f
 // jp-convention staged records for the backward pass, 32 floats per hypothesis (see k_backward.hip).
 constexpr int BWD_STRIDE = 32;
 int backward_num_partial_rows(int P);  // rows of G12_part (pixel tiles x waves), upper bound
-int backward_hyp_tile();
+int backward_hyp_tile(int N, int P);  // hypothesis tile chosen for a launch (16..128), see k_backward.hip
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [partial rows][N][12] floats
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
-                          float clampv, float tau, float beta, float* grad_part, float* G12_part, int* pixel_tiles_used);
+                          float clampv, float tau, float beta, float* grad_part, float* G12_part, int* pixel_tiles_used, int HT);
 // Epilogue: grad_xyz (P x 3 double) += sum over hyp tiles; then per hypothesis G6 = [G9 * dRdH, G3],
 // S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
