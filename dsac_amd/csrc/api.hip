@@ -621,7 +621,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     const int HT = dk::backward_hyp_tile(N, c->F.P);
     const int NT = (N + HT - 1) / HT;
     const int PTmax = dk::backward_num_partial_rows(c->F.P);
-    HIP_TRY(c, c->bwd_staged.reserve((size_t)N * 12 * sizeof(float)));
+    HIP_TRY(c, c->bwd_staged.reserve((size_t)N * dk::BWD_STRIDE * sizeof(float)));
     HIP_TRY(c, c->dRdH.reserve((size_t)N * 27 * sizeof(double)));
     HIP_TRY(c, c->grad_part.reserve((size_t)NT * P * 3 * sizeof(float)));
     HIP_TRY(c, c->g12_part.reserve((size_t)PTmax * N * 12 * sizeof(float)));

@@ -29,7 +29,14 @@ constexpr int K4_THREADS = 256;
 constexpr int K4_PXG = 2;     // 8 pixels per lane on the vector path
 constexpr int K4_PXG_C = K4_PXG;
 constexpr int K4_HT_MAX = 128;  // LDS capacity for the hypothesis records of a tile; the tile size itself is chosen per launch
-constexpr int BWD_REC = 12;  // floats per hypothesis: R'0|t'0, R'1|t'1, R'2|t'2
+constexpr int BWD_REC = BWD_STRIDE;
+// Record of one hypothesis, six float4 read by K4 with ds_read_b128 and used as they are (jp convention: E = R' X + t'):
+//   [0] ( R'00, -R'10,  R'01, -R'11)   column pairs for the packed chain (E.x, -E.y) = c0 X + c1 Y + c2 Z + c3
+//   [1] ( R'02, -R'12,  t'0,  -t'1 )
+//   [2] ( R'20,  R'21,  R'22,  t'2 )   E.z
+//   [3] ( R'00,  R'01, -R'10, -R'11)   gx.xy += (R'0.xy) C0 + (-R'1.xy)(-C1) + (-R'2.xy)(-C2)
+//   [4] (-R'20, -R'21,  R'02, -R'12)
+//   [5] (-R'22,  0, 0, 0)              gx.z
 
 
 
@@ -46,11 +53,14 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
     double R[9], t[3];
     dm::cv2our(cv6, R, t);
     float* o = rec + (size_t)h * BWD_REC;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        o[i * 4 + 0] = (float)R[i * 3 + 0]; o[i * 4 + 1] = (float)R[i * 3 + 1]; o[i * 4 + 2] = (float)R[i * 3 + 2];
-        o[i * 4 + 3] = (float)t[i];
-    }
+    const float r00 = (float)R[0], r01 = (float)R[1], r02 = (float)R[2], r10 = (float)R[3], r11 = (float)R[4], r12 = (float)R[5];
+    const float r20 = (float)R[6], r21 = (float)R[7], r22 = (float)R[8], t0 = (float)t[0], t1 = (float)t[1], t2 = (float)t[2];
+    o[0] = r00; o[1] = -r10; o[2] = r01; o[3] = -r11;
+    o[4] = r02; o[5] = -r12; o[6] = t0; o[7] = -t1;
+    o[8] = r20; o[9] = r21; o[10] = r22; o[11] = t2;
+    o[12] = r00; o[13] = r01; o[14] = -r10; o[15] = -r11;
+    o[16] = -r20; o[17] = -r21; o[18] = r02; o[19] = -r12;
+    o[20] = -r22; o[21] = 0.f; o[22] = 0.f; o[23] = 0.f;
     // rod = Rodrigues(R'), dRdH = d Rodrigues(rod) / d rod   (core/cnn_softam.h:505-509)
     double rod[3], Rre[9], J[27];
     dm::rodrigues_m2v(R, rod);
@@ -186,15 +196,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     // which of the 12 per-hypothesis sums this lane holds after wave_sum12 (-1: none)
     const int gslot = ((lane & 12) == 0 && (lane & 3) != 3) ? 6 * (lane >> 5) + 3 * ((lane >> 4) & 1) + ((lane & 3) == 0 ? 0 : (lane & 3) == 2 ? 1 : 2) : -1;
     for (int h = 0; h < nh; h++) {
+        // all sign bookkeeping and pairing was done once per hypothesis in k_backward_prep: the loop below has no negations
+        // (on packed operands they cost register moves), (E.x, -E.y) yields (du, dv) and (C0, -C1, -C2) directly, the accumulators
+        // that receive -C1 / -C2 use negated constants (gx) or are negated once per hypothesis (G)
         const f4* sp = reinterpret_cast<const f4*>(s_rec + h * BWD_REC);
-        const f4 r0 = sp[0], r1 = sp[1], r2 = sp[2];
-        // Sign bookkeeping is folded into per-hypothesis constants so that the pixel loop has no negations (on packed operands they
-        // cost register moves): the y row of R' is negated in the column pairs, which yields (E.x, -E.y) and with it (du, dv) and
-        // (C0, -C1, -C2) directly; the accumulators that receive -C1 / -C2 use negated constants (gx) or are negated once per
-        // hypothesis (G).
-        const f2 c0 = {r0.x, -r1.x}, c1 = {r0.y, -r1.y}, c2 = {r0.z, -r1.z}, c3 = {r0.w, -r1.w};
-        const f2 r0xy = {r0.x, r0.y}, nr1xy = {-r1.x, -r1.y}, nr2xy = {-r2.x, -r2.y};
-        const float nr1z = -r1.z, nr2z = -r2.z;
+        const f4 q0 = sp[0], q1 = sp[1], r2 = sp[2], q3 = sp[3], q4 = sp[4], q5 = sp[5];
+        const f2 c0 = {q0.x, q0.y}, c1 = {q0.z, q0.w}, c2 = {q1.x, q1.y}, c3 = {q1.z, q1.w};
+        const f2 r0xy = {q3.x, q3.y}, nr1xy = {q3.z, q3.w}, nr2xy = {q4.x, q4.y};
+        const float r0z = q4.z, nr1z = q4.w, nr2z = q5.x;
         // G pairs: Ga[i] = C_i * (X, Y)  ;  Gb[i] = C_i * (Z, 1)
         f2 Ga[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}}, Gb[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
                 const f2 de = d * exy;                            // (du E.x, -dv E.y)
                 const float nC2 = (de.x + de.y) * (wfz * iz);     // -C2
                 gxy[i] = __builtin_elementwise_fma(r0xy, f2{Cn.x, Cn.x}, __builtin_elementwise_fma(nr1xy, f2{Cn.y, Cn.y}, __builtin_elementwise_fma(nr2xy, f2{nC2, nC2}, gxy[i])));
-                gz[i] = fmaf(r0.z, Cn.x, fmaf(nr1z, Cn.y, fmaf(nr2z, nC2, gz[i])));
+                gz[i] = fmaf(r0z, Cn.x, fmaf(nr1z, Cn.y, fmaf(nr2z, nC2, gz[i])));
                 Ga[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, xy[i], Ga[0]); Gb[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, zw[i], Gb[0]);
                 Ga[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, xy[i], Ga[1]); Gb[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, zw[i], Gb[1]);   // -C1 sums
                 Ga[2] = __builtin_elementwise_fma(f2{nC2, nC2}, xy[i], Ga[2]);   Gb[2] = __builtin_elementwise_fma(f2{nC2, nC2}, zw[i], Gb[2]);     // -C2 sums

@@ -50,8 +50,8 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
 
 // ---- k_backward.hip --------------------------------------------------------------------------------
-// jp-convention staged records for the backward pass, 32 floats per hypothesis (see k_backward.hip).
-constexpr int BWD_STRIDE = 32;
+// jp-convention staged records for the backward pass, BWD_STRIDE floats per hypothesis (see k_backward.hip).
+constexpr int BWD_STRIDE = 24;  // six float4 per hypothesis, already sign-folded and pair-packed for K4's packed-fp32 chains
 int backward_num_partial_rows(int P);  // rows of G12_part (pixel tiles x waves), upper bound
 int backward_hyp_tile(int N, int P);  // hypothesis tile chosen for a launch (16..128), see k_backward.hip
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
