@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- hypotheses scored / s over a 640x480 scene-coordinate map (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one synthetic frame of BASELINE.json configs[1]
-("chess"-like single frame, 256 hypotheses, 640x480 coordinate map, one MI355X):
+One "step" = one pass of the hot path over one batch of synthetic input of BASELINE.json configs[1]
+("chess"-like frame, 256 hypotheses, 640x480 coordinate map, one MI355X), by default 8 independent frames per step:
     K1 sample 256 minimal sets + P3P   ->  K2 reproject all 307 200 points under all 256 poses
     (error images, the score-CNN input of the reference, + fused soft-inlier sums)  ->  K3 softmax.
-The frame is resident in HBM before the timed region; every output stays in HBM.  With --gpus N every rank
-owns its own frame (images shard across GPUs, no data-path collective: "scaling": "weak").
+The frames are resident in HBM before the timed region; every output stays in HBM.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel K2 (k_reproject): algorithmic bytes
-per launch (12*P + 48*N + 4*N*P + 4*N) over the average launch duration measured with HIP
-events on the engine's stream inside the timed region.  `cpu_baseline` is the CPU oracle (a port of the
-reference path, g++ -Ofast -fopenmp) timed on this box's host cores on a bounded sample.
+--gpus N: one process per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process is one rank; without it
+`python bench.py --gpus N` LAUNCHES the N ranks itself (rank r on GPU r, RCCL) and relays rank 0's line.  Every rank owns its own
+frames (images shard across GPUs, no data-path collective: "scaling": "weak"); `n_gpus` is the number of ranks that actually joined.
+
+--workload config3 runs BASELINE.json configs[3] instead: 64 images x 256 hypotheses sharded round-robin over the ranks
+(dsac_amd.dist.shard_images), the 64 x (6 + N) results gathered on rank 0 (gather_frame_results) inside the timed region; the
+total work is fixed ("scaling": "strong").
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel K2 (k_reproject): algorithmic bytes per launch
+(12*P + 48*N + 4*N*P + 4*N per frame) over the average launch duration measured with HIP events on the engine's
+stream inside the timed region (every launch when steps <= 64).  `single_frame` repeats the measurement with ONE frame per step (the
+literal configs[1]); `rates` separates the kernel-only (K2) rate from the per-image (K1+K2+K3) rate.  `cpu_baseline` is the CPU oracle
+(a port of the reference path, g++ -Ofast -fopenmp) timed on this box's host cores on a bounded sample, plus a 1-thread number.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +35,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+CONFIG3_IMAGES = 64    # BASELINE.json configs[3]
 
 
 def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
@@ -32,7 +43,15 @@ def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
     return 12 * P + (8 * P if explicit_uv else 0) + 48 * N + (4 * N * P if write_err else 0) + 4 * N
 
 
-def main():
+def event_stride_for(steps, requested):
+    """Every K2 launch is timed when the run is short (the driver's --steps 20 would otherwise leave 3 samples); long runs time
+    about 64 launches spread over the region (event records are not free on the stream)."""
+    if requested is not None and requested >= 0:
+        return requested
+    return 1 if steps <= 64 else max(1, steps // 64)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -40,90 +59,241 @@ def main():
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--workload", choices=("frames", "config3"), default="frames",
+                    help="frames: BASELINE.json configs[1] frames, --frames-per-step per step and rank (weak scaling).  config3: configs[3], 64 images x "
+                         "--hyps hypotheses sharded over the ranks, results gathered on rank 0 (strong scaling); a step is one pass over the 64 images")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "1")),
                     help="engine contexts (HIP streams) per GPU")
-    ap.add_argument("--overlap", choices=("pipeline", "gated", "stages", "frames"), default="gated",
+    ap.add_argument("--overlap", choices=("none", "pipeline", "gated", "stages", "frames"), default=os.environ.get("DSAC_BENCH_OVERLAP", "gated"),
                     help="With 2 contexts: 'gated' (default) = frames alternate between two contexts whose K2 launches are serialised by events (dsac_set_k2_events): K1/K3 of "
-                         "one frame run under K2 of the other and K2 runs alone.  'frames' = the same without the serialisation: two K2 launches may share the GPU -- 5-10 %% "
-                         "more throughput on some boxes, but each K2 launch then takes ~25 %% longer, which lowers roofline.frac (profiles/r01_streams_modes.txt).  'pipeline' = "
-                         "one context, dsac_sample_ahead / dsac_score_sampled: K1 of frame i+1 on the context's auxiliary stream under K2/K3 of frame i.  'stages' = stream A "
-                         "samples frame i+1 while stream B scores frame i")
+                         "one frame run under K2 of the other and K2 runs alone.  'frames' = the same without the serialisation.  'pipeline' = one context, "
+                         "dsac_sample_ahead / dsac_score_sampled: K1 of step i+1 on the context's auxiliary stream under K2/K3 of step i, consecutive steps on DIFFERENT "
+                         "frames.  'stages' = stream A samples frame i+1 while stream B scores frame i.  With one context and not 'pipeline': no overlap")
     ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSAC_BENCH_FRAMES", "8")),
                     help="independent 640x480 frames (each with --hyps hypotheses) batched into one step: dsac_set_frames / dsac_score_hypotheses_frames carry "
                          "them through K1, K2, K3 in three launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the extra single-frame (literal configs[1]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed clock / TLB settling before the warm-up steps (not counted as steps)")
     ap.add_argument("--separate-calls", action="store_true", help="use dsac_sample / dsac_reproject / dsac_softmax instead of the fused call")
-    ap.add_argument("--event-stride", type=int, default=8, help="time every n-th K2 launch with HIP events (0 = none)")
-    ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] style)")
+    ap.add_argument("--event-stride", type=int, default=-1, help="time every n-th K2 launch with HIP events (0 = none, -1 = every launch up to 64 steps)")
+    ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] with --hyps 4096)")
     ap.add_argument("--k2-mode", choices=("both", "err", "soft"), default="both", help="K2 outputs: error images and/or soft-inlier sums")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="exercise launch / shard / gather / reporting without touching a GPU (CPU tests, gloo)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment
+# ---------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Spawn n ranks of this script (rank r -> LOCAL_RANK r -> GPU r), wait for all of them, propagate failure.  Rank 0 prints the JSON
+    line on the inherited stdout.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DSAC_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC, needed by RCCL on these hosts
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("DSAC_BENCH_LAUNCH_TIMEOUT", "1800"))
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            r = p.poll()
+            if r is not None:
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:  # one rank failed: the others would wait for it in a collective until the timeout
+                        q.terminate()
+        if time.time() > deadline:
+            for q in pending:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def init_distributed(args):
+    """Returns (rank, local_rank, world, backend, dist or None).  world is what actually joined the process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): refusing to report a rank count that is not the one running" % (world, args.gpus))
+    backend = os.environ.get("DSAC_BENCH_BACKEND", "gloo" if args.dry_run else "nccl")  # "nccl" is RCCL on ROCm
+    if world == 1:
+        return rank, local_rank, 1, backend, None
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend == "nccl":
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev:
+            raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible (one rank per GPU)" % (local_rank, ndev))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    joined = dist.get_world_size()
+    if joined != args.gpus:
+        raise SystemExit("%d ranks joined, --gpus %d" % (joined, args.gpus))
+    return rank, local_rank, joined, backend, dist
+
+
+def cpu_baseline(args, fr, N, H, W):
+    """The oracle (port of the reference path) on the host cores: all threads, and one thread."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = orc.num_threads()
+    sec1, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=1)
+    reps = int(max(1, min(64, round(args.cpu_seconds / max(sec1, 1e-3)))))
+    sec, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=reps)
+    out = {"value": N * reps / sec, "unit": "hyp/s", "cores": cores, "kind": "port",
+           "sample": "%d frame(s) x %d hypotheses x %dx%d, same workload (sample+P3P, error images, soft-inlier, softmax), "
+                     "oracle built g++ -Ofast -fopenmp, %.1f s" % (reps, N, W, H, sec)}
+    # one thread (deterministic RNG stream order, SURVEY.md 8(d)); bounded: a quarter of the hypotheses of one frame
+    n1 = max(16, N // 4)
+    orc.set_num_threads(1)
+    try:
+        s1, _ = orc.time_forward(n1, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=1)
+    finally:
+        orc.set_num_threads(cores)
+    out["one_thread"] = {"value": n1 / s1, "unit": "hyp/s", "cores": 1, "sample": "%d hypotheses x %dx%d, %.1f s" % (n1, W, H, s1)}
+    return out
+
+
+def run_dry(args, rank, world, dist):
+    """No GPU: the rank/shard/gather plumbing and the JSON contract with a stand-in for the engine (CPU tests)."""
+    import torch
+    from dsac_amd import dist as ddist
+    N = args.hyps
+    K = args.steps
+    if args.workload == "config3":
+        mine = ddist.shard_images(CONFIG3_IMAGES, rank, world)
+        res = torch.tensor([[float(i)] * (6 + N) for i in mine], dtype=torch.float64).reshape(len(mine), 6 + N)
+        t0 = time.perf_counter()
+        for _ in range(K):
+            allres = ddist.gather_frame_results(mine, res, CONFIG3_IMAGES)
+        elapsed = time.perf_counter() - t0
+        assert torch.equal(allres[:, 0], torch.arange(CONFIG3_IMAGES, dtype=torch.float64)), "gather lost or misplaced frames"
+        total = CONFIG3_IMAGES * N * K
+        scaling, per_step = "strong", CONFIG3_IMAGES
+    else:
+        t0 = time.perf_counter()
+        time.sleep(0.01)
+        elapsed = time.perf_counter() - t0
+        total = N * args.frames_per_step * K * world
+        scaling, per_step = "weak", args.frames_per_step * world
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "hypotheses scored/sec over 640x480 coord map", "value": total / elapsed, "unit": "hyp/s", "n_gpus": world, "steps": K,
+                          "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN (no GPU work): %s" % args.workload, "frames_per_step_all_ranks": per_step}}), flush=True)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no torchrun environment: this process becomes the launcher of the N ranks
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+
+    rank, local_rank, world, backend, dist = init_distributed(args)
+    if args.dry_run:
+        run_dry(args, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import torch
     import dsac_amd
     from dsac_amd import synth
+    from dsac_amd import dist as ddist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     distributed = world > 1
-    backend = os.environ.get("DSAC_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only to exercise the N>1 path on one GPU
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    if distributed and backend == "nccl" and local_rank >= ndev:
-        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
-    local_rank = local_rank % ndev
+    local_rank = local_rank % ndev  # only reachable with a non-RCCL backend (several ranks exercising one GPU)
     torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where the tiny timing tensors are reduced
 
     N, H, W = args.hyps, args.height, args.width
     P = H * W
     K, Wm = args.steps, args.warmup
+    config3 = args.workload == "config3"
 
-    # one frame per rank (seed 1305 + rank: the reference's ThreadRand seed), uploaded before timing; with --frames-per-step B a batch of
-    # B different frames per rank
+    # frames: seed 1305 + rank (the reference's ThreadRand seed), uploaded before timing
     B = max(1, args.frames_per_step)
-    batched = B > 1
-    if batched and (args.kernel_only or args.separate_calls or args.k2_mode != "both" or args.overlap == "stages" or N % 128 != 0):
-        B, batched = 1, False  # those modes time single frames (K2-only runs, the in-context pipeline, odd hypothesis counts)
+    if config3:
+        mine = ddist.shard_images(CONFIG3_IMAGES, rank, world)  # image i -> rank i mod world
+        B = min(B, max(1, len(mine)))
+        if N % 128 != 0:
+            raise SystemExit("--workload config3 needs --hyps to be a multiple of 128")
+    batched = B > 1 or config3
+    if batched and not config3 and (args.kernel_only or args.separate_calls or args.k2_mode != "both" or args.overlap == "stages" or N % 128 != 0):
+        B, batched = 1, False  # those modes time single frames (K2-only runs, odd hypothesis counts)
+    pipelined = (args.overlap == "pipeline" and not args.kernel_only and args.k2_mode == "both" and not args.separate_calls and not config3)
     fr = synth.chess_like_frame(H, W, seed=1305 + rank)
-    if batched:
-        frs = [fr] + [synth.chess_like_frame(H, W, seed=1305 + world * 1000 + rank * B + f) for f in range(1, B)]
-        xyz = torch.from_numpy(np.ascontiguousarray(np.stack([f_["xyz"] for f_ in frs]))).to(dev)
+    if config3:
+        imgs = [synth.chess_like_frame(H, W, seed=1305 + i) for i in mine]  # SURVEY.md 8(d) config 4: seeds 1305 + i
+        # the rank's images in batches of B frames (the last batch may be smaller; hypothesis counts stay multiples of 128)
+        batches = [list(range(s, min(s + B, len(mine)))) for s in range(0, len(mine), B)]
+        xyz_batches = [torch.from_numpy(np.ascontiguousarray(np.stack([imgs[j]["xyz"] for j in b]))).to(dev) for b in batches]
+    elif batched:
+        def make_batch(tag):
+            frs = [synth.chess_like_frame(H, W, seed=1305 + world * 1000 * (tag + 1) + rank * B + f) for f in range(B)]
+            return torch.from_numpy(np.ascontiguousarray(np.stack([f_["xyz"] for f_ in frs]))).to(dev)
+        xyz_batches = [make_batch(0)] + ([make_batch(1)] if pipelined else [])  # the pipeline alternates between two batches of frames
     else:
-        xyz = torch.from_numpy(fr["xyz"]).to(dev)
-    pipelined = (args.overlap == "pipeline" and not args.kernel_only and args.k2_mode == "both" and not args.separate_calls)
-    n_ctx = 1 if pipelined else max(1, args.streams)
+        xyz_batches = [torch.from_numpy(fr["xyz"]).to(dev)]
+        if pipelined:
+            xyz_batches.append(torch.from_numpy(synth.chess_like_frame(H, W, seed=5000 + rank)["xyz"]).to(dev))
+    n_ctx = 1 if (pipelined or config3) else max(1, args.streams)
     n_buf = 2 if pipelined else n_ctx
+    stride = event_stride_for(K, args.event_stride)
     engines, bufs = [], []
+
+    def set_frames_of(eng, x):
+        if batched:
+            eng.set_frames(x, None, H, W, fr["cam"], borrow=True)
+        else:
+            eng.set_frame(x, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
+
     for i in range(n_ctx):
         st = torch.cuda.Stream(device=dev)
         eng = dsac_amd.Engine(local_rank, stream=st)
-        if batched:
-            eng.set_frames(xyz, None, H, W, fr["cam"], borrow=True)
-        else:
-            eng.set_frame(xyz, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
-        eng.profile_enable(args.event_stride > 0, stride=max(1, args.event_stride))
+        set_frames_of(eng, xyz_batches[0])
+        eng.profile_enable(stride > 0, stride=max(1, stride))
         engines.append((eng, st))
-    NB = N * B  # hypotheses per step and context
+    NB = N * B  # hypotheses per launch and context
     for i in range(n_buf):
         bufs.append(dict(
             poses=torch.zeros(NB, 6, dtype=torch.float64, device=dev), sets=torch.zeros(NB, 4, dtype=torch.int32, device=dev),
             ok=torch.zeros(NB, dtype=torch.uint8, device=dev), err=torch.empty(NB, P, dtype=torch.float32, device=dev),
             soft=torch.zeros(NB, dtype=torch.float64, device=dev), w=torch.zeros(NB, dtype=torch.float64, device=dev),
             ent=torch.zeros(B, dtype=torch.float64, device=dev), avg=torch.zeros(B, 6, dtype=torch.float64, device=dev)))
+    for b in bufs:
+        b["err"].zero_()  # first touch of the 2.5 GB of error images happens here, not in a timed launch
     gated = (n_ctx == 2 and args.overlap == "gated")
     if gated:
         # K2 launches of the two contexts run back to back (never overlapping each other); K1 / K3 of one frame overlap K2 of the other
@@ -137,11 +307,16 @@ def main():
         rp = synth.random_poses(N, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])
         for b in bufs:
             b["poses"].copy_(torch.from_numpy(rp))
+    if config3:
+        results = torch.zeros(len(mine), 6 + N, dtype=torch.float64, device=dev)  # per image: soft-argmax pose (6) + softmax weights (N)
     torch.cuda.synchronize(dev)
 
     staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
     ev_sampled = [torch.cuda.Event() for _ in range(2)]
     ev_scored = [None, None]
+
+    def seed_of(i):
+        return 1305 + 7919 * i + rank
 
     def step_staged(i):
         # two-stage software pipeline over double-buffered pose sets: K1 of frame i+1 runs under K2/K3 of frame i
@@ -150,7 +325,7 @@ def main():
         b = bufs[k]
         if ev_scored[k] is not None:
             stA.wait_event(ev_scored[k])       # the scoring stage has finished reading this buffer
-        engA.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
+        engA.sample(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
         ev_sampled[k].record(stA)
         stB.wait_event(ev_sampled[k])
         engB.reproject(b["poses"], N=N, clamp=100.0, err=b["err"], soft=b["soft"], tau=10.0, beta=0.5)
@@ -158,19 +333,36 @@ def main():
         ev_scored[k] = torch.cuda.Event()
         ev_scored[k].record(stB)
 
-    def seed_of(i):
-        return 1305 + 7919 * i + rank
-
     def step_pipelined(i):
-        # software pipeline inside ONE context: K1 of frame i+1 (aux stream) under K2/K3 of frame i (main stream)
+        # software pipeline inside ONE context: K1 of step i+1 (aux stream, on the OTHER batch of frames) under K2/K3 of step i
         eng, _ = engines[0]
         k = i & 1
         nb = bufs[1 - k]
+        set_frames_of(eng, xyz_batches[(i + 1) & 1])  # borrowed frames: the slot remembers the frame it was sampled from
         eng.sampleAhead(1 - k, NB, seed_of(i + 1), nb["poses"], nb["sets"], nb["ok"], thr=10.0, max_tries=1 << 16)
         b = bufs[k]
         eng.scoreSampled(k, b["poses"], b["soft"], b["w"], ent=b["ent"], avg=b["avg"], err=err_shared, clamp=100.0, tau=10.0, beta=0.5, scale=0.1)
 
+    def step_config3(i):
+        # one pass over this rank's share of the 64 images, then the gather of 64 x (6 + N) numbers on rank 0's side
+        eng, st = engines[0]
+        b = bufs[0]
+        with torch.cuda.stream(st):
+            for bi, idx in enumerate(batches):
+                nb_ = len(idx)
+                eng.set_frames(xyz_batches[bi], None, H, W, fr["cam"], borrow=True)
+                n_ = nb_ * N
+                eng.scoreHypothesesFrames(N, seed=1305 + 64 * i + mine[idx[0]], thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
+                                          err=b["err"][:n_], out=(b["poses"][:n_], b["sets"][:n_], b["ok"][:n_], b["soft"][:n_], b["w"][:n_],
+                                                                  b["ent"][:nb_], b["avg"][:nb_]))
+                results[idx[0]:idx[0] + nb_, :6] = b["avg"][:nb_]
+                results[idx[0]:idx[0] + nb_, 6:] = b["w"][:n_].view(nb_, N)
+        st.synchronize()
+        return ddist.gather_frame_results(mine, results if backend == "nccl" else results.cpu(), CONFIG3_IMAGES)
+
     def step(i):
+        if config3:
+            return step_config3(i)
         if pipelined:
             return step_pipelined(i)
         if staged:
@@ -179,16 +371,16 @@ def main():
         b = bufs[i % n_ctx]
         if batched:
             # three launches for B frames: K1 over B*N waves, K2 over B*N error images, K3 with one workgroup per frame
-            eng.scoreHypothesesFrames(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
+            eng.scoreHypothesesFrames(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
                                       err=b["err"], out=(b["poses"], b["sets"], b["ok"], b["soft"], b["w"], b["ent"], b["avg"]))
             return
         if not args.kernel_only and args.k2_mode == "both" and not args.separate_calls:
             # one C-ABI call: K1 (+ staged pose records) -> K2 -> soft reduce -> K3
-            eng.scoreHypotheses(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
+            eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
                                 err=b["err"], out=(b["poses"], b["sets"], b["ok"], b["soft"], b["w"], b["ent"], b["avg"]))
             return
         if not args.kernel_only:
-            eng.sample(N, seed=1305 + 7919 * i + rank, thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
+            eng.sample(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, out=(b["poses"], b["sets"], b["ok"]))
         eng.reproject(b["poses"], N=N, clamp=100.0, err=b["err"] if args.k2_mode != "soft" else None,
                       soft=b["soft"] if args.k2_mode != "err" else None, tau=10.0, beta=0.5)
         if not args.kernel_only:
@@ -202,8 +394,19 @@ def main():
     if pipelined:
         err_shared = bufs[0]["err"]  # the scoring stage is serial: one error-image buffer
         engines[0][0].sampleAhead(0, NB, seed_of(0), bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"], thr=10.0, max_tries=1 << 16)
+    # untimed settling phase (not steps): the same work until --prewarm-ms have passed, so that clocks, TLBs and the power governor are in
+    # their sustained state when the warm-up steps start
+    ctr = 0  # steps are numbered consecutively across pre-warm, warm-up and timed region (the pipelined mode's slots alternate strictly)
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        step(ctr)
+        ctr += 1
+        if ctr % 8 == 0:
+            sync_all()
+    n_pre = ctr
     for i in range(Wm):
-        step(i)
+        step(ctr)
+        ctr += 1
     sync_all()
     for eng, _ in engines:
         eng.profile_read(0, reset=True)
@@ -212,8 +415,10 @@ def main():
         dist.barrier()
     sync_all()
     t0 = time.perf_counter()
+    last = None
     for i in range(K):
-        step(Wm + i)
+        last = step(ctr)
+        ctr += 1
     sync_all()
     if distributed:
         dist.barrier()
@@ -226,6 +431,40 @@ def main():
         k2_n += n
     ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
     wsum = float(bufs[0]["w"][:N].sum().item()) if not args.kernel_only else 1.0
+    if config3 and rank == 0:
+        ws = last[:, 6:].sum(1)
+        assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
+
+    # literal configs[1]: ONE frame per step on the same context (fused call), its own K2 timing
+    single = None
+    if not args.no_single_frame and not args.kernel_only and not config3 and args.k2_mode == "both" and rank == 0:
+        eng, _ = engines[0]
+        b = bufs[0]
+        x1 = xyz_batches[0][0] if batched else xyz_batches[0]
+        eng.set_frame(x1, None, H, W, fr["cam"], borrow=True)
+        eng.profile_enable(True, stride=1)
+
+        def one(i):
+            eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"][:N],
+                                out=(b["poses"][:N], b["sets"][:N], b["ok"][:N], b["soft"][:N], b["w"][:N], b["ent"][:1], b["avg"][0]))
+        for i in range(20):
+            one(ctr + i)
+        eng.synchronize()
+        eng.profile_read(0, reset=True)
+        n1 = 100
+        t1 = time.perf_counter()
+        for i in range(n1):
+            one(ctr + 20 + i)
+        eng.synchronize()
+        e1 = time.perf_counter() - t1
+        ms1, c1 = eng.profile_read(0, reset=True)
+        k2_1 = ms1 / max(1, c1) * 1e-3
+        ab1 = algorithmic_bytes_k2(N, P, explicit_uv=False)
+        single = {"workload": "BASELINE.json configs[1] literally: ONE %dx%d frame x %d hypotheses per step (K1 -> K2 -> K3, one context, no overlap)" % (W, H, N),
+                  "value": N * n1 / e1, "unit": "hyp/s", "steps": n1, "us_per_frame": e1 / n1 * 1e6,
+                  "roofline": {"kernel": "k_reproject (K2)", "achieved": ab1 / k2_1 / 1e9 if k2_1 > 0 else 0.0, "unit": "GB/s",
+                               "frac": (ab1 / k2_1 / 1e9 / HBM_PEAK_GBS) if k2_1 > 0 else 0.0, "avg_launch_us": k2_1 * 1e6, "launches_timed": c1,
+                               "algorithmic_bytes_per_launch": ab1}}
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -236,10 +475,15 @@ def main():
         k2_ms, k2_n = float(kk[0].item()), int(kk[1].item())
 
     if rank == 0:
-        total_hyps = N * B * K * world
+        if config3:
+            total_hyps = CONFIG3_IMAGES * N * K
+            frames_per_launch = B
+        else:
+            total_hyps = N * B * K * world
+            frames_per_launch = B
         value = total_hyps / elapsed
         k2_avg_s = (k2_ms / max(1, k2_n)) * 1e-3
-        abytes = B * algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=args.k2_mode != "soft")  # one launch carries B frames
+        abytes = frames_per_launch * algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=args.k2_mode != "soft")  # one launch carries B frames
         achieved = abytes / k2_avg_s / 1e9 if k2_avg_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
@@ -250,33 +494,39 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if config3:
+            cfg_name = ("BASELINE.json configs[3]: %d 'chess'-like images x %d hypotheses, %dx%d coord maps, sharded round-robin over %d rank(s) "
+                        "(%d images per launch), results (6 + N per image) gathered" % (CONFIG3_IMAGES, N, W, H, world, B))
+        elif args.kernel_only:
+            cfg_name = ("BASELINE.json configs[2]: %d random poses over a %dx%d coord map, K2 only" % (N, W, H) if N >= 1024 else
+                        "K2 only on %d random poses over a %dx%d coord map (BASELINE.json configs[2] style at configs[1]'s hypothesis count)" % (N, W, H))
+        else:
+            cfg_name = ("BASELINE.json configs[1]: 'chess'-like frame, %d hypotheses, %dx%d coord map%s, K1 sample+P3P -> K2 reproject (error images + "
+                        "soft-inlier) -> K3 softmax" % (N, W, H, (" x %d independent frames per step (one launch each for K1, K2, K3)" % B) if batched
+                                                         else " (single frame per step)"))
         out = {
             "metric": "hypotheses scored/sec over 640x480 coord map",
             "value": value, "unit": "hyp/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong" if config3 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: 'chess'-like frame, %d hypotheses, %dx%d coord map%s, %s"
-                                    % (N, W, H, (" x %d independent frames per step (one launch each for K1, K2, K3)" % B) if batched else " (single frame per step)", "K2 only on random poses" if args.kernel_only else
-                                       "K1 sample+P3P -> K2 reproject (error images + soft-inlier) -> K3 softmax")),
-                       "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": B, "streams_per_gpu": n_ctx,
-                       "overlap": ("in-context software pipeline: K1(i+1) || K2,K3(i)" if pipelined else "K2 launches serialised across 2 contexts, K1/K3 overlap them" if gated else "sampling stage || scoring stage" if staged
+            "config": {"workload": cfg_name,
+                       "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": CONFIG3_IMAGES if config3 else B, "streams_per_gpu": n_ctx,
+                       "overlap": ("in-context software pipeline: K1(i+1) || K2,K3(i), alternating frame batches" if pipelined else
+                                   "K2 launches serialised across 2 contexts, K1/K3 overlap them" if gated else "sampling stage || scoring stage" if staged
                                    else ("frames round-robin" if n_ctx > 1 else "none")),
-                       "parallelism": "images sharded over %d GPU(s), no data-path collective" % world,
-                       "accepted_fraction": ok_frac, "softmax_sum": wsum},
+                       "parallelism": "images sharded over %d GPU(s), no data-path collective%s" % (world, "; results gathered on rank 0" if config3 else ""),
+                       "prewarm_steps_untimed": n_pre, "accepted_fraction": ok_frac, "softmax_sum": wsum},
             "roofline": {"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": abytes,
-                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n},
+                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n, "event_stride": stride},
+            # kernel-only (K2) and per-image (K1 + K2 + K3) rates reported separately
+            "rates": {"per_image_hyp_s": value, "kernel_only_k2_hyp_s": (N * frames_per_launch / k2_avg_s * world) if k2_avg_s > 0 else None,
+                      "unit": "hyp/s", "note": "per_image = whole step (K1 sample+P3P, K2, soft reduce, K3); kernel_only = hypotheses per K2 launch / its duration"},
         }
+        if single is not None:
+            out["single_frame"] = single
         if not args.no_cpu_baseline and world == 1:
-            from oracle import oracle as orc
-            orc.build()
-            cores = orc.num_threads()
-            sec1, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=1)
-            reps = int(max(1, min(64, round(args.cpu_seconds / max(sec1, 1e-3)))))
-            sec, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=reps)
-            out["cpu_baseline"] = {"value": N * reps / sec, "unit": "hyp/s", "cores": cores, "kind": "port",
-                                   "sample": "%d frame(s) x %d hypotheses x %dx%d, same workload (sample+P3P, error images, soft-inlier, softmax), "
-                                             "oracle built g++ -Ofast -fopenmp, %.1f s" % (reps, N, W, H, sec)}
+            out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
         print(json.dumps(out), flush=True)
 
     for eng, _ in engines:

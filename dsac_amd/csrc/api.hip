@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -49,20 +50,26 @@ struct dsac_ctx {
     // scratch, one buffer per role so that calls can be chained without aliasing
     DevBuf staged, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
     int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
-    // staging for host-pointer arguments: slots are bump-allocated per call
-    std::vector<DevBuf> slots;
+    // staging for host-pointer arguments: slots are bump-allocated per call.  A deque: next_slot() hands out references that
+    // must stay valid while further slots are appended within the same call
+    std::deque<DevBuf> slots;
     size_t slot_next = 0;
     struct Pending { void* host; const void* dev; size_t bytes; };
     std::vector<Pending> pending;
-    int reproject_variant = -1;  // auto
+    dk::K2Opts k2;  // launch knobs, read once in dsac_create (DSAC_K2_*) or set with dsac_set_option; no process-wide state
+    dk::K1Opts k1;
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
 
     // two-slot software pipeline (dsac_sample_ahead / dsac_score_sampled): K1 of frame i+1 on `aux` under K2/K3 of frame i
     hipStream_t aux = nullptr, aux2 = nullptr;  // aux: K1 of the next frame; aux2: K3 tail of the previous frame
     DevBuf slot_staged[2], slot_soft_part[2];
-    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr}, slot_reduced[2] = {nullptr, nullptr};
-    bool slot_free_recorded[2] = {false, false}, slot_reduced_recorded[2] = {false, false};
+    hipEvent_t slot_ready[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr}, slot_reduced[2] = {nullptr, nullptr},
+               slot_done[2] = {nullptr, nullptr};  // ready: K1 done; free: K2 done; reduced: partial sums consumed; done: K3 tail done
+    bool slot_free_recorded[2] = {false, false}, slot_reduced_recorded[2] = {false, false}, slot_done_recorded[2] = {false, false};
+    bool slot_pending[2] = {false, false};  // sampled, not yet scored
     int slot_N[2] = {0, 0};
+    dk::FrameDev slot_F[2]{};               // the frame a slot was sampled from (its score call reprojects against the same one)
+    hipEvent_t frame_ready = nullptr;       // recorded on `stream` after a frame copy; the auxiliary stream waits for it before K1
 
     // measurement hooks: event pairs around the dominant kernels
     bool profiling = false;
@@ -212,12 +219,14 @@ int dsac_create(dsac_ctx** out, int device) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(nullptr, DSAC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->own_stream = true;
-    const char* v = getenv("DSAC_K2_VARIANT");
-    if (v) c->reproject_variant = atoi(v);
-    const char* o = getenv("DSAC_K2_ORDER");
-    if (o) dk::reproject_set_order(atoi(o) != 0);
-    const char* kf = getenv("DSAC_K2_FLAGS");
-    if (kf) dk::reproject_set_flags(atoi(kf));
+    // experiment knobs, per context (dsac_set_option changes them later)
+    if (const char* v = getenv("DSAC_K2_VARIANT")) c->k2.variant = atoi(v);
+    if (const char* v = getenv("DSAC_K2_ORDER")) c->k2.pixel_minor = atoi(v) != 0;
+    if (const char* v = getenv("DSAC_K2_FLAGS")) c->k2.flags = atoi(v);
+    if (const char* v = getenv("DSAC_K1_WPB")) c->k1.wpb = atoi(v);
+    if (const char* v = getenv("DSAC_K1_PRIO")) c->k1.prio = atoi(v);
+    if (const char* v = getenv("DSAC_K1_HPW")) c->k1.hpw = atoi(v);
+    if (const char* v = getenv("DSAC_K1_HORN")) c->k1.horn = atoi(v) != 0;
     *out = c;
     return DSAC_OK;
 }
@@ -238,7 +247,9 @@ void dsac_destroy(dsac_ctx* c) {
         if (c->slot_reduced[k]) (void)hipEventDestroy(c->slot_reduced[k]);
         if (c->slot_ready[k]) (void)hipEventDestroy(c->slot_ready[k]);
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
+        if (c->slot_done[k]) (void)hipEventDestroy(c->slot_done[k]);
     }
+    if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,12 +296,18 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
     const size_t P = P1 * (size_t)frames;              // cells to copy for xyz
     const size_t Puv = uv_per_frame ? P : P1;
     const bool borrow = (flags & DSAC_FRAME_BORROW) != 0;
+    if (!borrow && (c->slot_pending[0] || c->slot_pending[1]))
+        return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: a pipelined slot is sampled but not yet scored; the library's own frame copy cannot be replaced "
+                                         "underneath it (use DSAC_FRAME_BORROW frames with the pipelined calls)");
     if (borrow) {
         if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
         if (flags & DSAC_FRAME_QUANTISE_INT16) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: cannot quantise a borrowed frame");
         c->F.xyz = xyz;
         c->F.uv = uv;
     } else {
+        // K1 of an earlier pipelined slot (auxiliary stream) may still be reading the library's copy: order the overwrite behind it
+        for (int k = 0; k < 2; k++)
+            if (c->aux && c->slot_N[k] > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_ready[k], 0));
         HIP_TRY(c, c->frame_xyz.reserve(P * 3 * sizeof(float)));
         HIP_TRY(c, hipMemcpyAsync(c->frame_xyz.p, xyz, P * 3 * sizeof(float), hipMemcpyDefault, c->stream));
         c->F.xyz = c->frame_xyz.as<float>();
@@ -307,6 +324,7 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
             HIP_TRY(c, hipGetLastError());
         }
         if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) HIP_TRY(c, hipStreamSynchronize(c->stream));  // host source may be freed after return
+        if (c->frame_ready) HIP_TRY(c, hipEventRecord(c->frame_ready, c->stream));  // the auxiliary stream's K1 waits for the copy
     }
     c->F.H = H; c->F.W = W; c->F.P = (int)P1;
     c->F.fx = fx; c->F.fy = fy; c->F.cx = cx; c->F.cy = cy;
@@ -345,7 +363,7 @@ int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, 
     ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
     ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
     ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
-    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok));
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, nullptr, 0, c->k1));
     return end_call(c);
 }
 
@@ -376,7 +394,7 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, c->reproject_variant, &used));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, c->k2, &used));
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
@@ -436,12 +454,12 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
     HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
     // K1 writes the poses AND their staged K2 records (no separate pose_prep launch)
-    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>(), Nf));
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>(), Nf, c->k1));
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->reproject_variant, &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->k2, &used, Nf));
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
@@ -477,7 +495,10 @@ static int pipeline_init(dsac_ctx* c) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->slot_ready[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->slot_free[k], hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->slot_reduced[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->slot_done[k], hipEventDisableTiming));
     }
+    HIP_TRY(c, hipEventCreateWithFlags(&c->frame_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->frame_ready, c->stream));  // covers a frame copy enqueued before the pipeline existed
     return DSAC_OK;
 }
 
@@ -498,26 +519,34 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
     HIP_TRY(c, hipSetDevice(c->device));
     ARG_TRY(pipeline_init(c));
     HIP_TRY(c, c->slot_staged[slot].reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
-    if (c->slot_free_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_free[slot], 0));  // the scorer is done with this slot
-    HIP_TRY(c, dk::sample(c->aux, N, seed, sets_or_null, c->F, (int)thr, max_tries, poses, sets_out, ok, c->slot_staged[slot].as<float>(), Nf));
+    if (c->slot_pending[slot]) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot %d is sampled but not yet scored", slot);
+    if (c->slot_free_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_free[slot], 0));  // K2 of the slot's previous use has read its staged poses
+    // ... and the K3 tail of that use (second auxiliary stream) has read the caller's `poses` for the soft-argmax average
+    if (c->slot_done_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_done[slot], 0));
+    HIP_TRY(c, hipStreamWaitEvent(c->aux, c->frame_ready, 0));  // a frame copy enqueued on the main stream has landed
+    c->slot_F[slot] = c->F;  // the slot scores against the frame it was sampled from, whatever is current at score time
+    HIP_TRY(c, dk::sample(c->aux, N, seed, sets_or_null, c->F, (int)thr, max_tries, poses, sets_out, ok, c->slot_staged[slot].as<float>(), Nf, c->k1));
     HIP_TRY(c, hipEventRecord(c->slot_ready[slot], c->aux));
     c->slot_N[slot] = N;
+    c->slot_pending[slot] = true;
     return DSAC_OK;
 }
 
 int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float beta, double scale, const double* poses, float* err_or_null,
                        double* scores, double* w, double* entropy_or_null, double* avg6_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_score_sampled: ctx is NULL");
-    if (slot < 0 || slot > 1 || !c->aux || c->slot_N[slot] <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: no dsac_sample_ahead on this slot");
+    if (slot < 0 || slot > 1 || !c->aux || c->slot_N[slot] <= 0 || !c->slot_pending[slot])
+        return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: no dsac_sample_ahead pending on this slot");
     if (!scores || !w || (avg6_or_null && !poses)) return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: scores/w (and poses with avg6) must be non-NULL");
     if (!is_device_ptr(scores) || !is_device_ptr(w) || (err_or_null && !is_device_ptr(err_or_null)) || (poses && !is_device_ptr(poses)) ||
         (entropy_or_null && !is_device_ptr(entropy_or_null)) || (avg6_or_null && !is_device_ptr(avg6_or_null)))
         return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: the pipelined calls need device pointers");
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->slot_N[slot];
-    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    const dk::FrameDev& SF = c->slot_F[slot];
+    const int frames = SF.frames > 1 ? SF.frames : 1;
     const int Nf = frames > 1 ? N / frames : 0;
-    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    const int tiles = dk::reproject_num_pixel_tiles(SF.P);
     HIP_TRY(c, c->slot_soft_part[slot].reserve((size_t)tiles * N * sizeof(float)));
     float* part = c->slot_soft_part[slot].as<float>();
     // main stream: nothing but the bandwidth-bound kernel, back to back
@@ -526,16 +555,19 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     int used = 0;
     {
         ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), c->F, clampv, err_or_null, tau, beta, part, c->reproject_variant, &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, c->k2, &used, Nf));
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
     c->slot_free_recorded[slot] = true;
+    c->slot_pending[slot] = false;
     // second auxiliary stream: the small latency-bound tail (partial sums -> scores -> softmax) runs under the next K2
     HIP_TRY(c, hipStreamWaitEvent(c->aux2, c->slot_free[slot], 0));
     HIP_TRY(c, dk::reduce_soft(c->aux2, N, used, part, scores));
     HIP_TRY(c, hipEventRecord(c->slot_reduced[slot], c->aux2));
     c->slot_reduced_recorded[slot] = true;
     HIP_TRY(c, dk::softmax(c->aux2, frames > 1 ? Nf : N, scores, scale, w, entropy_or_null, avg6_or_null ? poses : nullptr, avg6_or_null, frames));
+    HIP_TRY(c, hipEventRecord(c->slot_done[slot], c->aux2));  // `poses` of this slot may be overwritten by the next dsac_sample_ahead
+    c->slot_done_recorded[slot] = true;
     return DSAC_OK;
 }
 
@@ -553,6 +585,20 @@ int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     ARG_TRY(out_arg(c, J, (size_t)N * 72, &d_J));
     HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, eps, d_J));
     return end_call(c);
+}
+
+int dsac_set_option(dsac_ctx* c, const char* key, int value) {
+    if (!c || !key) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: NULL argument");
+    const std::string k = key;
+    if (k == "k2_variant") c->k2.variant = value;
+    else if (k == "k2_order") c->k2.pixel_minor = value != 0;
+    else if (k == "k2_flags") c->k2.flags = value;
+    else if (k == "k1_wpb") c->k1.wpb = value;
+    else if (k == "k1_prio") c->k1.prio = value;
+    else if (k == "k1_hpw") c->k1.hpw = value;
+    else if (k == "k1_horn") c->k1.horn = value != 0;
+    else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
+    return DSAC_OK;
 }
 
 int dsac_set_k2_events(dsac_ctx* c, void* wait_before_or_null, void* record_after_or_null) {
@@ -595,6 +641,11 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
                                  double* grad_xyz) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "%s: ctx is NULL", who);
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "%s: no frame set", who);
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "%s: a frame batch is set; only dsac_score_hypotheses_frames works on batches", who);
+    // the reference's jp-convention Jacobians use one focal length, f = camMat(0,0), for both axes (core/cnn_softam.h:406,466);
+    // a camera with fx != fy would make this backward inconsistent with the forward kernels, which honour both
+    if (c->F.fx != c->F.fy) return fail(c, DSAC_ERR_INVALID, "%s: needs fx == fy (got %g, %g): dProjectdObj / dProjectdHyp use a single focal length", who,
+                                        (double)c->F.fx, (double)c->F.fy);
     if (N < 0 || !poses || !sets || !grad_xyz || (!d_err && !g)) return fail(c, DSAC_ERR_INVALID, "%s: NULL argument", who);
     if ((flags & DSAC_BWD_QUIRK_TRANSPOSE) && c->F.H != c->F.W)
         return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_QUIRK_TRANSPOSE needs a square map (H=%d W=%d)", who, c->F.H, c->F.W);
@@ -642,6 +693,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
 int dsac_last_pose_gradients(dsac_ctx* c, int N, double* G6) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_last_pose_gradients: ctx is NULL");
     if (N < 0 || !G6) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: NULL argument or negative count");
+    if (c->have_frame && c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: a frame batch is set");
     if (N > c->g6_n) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: %d requested, the last score-backward call had %d", N, c->g6_n);
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -27,7 +27,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int K4_THREADS = 256;
 constexpr int K4_PXG = 2;     // 8 pixels per lane on the vector path
-constexpr int K4_PXG_C = K4_PXG;
 constexpr int K4_HT_MAX = 128;  // LDS capacity for the hypothesis records of a tile; the tile size itself is chosen per launch
 constexpr int BWD_REC = BWD_STRIDE;
 // Record of one hypothesis, six float4 read by K4 with ds_read_b128 and used as they are (jp convention: E = R' X + t'):
@@ -338,20 +337,30 @@ __global__ __launch_bounds__(256) void k_grad_reduce(int P, int W, int H, int hy
     grad_xyz[dst] += s;
 }
 
-// finish (b): one thread per hypothesis: G12 = sum over pixel tiles; G6 = [G9 . dRdH, G3]; S = G6 * dPNP; scatter.
-__global__ __launch_bounds__(64) void k_support_scatter(int N, int W, int pixel_tiles, const float* __restrict__ G12_part,
-                                                        const double* __restrict__ dRdH, const double* __restrict__ dpnp,
-                                                        const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
-                                                        double* __restrict__ G6_out) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+// finish (b): one WAVE per hypothesis: G12 = sum over the partial rows (lanes stride over the rows, 48 contiguous bytes per row and
+// lane, fp64 accumulation, fixed butterfly -> deterministic); G6 = [G9 . dRdH, G3]; S = G6 * dPNP; lanes 0..11 scatter the 4 x 3 sums.
+// (Round 1 ran this as one THREAD per hypothesis walking all partial rows serially: 201 us for 600 rows, more than the main pass.)
+__global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel_tiles, const float* __restrict__ G12_part,
+                                                         const double* __restrict__ dRdH, const double* __restrict__ dpnp,
+                                                         const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
+                                                         double* __restrict__ G6_out) {
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (h >= N) return;
     double G[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) G[i] = 0;
-    for (int t = 0; t < pixel_tiles; t++) {
-        const float* src = G12_part + ((size_t)t * N + h) * 12;
+    for (int t = lane; t < pixel_tiles; t += 64) {
+        const f4* src = reinterpret_cast<const f4*>(G12_part + ((size_t)t * N + h) * 12);
+        const f4 a = src[0], b = src[1], c = src[2];
+        G[0] += (double)a.x; G[1] += (double)a.y; G[2] += (double)a.z; G[3] += (double)a.w;
+        G[4] += (double)b.x; G[5] += (double)b.y; G[6] += (double)b.z; G[7] += (double)b.w;
+        G[8] += (double)c.x; G[9] += (double)c.y; G[10] += (double)c.z; G[11] += (double)c.w;
+    }
 #pragma unroll
-        for (int i = 0; i < 12; i++) G[i] += (double)src[i];
+    for (int i = 0; i < 12; i++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) G[i] += __shfl_xor(G[i], o, 64);
     }
     double G6[6];
 #pragma unroll
@@ -362,12 +371,14 @@ __global__ __launch_bounds__(64) void k_support_scatter(int N, int W, int pixel_
         G6[i] = s;
         G6[3 + i] = G[9 + i];
     }
-    if (G6_out) {
+    if (G6_out && lane < 6) {
+        double v = G6[0];
 #pragma unroll
-        for (int i = 0; i < 6; i++) G6_out[(size_t)h * 6 + i] = G6[i];
+        for (int i = 1; i < 6; i++) v = (lane == i) ? G6[i] : v;
+        G6_out[(size_t)h * 6 + lane] = v;
     }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    if (lane < 12) {
+        const int i = lane / 3, c = lane - 3 * i;  // support point, channel
         int p = sets[(size_t)h * 4 + i];
         p = min(max(p, 0), P - 1);
         size_t base = (size_t)p * 3;
@@ -375,13 +386,10 @@ __global__ __launch_bounds__(64) void k_support_scatter(int N, int W, int pixel_
             const int y = p / W, x = p - y * W;
             base = ((size_t)x * W + y) * 3;  // core/cnn_softam.h:641
         }
+        double s = 0;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) s += G6[k] * dpnp[(size_t)h * 72 + k * 12 + i * 3 + c];
-            atomicAdd(&grad_xyz[base + c], s);
-        }
+        for (int k = 0; k < 6; k++) s += G6[k] * dpnp[(size_t)h * 72 + k * 12 + lane];
+        atomicAdd(&grad_xyz[base + c], s);
     }
 }
 
@@ -391,7 +399,7 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
     if (N <= 0) return hipSuccess;
     const size_t n3 = (size_t)F.P * 3;
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
-    hipLaunchKernelGGL(k_support_scatter, dim3((N + 63) / 64), dim3(64), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
+    hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
                        G6_scratch);
     return hipGetLastError();
 }

@@ -48,12 +48,6 @@ hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev&
 // --------------------------------------------------------------------------------------------------
 constexpr int K2_THREADS = 256;
 
-// block order of K2 (see the decode in the kernels); process-wide tuning knob
-static bool g_k2_pixel_minor = true;
-static int g_k2_flags = 0;
-void reproject_set_flags(int f) { g_k2_flags = f; }
-void reproject_set_order(bool pixel_minor) { g_k2_pixel_minor = pixel_minor; }
-
 DM_INLINE float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -407,17 +401,17 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
 
 template <int HT, int KM_CH = KM_CH_DEFAULT>
 static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
-                                        float kB, float* soft_part, int* tiles_used, int Nf) {
+                                        float kB, float* soft_part, int* tiles_used, int Nf, bool pixel_minor, int kflags) {
     const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
     const int grid = ((PT + 7) / 8) * 8 * NTa;
-    const int NT = g_k2_pixel_minor ? -NTa : NTa;
+    const int NT = pixel_minor ? -NTa : NTa;
     if (tiles_used) *tiles_used = PT;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2M(E, S, U)                                                                                                               \
     hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
-                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags, Nf, F.xyz_stride, F.uv_stride)
+                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2M(true, true, true); else DSAC_K2M(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2M(true, false, true); else DSAC_K2M(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2M(false, true, true); else DSAC_K2M(false, true, false); }
@@ -429,16 +423,16 @@ int reproject_num_pixel_tiles(int P) { return (P + K2_THREADS - 1) / K2_THREADS;
 
 template <int PX, int HT, bool SPOSE>
 static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
-                                   float* soft_part, int Nf) {
+                                   float* soft_part, int Nf, bool pixel_minor, int kflags) {
     const int tile = K2_THREADS * PX;
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
     const int grid = ((PT + 7) / 8) * 8 * NTa;
-    const int NT = g_k2_pixel_minor ? -NTa : NTa;
+    const int NT = pixel_minor ? -NTa : NTa;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2(E, S, U)                                                                                                              \
     hipLaunchKernelGGL((k_reproject<PX, HT, E, S, U, SPOSE>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, \
-                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, g_k2_flags, Nf, F.xyz_stride, F.uv_stride)
+                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2(true, true, true); else DSAC_K2(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2(true, false, true); else DSAC_K2(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2(false, true, true); else DSAC_K2(false, true, false); }
@@ -447,9 +441,9 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
 }
 
 // variant: -1 = auto (default) ; 0 = VALU kernel, LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ;
-//          2 = LDS, HT = 16 ; 3 = LDS, HT = 64
+//          2 = LDS, HT = 16 ; 3 = LDS, HT = 64 ; 4..9, 14..16 = matrix-core forms <HT, chunks per wave> ; 10..13 = 1..8 rows per workgroup
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
-                     float* soft_part, int variant, int* tiles_used, int Nf) {
+                     float* soft_part, const K2Opts& opts, int* tiles_used, int Nf) {
     if (tiles_used) *tiles_used = 0;
     if (N <= 0 || F.P <= 0 || (!err && !soft_part)) return hipSuccess;
     if (Nf <= 0 || F.frames <= 1) Nf = N > 0 ? ((N + 127) / 128) * 128 : 128;  // one frame: every tile maps to frame 0
@@ -459,44 +453,46 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0);
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
-    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+    const int kf = opts.flags;
+    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf);
+    const int variant = opts.variant;
     if (variant < 0) {
         // auto (measured on MI355X, profiles/r01_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited:
-        // matrix-core form (HT = 64), pixel tiles innermost except for very large launches.  Error images only: store-limited:
-        // the VALU kernel with pixel tiles innermost has the best store stream.
+        // matrix-core form (HT = 64), pixel tiles innermost.  Error images only: store-limited: the VALU kernel with pixel tiles
+        // innermost has the best store stream.
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
-        const bool saved = g_k2_pixel_minor;
-        hipError_t e;
         if (soft_part) {
             // big launches (> 1.5 GB of error images: N = 4096, or a batch of frames): 1024 pixels per workgroup (4 chunks per wave, 92
             // VGPRs) is 2 % faster than 512 (profiles/r01_k2_batch_variants.txt, r01_k2_big_variants.txt); small ones keep 512
-            g_k2_pixel_minor = true;
-            e = big ? launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf)
-                    : launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
+            return big ? launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, true, kf)
+                       : launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, true, kf);
         }
-        else { g_k2_pixel_minor = true; e = launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf); }
-        g_k2_pixel_minor = saved;
-        return e;
+        return launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, true, kf);
     }
+    const bool pm = opts.pixel_minor;
+#define DSAC_MF(HT_, CH_) launch_reproject_mfma<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf)
+#define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf)
     switch (variant) {
-        case 4: return launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 5: return launch_reproject_mfma<128>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 6: return launch_reproject_mfma<32>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 10: return launch_reproject<4, 1, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 11: return launch_reproject<4, 2, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 12: return launch_reproject<4, 4, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 13: return launch_reproject<4, 8, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 14: return (Nf % 256) ? hipErrorInvalidValue : launch_reproject_mfma<256, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 15: return (Nf % 256) ? hipErrorInvalidValue : launch_reproject_mfma<256, 2>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 16: return launch_reproject_mfma<128, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 7: return launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 8: return launch_reproject_mfma<64, 1>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 9: return launch_reproject_mfma<32, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf);
-        case 1: return launch_reproject<4, 32, true>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 2: return launch_reproject<4, 16, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        case 3: return launch_reproject<4, 64, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
-        default: return launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf);
+        case 4: return DSAC_MF(64, KM_CH_DEFAULT);
+        case 5: return DSAC_MF(128, KM_CH_DEFAULT);
+        case 6: return DSAC_MF(32, KM_CH_DEFAULT);
+        case 10: return DSAC_VA(4, 1, false);
+        case 11: return DSAC_VA(4, 2, false);
+        case 12: return DSAC_VA(4, 4, false);
+        case 13: return DSAC_VA(4, 8, false);
+        case 14: return (Nf % 256) ? hipErrorInvalidValue : DSAC_MF(256, 1);
+        case 15: return (Nf % 256) ? hipErrorInvalidValue : DSAC_MF(256, 2);
+        case 16: return DSAC_MF(128, 1);
+        case 7: return DSAC_MF(64, 4);
+        case 8: return DSAC_MF(64, 1);
+        case 9: return DSAC_MF(32, 4);
+        case 1: return DSAC_VA(4, 32, true);
+        case 2: return DSAC_VA(4, 16, false);
+        case 3: return DSAC_VA(4, 64, false);
+        default: return DSAC_VA(4, 32, false);
     }
+#undef DSAC_MF
+#undef DSAC_VA
 }
 
 // --------------------------------------------------------------------------------------------------

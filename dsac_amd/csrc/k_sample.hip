@@ -10,7 +10,6 @@
 // K5 replaces dPNP (core/cnn_softam.h:101-146): one lane per (hypothesis, coordinate, +/-) P3P solve,
 // 24 lanes per hypothesis; central differences are formed after a wave-local exchange.
 #include "kernels.h"
-#include <cstdlib>
 #include "dmath.h"
 
 namespace dk {
@@ -25,12 +24,13 @@ DM_INLINE void load_point(const FrameDev& F, int p, float X[3], float uv[2]) {
 }
 
 // P3P + the 4-point re-projection check of core/cnn_softam.h:1042-1059.
+template <bool HORN>
 DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr_int, double cv6[6]) {
     float X[4][3], uv[4][2];
 #pragma unroll
     for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
     const dm::Cam K = make_cam(F);
-    if (!dm::p3p(X, uv, K, cv6)) return false;
+    if (!dm::p3p<HORN>(X, uv, K, cv6)) return false;
     double R[9];
     dm::rodrigues_v2m<false>(cv6, R, nullptr);
     bool good = true;
@@ -90,7 +90,9 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // measured (scripts/k1_bench.py, 640x480 synthetic frame): N=2048 takes 65 us with HPW=1, 91 us with 2, 183 us with 4 -- a
 // hypothesis needs ~20 attempts here (4 noisy inliers rarely re-project the 4th point within 10 px), so the 16 attempt lanes
 // of HPW=1 are busy and fewer lanes per hypothesis only serialise.  HPW=1 stays the default; the knob is for easy frames.
-template <int WPB, int HPW>
+// HORN: align the P3P triangle with Horn's quaternion method (4x4 Jacobi) as OpenCV does instead of the orthonormal triad --
+// the parity mode (poses equal the oracle's to rounding also on near-degenerate sets); several times slower, the triad is the default.
+template <int WPB, int HPW, bool HORN = false>
 __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                      int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
                                                      int Nf) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
             dm::P3PSetup S;
             if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
                 const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
-                cand = dm::p3p_eval_root(S, K, x, Rc, Tc, reproj);
+                cand = dm::p3p_eval_root<HORN>(S, K, x, Rc, Tc, reproj);
             }
         }
         // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
 }
 
 // Given sets: one lane per hypothesis.
+template <bool HORN>
 __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restrict__ sets_in, FrameDev F, int thr_int,
                                                   double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok,
                                                   float* __restrict__ staged) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restri
 #pragma unroll
     for (int k = 0; k < 4; k++) set4[k] = sets_in[(size_t)h * 4 + k];
     double cv6[6] = {0, 0, 0, 0, 0, 0};
-    const bool good = solve_and_check(F, set4, thr_int, cv6);
+    const bool good = solve_and_check<HORN>(F, set4, thr_int, cv6);
 #pragma unroll
     for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = good ? cv6[k] : 0.0;
     if (sets_out != sets_in) {
@@ -213,25 +216,20 @@ __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restri
 }
 
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries, double* poses,
-                  int32_t* sets_out, uint8_t* ok, float* staged, int Nf) {
+                  int32_t* sets_out, uint8_t* ok, float* staged, int Nf, const K1Opts& o) {
     if (N <= 0) return hipSuccess;
     if (sets_in && Nf > 0 && F.frames > 1) return hipErrorInvalidValue;  // given sets are evaluated on one frame only
-    if (sets_in) hipLaunchKernelGGL(k_eval_sets, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
-    else {
-        static int wpb = -1, prio = 0, hpw = 0;
-        if (wpb < 0) {  // knobs for experiments: DSAC_K1_WPB in {1, 4, 8}, DSAC_K1_PRIO in 0..3, DSAC_K1_HPW in {1, 2, 4}
-            const char* e = getenv("DSAC_K1_WPB");
-            wpb = e ? atoi(e) : 4;
-            const char* q = getenv("DSAC_K1_PRIO");
-            prio = q ? atoi(q) : 3;
-            const char* g = getenv("DSAC_K1_HPW");
-            hpw = g ? atoi(g) : 0;
-        }
-        const int H2 = hpw > 0 ? hpw : 1;  // see the measurement in the kernel's comment
-#define DSAC_K1(W, G) hipLaunchKernelGGL((k_sample<W, G>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
-        if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4); else DSAC_K1(1, 4); }
-        else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2); else if (wpb >= 4) DSAC_K1(4, 2); else DSAC_K1(1, 2); }
-        else { if (wpb >= 8) DSAC_K1(8, 1); else if (wpb >= 4) DSAC_K1(4, 1); else DSAC_K1(1, 1); }
+    if (sets_in) {
+        if (o.horn) hipLaunchKernelGGL(k_eval_sets<true>, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
+        else hipLaunchKernelGGL(k_eval_sets<false>, dim3((N + 63) / 64), dim3(64), 0, st, N, sets_in, F, thr_int, poses, sets_out, ok, staged);
+    } else {
+        const int wpb = o.wpb, prio = o.prio;
+        const int H2 = o.hpw > 0 ? o.hpw : 1;  // see the measurement in the kernel's comment
+#define DSAC_K1(W, G, HN) hipLaunchKernelGGL((k_sample<W, G, HN>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
+        if (o.horn) DSAC_K1(1, 1, true);
+        else if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4, false); else DSAC_K1(1, 4, false); }
+        else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2, false); else if (wpb >= 4) DSAC_K1(4, 2, false); else DSAC_K1(1, 2, false); }
+        else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }
 #undef DSAC_K1
     }
     return hipGetLastError();

@@ -27,13 +27,17 @@ constexpr int POSE_STRIDE = 12;
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
 
 // K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
-void reproject_set_order(bool pixel_minor);  // block order knob (default: pixel tiles innermost)
-void reproject_set_flags(int flags);         // bit0: plain (cached) stores instead of non-temporal
+// Launch knobs of K2; they live in the context (read once from the environment in dsac_create), never in process-wide state.
+struct K2Opts {
+    bool pixel_minor = true;  // block order: pixel tiles innermost (DSAC_K2_ORDER)
+    int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
+    int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
+};
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
 // Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of 64 then); 0 = one frame.
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
-                     float* soft_part, int variant, int* tiles_used, int Nf = 0);
+                     float* soft_part, const K2Opts& opts, int* tiles_used, int Nf = 0);
 // soft[h] = sum over pixel tiles of soft_part[tile][h]   (double, deterministic)
 hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft);
 
@@ -45,8 +49,15 @@ hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, do
 // ---- k_sample.hip ----------------------------------------------------------------------------------
 // Nf > 0 (frame batch): hypothesis h belongs to frame h / Nf and draws from the stream of (seed + frame, h % Nf), i.e. exactly
 // what a single-frame call with seed + frame would draw.
+// Launch knobs of K1 (context state like K2Opts): waves per workgroup (DSAC_K1_WPB in {1, 4, 8}), wave priority (DSAC_K1_PRIO 0..3),
+// hypotheses per wave (DSAC_K1_HPW in {1, 2, 4}), Horn alignment of the P3P triangle as in OpenCV instead of the triad (DSAC_K1_HORN).
+struct K1Opts {
+    int wpb = 4, prio = 3, hpw = 1;
+    bool horn = false;
+};
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
-                  double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr, int Nf = 0);  // staged: K2 records (N x 12)
+                  double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr, int Nf = 0,
+                  const K1Opts& opts = K1Opts());  // staged: K2 records (N x 12)
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
 
 // ---- k_backward.hip --------------------------------------------------------------------------------

@@ -82,6 +82,10 @@ class Engine:
         check(self._ctx, lib.dsac_device_info(self._ctx, C.byref(cus), C.byref(clk), C.byref(mem), name))
         return dict(cus=cus.value, clock_khz=clk.value, mem_bytes=mem.value, arch=name.value.decode())
 
+    def set_option(self, key, value):
+        """Per-context launch knob (dsac_set_option): k2_variant, k2_order, k2_flags, k1_wpb, k1_prio, k1_hpw, k1_horn."""
+        check(self._ctx, lib.dsac_set_option(self._ctx, str(key).encode(), int(value)))
+
     def set_k2_events(self, wait_before=None, record_after=None):
         """Gate around the bandwidth-bound kernel (see dsac_set_k2_events).  Events: torch.cuda.Event or raw hipEvent_t."""
         def addr(ev):

@@ -32,8 +32,11 @@
  * is the reference's safeSolvePnP behaviour (core/cnn_softam.h:66-71).  NaN policy as the reference
  * (zero Jacobians).
  *
- * Threading: a context is single-threaded; use one context per host thread / stream / GPU.  No global
- * state.  There is NO CPU fallback: without a HIP device dsac_create fails with DSAC_ERR_NO_DEVICE.
+ * Threading: a context is single-threaded; use one context per host thread / stream / GPU.  The library keeps no
+ * process-wide mutable state: launch knobs live in the context (dsac_set_option), and the only state outside a context is
+ * the calling thread's own last-error string (thread_local; dsac_last_error(NULL) after a failed dsac_create).  Contexts on
+ * different host threads may be used concurrently.  There is NO CPU fallback: without a HIP device dsac_create fails with
+ * DSAC_ERR_NO_DEVICE.
  *
  * Sampling RNG (shared bit-exactly with the CPU oracle so that minimal sets are identical):
  *   mix64(z): z += 0x9E3779B97F4A7C15; z = (z ^ (z>>30)) * 0xBF58476D1CE4E5B9;
@@ -82,6 +85,13 @@ void* dsac_get_stream(dsac_ctx* ctx);
 int dsac_synchronize(dsac_ctx* ctx);
 /* device facts for reports: CU count, clock (kHz), total memory (bytes), gcnArchName into name[64] */
 int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64);
+/* Per-context launch knobs (the reference's GlobalProperties singleton, core/properties.h, made per-context and explicit).
+ * Keys: "k2_variant" (-1 = auto policy; otherwise one fixed kernel form of K2, for A/B runs and tests), "k2_order" (1 = pixel tiles
+ * innermost), "k2_flags" (bit0: cached instead of non-temporal stores), "k1_wpb" / "k1_prio" / "k1_hpw" (K1 waves per workgroup, wave
+ * priority, hypotheses per wave), "k1_horn" (1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P)
+ * does -- parity mode, slower; 0 = orthonormal triad, equal to rounding).  The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER,
+ * DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_HORN give the initial values at dsac_create. */
+int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
 
 /* ---- frame ------------------------------------------------------------------------------------ */
 /* Replaces the (estObj, sampling, camMat) triple every reference function takes
@@ -143,8 +153,12 @@ int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* se
  * the bandwidth-bound scoring of frame i, the small K3 tail of frame i runs under K2 of frame i+1, and K2 launches follow
  * each other back to back on the context's stream.  The error images are complete in stream order; scores / w / entropy /
  * avg6 are complete after dsac_synchronize (they are produced on the auxiliary stream).  Device pointers only
- * (the calls never block); poses/sets_out/ok of a slot must stay untouched until its score call has been issued,
- * and dsac_synchronize waits for both streams. */
+ * (the calls never block); poses/sets_out/ok of a slot must stay untouched until its score call has been issued
+ * (the library orders the slot's next dsac_sample_ahead behind the readers of its previous use), and dsac_synchronize
+ * waits for all streams.  A slot remembers the frame that was current when it was sampled and is scored against that frame, so
+ * a stream of different frames is pipelined by calling dsac_set_frame(..., DSAC_FRAME_BORROW) before each dsac_sample_ahead;
+ * frames the library copies itself (no DSAC_FRAME_BORROW) cannot be replaced while a slot is sampled but not yet scored
+ * (DSAC_ERR_INVALID).  Each slot alternates strictly: sample_ahead, score_sampled, sample_ahead, ... */
 int dsac_sample_ahead(dsac_ctx* ctx, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
                       int32_t* sets_out, uint8_t* ok);
 int dsac_score_sampled(dsac_ctx* ctx, int slot, float clamp, float tau, float beta, double scale, const double* poses, float* err_or_null,
@@ -164,7 +178,13 @@ int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, double* J);
  * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into. */
 int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
                         unsigned flags, double* grad_xyz);
-/* Same with the soft-inlier score: d_err[h][p] = g[h] * d soft[h] / d err[h][p], formed in-kernel
+/* The backward calls need fx == fy: the reference's Jacobians use the single focal length camMat(0,0) for both axes
+ * (core/cnn_softam.h:406,466); a camera with two focal lengths is rejected with DSAC_ERR_INVALID rather than differentiated
+ * inconsistently with the forward kernels.  Quirk 7 of the reference (dProjectdHyp writes the re-derived rotation back into the
+ * hypothesis through a const reference, :506-508, so the rotation drifts by round-off from pixel to pixel) is NOT reproduced: the
+ * product is the "fixed" mode (rotation re-derived once per hypothesis); the parity mode is the oracle's quirk_rot_writeback
+ * switch, and tests/test_gpu_backward.py::test_quirk7_rot_writeback bounds the difference between the two.
+ * Same with the soft-inlier score: d_err[h][p] = g[h] * d soft[h] / d err[h][p], formed in-kernel
  * (no N x P read).  g = dLoss/d soft[h]. */
 int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
                              float beta, const double* dpnp_or_null, unsigned flags, double* grad_xyz);

@@ -44,3 +44,50 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["traffic"] is not None and 0.98 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.10
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def _run_bench(*flags, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=e, capture_output=True, text=True, timeout=300)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` without a torchrun environment spawns 2 ranks (gloo here, RCCL on the GPUs), and the line reports the
+    number of ranks that joined.  --dry-run replaces the engine; launch, rendezvous, MAX-over-ranks timing and the line are the real code."""
+    r = _run_bench("--gpus", "2", "--steps", "3", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["frames_per_step_all_ranks"] == 16  # 8 frames per rank
+
+
+def test_config3_shards_64_images_and_gathers_them():
+    """BASELINE.json configs[3]: 64 images round-robin over the ranks, 64 x (6 + N) results gathered (dist.shard_images / gather_frame_results);
+    the dry run fills row i with the image index and checks on rank 0 that every image arrived in its place."""
+    for world in (1, 2, 3):
+        r = _run_bench("--gpus", str(world), "--steps", "2", "--workload", "config3", "--dry-run", "--hyps", "128")
+        assert r.returncode == 0, r.stderr
+        d = _json_line(r.stdout)
+        assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["frames_per_step_all_ranks"] == 64
+
+
+def test_rank_count_mismatch_is_refused():
+    r = _run_bench("--gpus", "4", "--steps", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_short_runs_time_every_k2_launch():
+    b = _bench()
+    assert b.event_stride_for(20, -1) == 1 and b.event_stride_for(64, -1) == 1   # the driver's --steps 20: 20 samples, not 3
+    assert b.event_stride_for(200, -1) == 3 and b.event_stride_for(200, 8) == 8 and b.event_stride_for(20, 0) == 0

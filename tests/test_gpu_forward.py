@@ -273,6 +273,57 @@ def test_in_context_pipeline_equals_the_fused_call(engine, frame40):
         engine.sampleAhead(0, N, 1, np.zeros((N, 6)), np.zeros((N, 4), np.int32), np.zeros(N, np.uint8))  # host pointers are rejected
 
 
+def test_pipeline_streams_different_frames_without_syncs(engine, synth):
+    """The steady-state loop of the pipelined pair over a stream of DIFFERENT frames (DSAC_FRAME_BORROW before each dsac_sample_ahead),
+    no synchronisation until the end: every step must give the bits of the fused call on its own frame.  Per-slot pose buffers are
+    reused every second step, so K1 of step i+2 may only start once the K3 tail of step i has read them (the soft-argmax average),
+    and a slot must be scored against the frame it was sampled from, not the one current at score time."""
+    import torch
+    dev = torch.device("cuda", 0)
+    H, W, N, S = 480, 640, 256, 7
+    P = H * W
+    frames = [synth.chess_like_frame(H, W, seed=700 + i) for i in range(S)]
+    cam = frames[0]["cam"]
+    xyz = [torch.from_numpy(fr["xyz"]).to(dev) for fr in frames]
+    ref = []
+    for i in range(S):
+        engine.set_frame(xyz[i], None, H, W, cam, borrow=True)
+        ref.append(engine.scoreHypotheses(N, seed=40 + i, scale=1e-3))
+    slot = [dict(poses=torch.zeros(N, 6, dtype=torch.float64, device=dev), sets=torch.zeros(N, 4, dtype=torch.int32, device=dev),
+                 ok=torch.zeros(N, dtype=torch.uint8, device=dev)) for _ in range(2)]
+    outs = [dict(soft=torch.zeros(N, dtype=torch.float64, device=dev), w=torch.zeros(N, dtype=torch.float64, device=dev),
+                 ent=torch.zeros(1, dtype=torch.float64, device=dev), avg=torch.zeros(6, dtype=torch.float64, device=dev)) for _ in range(S)]
+    err = torch.empty(N, P, dtype=torch.float32, device=dev)
+    engine.synchronize()
+    engine.set_frame(xyz[0], None, H, W, cam, borrow=True)
+    engine.sampleAhead(0, N, 40, slot[0]["poses"], slot[0]["sets"], slot[0]["ok"])
+    for i in range(S):
+        k = i & 1
+        if i + 1 < S:
+            engine.set_frame(xyz[i + 1], None, H, W, cam, borrow=True)  # the frame of the NEXT step becomes current ...
+            nb = slot[1 - k]
+            engine.sampleAhead(1 - k, N, 40 + i + 1, nb["poses"], nb["sets"], nb["ok"])
+        o = outs[i]
+        engine.scoreSampled(k, slot[k]["poses"], o["soft"], o["w"], ent=o["ent"], avg=o["avg"], err=err, scale=1e-3)  # ... while this one scores frame i
+    engine.synchronize()
+    for i in range(S):
+        p, s_, ok, sc, w, ent, avg = ref[i]
+        o = outs[i]
+        assert np.array_equal(o["soft"].cpu().numpy(), sc), "step %d scored against the wrong frame or poses" % i
+        assert np.array_equal(o["w"].cpu().numpy(), w) and o["ent"].item() == ent[0]
+        assert np.array_equal(o["avg"].cpu().numpy(), avg), "step %d: soft-argmax pose mixed two frames' hypotheses" % i
+    # the library's own frame copy cannot be swapped underneath a sampled slot
+    engine.set_frame(frames[0]["xyz"], None, H, W, cam)
+    engine.sampleAhead(0, N, 1, slot[0]["poses"], slot[0]["sets"], slot[0]["ok"])
+    with pytest.raises(Exception):
+        engine.set_frame(frames[1]["xyz"], None, H, W, cam)
+    with pytest.raises(Exception):
+        engine.sampleAhead(0, N, 2, slot[0]["poses"], slot[0]["sets"], slot[0]["ok"])  # slot 0 is still pending
+    engine.scoreSampled(0, slot[0]["poses"], outs[0]["soft"], outs[0]["w"], err=err)
+    engine.synchronize()
+    engine.set_frame(frames[1]["xyz"], None, H, W, cam)  # fine again
+
+
 def test_quantise_flag(engine, orc, synth):
     fr = synth.chess_like_frame(40, 40, seed=4, quantise_int16=False)
     engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"], quantise_int16=True)

@@ -1,0 +1,230 @@
+"""Oracle parity on the configurations that bench.py actually times.
+
+  * the bench shape: 8 frames x 256 hypotheses x 640x480 in one dsac_score_hypotheses_frames call, i.e. the big-launch form of K2
+    (more than 1.5 GB of error images per launch) is the kernel under test;
+  * BASELINE.json configs[2]: 4096 random poses over a 640x480 random coordinate map, error images only and error images + soft;
+  * every selectable K2 kernel form (dsac_set_option "k2_variant") on a 640x480 frame.
+
+The error images of these launches are 2.5 - 5 GB and stay on the GPU; a random sample of rows (>= 64 per launch) is compared with
+orc.get_diff_maps (the restatement of getDiffMap, core/cnn_softam.h:319-362), ALL soft-inlier scores with orc.soft_inlier and ALL
+softmax weights with orc.softMax.  Tolerances as everywhere else in the suite: residuals 1e-3 px (clamp-edge cells excluded), soft
+scores 1e-4 relative.  Softmax weights: K3 itself is checked to 1e-12 on the GPU's own scores; the weights that follow from the
+oracle's scores are checked to 5e-3 absolute -- at this map size a score is a sum of 307 200 sigmoids and enters the softmax scaled by
+0.1, so the fp32 rounding of the residuals (1e-4 px) moves a weight by up to ~1e-3 of itself.
+"""
+import numpy as np
+import pytest
+
+from conftest import excl_clamp_edge
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+P = H * W
+TAU, BETA, SCALE, CLAMP = 10.0, 0.5, 0.1, 100.0
+
+
+def _check_rows(orc, err_dev, rows, poses, xyz, uv, cam, what):
+    """error-image rows `rows` (indices into err_dev, a torch tensor N x P on the GPU) vs the oracle for the same poses"""
+    import torch
+    got = err_dev[torch.as_tensor(rows, device=err_dev.device)].cpu().numpy()
+    ref = orc.get_diff_maps(poses[rows], xyz, uv, H, W, cam)
+    m = excl_clamp_edge(got, ref, CLAMP)
+    assert m.mean() > 0.01, what
+    worst = np.abs(got - ref)[m].max()
+    assert worst <= 1e-3, "%s: max |err - oracle| = %.3e px" % (what, worst)
+    assert np.abs(got - ref).max() <= 2e-3, what
+    return worst
+
+
+def _check_scores(orc, soft_gpu, w_gpu, poses, xyz, uv, cam, what, engine=None):
+    """all soft-inlier scores and softmax weights of one frame"""
+    ref_err = orc.get_diff_maps(poses, xyz, uv, H, W, cam)
+    soft_ref = orc.soft_inlier(ref_err, TAU, BETA)
+    rel = np.abs(soft_gpu - soft_ref).max() / max(1.0, np.abs(soft_ref).max())
+    assert rel <= 1e-4, "%s: soft scores differ by %.3e (relative to the largest)" % (what, rel)
+    # K3 proper: the GPU's softmax of the GPU's own scores
+    assert np.abs(w_gpu - orc.softMax(SCALE * soft_gpu)).max() <= 1e-12, what
+    dw = np.abs(w_gpu - orc.softMax(SCALE * soft_ref)).max()
+    assert dw <= 5e-3, "%s: softmax weights differ by %.3e" % (what, dw)
+    if engine is not None:
+        # with the bench's scale (0.1) a 640x480 softmax is one-hot (scores ~1e5); a scale that spreads the weights makes the comparison bite
+        w2, _, _ = engine.softMax(soft_gpu, 1e-3)
+        dw2 = np.abs(w2 - orc.softMax(1e-3 * soft_ref)).max()
+        assert dw2 <= 1e-3, "%s: softmax weights (scale 1e-3) differ by %.3e" % (what, dw2)
+        dw = max(dw, dw2)
+    return rel, dw
+
+
+def test_bench_shape_frame_batch_against_the_oracle(engine, orc, synth):
+    """bench.py's default step: 8 frames x 256 hypotheses x 640x480 through dsac_score_hypotheses_frames."""
+    import torch
+    dev = torch.device("cuda", 0)
+    F, N = 8, 256
+    frames = [synth.chess_like_frame(H, W, seed=1305 + 1000 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    cam = frames[0]["cam"]
+    uv = synth.pixel_grid(H, W)
+    engine.set_option("k2_variant", -1)  # the auto policy, as in the bench
+    engine.set_frames(xyz, None, H, W, cam, borrow=True)
+    err = torch.empty(F * N, P, dtype=torch.float32, device=dev)
+    poses = torch.zeros(F * N, 6, dtype=torch.float64, device=dev); sets = torch.zeros(F * N, 4, dtype=torch.int32, device=dev)
+    ok = torch.zeros(F * N, dtype=torch.uint8, device=dev); soft = torch.zeros(F * N, dtype=torch.float64, device=dev)
+    w = torch.zeros(F * N, dtype=torch.float64, device=dev); ent = torch.zeros(F, dtype=torch.float64, device=dev)
+    avg = torch.zeros(F, 6, dtype=torch.float64, device=dev)
+    engine.profile_enable(True, stride=1)
+    engine.scoreHypothesesFrames(N, seed=4711, thr=10.0, max_tries=1 << 16, clamp=CLAMP, tau=TAU, beta=BETA, scale=SCALE, err=err,
+                                 out=(poses, sets, ok, soft, w, ent, avg))
+    engine.synchronize()
+    ms, n = engine.profile_read(0, reset=True)
+    engine.profile_enable(False)
+    assert n == 1  # one K2 launch carried the 8 frames
+    assert int(ok.sum().item()) == F * N
+    ph, sh, wh, sf = poses.cpu().numpy(), sets.cpu().numpy(), w.cpu().numpy(), soft.cpu().numpy()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for f in range(F):
+        sl = slice(f * N, (f + 1) * N)
+        # minimal sets: what the oracle draws for seed + f on this frame
+        pr, sr, okr, _ = orc.sample(N, 4711 + f, frames[f]["xyz"], uv, H, W, cam, thr=10.0, max_tries=1 << 16)
+        assert np.array_equal(sh[sl], sr), "frame %d: minimal sets differ from the oracle's" % f
+        rows = f * N + rng.choice(N, 10, replace=False)  # 80 rows in total
+        worst = max(worst, _check_rows(orc, err, rows, ph, frames[f]["xyz"], uv, cam, "frame %d" % f))
+        rel, dw = _check_scores(orc, sf[sl], wh[sl], ph[sl], frames[f]["xyz"], uv, cam, "frame %d" % f, engine=engine if f == 0 else None)
+        aref = orc.avg_pose(wh[sl], ph[sl])
+        assert np.abs(avg[f].cpu().numpy() - aref).max() <= 1e-9 * max(1.0, np.abs(aref).max())
+        assert abs(ent[f].item() - orc.entropy(wh[sl])) <= 1e-9
+    print("bench shape: K2 %.1f us, worst residual difference %.2e px, last frame soft rel %.2e, dw %.2e" % (ms * 1e3, worst, rel, dw))
+
+
+@pytest.mark.parametrize("mode", ["err", "both"])
+def test_config2_4096_hypotheses_against_the_oracle(engine, orc, synth, mode):
+    """BASELINE.json configs[2]: random coordinate map (seed 7), 4096 random poses, K2 alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N = 4096
+    fr = synth.roofline_frame(H, W, seed=7)
+    cam = fr["cam"]
+    poses = synth.random_poses(N, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])
+    xyz = torch.from_numpy(fr["xyz"]).to(dev)
+    engine.set_option("k2_variant", -1)
+    engine.set_frame(xyz, None, H, W, cam, borrow=True)
+    err = torch.empty(N, P, dtype=torch.float32, device=dev)  # 5.03 GB
+    soft = torch.zeros(N, dtype=torch.float64, device=dev) if mode == "both" else None
+    pd = torch.from_numpy(poses).to(dev)
+    engine.reproject(pd, N=N, clamp=CLAMP, err=err, soft=soft, tau=TAU, beta=BETA)
+    engine.synchronize()
+    assert float(err.max().item()) <= CLAMP and float(err.min().item()) >= 0.0
+    rows = np.random.default_rng(1).choice(N, 64, replace=False)
+    worst = _check_rows(orc, err, rows, poses, fr["xyz"], fr["uv"], cam, "configs[2] " + mode)
+    if soft is not None:
+        # all 4096 soft scores: the oracle's error images in slabs of 256 hypotheses
+        sg = soft.cpu().numpy()
+        sr = np.concatenate([orc.soft_inlier(orc.get_diff_maps(poses[i:i + 256], fr["xyz"], fr["uv"], H, W, cam), TAU, BETA) for i in range(0, N, 256)])
+        rel = np.abs(sg - sr).max() / max(1.0, np.abs(sr).max())
+        assert rel <= 1e-4, "configs[2] soft scores differ by %.3e" % rel
+        w, entr, _ = engine.softMax(sg, SCALE)
+        assert np.abs(w - orc.softMax(SCALE * sg)).max() <= 1e-12
+        assert np.abs(w - orc.softMax(SCALE * sr)).max() <= 5e-3
+    print("configs[2] %s: worst residual difference %.2e px" % (mode, worst))
+    del err
+    torch.cuda.empty_cache()
+
+
+@pytest.fixture(scope="module")
+def variant_case(orc, synth):
+    """one 640x480 frame, 256 hypotheses of which 24 rows and all scores are compared per kernel form"""
+    fr = synth.chess_like_frame(H, W, seed=2024)
+    uv = synth.pixel_grid(H, W)
+    N = 256
+    poses, sets, ok, _ = orc.sample(N, 9, fr["xyz"], uv, H, W, fr["cam"], thr=10.0, max_tries=1 << 16)
+    poses[3] = 0.0  # a failed hypothesis' zero pose (safeSolvePnP, core/cnn_softam.h:66-71) rides along
+    ref_err = orc.get_diff_maps(poses, fr["xyz"], uv, H, W, fr["cam"])
+    return dict(fr=fr, uv=uv, N=N, poses=poses, ref_err=ref_err, soft=orc.soft_inlier(ref_err, TAU, BETA))
+
+
+# every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 4-9 and 14-16 matrix-core forms
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("order", [1, 0])
+def test_every_k2_kernel_form_against_the_oracle(engine, variant_case, variant, order):
+    import torch
+    c = variant_case
+    dev = torch.device("cuda", 0)
+    N = c["N"]
+    engine.set_option("k2_variant", variant)
+    engine.set_option("k2_order", order)
+    try:
+        engine.set_frame(c["fr"]["xyz"], None, H, W, c["fr"]["cam"])
+        err = torch.empty(N, P, dtype=torch.float32, device=dev)
+        soft = torch.zeros(N, dtype=torch.float64, device=dev)
+        engine.reproject(torch.from_numpy(c["poses"]).to(dev), N=N, clamp=CLAMP, err=err, soft=soft, tau=TAU, beta=BETA)
+        engine.synchronize()
+        rows = np.concatenate([[0, 3, N - 1], np.random.default_rng(variant + 100).choice(N, 21, replace=False)])
+        got = err[torch.as_tensor(rows, device=dev)].cpu().numpy()
+        ref = c["ref_err"][rows]
+        m = excl_clamp_edge(got, ref, CLAMP)
+        assert np.abs(got - ref)[m].max() <= 1e-3, "variant %d" % variant
+        sg = soft.cpu().numpy()
+        assert np.abs(sg - c["soft"]).max() <= 1e-4 * max(1.0, np.abs(c["soft"]).max()), "variant %d" % variant
+        # error images only and scores only go through the same switch
+        err2 = torch.empty(N, P, dtype=torch.float32, device=dev)
+        engine.reproject(torch.from_numpy(c["poses"]).to(dev), N=N, clamp=CLAMP, err=err2)
+        soft2 = torch.zeros(N, dtype=torch.float64, device=dev)
+        engine.reproject(torch.from_numpy(c["poses"]).to(dev), N=N, clamp=CLAMP, soft=soft2, tau=TAU, beta=BETA)
+        engine.synchronize()
+        if variant >= 0:  # a fixed kernel form does the same arithmetic whatever it writes; the auto policy may pick different forms
+            assert torch.equal(err2, err), "variant %d: error images depend on whether the scores are requested" % variant
+        else:
+            assert float((err2 - err).abs().max().item()) <= 5e-4
+        assert np.allclose(soft2.cpu().numpy(), sg, rtol=1e-6, atol=1e-6 * np.abs(sg).max())
+    finally:
+        engine.set_option("k2_variant", -1)
+        engine.set_option("k2_order", 1)
+
+
+def test_two_contexts_on_two_host_threads(orc, synth):
+    """The library keeps no process-wide mutable state (include/dsac_hip.h, Threading): two contexts driven concurrently from two host
+    threads with DIFFERENT launch knobs, frames and seeds give what each gives alone."""
+    import threading
+    import dsac_amd
+    frs = [synth.chess_like_frame(H, W, seed=50 + i) for i in range(2)]
+    knobs = [dict(k2_variant=0, k2_order=0, k1_wpb=1), dict(k2_variant=7, k2_order=1, k1_wpb=4)]
+    N = 128
+
+    def run(i, reps, out):
+        with dsac_amd.Engine(0) as e:
+            for k, v in knobs[i].items():
+                e.set_option(k, v)
+            e.set_frame(frs[i]["xyz"], None, H, W, frs[i]["cam"])
+            res = None
+            for r in range(reps):
+                err = np.zeros((4, P), np.float32)
+                p, s, ok, sc, w, ent, avg = e.scoreHypotheses(N, seed=900 + i, scale=SCALE)
+                e.reproject(p[:4], err=err)
+                cur = (p, s, sc, w, avg, err)
+                if res is not None:
+                    assert all(np.array_equal(a, b) for a, b in zip(res, cur)), "context %d is not reproducible under concurrency" % i
+                res = cur
+            out[i] = res
+
+    alone = [None, None]
+    for i in range(2):
+        run(i, 1, alone)
+    both = [None, None]
+    errs = []
+
+    def guarded(i):
+        try:
+            run(i, 6, both)
+        except Exception as ex:  # surfaces in the main thread
+            errs.append(ex)
+
+    ts = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        assert all(np.array_equal(a, b) for a, b in zip(alone[i], both[i])), "context %d changes its result when another thread runs" % i
+        ref = orc.get_diff_maps(both[i][0][:4], frs[i]["xyz"], synth.pixel_grid(H, W), H, W, frs[i]["cam"])
+        m = excl_clamp_edge(both[i][5], ref, CLAMP)
+        assert np.abs(both[i][5] - ref)[m].max() <= 1e-3
