@@ -243,15 +243,9 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject(const float* __restric
 // [3N x 4] (rows R_i | t_i of every pose) x [4 x P] (X, Y, Z, 1 of every pixel) -- a GEMM with K = 4, which is
 // exactly one v_mfma_f32_16x16x4_f32 per 16 x 16 output tile (fp32 in, fp32 accumulate, bit-equal to an fmaf
 // chain).  rocprof showed the all-VALU kernel issue-bound on the vector ALUs (SQ_ACTIVE_INST_VALU ~ every
-// SIMD cycle) with HBM at ~63 %; moving the 9 FMAs per (hypothesis, pixel) to the matrix pipe, which runs
-// concurrently with the VALU, halves the VALU work per pair (rcp, 2 fma, mul, fma, sqrt, min remain).
-//
-// Tile layout per MFMA:  A[i][k]: i = 4*g + comp  (g = hypothesis within a group of 4, comp = x,y,z,pad)
-//                        B[k][j]: j = pixel column c, k = X,Y,Z,1
-//                        D: lane (g = lane/16, c = lane%16) receives rows 4g..4g+3 of column c
-// i.e. after one MFMA each lane holds (xc, yc, zc, -) of ONE (hypothesis, pixel) pair.  Four MFMAs with
-// column c -> pixel 4c + m (m = 0..3) give the lane 4 consecutive pixels of its hypothesis, which it
-// finishes on the VALU and stores as one 16-byte dwordx4 (16 lanes = 256 contiguous bytes per error-image row).
+// SIMD cycle) with HBM at ~63 %; the 9 FMAs per (hypothesis, pixel) move to the matrix pipe, which runs
+// concurrently with the VALU.  (Round 1's operand layout -- rows (hypothesis, x/y/z/pad), one pair per lane -- is gone: the
+// hypothesis-pair layout below needs 12 instead of 16 MFMAs per 1024 pairs and half the VALU work; see k_reproject_hp.)
 // --------------------------------------------------------------------------------------------------
 DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
     int x = __builtin_bit_cast(int, v);
@@ -265,28 +259,75 @@ DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, res
     return v;
 }
 
-constexpr int KM_CH_DEFAULT = 2;  // 64-pixel chunks per wave, all held in registers (template parameter KM_CH)
-
-// Finish one (hypothesis, pixel) pair from the MFMA outputs d = (xc, yc, zc, -): (xc, yc) are adjacent registers, so one
-// packed fma gives (du, dv) and one packed mul their squares.
-DM_INLINE float finish_pair(const f4 d, float iz, f2 ppix, float clampv) {
-    const f2 dd = pk_fma(-f2{d.x, d.y}, splat(iz), ppix);
-    const f2 q = dd * dd;
-    return fminf(__builtin_amdgcn_sqrtf(q.x + q.y), clampv);
+// --------------------------------------------------------------------------------------------------
+// K2, matrix-core form with HYPOTHESIS-PAIR packed finishing (round 2).  Same GEMM, other operand roles: per group of 16 hypotheses
+// three A operands hold their x-, y- and z-rows (A_x[i][k] = fx R0[k] | fx t0 of hypothesis i, ...), B is unchanged (X, Y, Z, 1 of the
+// pixel columns).  D_x / D_y / D_z of one v_mfma_f32_16x16x4_f32 each then give lane (g, c) the SAME component of FOUR hypotheses
+// (4g .. 4g+3) for pixel column c in four adjacent registers, so every finishing operation runs packed over a hypothesis pair
+// (v_pk_fma_f32 / v_pk_mul_f32: du, dv, du^2 + dv^2, the sigmoid's affine map and 1 + 2^t), the pixel position is a broadcast operand,
+// and there is no padding row: 12 MFMAs per 1024 (hypothesis, pixel) pairs instead of 16, ~5 plain VALU operations per pair instead of
+// ~11 (the 4 transcendentals per pair -- rcp z, sqrt, exp2, rcp -- are what is left).  With m = 0..3 as before (column c -> pixel
+// 4c + m) a lane ends up with 4 consecutive pixels of each of its 4 hypotheses: four dwordx4 stores, each wave store still 4 rows x 256 B.
+// Arithmetic per pair is the VALU kernel's (fma(dv, dv, du*du)), the transform is the exact fp32 MFMA.
+// --------------------------------------------------------------------------------------------------
+// One 64-pixel chunk of 16 hypotheses: 12 MFMAs, then three phases on the VALU.
+//   1. packed over HYPOTHESIS pairs (adjacent MFMA output registers): iz = 1 / zc, du = pu + nx iz, dv = pv + ny iz, q = du^2 + dv^2.
+//      nx / ny are the NEGATED camera-frame x / y (the A rows carry the sign, so that no negation is left in the loop).
+//   2. e[r][m] = min(sqrt(q), clamp): scalar operations, which write each result straight into the register it is stored from
+//      (ev[r] = 4 consecutive pixels of hypothesis r, one dwordx4) -- the 4 x 4 transpose between the two packings costs nothing.
+//   3. soft-inlier sigmoid packed over PIXEL pairs of one hypothesis, accumulated per hypothesis.
+// Z == 0 detection of the fast path: zacc accumulates iz^2 -- rcp(0) = inf sticks (as would a NaN), anything finite stays finite unless
+// |z| < 5e-20, which only sends the wave down the (always exact) slow path once more.
+template <bool EXACT_Z, bool SOFT>
+DM_INLINE bool hp_chunk(float ax, float ay, float az, const float (&Bm)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4],
+                        f2 (&sloc)[4]) {
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f2 qq[4][2];
+    f2 zacc = splat(0.f);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const f4 nx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, Bm[m], z4, 0, 0, 0);
+        const f4 ny = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, Bm[m], z4, 0, 0, 0);
+        const f4 dz = __builtin_amdgcn_mfma_f32_16x16x4f32(az, Bm[m], z4, 0, 0, 0);
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const f2 x = pr ? f2{nx.z, nx.w} : f2{nx.x, nx.y};
+            const f2 y = pr ? f2{ny.z, ny.w} : f2{ny.x, ny.y};
+            const f2 z = pr ? f2{dz.z, dz.w} : f2{dz.x, dz.y};
+            f2 iz = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
+            if (EXACT_Z) {  // projectPoints: z = Z ? 1/Z : 1
+                iz.x = (z.x == 0.0f) ? 1.0f : iz.x;
+                iz.y = (z.y == 0.0f) ? 1.0f : iz.y;
+            } else {
+                zacc = pk_fma(iz, iz, zacc);
+            }
+            const f2 du = pk_fma(x, iz, splat(ppix[m].x));
+            const f2 dv = pk_fma(y, iz, splat(ppix[m].y));
+            qq[m][pr] = pk_fma(dv, dv, du * du);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pr = r >> 1;
+        ev[r].x = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[0][pr].y : qq[0][pr].x), clampv);
+        ev[r].y = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[1][pr].y : qq[1][pr].x), clampv);
+        ev[r].z = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[2][pr].y : qq[2][pr].x), clampv);
+        ev[r].w = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[3][pr].y : qq[3][pr].x), clampv);
+        if (SOFT) sloc[r] = soft_inlier2(f2{ev[r].x, ev[r].y}, kA, kB) + soft_inlier2(f2{ev[r].z, ev[r].w}, kA, kB);
+    }
+    return EXACT_Z ? false : !(zacc.x + zacc.y <= 3.0e38f);
 }
 
 template <int HT, bool ERR, bool SOFT, bool UV, int KM_CH>
-__global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __restrict__ staged, const float* __restrict__ xyz,
-                                                               const float* __restrict__ uv, float* __restrict__ err,
-                                                               float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
-                                                               float cy, float clampv, float kA, float kB, int kflags, int Nf,
-                                                               long long xyz_stride, long long uv_stride) {
-    static_assert(HT % 4 == 0, "hypothesis tile must be a multiple of 4");
+__global__ __launch_bounds__(K2_THREADS) void k_reproject_hp(const float* __restrict__ staged, const float* __restrict__ xyz,
+                                                             const float* __restrict__ uv, float* __restrict__ err,
+                                                             float* __restrict__ soft_part, int N, int P, int W, int PT, int NT, float cx,
+                                                             float cy, float clampv, float kA, float kB, int kflags, int Nf,
+                                                             long long xyz_stride, long long uv_stride) {
+    static_assert(HT % 16 == 0, "hypothesis tile must be a multiple of 16");
     const int b = blockIdx.x;
     const int q = b >> 3;
-    // order: NT > 0 -> hypothesis tiles innermost (same pixel tile back to back);  NT < 0 -> pixel tiles
-    // innermost (the resident blocks write a contiguous band of error-image rows), |NT| hypothesis tiles.
-    int ht, pt;
+    int ht, pt;  // block order as in k_reproject (NT > 0: hypothesis tiles innermost; NT < 0: pixel tiles innermost)
     if (NT > 0) { ht = q % NT; pt = (q / NT) * 8 + (b & 7); }
     else { const int PTG = (PT + 7) >> 3; ht = q / PTG; pt = (q % PTG) * 8 + (b & 7); }
     if (pt >= PT) return;
@@ -300,17 +341,18 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
         if (UV) uv += (long long)frame * uv_stride;
     }
 
-    // A operands in MFMA lane order: s_A[gi*64 + l] = record[h0 + 4 gi + (l%16)/4][comp = (l%16)%4][k = l/16]
-    __shared__ float s_A[(HT / 4) * 64];
+    // A operands in MFMA lane order: s_A[(gi*3 + comp)*64 + l] = record[h0 + 16 gi + l%16][comp][k = l/16]; hypotheses beyond the
+    // ragged end repeat the last valid one (their results are never stored, and a zero record would send every wave down the Z == 0 path)
+    __shared__ float s_A[(HT / 16) * 3 * 64];
     __shared__ float s_soft[SOFT ? (K2_THREADS / 64) * HT : 1];
-    for (int i = tid; i < (HT / 4) * 64; i += K2_THREADS) {
-        const int l = i & 63, gi = i >> 6;
-        const int row = l & 15, k = l >> 4;
-        const int hyp = 4 * gi + (row >> 2), comp = row & 3;
-        s_A[i] = (comp < 3 && hyp < nh) ? staged[(size_t)(h0 + hyp) * POSE_STRIDE + comp * 4 + k] : 0.0f;
+    for (int i = tid; i < (HT / 16) * 3 * 64; i += K2_THREADS) {
+        const int l = i & 63, cg = i >> 6;
+        const int comp = cg % 3, gi = cg / 3;
+        const int hyp = min(16 * gi + (l & 15), nh - 1), k = l >> 4;
+        const float v = staged[(size_t)(h0 + hyp) * POSE_STRIDE + comp * 4 + k];
+        s_A[i] = comp < 2 ? -v : v;  // x and y rows negated: the MFMA yields (-xc, -yc, zc), du = pu + (-xc) / zc needs no sign flip
     }
 
-    // per-chunk operands: B (coordinate g of pixel 4c + m) and the lane's 4 pixel positions as (u - cx, v - cy) pairs
     float Bm[KM_CH][4];
     f2 ppix[KM_CH][4];
     int p0[KM_CH];
@@ -335,8 +377,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
                 ppix[ch][0] = ppix[ch][1] = ppix[ch][2] = ppix[ch][3] = splat(0.f);
             }
         } else {
-            // implicit grid: one integer division per chunk, then walk (with row wrap)
-            int y = p0[ch] / W, x = p0[ch] - y * W;
+            int y = p0[ch] / W, x = p0[ch] - y * W;  // implicit grid: one integer division per chunk, then walk (with row wrap)
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 ppix[ch][m] = f2{(float)x - cx, (float)y - cy};
@@ -346,45 +387,50 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
     }
     __syncthreads();
 
-#pragma unroll 2
-    for (int gi = 0; gi < HT / 4; gi++) {
-        if (4 * gi >= nh) break;
-        const float a = s_A[gi * 64 + lane];
-        const int hyp = 4 * gi + g;
-        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        float ssum = 0.f;
+    for (int gi = 0; gi < HT / 16; gi++) {
+        if (16 * gi >= nh) break;
+        const float ax = s_A[(gi * 3 + 0) * 64 + lane], ay = s_A[(gi * 3 + 1) * 64 + lane], az = s_A[(gi * 3 + 2) * 64 + lane];
+        const int hyp0 = 16 * gi + 4 * g;  // this lane's 4 hypotheses: hyp0 .. hyp0 + 3
+        f2 ssum[4] = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
 #pragma unroll
         for (int ch = 0; ch < KM_CH; ch++) {
-            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][0], z4, 0, 0, 0);
-            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][1], z4, 0, 0, 0);
-            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][2], z4, 0, 0, 0);
-            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bm[ch][3], z4, 0, 0, 0);
-            // finish on the VALU
-            float iz0 = __builtin_amdgcn_rcpf(d0.z), iz1 = __builtin_amdgcn_rcpf(d1.z);
-            float iz2 = __builtin_amdgcn_rcpf(d2.z), iz3 = __builtin_amdgcn_rcpf(d3.z);
-            // projectPoints' "z = Z ? 1/Z : 1": one test for the 4 pixels, wave-uniform slow path (practically never)
-            const float zmin = fminf(fminf(fabsf(d0.z), fabsf(d1.z)), fminf(fabsf(d2.z), fabsf(d3.z)));
-            if (__builtin_expect(__any(zmin == 0.0f), 0)) {
-                iz0 = (d0.z == 0.0f) ? 1.0f : iz0; iz1 = (d1.z == 0.0f) ? 1.0f : iz1;
-                iz2 = (d2.z == 0.0f) ? 1.0f : iz2; iz3 = (d3.z == 0.0f) ? 1.0f : iz3;
-            }
-            const float e0 = finish_pair(d0, iz0, ppix[ch][0], clampv);
-            const float e1 = finish_pair(d1, iz1, ppix[ch][1], clampv);
-            const float e2 = finish_pair(d2, iz2, ppix[ch][2], clampv);
-            const float e3 = finish_pair(d3, iz3, ppix[ch][3], clampv);
-            if (ERR && valid[ch] && hyp < nh) {
-                const f4 o = {e0, e1, e2, e3};
-                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp) * P + p0[ch]);
-                if (kflags & 1) *dst = o; else __builtin_nontemporal_store(o, dst);
-            }
+            f4 ev[4];  // ev[r] = 4 consecutive pixels of hypothesis hyp0 + r
+            f2 sloc[4];
+            // projectPoints' "z = Z ? 1/Z : 1": one test for the 16 pairs, wave-uniform slow path (practically never) that redoes the chunk
+            if (__builtin_expect(__any(hp_chunk<false, SOFT>(ax, ay, az, Bm[ch], ppix[ch], clampv, kA, kB, ev, sloc)), 0))
+                (void)hp_chunk<true, SOFT>(ax, ay, az, Bm[ch], ppix[ch], clampv, kA, kB, ev, sloc);
             if (SOFT) {
-                const f2 s2 = soft_inlier2(f2{e0, e1}, kA, kB) + soft_inlier2(f2{e2, e3}, kA, kB);
-                ssum += valid[ch] ? (s2.x + s2.y) : 0.f;
+                const f2 vf = splat(valid[ch] ? 1.0f : 0.0f);
+#pragma unroll
+                for (int r = 0; r < 4; r++) ssum[r] = pk_fma(sloc[r], vf, ssum[r]);
+            }
+            if (ERR && valid[ch]) {
+                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp0) * P + p0[ch]);
+                const size_t rs = (size_t)P / 4;  // row stride in f4 (P % 4 == 0)
+                if (nh == HT) {  // full tile (uniform): no per-row guards
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (kflags & 1) dst[r * rs] = ev[r]; else __builtin_nontemporal_store(ev[r], dst + r * rs);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (hyp0 + r < nh) { if (kflags & 1) dst[r * rs] = ev[r]; else __builtin_nontemporal_store(ev[r], dst + r * rs); }
+                    }
+                }
             }
         }
         if (SOFT) {
-            ssum = row16_sum(ssum);  // the 16 lanes of a row hold the same hypothesis
-            if (c == 0 && hyp < nh) s_soft[wave * HT + hyp] = ssum;  // written exactly once per (wave, hypothesis)
+            // the 16 lanes of a DPP row hold the same 4 hypotheses
+            const float s0 = row16_sum(ssum[0].x + ssum[0].y), s1 = row16_sum(ssum[1].x + ssum[1].y);
+            const float s2 = row16_sum(ssum[2].x + ssum[2].y), s3 = row16_sum(ssum[3].x + ssum[3].y);
+            if (c == 0) {  // written exactly once per (wave, hypothesis)
+                float* dst = s_soft + wave * HT + hyp0;
+                if (hyp0 + 0 < nh) dst[0] = s0;
+                if (hyp0 + 1 < nh) dst[1] = s1;
+                if (hyp0 + 2 < nh) dst[2] = s2;
+                if (hyp0 + 3 < nh) dst[3] = s3;
+            }
         }
     }
 
@@ -399,9 +445,9 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_mfma(const float* __re
     }
 }
 
-template <int HT, int KM_CH = KM_CH_DEFAULT>
-static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
-                                        float kB, float* soft_part, int* tiles_used, int Nf, bool pixel_minor, int kflags) {
+template <int HT, int KM_CH>
+static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
+                                      float kB, float* soft_part, int* tiles_used, int Nf, bool pixel_minor, int kflags) {
     const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
@@ -409,13 +455,13 @@ static hipError_t launch_reproject_mfma(hipStream_t st, int N, const float* stag
     const int NT = pixel_minor ? -NTa : NTa;
     if (tiles_used) *tiles_used = PT;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
-#define DSAC_K2M(E, S, U)                                                                                                               \
-    hipLaunchKernelGGL((k_reproject_mfma<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
+#define DSAC_K2H(E, S, U)                                                                                                             \
+    hipLaunchKernelGGL((k_reproject_hp<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
                        F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
-    if (ERR && SOFT) { if (UV) DSAC_K2M(true, true, true); else DSAC_K2M(true, true, false); }
-    else if (ERR) { if (UV) DSAC_K2M(true, false, true); else DSAC_K2M(true, false, false); }
-    else if (SOFT) { if (UV) DSAC_K2M(false, true, true); else DSAC_K2M(false, true, false); }
-#undef DSAC_K2M
+    if (ERR && SOFT) { if (UV) DSAC_K2H(true, true, true); else DSAC_K2H(true, true, false); }
+    else if (ERR) { if (UV) DSAC_K2H(true, false, true); else DSAC_K2H(true, false, false); }
+    else if (SOFT) { if (UV) DSAC_K2H(false, true, true); else DSAC_K2H(false, true, false); }
+#undef DSAC_K2H
     return hipGetLastError();
 }
 
@@ -440,8 +486,9 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
     return hipGetLastError();
 }
 
-// variant: -1 = auto (default) ; 0 = VALU kernel, LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ;
-//          2 = LDS, HT = 16 ; 3 = LDS, HT = 64 ; 4..9, 14..16 = matrix-core forms <HT, chunks per wave> ; 10..13 = 1..8 rows per workgroup
+// variant: -1 = auto (default) ; VALU forms: 0 = LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ; 2 = HT 16 ;
+//          3 = HT 64 ; 10..13 = 1, 2, 4, 8 hypothesis rows per workgroup ; matrix-core forms <HT, 64-pixel chunks per wave>: 20 = <64,2>,
+//          21 = <64,4>, 22 = <128,2>, 23 = <32,2>, 24 = <64,1>, 25 = <128,4>, 26 = <32,4>, 27 = <128,1>.  Unknown values are an error.
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
                      float* soft_part, const K2Opts& opts, int* tiles_used, int Nf) {
     if (tiles_used) *tiles_used = 0;
@@ -455,44 +502,39 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
     const int kf = opts.flags;
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf);
-    const int variant = opts.variant;
-    if (variant < 0) {
-        // auto (measured on MI355X, profiles/r01_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited:
-        // matrix-core form (HT = 64), pixel tiles innermost.  Error images only: store-limited: the VALU kernel with pixel tiles
-        // innermost has the best store stream.
-        const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
-        if (soft_part) {
-            // big launches (> 1.5 GB of error images: N = 4096, or a batch of frames): 1024 pixels per workgroup (4 chunks per wave, 92
-            // VGPRs) is 2 % faster than 512 (profiles/r01_k2_batch_variants.txt, r01_k2_big_variants.txt); small ones keep 512
-            return big ? launch_reproject_mfma<64, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, true, kf)
-                       : launch_reproject_mfma<64>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, true, kf);
-        }
-        return launch_reproject<4, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, true, kf);
-    }
-    const bool pm = opts.pixel_minor;
-#define DSAC_MF(HT_, CH_) launch_reproject_mfma<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf)
+    const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
 #define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf)
+#define DSAC_HP(HT_, CH_) launch_reproject_hp<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf)
+    int variant = opts.variant;
+    if (variant < 0) {
+        // auto (measured on MI355X, profiles/r02_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited: matrix-core
+        // form; 1024 pixels per workgroup for big launches (> 1.5 GB of error images: N = 4096 or a batch of frames: 443 vs 460-508 us for
+        // the 8-frame batch), 256 for a single frame of 256 hypotheses.  Error images only: store-limited, the VALU kernel with pixel
+        // tiles innermost has the best store stream (N = 256: 56.6 vs 58.9 us; N = 4096: equal).
+        const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
+        variant = soft_part ? (big ? 21 : 24) : 0;
+    }
     switch (variant) {
-        case 4: return DSAC_MF(64, KM_CH_DEFAULT);
-        case 5: return DSAC_MF(128, KM_CH_DEFAULT);
-        case 6: return DSAC_MF(32, KM_CH_DEFAULT);
+        case 0: return DSAC_VA(4, 32, false);
+        case 1: return DSAC_VA(4, 32, true);
+        case 2: return DSAC_VA(4, 16, false);
+        case 3: return DSAC_VA(4, 64, false);
         case 10: return DSAC_VA(4, 1, false);
         case 11: return DSAC_VA(4, 2, false);
         case 12: return DSAC_VA(4, 4, false);
         case 13: return DSAC_VA(4, 8, false);
-        case 14: return (Nf % 256) ? hipErrorInvalidValue : DSAC_MF(256, 1);
-        case 15: return (Nf % 256) ? hipErrorInvalidValue : DSAC_MF(256, 2);
-        case 16: return DSAC_MF(128, 1);
-        case 7: return DSAC_MF(64, 4);
-        case 8: return DSAC_MF(64, 1);
-        case 9: return DSAC_MF(32, 4);
-        case 1: return DSAC_VA(4, 32, true);
-        case 2: return DSAC_VA(4, 16, false);
-        case 3: return DSAC_VA(4, 64, false);
-        default: return DSAC_VA(4, 32, false);
+        case 20: return DSAC_HP(64, 2);
+        case 21: return DSAC_HP(64, 4);
+        case 22: return DSAC_HP(128, 2);
+        case 23: return DSAC_HP(32, 2);
+        case 24: return DSAC_HP(64, 1);
+        case 25: return DSAC_HP(128, 4);
+        case 26: return DSAC_HP(32, 4);
+        case 27: return DSAC_HP(128, 1);
+        default: return hipErrorInvalidValue;
     }
-#undef DSAC_MF
 #undef DSAC_VA
+#undef DSAC_HP
 }
 
 // --------------------------------------------------------------------------------------------------

@@ -143,8 +143,8 @@ def variant_case(orc, synth):
     return dict(fr=fr, uv=uv, N=N, poses=poses, ref_err=ref_err, soft=orc.soft_inlier(ref_err, TAU, BETA))
 
 
-# every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 4-9 and 14-16 matrix-core forms
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+# every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 20-27 matrix-core forms
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24, 25, 26, 27])
 @pytest.mark.parametrize("order", [1, 0])
 def test_every_k2_kernel_form_against_the_oracle(engine, variant_case, variant, order):
     import torch
@@ -175,7 +175,7 @@ def test_every_k2_kernel_form_against_the_oracle(engine, variant_case, variant, 
         if variant >= 0:  # a fixed kernel form does the same arithmetic whatever it writes; the auto policy may pick different forms
             assert torch.equal(err2, err), "variant %d: error images depend on whether the scores are requested" % variant
         else:
-            assert float((err2 - err).abs().max().item()) <= 5e-4
+            assert float((err2 - err).abs().max().item()) <= 1.5e-3  # each form is within 1e-3 px of the oracle
         assert np.allclose(soft2.cpu().numpy(), sg, rtol=1e-6, atol=1e-6 * np.abs(sg).max())
     finally:
         engine.set_option("k2_variant", -1)
@@ -228,3 +228,16 @@ def test_two_contexts_on_two_host_threads(orc, synth):
         ref = orc.get_diff_maps(both[i][0][:4], frs[i]["xyz"], synth.pixel_grid(H, W), H, W, frs[i]["cam"])
         m = excl_clamp_edge(both[i][5], ref, CLAMP)
         assert np.abs(both[i][5] - ref)[m].max() <= 1e-3
+
+
+def test_unknown_k2_variant_is_an_error(engine, frame40):
+    import dsac_amd
+    engine.set_frame(frame40["xyz"], frame40["uv"], 40, 40, frame40["cam"])
+    engine.set_option("k2_variant", 99)
+    try:
+        with pytest.raises(dsac_amd.capi.DsacError):
+            engine.getDiffMap(np.zeros((2, 6)))
+    finally:
+        engine.set_option("k2_variant", -1)
+    with pytest.raises(dsac_amd.capi.DsacError):
+        engine.set_option("no_such_knob", 1)
