@@ -389,51 +389,39 @@ DM_INLINE void align3_horn(const double M[3][3], const double X[3][3], double R[
 // ------------------------------------------------------------------------------------------------
 // solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
 // Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
-
-// ------------------------------------------------------------------------------------------------
-// solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
-// Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
 // (p3p) or by four neighbouring lanes in parallel (p3p_setup + p3p_eval_root, used by K1).
 // ------------------------------------------------------------------------------------------------
+// The setup keeps only what the quartic and the length recovery need (20 doubles).  The object points stay in their float
+// registers, the 4th image point and the object triangle's triad are re-derived per root: K1 evaluates the roots on four lanes in
+// parallel, so hoisting them bought nothing there and cost 46 live registers across the quartic solve (288 -> 2 waves per SIMD).
 struct P3PSetup {
     double f[3][3];   // unit bearing vectors of points 0..2
-    double Xw[3][3];  // object points 0..2
-    double X3[3];     // 4th object point
-    double mu3, mv3;  // 4th image point (pixels, after the float round trip of undistortPoints)
     double a, b, p, q, r, d2, inv_b0;
     double roots[4];
-    double Ew[9];     // orthonormal triad of the object triangle
     int n;
 };
 
+// undistortPoints (zero distortion) rounds the normalised coordinates to float; the solver then maps them back to pixels.
+DM_INLINE void p3p_image_point(const float uv[2], const Cam& K, double& mu, double& mv) {
+    const float xn = (float)(((double)uv[0] - K.cx) * (1. / K.fx));
+    const float yn = (float)(((double)uv[1] - K.cy) * (1. / K.fy));
+    mu = (double)xn * K.fx + K.cx;
+    mv = (double)yn * K.fy + K.cy;
+}
+
 DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K, P3PSetup& S) {
-    // undistortPoints (zero distortion) rounds the normalised coordinates to float; the solver then maps
-    // them back to pixels and normalises again in double.
-    double mu[4], mv[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float xn = (float)(((double)uv[i][0] - K.cx) * (1. / K.fx));
-        const float yn = (float)(((double)uv[i][1] - K.cy) * (1. / K.fy));
-        mu[i] = (double)xn * K.fx + K.cx;
-        mv[i] = (double)yn * K.fy + K.cy;
-    }
-    S.mu3 = mu[3]; S.mv3 = mv[3];
     const double inv_fx = 1. / K.fx, inv_fy = 1. / K.fy, cx_fx = K.cx / K.fx, cy_fy = K.cy / K.fy;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        const double u = inv_fx * mu[i] - cx_fx, v = inv_fy * mv[i] - cy_fy;
+        double mu, mv;
+        p3p_image_point(uv[i], K, mu, mv);
+        const double u = inv_fx * mu - cx_fx, v = inv_fy * mv - cy_fy;
         const double k = 1. / sqrt(u * u + v * v + 1);
         S.f[i][0] = u * k; S.f[i][1] = v * k; S.f[i][2] = k;
     }
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) S.Xw[i][j] = X[i][j];
-    S.X3[0] = X[3][0]; S.X3[1] = X[3][1]; S.X3[2] = X[3][2];
-    triad(S.Xw, S.Ew);
 
     auto dist = [&](int a, int b) {
-        const double dx = S.Xw[a][0] - S.Xw[b][0], dy = S.Xw[a][1] - S.Xw[b][1], dz = S.Xw[a][2] - S.Xw[b][2];
+        const double dx = (double)X[a][0] - (double)X[b][0], dy = (double)X[a][1] - (double)X[b][1], dz = (double)X[a][2] - (double)X[b][2];
         return sqrt(dx * dx + dy * dy + dz * dz);
     };
     auto dot = [&](int a, int b) { return S.f[a][0] * S.f[b][0] + S.f[a][1] * S.f[b][1] + S.f[a][2] * S.f[b][2]; };
@@ -464,7 +452,8 @@ DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K
 
 // One quartic root x -> (R, T, squared reprojection error of the 4th point).  false: root rejected.
 template <bool HORN = false>
-DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double Rc[9], double Tc[3], double& reproj) {
+DM_INLINE bool p3p_eval_root(const P3PSetup& S, const float X[4][3], const float uv[4][2], const Cam& K, double x, double Rc[9], double Tc[3],
+                             double& reproj) {
     if (!(x > 0)) return false;
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
@@ -488,13 +477,25 @@ DM_INLINE bool p3p_eval_root(const P3PSetup& S, const Cam& K, double x, double R
     for (int k = 0; k < 3; k++)
 #pragma unroll
         for (int j = 0; j < 3; j++) M[k][j] = L[k] * S.f[k][j];
-    if (HORN) align3_horn(M, S.Xw, Rc, Tc);
-    else align3(M, S.Xw, S.Ew, Rc, Tc);
-    const double X3p = Rc[0] * S.X3[0] + Rc[1] * S.X3[1] + Rc[2] * S.X3[2] + Tc[0];
-    const double Y3p = Rc[3] * S.X3[0] + Rc[4] * S.X3[1] + Rc[5] * S.X3[2] + Tc[1];
-    const double Z3p = Rc[6] * S.X3[0] + Rc[7] * S.X3[1] + Rc[8] * S.X3[2] + Tc[2];
+    double Xw[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Xw[i][j] = X[i][j];
+    if (HORN) align3_horn(M, Xw, Rc, Tc);
+    else {
+        double Ew[9];
+        triad(Xw, Ew);
+        align3(M, Xw, Ew, Rc, Tc);
+    }
+    const double X30 = X[3][0], X31 = X[3][1], X32 = X[3][2];
+    const double X3p = Rc[0] * X30 + Rc[1] * X31 + Rc[2] * X32 + Tc[0];
+    const double Y3p = Rc[3] * X30 + Rc[4] * X31 + Rc[5] * X32 + Tc[1];
+    const double Z3p = Rc[6] * X30 + Rc[7] * X31 + Rc[8] * X32 + Tc[2];
     const double mu3p = K.cx + K.fx * X3p / Z3p, mv3p = K.cy + K.fy * Y3p / Z3p;
-    reproj = (mu3p - S.mu3) * (mu3p - S.mu3) + (mv3p - S.mv3) * (mv3p - S.mv3);
+    double mu3, mv3;
+    p3p_image_point(uv[3], K, mu3, mv3);
+    reproj = (mu3p - mu3) * (mu3p - mu3) + (mv3p - mv3) * (mv3p - mv3);
     return true;
 }
 
@@ -509,7 +510,7 @@ DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, doub
     for (int i = 0; i < 4; i++) {
         if (i >= S.n) continue;
         double Rc[9], Tc[3], reproj;
-        if (!p3p_eval_root<HORN>(S, K, S.roots[i], Rc, Tc, reproj)) continue;
+        if (!p3p_eval_root<HORN>(S, X, uv, K, S.roots[i], Rc, Tc, reproj)) continue;
         if (!have || best > reproj) {
             have = true;
             best = reproj;

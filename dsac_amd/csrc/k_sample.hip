@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, Frame
             dm::P3PSetup S;
             if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
                 const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
-                cand = dm::p3p_eval_root<HORN>(S, K, x, Rc, Tc, reproj);
+                cand = dm::p3p_eval_root<HORN>(S, X, uv, K, x, Rc, Tc, reproj);
             }
         }
         // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
