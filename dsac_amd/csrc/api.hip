@@ -58,6 +58,7 @@ struct dsac_ctx {
     std::vector<Pending> pending;
     dk::K2Opts k2;  // launch knobs, read once in dsac_create (DSAC_K2_*) or set with dsac_set_option; no process-wide state
     dk::K1Opts k1;
+    int k4_variant = -1;  // K4 main-pass form (dk::backward_plan), DSAC_K4_VARIANT / dsac_set_option("k4_variant")
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
 
     // two-slot software pipeline (dsac_sample_ahead / dsac_score_sampled): K1 of frame i+1 on `aux` under K2/K3 of frame i
@@ -227,6 +228,7 @@ int dsac_create(dsac_ctx** out, int device) {
     if (const char* v = getenv("DSAC_K1_PRIO")) c->k1.prio = atoi(v);
     if (const char* v = getenv("DSAC_K1_HPW")) c->k1.hpw = atoi(v);
     if (const char* v = getenv("DSAC_K1_HORN")) c->k1.horn = atoi(v) != 0;
+    if (const char* v = getenv("DSAC_K4_VARIANT")) c->k4_variant = atoi(v);
     *out = c;
     return DSAC_OK;
 }
@@ -597,6 +599,7 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k1_prio") c->k1.prio = value;
     else if (k == "k1_hpw") c->k1.hpw = value;
     else if (k == "k1_horn") c->k1.horn = value != 0;
+    else if (k == "k4_variant") c->k4_variant = value;
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
     return DSAC_OK;
 }
@@ -669,23 +672,20 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>()));
         d_dpnp = s.as<double>();
     }
-    const int HT = dk::backward_hyp_tile(N, c->F.P);
-    const int NT = (N + HT - 1) / HT;
-    const int PTmax = dk::backward_num_partial_rows(c->F.P);
+    const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
     HIP_TRY(c, c->bwd_staged.reserve((size_t)N * dk::BWD_STRIDE * sizeof(float)));
     HIP_TRY(c, c->dRdH.reserve((size_t)N * 27 * sizeof(double)));
-    HIP_TRY(c, c->grad_part.reserve((size_t)NT * P * 3 * sizeof(float)));
-    HIP_TRY(c, c->g12_part.reserve((size_t)PTmax * N * 12 * sizeof(float)));
+    HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * P * 3 * sizeof(float)));
+    HIP_TRY(c, c->g12_part.reserve((size_t)plan.rows * N * 12 * sizeof(float)));
     HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
     HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
-    int PT = 0;
     {
         ProfScope ps(c, 1);
         HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
-                                      c->g12_part.as<float>(), &PT, HT));
+                                      c->g12_part.as<float>(), plan));
     }
-    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), NT, c->g12_part.as<float>(), PT, c->dRdH.as<double>(), d_dpnp,
-                                         d_sets, flags, d_grad, c->g6.as<double>()));
+    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.NT, c->g12_part.as<float>(), plan.rows, c->dRdH.as<double>(),
+                                         d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(), plan.variant > 0 ? c->bwd_staged.as<float>() : nullptr));
     c->g6_n = N;
     return end_call(c);
 }

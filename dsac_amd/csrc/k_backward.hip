@@ -278,33 +278,315 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
 }
 
 
-// Hypothesis tile of a launch (a kernel argument, <= K4_HT_MAX).  32 everywhere: a round-counting model (workgroups / (2 per CU),
-// cost ~ rounds x HT) suggested 86 for N = 256 on a 640 x 480 map (450 workgroups in one round instead of 1200 in 2.34) and 103 for
-// N = 1024; measured, 86 gains 3 % at N = 256 (175 -> 169 us) and 103 loses 5 % at N = 1024 (575 -> 602 us) -- workgroups do not
-// run in lock-step rounds, and long tiles have the longer tail.
-int backward_hyp_tile(int N, int P) {
-    (void)N; (void)P;
-    return 32;
+// --------------------------------------------------------------------------------------------------
+// K4 main pass, matrix-core form with per-lane hypothesis ownership (round 2).
+//
+// The rigid transform E = R'X + t' of 16 pixels under 16 hypotheses is three v_mfma_f32_16x16x4_f32 (exact fp32): the A operand holds
+// (X, Y, Z, 1) of 16 consecutive pixels (rows), the B operands the x-, negated y- and z-rows of 16 hypotheses (columns).  Lane (g, c)
+// of the wave then owns ONE hypothesis (column c) and FOUR CONSECUTIVE PIXELS (rows 4g .. 4g+3) in four adjacent registers, so
+//   * d_err arrives as one dwordx4 per lane in exactly that layout and every per-pair operation runs packed over a PIXEL pair
+//     (v_pk_fma_f32 / v_pk_mul_f32) with no register shuffles;
+//   * the 12 per-hypothesis sums are plain register accumulators of the lane over its pixels -- the 35-instruction wave reduction
+//     per (wave, hypothesis) of the VALU form is gone.  They are accumulated against E (already in registers) instead of X:
+//     sum_p C_j X = R'^T (sum_p C_j E - t' sum_p C_j), applied once per hypothesis in the finish kernel, so the pixel coordinates are
+//     not kept in registers at all.  Per 16-hypothesis group a 9-swap transpose-reduce over the 4 lane groups (v_permlane32_swap /
+//     v_permlane16_swap) leaves 3 of the 12 sums in every lane, which it adds into LDS -- the workgroup is PERSISTENT over pixel
+//     tiles, the LDS copy accumulates over all of them and is written out once;
+//   * grad[p] += w R'^T c accumulates over the hypothesis loop in registers (12 per 16-pixel chunk) and is summed over the 16
+//     hypothesis lanes of a DPP row once per pixel tile.
+// A pixel tile is 64 * CH consecutive pixels (wave w: chunks w*CH .. w*CH+CH-1 of 16 pixels), a workgroup owns HT <= 256 hypotheses
+// (records staged in LDS once) and walks the tiles pt0, pt0 + G, ...
+//   grad_part : [hyp tile][P*3]        G12_part : [G pixel workgroups][N][12]  (E-based sums, see k_support_scatter)
+// --------------------------------------------------------------------------------------------------
+constexpr int K4M_HT_MAX = 256;
+
+DM_INLINE float row16_sum_f(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+    v += dpp_merge<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
+    v += dpp_merge<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
+    v += dpp_merge<0x141, 0xf>(0.f, v);  // row_half_mirror
+    v += dpp_merge<0x140, 0xf>(0.f, v);  // row_mirror
+    return v;
 }
 
-int backward_num_partial_rows(int P) { return ((P + K4_THREADS - 1) / K4_THREADS) * (K4_THREADS / 64); }  // upper bound (scalar path)
+template <int CH, bool SOFTMODE, bool UV>
+__global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float* __restrict__ rec, const float* __restrict__ xyz,
+                                                                    const float* __restrict__ uv, const float* __restrict__ d_err,
+                                                                    const double* __restrict__ g, float* __restrict__ grad_part,
+                                                                    float* __restrict__ G12_part, int N, int P, int W, int PT, int NT, int G,
+                                                                    float f, float cx, float cy, float clampv, float kA, float kB, float beta, int HT) {
+    const int ht = blockIdx.x % NT;   // hypothesis tile of this workgroup
+    const int pw = blockIdx.x / NT;   // its index among the G workgroups that share the pixel tiles
+    const int h0 = ht * HT;
+    const int nh = min(HT, N - h0);
+    const int ngi = (nh + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, gq = lane >> 4;
+
+    // LDS: MFMA B operands in lane order (x row, negated y row, z row of 16 hypotheses), the per-hypothesis coefficients of the
+    // gradient accumulation, and the 12 sums of every (hypothesis, wave) accumulated over the workgroup's pixel tiles
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_B = s_dyn;                                  // [ngi][3][64]
+    float* s_C = s_B + (K4M_HT_MAX / 16) * 3 * 64;       // [HT][12]: r0 (3), nr1 (3), nr2 (3), g, pad
+    float* s_G = s_C + K4M_HT_MAX * 12;                  // [ngi][4 waves][16][12]
+    for (int i = tid; i < ngi * 3 * 64; i += K4_THREADS) {
+        const int l = i & 63, cg = i >> 6;
+        const int comp = cg % 3, gi = cg / 3;
+        const int hyp = min(16 * gi + (l & 15), nh - 1), k = l >> 4;  // ragged end: repeat the last record (its contributions are masked)
+        const float* o = rec + (size_t)(h0 + hyp) * BWD_REC;
+        // record (k_backward_prep): [0] (R'00,-R'10,R'01,-R'11) [1] (R'02,-R'12,t'0,-t'1) [2] (R'20,R'21,R'22,t'2)
+        s_B[i] = comp == 0 ? o[2 * k] : comp == 1 ? o[2 * k + 1] : o[8 + k];
+    }
+    for (int i = tid; i < ngi * 16 * 12; i += K4_THREADS) {
+        const int hyp = i / 12, j = i - hyp * 12;
+        const float* o = rec + (size_t)(h0 + min(hyp, nh - 1)) * BWD_REC;
+        // r0 = (R'00,R'01,R'02) = o[12],o[13],o[18]; nr1 = -(R'10,R'11,R'12) = o[14],o[15],o[19]; nr2 = -(R'20,R'21,R'22) = o[16],o[17],o[20]
+        const int off = (int)((0x854732610ull >> (4 * j)) & 15ull);  // j -> {0,1,6,2,3,7,4,5,8} (+12)
+        float v = 0.f;
+        if (j < 9) v = o[12 + off];
+        else if (j == 9) v = (SOFTMODE && hyp < nh) ? (float)g[h0 + hyp] : 0.f;
+        s_C[i] = v;
+    }
+    for (int i = tid; i < ngi * 4 * 16 * 12; i += K4_THREADS) s_G[i] = 0.f;
+    __syncthreads();
+
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f2 zero2 = {0.f, 0.f};
+    for (int pt = pw; pt < PT; pt += G) {
+        // per chunk: the MFMA A operand (coordinate gq of pixel base + c) and the position of this lane's own 4 pixels (base + 4 gq + 0..3)
+        float Aop[CH];
+        f2 pu[CH][2], pv[CH][2];
+        int p0[CH];
+        bool valid[CH];
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            const int base = (pt * (K4_THREADS / 64) * CH + wave * CH + ch) * 16;
+            p0[ch] = base + 4 * gq;
+            valid[ch] = p0[ch] < P;  // P % 4 == 0
+            const int pa = min(base + c, P - 1);
+            Aop[ch] = (gq < 3) ? xyz[(size_t)pa * 3 + gq] : 1.0f;
+            const int pl = min(p0[ch], P - 4);
+            if (UV) {
+                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)pl * 2);
+                const f4 u0 = su[0], u1 = su[1];
+                pu[ch][0] = f2{u0.x - cx, u0.z - cx}; pv[ch][0] = f2{u0.y - cy, u0.w - cy};
+                pu[ch][1] = f2{u1.x - cx, u1.z - cx}; pv[ch][1] = f2{u1.y - cy, u1.w - cy};
+            } else {
+                // implicit grid, W % 4 == 0 (launcher): the 4 pixels of a lane share a row
+                const int y = pl / W, x = pl - y * W;
+                const float xs = (float)x - cx, ys = (float)y - cy;
+                pu[ch][0] = f2{xs, xs + 1.f}; pu[ch][1] = f2{xs + 2.f, xs + 3.f};
+                pv[ch][0] = pv[ch][1] = f2{ys, ys};
+            }
+        }
+        f2 gx[CH][2], gy[CH][2], gz[CH][2];
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++)
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) gx[ch][pp] = gy[ch][pp] = gz[ch][pp] = zero2;
+
+        // d_err of the first group (one dwordx4 per chunk: 4 consecutive pixels of hypothesis c)
+        f4 wn[CH];
+        auto load_w = [&](int gi, f4 (&dst)[CH]) {
+            const int hyp = 16 * gi + c;
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) {
+                if (!SOFTMODE && hyp < nh && valid[ch]) dst[ch] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(d_err + (size_t)(h0 + hyp) * P + p0[ch]));
+                else dst[ch] = z4;
+            }
+        };
+        load_w(0, wn);
+
+        for (int gi = 0; gi < ngi; gi++) {
+            f4 wv[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) wv[ch] = wn[ch];
+            if (gi + 1 < ngi) load_w(gi + 1, wn);  // prefetch the next group's d_err under this group's arithmetic
+            const float bx = s_B[(gi * 3 + 0) * 64 + lane], by = s_B[(gi * 3 + 1) * 64 + lane], bz = s_B[(gi * 3 + 2) * 64 + lane];
+            const f4* cf = reinterpret_cast<const f4*>(s_C + (size_t)(16 * gi + c) * 12);
+            const f4 c0 = cf[0], c1 = cf[1], c2 = cf[2];  // (r0.x r0.y r0.z nr1.x) (nr1.y nr1.z nr2.x nr2.y) (nr2.z g - -)
+            const bool hyp_ok = 16 * gi + c < nh;
+            // S[j][m] = sum_p C_j * (E.x, -E.y, E.z, 1)_m with C_0 = C0, C_1 = -C1, C_2 = -C2; the two halves = the pixel pair's lanes
+            f2 S[3][4];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) S[j][k] = zero2;
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) {
+                const f4 ex4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], bx, z4, 0, 0, 0);   // E.x   of pixels p0 .. p0+3, hypothesis c
+                const f4 ny4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], by, z4, 0, 0, 0);   // -E.y
+                const f4 ez4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], bz, z4, 0, 0, 0);   // E.z
+                const bool lane_ok = hyp_ok && valid[ch];
+#pragma unroll
+                for (int pp = 0; pp < 2; pp++) {
+                    const f2 ex = pp ? f2{ex4.z, ex4.w} : f2{ex4.x, ex4.y};
+                    const f2 ny = pp ? f2{ny4.z, ny4.w} : f2{ny4.x, ny4.y};
+                    const f2 ez = pp ? f2{ez4.z, ez4.w} : f2{ez4.x, ez4.y};
+                    const f2 iz = {__builtin_amdgcn_rcpf(ez.x), __builtin_amdgcn_rcpf(ez.y)};
+                    const f2 fz = iz * f2{f, f};
+                    // (u - px, v - py) with px = -f E.x/E.z + cx, py = f E.y/E.z + cy
+                    const f2 du = __builtin_elementwise_fma(ex, fz, pu[ch][pp]);
+                    const f2 dv = __builtin_elementwise_fma(ny, fz, pv[ch][pp]);
+                    const f2 dq = __builtin_elementwise_fma(dv, dv, du * du);
+                    const f2 err = {__builtin_amdgcn_sqrtf(dq.x), __builtin_amdgcn_sqrtf(dq.y)};
+                    const f2 ee = err + f2{1e-8f, 1e-8f};
+                    const f2 ie = {__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
+                    f2 w;
+                    if (SOFTMODE) {
+                        const f2 ec = {fminf(err.x, clampv), fminf(err.y, clampv)};
+                        const f2 t = __builtin_elementwise_fma(f2{kA, kA}, ec, f2{kB, kB});
+                        const f2 dd = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f2{1.f, 1.f};
+                        const f2 sg = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+                        const float gb = c2.y * (-beta);
+                        w = (sg * f2{gb, gb}) * (f2{1.f, 1.f} - sg);
+                    } else {
+                        w = pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y};
+                    }
+                    // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0, err > CNN_OBJ_MAXINPUT -> 0 (the comparison is false for
+                    // the NaN / inf a zero E.z produces), lanes beyond the map or the ragged hypothesis end -> 0
+                    const bool k0 = lane_ok && (fabsf(ez.x) >= 1e-8f) && (err.x <= clampv);
+                    const bool k1 = lane_ok && (fabsf(ez.y) >= 1e-8f) && (err.y <= clampv);
+                    f2 wfz = (w * fz) * ie;                               // w f / (E.z (err + eps))
+                    wfz.x = k0 ? wfz.x : 0.f;
+                    wfz.y = k1 ? wfz.y : 0.f;
+                    const f2 wiz = {k0 ? wfz.x * iz.x : 0.f, k1 ? wfz.y * iz.y : 0.f};
+                    // a = -(du, dv)/(err+eps);  C0 = -a0 f/E.z ; C1 = a1 f/E.z ; C2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
+                    const f2 C0 = du * wfz;                               //  C0
+                    const f2 nC1 = dv * wfz;                              // -C1
+                    const f2 nC2 = __builtin_elementwise_fma(dv, ny, du * ex) * wiz;  // -C2
+                    gx[ch][pp] = __builtin_elementwise_fma(f2{c0.x, c0.x}, C0, __builtin_elementwise_fma(f2{c0.w, c0.w}, nC1, __builtin_elementwise_fma(f2{c1.z, c1.z}, nC2, gx[ch][pp])));
+                    gy[ch][pp] = __builtin_elementwise_fma(f2{c0.y, c0.y}, C0, __builtin_elementwise_fma(f2{c1.x, c1.x}, nC1, __builtin_elementwise_fma(f2{c1.w, c1.w}, nC2, gy[ch][pp])));
+                    gz[ch][pp] = __builtin_elementwise_fma(f2{c0.z, c0.z}, C0, __builtin_elementwise_fma(f2{c1.y, c1.y}, nC1, __builtin_elementwise_fma(f2{c2.x, c2.x}, nC2, gz[ch][pp])));
+                    // E is exactly 0 where a guard fired with a NaN / inf intermediate?  No: C_j are exactly 0 there and E is finite
+                    // (an MFMA of finite inputs), so the products below are exact zeros.
+                    S[0][0] = __builtin_elementwise_fma(C0, ex, S[0][0]); S[0][1] = __builtin_elementwise_fma(C0, ny, S[0][1]);
+                    S[0][2] = __builtin_elementwise_fma(C0, ez, S[0][2]); S[0][3] += C0;
+                    S[1][0] = __builtin_elementwise_fma(nC1, ex, S[1][0]); S[1][1] = __builtin_elementwise_fma(nC1, ny, S[1][1]);
+                    S[1][2] = __builtin_elementwise_fma(nC1, ez, S[1][2]); S[1][3] += nC1;
+                    S[2][0] = __builtin_elementwise_fma(nC2, ex, S[2][0]); S[2][1] = __builtin_elementwise_fma(nC2, ny, S[2][1]);
+                    S[2][2] = __builtin_elementwise_fma(nC2, ez, S[2][2]); S[2][3] += nC2;
+                }
+            }
+            // the 12 sums of hypothesis c over this lane's pixels (pair halves added), in the order a[3 j + m], a[9 + j] -> index
+            // q = 0..11; then the transpose-reduce over the 4 lane groups: lane (g, c) ends with the totals of q = 3 g .. 3 g + 2
+            float a[12];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) a[3 * j + k] = S[j][k].x + S[j][k].y;
+                a[9 + j] = S[j][3].x + S[j][3].y;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { lane_swap32(a[k], a[6 + k]); a[k] += a[6 + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lane_swap16(a[k], a[3 + k]); a[k] += a[3 + k]; }
+            float* dst = s_G + ((size_t)(gi * 4 + wave) * 16 + c) * 12 + 3 * gq;  // private to this lane: plain read-modify-write
+            dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2];
+        }
+
+        // grad: sum over the 16 hypothesis lanes of the row, lane c == 0 of every row stores its 4 pixels (12 consecutive floats)
+#pragma unroll
+        for (int ch = 0; ch < CH; ch++) {
+            float o[12];
+#pragma unroll
+            for (int pp = 0; pp < 2; pp++) {
+                o[6 * pp + 0] = row16_sum_f(gx[ch][pp].x); o[6 * pp + 1] = row16_sum_f(gy[ch][pp].x); o[6 * pp + 2] = row16_sum_f(gz[ch][pp].x);
+                o[6 * pp + 3] = row16_sum_f(gx[ch][pp].y); o[6 * pp + 4] = row16_sum_f(gy[ch][pp].y); o[6 * pp + 5] = row16_sum_f(gz[ch][pp].y);
+            }
+            if (c == 0 && valid[ch]) {
+                f4* dstg = reinterpret_cast<f4*>(grad_part + (size_t)ht * P * 3 + (size_t)p0[ch] * 3);
+                dstg[0] = f4{o[0], o[1], o[2], o[3]};
+                dstg[1] = f4{o[4], o[5], o[6], o[7]};
+                dstg[2] = f4{o[8], o[9], o[10], o[11]};
+            }
+        }
+    }
+
+    // G12 (E-based): sum over the 4 waves, one row per pixel workgroup
+    __syncthreads();
+    for (int i = tid; i < nh * 12; i += K4_THREADS) {
+        const int hyp = i / 12, j = i - hyp * 12;
+        const int gi = hyp >> 4, cc = hyp & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += s_G[((size_t)(gi * 4 + w) * 16 + cc) * 12 + j];
+        G12_part[((size_t)pw * N + h0 + hyp) * 12 + j] = v;
+    }
+}
+
+static size_t k4m_lds_bytes(int HT) {
+    const int ngi = (HT + 15) / 16;
+    return ((size_t)(K4M_HT_MAX / 16) * 3 * 64 + (size_t)K4M_HT_MAX * 12 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
+}
+
+// Launch plan (see kernels.h).  VALU form: hypothesis tile 32 -- a round-counting model (workgroups / (2 per CU), cost ~ rounds x HT)
+// suggested 86 for N = 256 on a 640 x 480 map and 103 for N = 1024; measured, 86 gains 3 % at N = 256 and 103 loses 5 % at N = 1024
+// (workgroups do not run in lock-step rounds, and long tiles have the longer tail).  Matrix-core form: all hypotheses of the frame in one
+// tile up to 256 (the d_err stream is read once either way; a single tile writes grad_part once).
+K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) {
+    K4Plan pl{};
+    const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
+    if (variant < 0) variant = 1;
+    // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
+    if (!vec || variant > 2 || (!F.uv && F.W % 4 != 0)) variant = 0;
+    pl.variant = variant;
+    if (variant == 0) {
+        pl.HT = 32;
+        const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
+        pl.rows = ((F.P + tile - 1) / tile) * (K4_THREADS / 64);
+    } else {
+        const int CH = variant == 1 ? 2 : 4;
+        pl.HT = min(K4M_HT_MAX, ((max(N, 1) + 15) / 16) * 16);
+        pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
+        // persistent workgroups: 2 per CU by LDS (72 KB each at HT = 256), shared between the hypothesis tiles; at least one per tile
+        const int PT = (F.P + 64 * CH - 1) / (64 * CH);
+        pl.rows = max(1, min(PT, (2 * 256 + pl.NT - 1) / pl.NT));
+        return pl;
+    }
+    pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
+    return pl;
+}
 
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g, float clampv,
-                          float tau, float beta, float* grad_part, float* G12_part, int* partial_rows_used, int HT) {
-    if (partial_rows_used) *partial_rows_used = 0;
+                          float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan) {
     if (N <= 0) return hipSuccess;
-    if (HT < 1 || HT > K4_HT_MAX) return hipErrorInvalidValue;
+    const int HT = plan.HT, NT = plan.NT;
     const bool soft = d_err == nullptr;
-    const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(grad_part) & 15) == 0);
-    const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
-    const int PT = (F.P + tile - 1) / tile;
-    const int NT = (N + HT - 1) / HT;
-    const int grid = ((PT + 7) / 8) * 8 * NT;
-    if (partial_rows_used) *partial_rows_used = PT * (K4_THREADS / 64);
     const float LOG2E = 1.4426950408889634f;
     const float kA = beta * LOG2E, kB = -beta * tau * LOG2E;
     const bool UV = F.uv != nullptr;
+    if (plan.variant > 0) {
+        if (HT < 16 || HT > K4M_HT_MAX || (reinterpret_cast<uintptr_t>(grad_part) & 15)) return hipErrorInvalidValue;
+        const int CH = plan.variant == 1 ? 2 : 4;
+        const int PT = (F.P + 64 * CH - 1) / (64 * CH);
+        const int G = plan.rows;
+        const int grid = G * NT;
+        const size_t lds = k4m_lds_bytes(HT);
+#define DSAC_K4M(C_, S_, U_)                                                                                                               \
+    do {                                                                                                                                    \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_backward_mfma<C_, S_, U_>),                                \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
+        if (e_ != hipSuccess) return e_;                                                                                                    \
+        hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,       \
+                           grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT);                            \
+    } while (0)
+        if (CH == 2) {
+            if (soft) { if (UV) DSAC_K4M(2, true, true); else DSAC_K4M(2, true, false); }
+            else { if (UV) DSAC_K4M(2, false, true); else DSAC_K4M(2, false, false); }
+        } else {
+            if (soft) { if (UV) DSAC_K4M(4, true, true); else DSAC_K4M(4, true, false); }
+            else { if (UV) DSAC_K4M(4, false, true); else DSAC_K4M(4, false, false); }
+        }
+#undef DSAC_K4M
+        return hipGetLastError();
+    }
+    if (HT < 1 || HT > K4_HT_MAX) return hipErrorInvalidValue;
+    const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(grad_part) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
+    const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
+    const int PT = (F.P + tile - 1) / tile;
+    const int grid = ((PT + 7) / 8) * 8 * NT;
 #define DSAC_K4(G_, V_, S_, U_)                                                                                                              \
     hipLaunchKernelGGL((k_score_backward<G_, V_, S_, U_>), dim3(grid), dim3(K4_THREADS), 0, st, staged_bwd, F.xyz, F.uv, d_err, g, grad_part, \
                        G12_part, N, F.P, F.W, PT, NT, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT)
@@ -343,7 +625,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(int P, int W, int H, int hy
 __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel_tiles, const float* __restrict__ G12_part,
                                                          const double* __restrict__ dRdH, const double* __restrict__ dpnp,
                                                          const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
-                                                         double* __restrict__ G6_out) {
+                                                         double* __restrict__ G6_out, const float* __restrict__ rec_e) {
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
@@ -361,6 +643,33 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
     for (int i = 0; i < 12; i++) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) G[i] += __shfl_xor(G[i], o, 64);
+    }
+    if (rec_e) {
+        // matrix-core main pass: the sums were taken against E = R'X + t' (signed as the kernel held them):
+        //   a[3j + m] = sum C~_j E~_m, a[9 + j] = sum C~_j  with C~ = (C0, -C1, -C2), E~ = (E.x, -E.y, E.z)
+        // sum_p C_j X_k = sum_m R'[m][k] (sum C_j E_m - t'_m sum C_j); R', t' as the fp32 record the kernel computed E from
+        const float* o = rec_e + (size_t)h * BWD_REC;
+        const double Rp[3][3] = {{o[0], o[2], o[4]}, {-(double)o[1], -(double)o[3], -(double)o[5]}, {o[8], o[9], o[10]}};
+        const double tp[3] = {o[6], -(double)o[7], o[11]};
+        const double sj[3] = {1, -1, -1}, sm[3] = {1, -1, 1};
+        double A[3][3], B[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            B[j] = sj[j] * G[9 + j];
+#pragma unroll
+            for (int m = 0; m < 3; m++) A[j][m] = sj[j] * sm[m] * G[3 * j + m];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                double v = 0;
+#pragma unroll
+                for (int m = 0; m < 3; m++) v += Rp[m][k] * (A[j][m] - tp[m] * B[j]);
+                G[3 * j + k] = v;
+            }
+            G[9 + j] = B[j];
+        }
     }
     double G6[6];
 #pragma unroll
@@ -395,12 +704,12 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags, double* grad_xyz,
-                                 double* G6_scratch) {
+                                 double* G6_scratch, const float* rec_if_e_based) {
     if (N <= 0) return hipSuccess;
     const size_t n3 = (size_t)F.P * 3;
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
     hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
-                       G6_scratch);
+                       G6_scratch, rec_if_e_based);
     return hipGetLastError();
 }
 

@@ -63,18 +63,26 @@ hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, f
 // ---- k_backward.hip --------------------------------------------------------------------------------
 // jp-convention staged records for the backward pass, BWD_STRIDE floats per hypothesis (see k_backward.hip).
 constexpr int BWD_STRIDE = 24;  // six float4 per hypothesis, already sign-folded and pair-packed for K4's packed-fp32 chains
-int backward_num_partial_rows(int P);  // rows of G12_part (pixel tiles x waves), upper bound
-int backward_hyp_tile(int N, int P);  // hypothesis tile chosen for a launch (16..128), see k_backward.hip
+// Launch plan of the K4 main pass: which kernel form, its hypothesis tile and the sizes of the two partial-sum buffers.
+//   variant 0 = VALU form (lane = 8 pixels, wave reduction of the 12 sums per hypothesis), 1 / 2 = matrix-core form with 2 / 4 16-pixel
+//   chunks per wave (lane = one hypothesis x 4 consecutive pixels), -1 = auto.  Maps that cannot be read as 16-byte vectors use variant 0.
+struct K4Plan {
+    int variant;  // resolved form
+    int HT, NT;   // hypotheses per workgroup, number of hypothesis tiles (rows of grad_part)
+    int rows;     // rows of G12_part the launch writes
+};
+K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant);
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [partial rows][N][12] floats
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
-                          float clampv, float tau, float beta, float* grad_part, float* G12_part, int* pixel_tiles_used, int HT);
+                          float clampv, float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan);
 // Epilogue: grad_xyz (P x 3 double) += sum over hyp tiles; then per hypothesis G6 = [G9 * dRdH, G3],
 // S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
-                                 double* grad_xyz, double* G6_scratch);
+                                 double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr);
+// rec_if_e_based: the BWD records when G12_part holds the matrix-core form's E-based sums (K4Plan.variant > 0), else nullptr
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                   const double* dpnp, double* grad_xyz, double* g);
 

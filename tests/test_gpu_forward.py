@@ -179,7 +179,7 @@ def test_dpnp_parity(engine, orc, frame40):
     print("dPNP rel err: median %.2e  p90 %.2e  max %.2e" % (np.median(rel), np.quantile(rel, 0.9), rel.max()))
     assert np.median(rel) <= 1e-6
     assert (rel <= 1e-4).mean() >= 0.9
-    assert rel.max() <= 5e-2
+    assert rel.max() <= 1e-3  # measured 1.7e-4 (Horn alignment in K5 as in OpenCV)
 
 
 def test_device_pointers_through_torch(engine, orc, frame40):
