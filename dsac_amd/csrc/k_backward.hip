@@ -527,7 +527,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     K4Plan pl{};
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
-    if (variant < 0) variant = 1;
+    if (variant < 0) variant = 2;  // 4 chunks per wave: 133 vs 147 us with 2 (N = 256, 640 x 480)
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 2 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
@@ -537,10 +537,13 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         pl.rows = ((F.P + tile - 1) / tile) * (K4_THREADS / 64);
     } else {
         const int CH = variant == 1 ? 2 : 4;
+        // Persistent workgroups, 2 per CU (register- and LDS-limited: 2 waves per SIMD), shared between the hypothesis tiles.  The biggest
+        // hypothesis tile wins: a round-counting model preferred HT = 128 for N = 256 on 640 x 480 (5 rounds of 128 instead of 3 of 256
+        // for the 1200 pixel tiles on 512 workgroups), measured it loses (145 vs 133 us; N = 1024: 541 vs 506) -- a workgroup that runs out
+        // of tiles early leaves the VALU to its SIMD neighbours, so the imbalance costs far less than the extra set-up.
+        const int PT = (F.P + 64 * CH - 1) / (64 * CH);
         pl.HT = min(K4M_HT_MAX, ((max(N, 1) + 15) / 16) * 16);
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
-        // persistent workgroups: 2 per CU by LDS (72 KB each at HT = 256), shared between the hypothesis tiles; at least one per tile
-        const int PT = (F.P + 64 * CH - 1) / (64 * CH);
         pl.rows = max(1, min(PT, (2 * 256 + pl.NT - 1) / pl.NT));
         return pl;
     }

@@ -79,11 +79,12 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // One wave per hypothesis.  Lane l evaluates quartic root (l & 3) of attempt base + (l >> 2): 16 attempts
 // per round, the four candidate poses of an attempt side by side (their Jacobi eigen-solves, the long pole
 // of P3P, run in parallel instead of in sequence).
-// WPB waves (hypotheses) per workgroup.  The kernel is meant to run underneath the bandwidth-bound K2 of another frame; a
-// K1 wave holds 278 registers (occupancy 1), so wherever it lands it takes more than half of that SIMD's register file
-// away from K2's waves.  Measured on MI355X (scripts/gpu_k1_layout.sh, default bench): 1 wave/workgroup (every CU gets one)
-// 91.3 us/step, 4 waves (one CU in four, all four SIMDs) 90.3, 8 waves (2 per SIMD, 100 B scratch) 94.6, 16 waves (128
-// VGPRs, 580 B scratch per lane) 125.  Raised wave priority is worth ~1 us.
+// WPB waves (hypotheses) per workgroup.  A K1 wave holds 288 registers (occupancy 1).  Round 1 ran K1 underneath the bandwidth-bound K2
+// of another frame and chose 4 waves per workgroup (one CU in four, all four SIMDs: 90.3 vs 91.3 us per step with 1, 94.6 with 8 = 2 per
+// SIMD and 100 B of scratch, 125 with 16).  Round 2's default step does not overlap (with K2 at 0.70 of HBM peak the overlap no longer
+// pays, profiles/r02_bench_modes.txt) and K1 alone is fastest with ONE wave per workgroup -- every CU gets work first:
+// N = 2048: 48.6 us (1) / 54.8 (4) / 49.4 (8) / 50.0 (register budget for 2 waves per SIMD, 140 B scratch); N = 4096: 66.8 / 83.7 / 76.4 /
+// 63.1 (profiles/r02_k1_variants.txt).  Raised wave priority is worth ~1 us under K2.
 // HPW hypotheses per wave: each hypothesis owns 64/HPW lanes = 16/HPW attempts per round (4 root lanes each).  Attempts are
 // consumed in index order and the lowest accepted index wins, so the result does not depend on HPW (the GPU tests pass with
 // DSAC_K1_HPW=2 and 4).  The idea was that the instruction stream of a round costs the same whether 4 or 64 lanes are live;
@@ -92,8 +93,10 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // of HPW=1 are busy and fewer lanes per hypothesis only serialise.  HPW=1 stays the default; the knob is for easy frames.
 // HORN: align the P3P triangle with Horn's quaternion method (4x4 Jacobi) as OpenCV does instead of the orthonormal triad --
 // the parity mode (poses equal the oracle's to rounding also on near-degenerate sets); several times slower, the triad is the default.
-template <int WPB, int HPW, bool HORN = false>
-__global__ __launch_bounds__(64 * WPB) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
+// MINW: minimum waves per SIMD the register allocation must leave room for (1: 288 registers, no scratch; 2: 256 registers + 140 B of
+// scratch per lane, two waves share a SIMD and hide each other's fp64 dependency chains)
+template <int WPB, int HPW, bool HORN = false, int MINW = 1>
+__global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                      int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
                                                      int Nf) {
     if (prio >= 3) __builtin_amdgcn_s_setprio(3);
@@ -227,6 +230,10 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         const int H2 = o.hpw > 0 ? o.hpw : 1;  // see the measurement in the kernel's comment
 #define DSAC_K1(W, G, HN) hipLaunchKernelGGL((k_sample<W, G, HN>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
         if (o.horn) DSAC_K1(1, 1, true);
+        else if (o.minw >= 2 && H2 == 1) {
+            if (wpb >= 4) hipLaunchKernelGGL((k_sample<4, 1, false, 2>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
+            else hipLaunchKernelGGL((k_sample<1, 1, false, 2>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
+        }
         else if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4, false); else DSAC_K1(1, 4, false); }
         else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2, false); else if (wpb >= 4) DSAC_K1(4, 2, false); else DSAC_K1(1, 2, false); }
         else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }

@@ -52,7 +52,7 @@ hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, do
 // Launch knobs of K1 (context state like K2Opts): waves per workgroup (DSAC_K1_WPB in {1, 4, 8}), wave priority (DSAC_K1_PRIO 0..3),
 // hypotheses per wave (DSAC_K1_HPW in {1, 2, 4}), Horn alignment of the P3P triangle as in OpenCV instead of the triad (DSAC_K1_HORN).
 struct K1Opts {
-    int wpb = 4, prio = 3, hpw = 1;
+    int wpb = 1, prio = 3, hpw = 1, minw = 1;  // minw: minimum waves per SIMD of the register allocation (DSAC_K1_MINW)
     bool horn = false;
 };
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,

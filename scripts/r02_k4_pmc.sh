@@ -23,7 +23,7 @@ for k, d in agg.items():
 PY
 }
 {
-for v in 0 1 2; do for m in d_err soft; do
+for v in 1 2; do for m in d_err; do
   export DSAC_K4_VARIANT=$v
   pmc k4v${v}_${m}_sq SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -- python $REPO/scripts/k4_one.py 256 $m 6
   pmc k4v${v}_${m}_b GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS -- python $REPO/scripts/k4_one.py 256 $m 6

@@ -188,7 +188,7 @@ def test_two_contexts_on_two_host_threads(orc, synth):
     import threading
     import dsac_amd
     frs = [synth.chess_like_frame(H, W, seed=50 + i) for i in range(2)]
-    knobs = [dict(k2_variant=0, k2_order=0, k1_wpb=1), dict(k2_variant=7, k2_order=1, k1_wpb=4)]
+    knobs = [dict(k2_variant=0, k2_order=0, k1_wpb=1), dict(k2_variant=21, k2_order=1, k1_wpb=4)]
     N = 128
 
     def run(i, reps, out):
