@@ -134,14 +134,83 @@ std::array<double, 6> Frame::dLossMax(const cv_trans_t& est, const Hypothesis& g
 }
 
 ProcessImageResult Frame::processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
-                                       const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha) {
+                                       const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha,
+                                       const std::vector<std::array<int32_t, 4>>* givenSets) {
     ProcessImageResult r;
-    sampleHypotheses(objHyps, seed, inlierThreshold2D, r.hyps, r.imgIdx);
+    if (givenSets && !givenSets->empty()) {
+        objHyps = (int)givenSets->size();
+        std::vector<double> poses((size_t)objHyps * 6);
+        std::vector<uint8_t> ok(objHyps);
+        r.imgIdx.assign(objHyps, {0, 0, 0, 0});
+        check(dsac_sample(ctx_, objHyps, seed, &(*givenSets)[0][0], (float)inlierThreshold2D, 1, poses.data(), &r.imgIdx[0][0], ok.data()), "dsac_sample");
+        r.hyps.resize(objHyps);
+        for (int h = 0; h < objHyps; h++) r.hyps[h] = unpack({poses[h * 6], poses[h * 6 + 1], poses[h * 6 + 2], poses[h * 6 + 3], poses[h * 6 + 4], poses[h * 6 + 5]});
+    } else {
+        sampleHypotheses(objHyps, seed, inlierThreshold2D, r.hyps, r.imgIdx);
+    }
     const std::vector<double> scores = softInlierScores(r.hyps, tau, beta);  // the score-CNN seam of cnn_softam.h:1072
     r.sfScores = softArgMax(scores, alpha, r.hyps, r.sfEntropy, r.avgHyp);
     r.refAvgHyp = refine(inlierCount, refSteps, (float)inlierThreshold2D, pixelIdxs, r.avgHyp, &r.inlierMap, &r.refStepsDone);
     r.loss = maxLoss(poseGT, r.refAvgHyp, &r.rotErr, &r.tErr, &r.correct);
     return r;
+}
+
+std::vector<double> Frame::backward(const ProcessImageResult& fwd, const Hypothesis& poseGT, int inlierThreshold2D, int inlierCount, int refSteps,
+                                    float subSampleFactor, const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha,
+                                    bool referenceIndexQuirk) {
+    const size_t P = (size_t)H_ * W_;
+    const int N = (int)fwd.hyps.size();
+    std::vector<double> grad(P * 3, 0.0);
+    // --- path I: derivative of the loss wrt the refined average hypothesis (train_ransac_softam.cpp:301-304) ...
+    const std::array<double, 6> dL = dLossMax(fwd.refAvgHyp, poseGT);
+    std::array<double, 6> v6 = dL;
+    if (fwd.refStepsDone > 0) {
+        // ... times the refinement's Jacobians wrt the object coordinates (:307-312) and wrt the average hypothesis (:315-318)
+        std::array<double, 36> Jhyp;
+        std::vector<int32_t> px;
+        std::vector<double> Jobj;
+        dRefine(inlierCount, refSteps, (float)inlierThreshold2D, subSampleFactor, pixelIdxs, fwd.avgHyp, fwd.inlierMap, Jhyp, px, Jobj);
+        for (size_t i = 0; i < px.size(); i++)
+            for (int c = 0; c < 3; c++) {
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += dL[k] * Jobj[i * 18 + k * 3 + c];
+                grad[(size_t)px[i] * 3 + c] += s;
+            }
+        for (int j = 0; j < 6; j++) {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += dL[k] * Jhyp[k * 6 + j];
+            v6[j] = s;
+        }
+    }
+    // ... the average is a weighted sum of hypotheses whose dPNP reaches the 4 support points of each (:344-357), and the softmax
+    // backward gives the score gradients of path II (:361-376): one call
+    const std::vector<double> J = dPNP(fwd.imgIdx);
+    const std::vector<double> p = flatten(fwd.hyps);
+    std::vector<double> g(N);
+    check(dsac_path1_and_softmax_backward(ctx_, N, v6.data(), fwd.sfScores.data(), p.data(), &fwd.imgIdx[0][0], J.data(), grad.data(), g.data()),
+          "dsac_path1_and_softmax_backward");
+    // --- path II: score gradients -> error images -> object coordinates (dScore, :379-383); the score is alpha * soft-inlier count
+    for (double& x : g) x *= alpha;
+    if (!referenceIndexQuirk) {
+        check(dsac_soft_score_backward(ctx_, N, p.data(), &fwd.imgIdx[0][0], g.data(), (float)CNN_OBJ_MAXINPUT, tau, beta, J.data(), 0u, grad.data()),
+              "dsac_soft_score_backward");
+        return grad;
+    }
+    // Parity mode for square (reference-sized) maps: the reference reads the score CNN's input gradient back x-major
+    // (core/lua_calls.h:329-335) and dScore then addresses pixel (y, x) as x*cols*3 + y*3 (cnn_softam.h:628,641).  Reproduced literally:
+    // the gradient images are formed explicitly, handed over transposed, and K4 writes to the transposed index.
+    const std::vector<float> err = getDiffMaps(fwd.hyps);
+    std::vector<float> dDiff((size_t)N * P);
+    for (int h = 0; h < N; h++)
+        for (int y = 0; y < H_; y++)
+            for (int x = 0; x < W_; x++) {
+                const double e = err[(size_t)h * P + (size_t)x * W_ + y];  // natural gradient of cell (x, y) lands in cell (y, x)
+                const double sg = 1.0 / (1.0 + std::exp(-(double)beta * ((double)tau - e)));
+                dDiff[(size_t)h * P + (size_t)y * W_ + x] = (float)(g[h] * (-(double)beta) * sg * (1.0 - sg));
+            }
+    check(dsac_score_backward(ctx_, N, p.data(), &fwd.imgIdx[0][0], dDiff.data(), J.data(), DSAC_BWD_QUIRK_TRANSPOSE, grad.data()),
+          "dsac_score_backward");
+    return grad;
 }
 
 std::vector<double> softMax(const std::vector<double>& scores) {

@@ -80,8 +80,16 @@ public:
                  std::vector<int32_t>& objPixels, std::vector<double>& dRefineObj);
     double maxLoss(const Hypothesis& gt, const cv_trans_t& est, double* rotErr = nullptr, double* tErr = nullptr, bool* correct = nullptr);
     std::array<double, 6> dLossMax(const cv_trans_t& est, const Hypothesis& gt);
+    // givenSets (optional): evaluate these minimal sets instead of drawing them (replay of a recorded run)
     ProcessImageResult processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
-                                    const std::vector<int32_t>& pixelIdxs, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
+                                    const std::vector<int32_t>& pixelIdxs, float tau = 10.f, float beta = 0.5f, double alpha = 0.1,
+                                    const std::vector<std::array<int32_t, 4>>* givenSets = nullptr);
+    // The backward section of the trainer, core/train_ransac_softam.cpp:288-394: dLoss/d(scene coordinates), H*W x 3, from the
+    // forward pass's results.  Path I: dLossMax . (dRefineObj + dRefineHyp . sum_h w_h dPNP_h); path II: softmax backward -> score
+    // gradients -> (soft-inlier) score backward.  referenceIndexQuirk reproduces the transposed pixel index of path II (:628,641).
+    std::vector<double> backward(const ProcessImageResult& fwd, const Hypothesis& poseGT, int inlierThreshold2D, int inlierCount, int refSteps,
+                                 float subSampleFactor, const std::vector<int32_t>& pixelIdxs, float tau = 10.f, float beta = 0.5f,
+                                 double alpha = 0.1, bool referenceIndexQuirk = false);
 
     dsac_ctx* context() { return ctx_; }
 

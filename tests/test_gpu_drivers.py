@@ -1,0 +1,98 @@
+"""The driver programs (dsac_amd/host/test_ransac_softam, train_ransac_softam: the shape of the reference's mains) on the GPU: the golden
+frame of the REAL reference (tests/golden/ref_frame_v1.npz) is laid out as a 7-Scenes-style scene, replayed from the reference's own
+minimal sets and shuffles, and the numbers in the output files are compared with what the reference produced for that frame."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dsac_amd", "host")
+G = os.path.join(ROOT, "tests", "golden", "ref_frame_v1.npz")
+
+
+def _scene(tmp, split, translation=None):
+    from dsac_amd import driver_io
+    from dsac_amd.synth import rodrigues
+    g = dict(np.load(G))
+    R = rodrigues(g["gt_jp6"][:3])
+    T = driver_io.pose_matrix_from_jp(R, g["gt_jp6"][3:], translation)
+    sets = (g["sampledPoints"][:, :, 1] * 40 + g["sampledPoints"][:, :, 0]).astype(np.int32)
+    driver_io.make_scene(os.path.join(tmp, split), "chess", [dict(name="frame-000000", xyz=g["estObj"], H=40, W=40, sampling=g["sampling"].astype(np.float32),
+                                                                 pose_T=T, sets=sets, perm=g["pixelIdxs"])])
+    if translation is not None:
+        with open(os.path.join(tmp, "translation.txt"), "w") as f:
+            f.write("%g %g %g\n" % tuple(translation))
+    with open(os.path.join(tmp, "default.config"), "w") as f:  # the frame's parameters come from the config file, as a scene directory's would
+        f.write("# golden frame\nrI 64\nrT2D %d\nrB %d\nrRI %d\nrSS %g\nfl %g\n" % (int(g["thr"]), int(g["inlier_count"]), int(g["ref_steps"]), float(g["sub_sample"]),
+                                                                                      float(g["cam"][0])))
+    return g
+
+
+def _export_reference(ref_cv6, translation):
+    """core/test_ransac_softam.cpp:161-210 in numpy"""
+    from dsac_amd.synth import rodrigues
+    from scipy.spatial.transform import Rotation
+    F = np.diag([1.0, -1.0, -1.0])
+    R, t = F @ rodrigues(ref_cv6[:3]), F @ ref_cv6[3:]  # cv2our (det > 0 here)
+    M = np.eye(4); M[:3, :3] = R; M[:3, 3] = t
+    M = np.linalg.inv(M) @ np.diag([1.0, -1.0, -1.0, 1.0])
+    v = np.concatenate([Rotation.from_matrix(M[:3, :3]).as_rotvec(), M[:3, 3] / 1000.0])
+    if translation is not None:
+        v[3:] += np.asarray(translation)
+    return v
+
+
+@pytest.mark.parametrize("translation", [None, (0.25, -0.5, 1.0)])
+def test_evaluation_program_on_the_golden_frame(tmp_path, translation):
+    tmp = str(tmp_path)
+    g = _scene(tmp, "test", translation)
+    out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-tau", str(float(g["tau"])), "-beta", str(float(g["beta"])), "-alpha", str(float(g["alpha"]))],
+                         cwd=tmp, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Processing test image 0 of 1." in out.stdout and "Avg. test loss:" in out.stdout and "Median Rot. Error:" in out.stdout
+    # file names and column order of core/test_ransac_softam.cpp:84-95, 212-263
+    err = np.loadtxt(os.path.join(tmp, "ransac_test_errors_obj_model_init.net_rdraw1_softam.txt")).reshape(-1, 10)
+    tot = np.loadtxt(os.path.join(tmp, "ransac_test_loss_obj_model_init.net_rdraw1_softam.txt")).reshape(7)
+    loss, ent, tErr, rotErr = err[0, :4]
+    assert abs(loss - float(g["loss"])) <= 1e-3 * max(1.0, float(g["loss"]))          # the pose file is parsed in float, as in the reference
+    assert abs(ent - float(g["sfEntropy"])) <= 2e-3
+    assert abs(tErr - float(g["tErr"])) <= 1e-2 and abs(rotErr - float(g["rotErr"])) <= 1e-4
+    want = _export_reference(g["refAvgHyp"], translation)
+    assert np.abs(err[0, 4:7] - want[:3]).max() <= 1e-5 and np.abs(err[0, 7:10] - want[3:]).max() <= 1e-5
+    # one image: mean = its value, stddev 0, medians = its errors
+    assert tot[0] == float(bool(g["correct"])) and abs(tot[1] - loss) <= 1e-9 and tot[2] == 0 and abs(tot[3] - ent) <= 1e-9 and tot[4] == 0
+    assert abs(tot[5] - rotErr) <= 1e-9 and abs(tot[6] - tErr) <= 1e-9
+
+
+def test_training_program_on_the_golden_frame(tmp_path):
+    tmp = str(tmp_path)
+    g = _scene(tmp, "training")
+    out = subprocess.run([os.path.join(HOST, "train_ransac_softam"), "-rounds", "1", "-quirk", "1", "-tau", str(float(g["tau"])), "-beta", str(float(g["beta"])),
+                          "-alpha", str(float(g["alpha"]))], cwd=tmp, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Round 0 of 1." in out.stdout and "Max gradient:" in out.stdout and "Zero gradients:" in out.stdout
+    log = np.loadtxt(os.path.join(tmp, "ransac_training_loss_train_obj.lua.txt")).reshape(-1, 3)  # round, loss, sfEntropy (train_ransac_softam.cpp:416-420)
+    assert log.shape[0] == 2 and log[0, 0] == 0 and log[1, 0] == 1
+    assert np.abs(log[:, 1] - float(g["loss"])).max() <= 1e-3 * max(1.0, float(g["loss"])) and np.abs(log[:, 2] - float(g["sfEntropy"])).max() <= 2e-3
+    # the gradient the scene-coordinate CNN would receive: statistics of the reference's dLoss_dObj for this frame
+    n = np.linalg.norm(g["dLoss_dObj"], axis=1)
+    gr = np.loadtxt(os.path.join(tmp, "ransac_training_grad_train_obj.lua.txt")).reshape(-1, 5)
+    assert abs(gr[0, 1] - n.max()) <= 1e-3 * n.max() and abs(gr[0, 2] - n.mean()) <= 1e-3 * n.mean()
+    assert abs(gr[0, 3] - np.sort(n)[len(n) // 2]) <= 1e-3 * n.max() and abs(gr[0, 4] - (n < 1e-8).sum()) <= 2
+
+
+def test_synthetic_run_and_config_precedence(tmp_path):
+    """-synth K: K synthetic frames, no files; 640x480 maps go through the full-resolution path."""
+    tmp = str(tmp_path)
+    out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", "3", "-rI", "128", "-omodel", "m.net", "-rdraw", "0"], cwd=tmp, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    err = np.loadtxt(os.path.join(tmp, "ransac_test_errors_m.net_rdraw0_softam.txt")).reshape(-1, 10)
+    tot = np.loadtxt(os.path.join(tmp, "ransac_test_loss_m.net_rdraw0_softam.txt"))
+    assert err.shape == (3, 10) and (err[:, 3] < 5).all() and (err[:, 2] < 50).all() and tot[0] == 1.0  # solvable frames: all within 5 deg / 5 cm
+    out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", "1", "-mw", "640", "-mh", "480"], cwd=tmp, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
