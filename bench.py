@@ -173,6 +173,12 @@ def cpu_baseline(args, fr, N, H, W):
     finally:
         orc.set_num_threads(cores)
     out["one_thread"] = {"value": n1 / s1, "unit": "hyp/s", "cores": 1, "sample": "%d hypotheses x %dx%d, %.1f s" % (n1, W, H, s1)}
+    # the reference's own map size (40 x 40, int16-quantised coordinates), all threads
+    from dsac_amd import synth as _synth
+    f40 = _synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
+    r40 = 20
+    s40, _ = orc.time_forward(N, 1305, f40["xyz"], f40["uv"], 40, 40, f40["cam"], reps=r40)
+    out["reference_size"] = {"value": N * r40 / s40, "unit": "hyp/s", "cores": cores, "sample": "%d frames x %d hypotheses x 40x40 int16 map, %.2f s" % (r40, N, s40)}
     return out
 
 
@@ -466,6 +472,48 @@ def main(argv=None):
                                "frac": (ab1 / k2_1 / 1e9 / HBM_PEAK_GBS) if k2_1 > 0 else 0.0, "avg_launch_us": k2_1 * 1e6, "launches_timed": c1,
                                "algorithmic_bytes_per_launch": ab1}}
 
+    # BASELINE.json configs[0] / SURVEY.md 8(d) config 1 in the reference-exact mode: P = 40 x 40 sub-sampled map, int16-quantised
+    # coordinates, 256 hypotheses, one frame per step (K1 -> K2 -> K3); 32 such frames per step as well (what a GPU is fed with)
+    refsize = None
+    if not args.no_single_frame and not args.kernel_only and not config3 and args.k2_mode == "both" and rank == 0:
+        eng, _ = engines[0]
+        f40 = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
+        x40 = torch.from_numpy(f40["xyz"]).to(dev)
+        u40 = torch.from_numpy(f40["uv"]).to(dev)
+        b = bufs[0]
+        refsize = {"workload": "reference-exact size: 40x40 stratified sub-sample, int16-quantised coordinates, %d hypotheses (core/lua_calls.h:33, core/types.h:43)" % N}
+        for nf in (1, 32):
+            if nf == 1:
+                eng.set_frame(x40, u40, 40, 40, f40["cam"], borrow=True)
+            else:
+                xs = torch.from_numpy(np.ascontiguousarray(np.stack([synth.chess_like_frame(40, 40, seed=1305 + k, quantise_int16=True)["xyz"] for k in range(nf)]))).to(dev)
+                eng.set_frames(xs, u40, 40, 40, f40["cam"], borrow=True)
+            nn = N * nf
+            if nf > 1 and N % 128 != 0:
+                continue
+            o = (torch.zeros(nn, 6, dtype=torch.float64, device=dev), torch.zeros(nn, 4, dtype=torch.int32, device=dev), torch.zeros(nn, dtype=torch.uint8, device=dev),
+                 torch.zeros(nn, dtype=torch.float64, device=dev), torch.zeros(nn, dtype=torch.float64, device=dev), torch.zeros(nf, dtype=torch.float64, device=dev),
+                 torch.zeros(nf, 6, dtype=torch.float64, device=dev))
+            e40 = torch.empty(nn, 1600, dtype=torch.float32, device=dev)
+
+            def one40(i):
+                if nf == 1:
+                    eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=e40,
+                                        out=(o[0], o[1], o[2], o[3], o[4], o[5][:1], o[6][0]))
+                else:
+                    eng.scoreHypothesesFrames(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=e40, out=o)
+            for i in range(20):
+                one40(i)
+            eng.synchronize()
+            n40 = 200
+            t40 = time.perf_counter()
+            for i in range(n40):
+                one40(20 + i)
+            eng.synchronize()
+            e40s = time.perf_counter() - t40
+            refsize["frames_per_step_%d" % nf] = {"value": nn * n40 / e40s, "unit": "hyp/s", "us_per_frame": e40s / n40 / nf * 1e6}
+        eng.profile_read(0, reset=True)
+
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -525,6 +573,8 @@ def main(argv=None):
         }
         if single is not None:
             out["single_frame"] = single
+        if refsize is not None:
+            out["reference_size"] = refsize
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
         print(json.dumps(out), flush=True)
