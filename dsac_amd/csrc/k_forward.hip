@@ -455,8 +455,10 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
     const int NT = pixel_minor ? -NTa : NTa;
     if (tiles_used) *tiles_used = PT;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
+    // experiment knob (k2_flags bits 8..15): that many 8-KiB units of unused dynamic LDS per workgroup cap the workgroups per CU
+    const size_t lds_pad = (size_t)((kflags >> 8) & 0xff) * 8192;
 #define DSAC_K2H(E, S, U)                                                                                                             \
-    hipLaunchKernelGGL((k_reproject_hp<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
+    hipLaunchKernelGGL((k_reproject_hp<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), lds_pad, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
                        F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2H(true, true, true); else DSAC_K2H(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2H(true, false, true); else DSAC_K2H(true, false, false); }

@@ -193,6 +193,157 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// K1 with work sharing inside a workgroup (round 2).  The launch time of k_sample is the time of its SLOWEST hypothesis: an attempt is
+// accepted with p ~ 0.05 on the synthetic frames, a round of 16 fails with 0.44, so the slowest of 2048 hypotheses needs ~9 rounds of
+// ~5.5 us while the average needs 1.8.  Here SW waves form a workgroup over SW consecutive hypotheses; a wave whose hypothesis is
+// accepted (or exhausted) joins one of the workgroup's unfinished hypotheses in the next round and evaluates the NEXT 16 attempts of
+// that hypothesis.  A round therefore consumes a contiguous block of 16 x (waves on it) attempt indices per hypothesis, the lowest
+// accepted index of the block wins, and blocks are consumed in increasing order -- the same "first accepted attempt in index order"
+// the one-wave form and the reference's sequential loop produce, independent of SW and of scheduling (the assignment of helpers is a
+// function of the done-state at the start of the round, exchanged through LDS with two barriers per round).
+// Measured (profiles/r02_k1_share.txt, 640x480 synthetic frame): N = 256 34.8 -> 29.2 us, N = 1024 36.3 -> 30.3 us; but N = 2048 48.4 -> 51.6
+// and N = 4096 66.9 -> 83.8 us -- once there are more waves than SIMDs the launch is throughput-bound and 4-wave workgroups at one wave
+// per SIMD place worse than single waves.  The launcher therefore shares only up to 1024 hypotheses (one frame, or a small batch).
+// --------------------------------------------------------------------------------------------------
+template <int SW>
+__global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
+                                                           int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
+                                                           int Nf) {
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    __shared__ int s_fin[SW];   // hypothesis w of the workgroup is finished: accepted, exhausted or beyond N
+    __shared__ int s_acc[SW];   // ... and was accepted
+    __shared__ int s_base[SW];  // next attempt index of hypothesis w
+    __shared__ int s_win[SW];   // lowest accepted attempt index found by wave w in this round (INT_MAX: none)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h_first = blockIdx.x * SW;
+    if (threadIdx.x < SW) {
+        s_fin[threadIdx.x] = (h_first + (int)threadIdx.x >= N) ? 1 : 0;
+        s_acc[threadIdx.x] = 0;
+        s_base[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int root = lane & 3;
+    const dm::Cam K = make_cam(F);
+    const float* xyz0 = F.xyz;
+    const float* uv0 = F.uv;
+    const double thr_hi = (double)thr_int + 0.01;
+    for (;;) {
+        // snapshot of the workgroup's state (uniform)
+        int fin[SW], base[SW];
+        int u = 0;
+#pragma unroll
+        for (int w = 0; w < SW; w++) { fin[w] = s_fin[w]; base[w] = s_base[w]; u += fin[w] ? 0 : 1; }
+        if (u == 0) break;
+        // target of every wave: its own hypothesis while unfinished; the k-th finished wave helps the (k mod u)-th unfinished hypothesis
+        int tgt[SW], slot[SW];
+        {
+            int unf[SW], nu = 0, k = 0;
+#pragma unroll
+            for (int w = 0; w < SW; w++) if (!fin[w]) unf[nu++] = w;
+#pragma unroll
+            for (int w = 0; w < SW; w++) {
+                if (!fin[w]) { tgt[w] = w; slot[w] = 0; }
+                else { tgt[w] = unf[k % nu]; slot[w] = 1 + k / nu; k++; }
+            }
+        }
+        int t = 0, sl = 0;
+#pragma unroll
+        for (int w = 0; w < SW; w++) if (w == wave) { t = tgt[w]; sl = slot[w]; }
+        int bt = 0;
+#pragma unroll
+        for (int w = 0; w < SW; w++) if (w == t) bt = base[w];
+        const int h = h_first + t;
+        const int frame = h / Nf;
+        F.xyz = xyz0 + (long long)frame * F.xyz_stride;
+        F.uv = uv0 ? uv0 + (long long)frame * F.uv_stride : nullptr;
+        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+        const long long att = (long long)bt + 16ll * sl + (lane >> 2);
+        const uint32_t attempt = (uint32_t)att;
+        int32_t set4[4];
+        bool live = att < (long long)max_tries;
+        if (live) live = draw_set(F, key, attempt, set4);
+        float X[4][3], uv[4][2];
+        double Rc[9], Tc[3], reproj = 0;
+        bool cand = false;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+            dm::P3PSetup S;
+            if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
+                const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
+                cand = dm::p3p_eval_root<false>(S, X, uv, K, x, Rc, Tc, reproj);
+            }
+        }
+        // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
+        int win = -1;
+        double best = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ci = __shfl((int)cand, (lane & ~3) | i, 64) != 0;
+            const double ri = __shfl(reproj, (lane & ~3) | i, 64);
+            if (ci && (win < 0 || best > ri)) { win = i; best = ri; }
+        }
+        bool good = false;
+        double cv6[6] = {0, 0, 0, 0, 0, 0};
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (live && win == root && !(reproj > thr_hi * thr_hi)) {  // early rejection as in k_sample
+            dm::rodrigues_m2v(Rc, cv6);
+            cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
+            dm::rodrigues_v2m<false>(cv6, R, nullptr);
+            good = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float uu, vv;
+                dm::project_f(R, cv6 + 3, K, X[j][0], X[j][1], X[j][2], uu, vv);
+                const float dx = uv[j][0] - uu, dy = uv[j][1] - vv;
+                good = good && (sqrt((double)dx * dx + (double)dy * dy) < (double)thr_int);
+            }
+        }
+        const unsigned long long m = __ballot(good);
+        const int wl = m ? (__ffsll((long long)m) - 1) : -1;  // lowest accepted lane of this wave = its lowest accepted attempt
+        const int mine = m ? (bt + 16 * sl + (wl >> 2)) : 0x7fffffff;
+        if (lane == 0) s_win[wave] = mine;
+        __syncthreads();
+        int best_t = 0x7fffffff, n_t = 0;
+#pragma unroll
+        for (int w = 0; w < SW; w++) if (tgt[w] == t) { best_t = min(best_t, s_win[w]); n_t++; }
+        if (mine == best_t && mine != 0x7fffffff && lane == wl) {  // attempt indices are unique per (hypothesis, wave): exactly one writer
+#pragma unroll
+            for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = cv6[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
+            ok[h] = 1;
+            if (staged) write_staged_R(F, R, cv6, staged + (size_t)h * POSE_STRIDE);
+        }
+        if (t == wave && lane == 0) {  // the owner advances its hypothesis
+            const int nb = bt + 16 * n_t;
+            s_base[wave] = nb;
+            if (best_t != 0x7fffffff) { s_fin[wave] = 1; s_acc[wave] = 1; }
+            else if (nb >= max_tries) s_fin[wave] = 1;
+        }
+        __syncthreads();
+    }
+    // no accepted attempt: zero pose, ok = 0; sets_out reports the last attempt's set
+    const int h = h_first + wave;
+    if (h < N && !s_acc[wave] && lane == 0) {
+        const int frame = h / Nf;
+        F.xyz = xyz0 + (long long)frame * F.xyz_stride;
+        F.uv = uv0 ? uv0 + (long long)frame * F.uv_stride : nullptr;
+        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+        int32_t set4[4];
+        draw_set(F, key, (uint32_t)(max_tries - 1), set4);
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) poses[(size_t)h * 6 + kk] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) sets_out[(size_t)h * 4 + kk] = set4[kk];
+        ok[h] = 0;
+        if (staged) { const double z6[6] = {0, 0, 0, 0, 0, 0}; write_staged(F, z6, staged + (size_t)h * POSE_STRIDE); }
+    }
+}
+
 // Given sets: one lane per hypothesis.
 template <bool HORN>
 __global__ __launch_bounds__(64) void k_eval_sets(int N, const int32_t* __restrict__ sets_in, FrameDev F, int thr_int,
@@ -229,7 +380,12 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         const int wpb = o.wpb, prio = o.prio;
         const int H2 = o.hpw > 0 ? o.hpw : 1;  // see the measurement in the kernel's comment
 #define DSAC_K1(W, G, HN) hipLaunchKernelGGL((k_sample<W, G, HN>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
+        const int NfK = Nf > 0 ? Nf : N;
         if (o.horn) DSAC_K1(1, 1, true);
+        else if (o.share >= 2 && H2 == 1 && (N <= 1024 || o.share_always) && (F.frames <= 1 || NfK % o.share == 0)) {  // a workgroup's hypotheses must share a frame
+            if (o.share >= 8) hipLaunchKernelGGL((k_sample_shared<8>), dim3((N + 7) / 8), dim3(512), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
+            else hipLaunchKernelGGL((k_sample_shared<4>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
+        }
         else if (o.minw >= 2 && H2 == 1) {
             if (wpb >= 4) hipLaunchKernelGGL((k_sample<4, 1, false, 2>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
             else hipLaunchKernelGGL((k_sample<1, 1, false, 2>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);

@@ -53,6 +53,8 @@ hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, do
 // hypotheses per wave (DSAC_K1_HPW in {1, 2, 4}), Horn alignment of the P3P triangle as in OpenCV instead of the triad (DSAC_K1_HORN).
 struct K1Opts {
     int wpb = 1, prio = 3, hpw = 1, minw = 1;  // minw: minimum waves per SIMD of the register allocation (DSAC_K1_MINW)
+    bool share_always = false;  // share beyond 1024 hypotheses as well (DSAC_K1_SHARE < 0)
+    int share = 4;  // waves of a workgroup that help each other's unfinished hypotheses (k_sample_shared; 0 / 1 = off, 4, 8; DSAC_K1_SHARE)
     bool horn = false;
 };
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,

@@ -88,7 +88,8 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
 /* Per-context launch knobs (the reference's GlobalProperties singleton, core/properties.h, made per-context and explicit).
  * Keys: "k2_variant" (-1 = auto policy; otherwise one fixed kernel form of K2, for A/B runs and tests), "k2_order" (1 = pixel tiles
  * innermost), "k2_flags" (bit0: cached instead of non-temporal stores), "k1_wpb" / "k1_prio" / "k1_hpw" (K1 waves per workgroup, wave
- * priority, hypotheses per wave), "k1_horn" (1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P)
+ * priority, hypotheses per wave), "k1_share" (4 or 8: the waves of a workgroup help each other's unfinished hypotheses -- same result, shorter
+ * tail; used up to 1024 hypotheses, a negative value forces it always; 0 = off), "k1_minw", "k4_variant" (K4 main-pass form), "k1_horn" (1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P)
  * does -- parity mode, slower; 0 = orthonormal triad, equal to rounding).  The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER,
  * DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_HORN give the initial values at dsac_create. */
 int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
