@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <cmath>
 #include <deque>
@@ -938,6 +939,71 @@ int dsac_refine_fd_set(dsac_ctx* c, const int32_t* set4, const int32_t* perm, in
     HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_set, d_map, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n));
     HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
     HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo));
+    return end_call(c);
+}
+
+int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* sets, const double* w, const double* avg_cv6, const double* ref_cv6,
+                        const double* gt_jp6, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const int32_t* inlier_map, float sub_sample,
+                        float eps_hyp, float eps_obj, double g_scale, double* dpnp_out_or_null, double* grad_xyz, double* g, double* dL_out_or_null,
+                        double* v6_out_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_backward_path1: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_backward_path1: no frame set");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    if (N <= 0 || !poses || !sets || !w || !avg_cv6 || !ref_cv6 || !gt_jp6 || !perm || !inlier_map || !grad_xyz || !g || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: NULL argument or bad count");
+    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: need 1 <= max_inl <= 256");
+    if (!(sub_sample > 0.f) || !(eps_hyp > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: sub_sample, eps_hyp, eps_obj must be > 0");
+    const int skip = (int)(1 / sub_sample);  // core/cnn_softam.h:871
+    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: sub_sample > 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double *d_poses, *d_w, *d_avg, *d_ref, *d_gt;
+    const int32_t *d_sets, *d_perm, *d_map;
+    double *d_dpnp, *d_grad, *d_g, *d_dL, *d_v6;
+    ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
+    ARG_TRY(in_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(in_arg(c, avg_cv6, 6, &d_avg));
+    ARG_TRY(in_arg(c, ref_cv6, 6, &d_ref));
+    ARG_TRY(in_arg(c, gt_jp6, 6, &d_gt));
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, inlier_map, P, &d_map));
+    ARG_TRY(out_arg(c, dpnp_out_or_null, (size_t)N * 72, &d_dpnp));
+    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    ARG_TRY(out_arg(c, g, (size_t)N, &d_g));
+    ARG_TRY(out_arg(c, dL_out_or_null, 6, &d_dL));
+    ARG_TRY(out_arg(c, v6_out_or_null, 6, &d_v6));
+    // the inlier map holds at most steps * max_inl hits, every skip-th of them is differentiated
+    const int cap = (int)std::min<size_t>(4096, (size_t)steps * (size_t)max_inl / (size_t)skip + 1);
+    const size_t B = 12 + 6 * (size_t)cap;
+    DevBuf& sc = next_slot(c);  // dL 6 | out4 4 | v6 6 | J_hyp 36 | J_obj cap*18 | rep poses B*6 | rep out B*6   (doubles)
+    const size_t nd = 6 + 4 + 6 + 36 + (size_t)cap * 18 + B * 6 + B * 6;
+    HIP_TRY(c, sc.reserve(nd * sizeof(double)));
+    double* base = sc.as<double>();
+    double *s_dL = d_dL ? d_dL : base, *s_out4 = base + 6, *s_v6 = d_v6 ? d_v6 : base + 10, *s_Jh = base + 16, *s_Jo = base + 52;
+    double *s_rp = s_Jo + (size_t)cap * 18, *s_ro = s_rp + B * 6;
+    DevBuf& si = next_slot(c);  // rep px/c B*2 | obj pixels cap + 1 | n 1  (int32) ; rep value B (float)
+    HIP_TRY(c, si.reserve((B * 2 + (size_t)cap + 2) * sizeof(int32_t) + B * sizeof(float)));
+    int32_t* s_rx = si.as<int32_t>();
+    int32_t* s_px = s_rx + B * 2;
+    int32_t* s_n = s_px + cap + 1;
+    float* s_rv = reinterpret_cast<float*>(s_n + 1);
+    if (!d_dpnp) {
+        DevBuf& sd = next_slot(c);
+        HIP_TRY(c, sd.reserve((size_t)N * 72 * sizeof(double)));
+        d_dpnp = sd.as<double>();
+    }
+    // dLossMax at the refined pose (train_ransac_softam.cpp:301-304)
+    HIP_TRY(c, dk::pose_loss(c->stream, 1, d_ref, d_gt, s_out4, s_dL));
+    // dRefineObj / dRefineHyp as one batch of finite-difference replicas (:307-341)
+    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n));
+    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, s_n, s_rp, d_perm, steps, max_inl, min_inl, thr, s_rx, s_rv, c->F, s_ro));
+    HIP_TRY(c, dk::refine_fd_finish(c->stream, s_ro, s_n, cap, skip, eps_hyp, eps_obj, s_Jh, s_Jo));
+    HIP_TRY(c, dk::path1_assemble(c->stream, s_dL, s_Jh, s_px, s_Jo, s_n, cap, (int)P, d_grad, s_v6));
+    // sum_h w_h dPNP_h to the support points and the softmax backward (:344-376)
+    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp));
+    HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale));
     return end_call(c);
 }
 

@@ -325,9 +325,10 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
     // LDS: MFMA B operands in lane order (x row, negated y row, z row of 16 hypotheses), the per-hypothesis coefficients of the
     // gradient accumulation, and the 12 sums of every (hypothesis, wave) accumulated over the workgroup's pixel tiles
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    float* s_B = s_dyn;                                  // [ngi][3][64]
-    float* s_C = s_B + (K4M_HT_MAX / 16) * 3 * 64;       // [HT][12]: r0 (3), nr1 (3), nr2 (3), g, pad
-    float* s_G = s_C + K4M_HT_MAX * 12;                  // [ngi][4 waves][16][12]
+    const int HT16 = (HT + 15) >> 4;
+    float* s_B = s_dyn;                                  // [HT/16][3][64]
+    float* s_C = s_B + HT16 * 3 * 64;                    // [HT][12]: r0 (3), nr1 (3), nr2 (3), g, pad
+    float* s_G = s_C + HT16 * 16 * 12;                   // [HT/16][4 waves][16][12]
     for (int i = tid; i < ngi * 3 * 64; i += K4_THREADS) {
         const int l = i & 63, cg = i >> 6;
         const int comp = cg % 3, gi = cg / 3;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
 
 static size_t k4m_lds_bytes(int HT) {
     const int ngi = (HT + 15) / 16;
-    return ((size_t)(K4M_HT_MAX / 16) * 3 * 64 + (size_t)K4M_HT_MAX * 12 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
+    return ((size_t)ngi * 3 * 64 + (size_t)ngi * 16 * 12 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
 }
 
 // Launch plan (see kernels.h).  VALU form: hypothesis tile 32 -- a round-counting model (workgroups / (2 per CU), cost ~ rounds x HT)
@@ -527,6 +528,9 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     K4Plan pl{};
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
+    // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
+    int ht_code = 0, wg_per_cu = 0;
+    if (variant >= 10) { wg_per_cu = variant / 100; ht_code = (variant / 10) % 10; variant = variant % 10; }
     if (variant < 0) variant = 2;  // 4 chunks per wave: 133 vs 147 us with 2 (N = 256, 640 x 480)
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 2 || (!F.uv && F.W % 4 != 0)) variant = 0;
@@ -542,9 +546,10 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // for the 1200 pixel tiles on 512 workgroups), measured it loses (145 vs 133 us; N = 1024: 541 vs 506) -- a workgroup that runs out
         // of tiles early leaves the VALU to its SIMD neighbours, so the imbalance costs far less than the extra set-up.
         const int PT = (F.P + 64 * CH - 1) / (64 * CH);
-        pl.HT = min(K4M_HT_MAX, ((max(N, 1) + 15) / 16) * 16);
+        const int ht_max = ht_code == 1 ? 64 : ht_code == 2 ? 128 : K4M_HT_MAX;
+        pl.HT = min(ht_max, ((max(N, 1) + 15) / 16) * 16);
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
-        pl.rows = max(1, min(PT, (2 * 256 + pl.NT - 1) / pl.NT));
+        pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : 2) * 256 + pl.NT - 1) / pl.NT));
         return pl;
     }
     pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
@@ -722,7 +727,7 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
 __global__ __launch_bounds__(256) void k_path1_softmax_bwd(int N, int P, const double* __restrict__ v6, const double* __restrict__ w,
                                                            const double* __restrict__ poses, const int32_t* __restrict__ sets,
                                                            const double* __restrict__ dpnp, double* __restrict__ grad_xyz,
-                                                           double* __restrict__ g) {
+                                                           double* __restrict__ g, double g_scale) {
     __shared__ double s_buf[256];
     const int tid = threadIdx.x;
     double v[6];
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(256) void k_path1_softmax_bwd(int N, int P, const d
         __syncthreads();
     }
     const double mean = s_buf[0];
-    for (int h = tid; h < N; h += 256) g[h] = w[h] * g[h] - w[h] * mean;
+    for (int h = tid; h < N; h += 256) g[h] = (w[h] * g[h] - w[h] * mean) * g_scale;
     // path I: grad[support px] += v6 . (w_h dPNP_h)
     if (dpnp && grad_xyz) {
         for (int idx = tid; idx < N * 12; idx += 256) {
@@ -763,9 +768,40 @@ __global__ __launch_bounds__(256) void k_path1_softmax_bwd(int N, int P, const d
 }
 
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
-                                  const double* dpnp, double* grad_xyz, double* g) {
+                                  const double* dpnp, double* grad_xyz, double* g, double g_scale) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_path1_softmax_bwd, dim3(1), dim3(256), 0, st, N, P, v6, w, poses, sets, dpnp, grad_xyz, g);
+    hipLaunchKernelGGL(k_path1_softmax_bwd, dim3(1), dim3(256), 0, st, N, P, v6, w, poses, sets, dpnp, grad_xyz, g, g_scale);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// core/train_ransac_softam.cpp:322 and :350-353 on the device: grad[px_i] += dL . dRefineObj_i (sparse 6 x 3 blocks, scaled by the
+// caller's skip already) and v6 = dL . dRefineHyp, so that the chain dLossMax -> dRefine -> dPNP / softmax backward needs no host round trip.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_path1_assemble(const double* __restrict__ dL, const double* __restrict__ J_hyp, const int32_t* __restrict__ obj_pixels,
+                                                        const double* __restrict__ J_obj, const int32_t* __restrict__ n_obj, int cap, int P,
+                                                        double* __restrict__ grad_xyz, double* __restrict__ v6) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(n_obj[0], cap);
+    if (i < n * 3) {
+        const int cell = i / 3, c = i - cell * 3;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += dL[k] * J_obj[(size_t)cell * 18 + k * 3 + c];
+        const int p = min(max(obj_pixels[cell], 0), P - 1);
+        grad_xyz[(size_t)p * 3 + c] += s;  // the selected cells are distinct
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 6) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += dL[k] * J_hyp[k * 6 + threadIdx.x];
+        v6[threadIdx.x] = s;
+    }
+}
+
+hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp, const int32_t* obj_pixels, const double* J_obj, const int32_t* n_obj,
+                          int cap, int P, double* grad_xyz, double* v6) {
+    hipLaunchKernelGGL(k_path1_assemble, dim3((cap * 3 + 255) / 256 + 1), dim3(256), 0, st, dL, J_hyp, obj_pixels, J_obj, n_obj, cap, P, grad_xyz, v6);
     return hipGetLastError();
 }
 

@@ -86,7 +86,10 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
                                  double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr);
 // rec_if_e_based: the BWD records when G12_part holds the matrix-core form's E-based sums (K4Plan.variant > 0), else nullptr
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
-                                  const double* dpnp, double* grad_xyz, double* g);
+                                  const double* dpnp, double* grad_xyz, double* g, double g_scale = 1.0);
+// grad[obj_pixels[i]] += dL . J_obj[i] for i < min(*n_obj, cap), v6 = dL . J_hyp
+hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp, const int32_t* obj_pixels, const double* J_obj, const int32_t* n_obj,
+                          int cap, int P, double* grad_xyz, double* v6);
 
 // ---- k_refine.hip ----------------------------------------------------------------------------------
 // inlier_map: map_stride == 0 -> H*W counters of problem 0 only; map_stride == H*W -> one map per problem

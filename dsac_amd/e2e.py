@@ -101,8 +101,9 @@ class TrainStep:
     """One update of both CNNs from one frame per rank (train_ransac_softam.cpp:225-430), the geometry on the engine.
 
     The engine runs on torch's current stream, so K1..K7 and the CNN kernels are ordered without events; the frame, the
-    hypotheses, the error images and their gradients never leave the GPU.  The few 6-vectors and the 6 x 6 / 6 x 12
-    Jacobians of the refinement stage go through the host (they are inputs of host-side control flow anyway)."""
+    hypotheses, the error images and their gradients never leave the GPU, and neither do the refined pose, the inlier map and the
+    Jacobians of the refinement stage: refinement, loss and the whole path-I chain (dsac_backward_path1) are enqueued with device
+    buffers; the step synchronises once, for the scalars it logs."""
 
     def __init__(self, device=0, hyps=256, ref_steps=8, inlier_count=100, thr=10.0, sub_sample=0.01, cam=(525.0, 525.0, 320.0, 240.0),
                  coord_net=None, score_net=None, lr_obj=1e-5, lr_score=1e-7, momentum=0.9):
@@ -123,6 +124,12 @@ class TrainStep:
         self.ent = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.avg = torch.zeros(6, dtype=torch.float64, device=self.dev)
         self.grad_xyz = torch.zeros(S * S, 3, dtype=torch.float64, device=self.dev)
+        self.ref = torch.zeros(6, dtype=torch.float64, device=self.dev)
+        self.imap = torch.zeros(S * S, dtype=torch.int32, device=self.dev)
+        self.sd = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.out4 = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        self.dpnp = torch.zeros(N, 6, 12, dtype=torch.float64, device=self.dev)
+        self.g = torch.zeros(N, dtype=torch.float64, device=self.dev)
 
     def params(self):
         return list(self.coord_net.parameters()) + list(self.score_net.parameters())
@@ -148,32 +155,34 @@ class TrainStep:
         scores = self.score_net(err)
         # ---- K3: softmax, entropy, soft-argmax pose ------------------------------------------------------------------
         eng.softMax(scores.detach().double().contiguous(), 1.0, self.poses, N=N, out=(self.w, self.ent, self.avg))
-        avg = self.avg.cpu().numpy()
-        # ---- K6, K7 forward --------------------------------------------------------------------------------------------
-        ref, sd, imap = eng.refine(avg, perm, max_inl=self.inlier_count, thr=float(int(self.thr)), want_inlier_map=True)
-        L = eng.maxLoss(ref[0], gt_jp6, want_grad=True)
-        # ---- backward, path I (train_ransac_softam.cpp:294-353) -------------------------------------------------------
-        dL = L["grad"]
+        # ---- K6, K7 forward, then path I + softmax backward: all enqueued on the stream, device buffers only (no host round trip) ---
+        from .capi import lib, ptr, check
+        ctx = eng._ctx
+        P = S * S
+        if getattr(self, "_perm_src", None) is not perm:  # the permutations are the same every step in the reference too (fixed seed)
+            self._perm_dev = torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32), device=self.dev)
+            self._perm_src = perm
+        gt_dev = torch.as_tensor(np.ascontiguousarray(gt_jp6, dtype=np.float64), device=self.dev)
+        steps = int(self._perm_dev.shape[0])
+        self.imap.zero_()
+        check(ctx, lib.dsac_refine(ctx, 1, ptr(self.avg), ptr(self._perm_dev), steps, int(self.inlier_count), 50, float(int(self.thr)), None, None,
+                                   ptr(self.ref), ptr(self.imap), ptr(self.sd)))
+        check(ctx, lib.dsac_loss(ctx, ptr(self.ref), ptr(gt_dev), ptr(self.out4), None))
         self.grad_xyz.zero_()
-        v6 = dL
-        if sd[0] > 0:
-            J_hyp, px, J_obj = eng.dRefine(avg, perm, imap, max_inl=self.inlier_count, thr=float(int(self.thr)), sub_sample=self.sub_sample)
-            if len(px):
-                rows = torch.as_tensor(np.einsum("k,ikc->ic", dL, J_obj), device=self.dev)
-                self.grad_xyz.index_add_(0, torch.as_tensor(px, device=self.dev, dtype=torch.long), rows)
-            v6 = dL @ J_hyp
-        dpnp = torch.zeros(N, 6, 12, dtype=torch.float64, device=self.dev)
-        eng.dPNP(self.sets, out=dpnp)
-        g = torch.zeros(N, dtype=torch.float64, device=self.dev)
-        eng.path1AndSoftmaxBackward(np.ascontiguousarray(v6), self.w, self.poses, self.sets, dpnp, grad=self.grad_xyz, out_g=g)
+        dpnp = self.dpnp
+        g = self.g
+        check(ctx, lib.dsac_backward_path1(ctx, N, ptr(self.poses), ptr(self.sets), ptr(self.w), ptr(self.avg), ptr(self.ref), ptr(gt_dev),
+                                           ptr(self._perm_dev), steps, int(self.inlier_count), 50, float(int(self.thr)), ptr(self.imap),
+                                           float(self.sub_sample), 0.001, 2.0, 1.0, ptr(dpnp), ptr(self.grad_xyz), ptr(g), None, None))
         # ---- backward, path II: score CNN (gradient clamp of train_score_softam.lua:97), then K4 -----------------------
         scores.backward(gradient=g.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
         d_err = err.grad.reshape(N, S * S).contiguous()  # (n, y, x): already the layout K4 reads
         eng.dScore(self.poses, self.sets, d_err, dpnp=dpnp, quirk_transpose=quirk_transpose, grad=self.grad_xyz)
         # ---- CNN 1 backward (gradient clamp of train_obj_softam.lua:105) ---------------------------------------------
         pred_m.backward(gradient=self.grad_xyz.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
-        return dict(loss=L["loss"], rotErr=L["rotErr"], tErr=L["tErr"], entropy=float(self.ent.item()), ref_steps=int(sd[0]),
-                    accepted=int(self.ok.sum().item()), refAvgHyp=ref[0], avgHyp=avg)
+        out4 = self.out4.cpu().numpy()  # the only synchronisation of the step: the scalars for the log
+        return dict(loss=float(out4[0]), rotErr=float(out4[1]), tErr=float(out4[2]), entropy=float(self.ent.item()), ref_steps=int(self.sd.item()),
+                    accepted=int(self.ok.sum().item()), refAvgHyp=self.ref.cpu().numpy(), avgHyp=self.avg.cpu().numpy())
 
     def step(self, *a, **kw):
         """forward_backward + gradient all-reduce over the ranks (RCCL on GPUs, a few flat buckets) + SGD update."""

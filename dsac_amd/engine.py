@@ -314,6 +314,23 @@ class Engine:
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
         return grad, g
 
+    def backwardPath1(self, poses, sets, w, avg_cv6, ref_cv6, gt_jp6, perm, inlier_map, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01,
+                      eps_hyp=0.001, eps_obj=2.0, g_scale=1.0, grad=None, out_g=None, out_dpnp=None, want_small=True):
+        """train_ransac_softam.cpp:294-376 as one device-side chain (dsac_backward_path1).  Returns dict(grad, g, dpnp[, dL, v6])."""
+        N = int(sets.shape[0])
+        perm = _np(perm, np.int32)
+        if grad is None:
+            grad = np.zeros((self.P, 3))
+        g = out_g if out_g is not None else np.zeros(N)
+        dL = np.zeros(6) if want_small else None
+        v6 = np.zeros(6) if want_small else None
+        check(self._ctx, lib.dsac_backward_path1(self._ctx, N, ptr(_np(poses, np.float64)), ptr(_np(sets, np.int32)), ptr(_np(w, np.float64)),
+                                                 ptr(_np(avg_cv6, np.float64)), ptr(_np(ref_cv6, np.float64)), ptr(_np(gt_jp6, np.float64)), ptr(perm),
+                                                 int(perm.shape[0]), int(max_inl), int(min_inl), float(thr), ptr(_np(inlier_map, np.int32)),
+                                                 float(sub_sample), float(eps_hyp), float(eps_obj), float(g_scale), ptr(out_dpnp), ptr(grad), ptr(g),
+                                                 ptr(dL), ptr(v6)))
+        return dict(grad=grad, g=g, dpnp=out_dpnp, dL=dL, v6=v6)
+
     # ---- producer side ------------------------------------------------------------------------------------------
     def gatherPatches(self, bgr, sampling_xy, patch=42, out=None):
         """Patch assembly of getCoordImg (cnn_softam.h:224-254): bgr H x W x 3 uint8, sampling_xy n x 2 int32 (x, y) ->
@@ -483,16 +500,20 @@ class Engine:
         gradients -> score backward.  With the soft-inlier score the last step is analytic; with a score CNN pass
         d_scores_fn(g N float64) -> dLoss/d(err images) N x H x W float32 (its backward, cnn_softam.h:605-606)."""
         grad = np.zeros((self.P, 3))
-        dL = self.dLossMax(fwd["refAvgHyp"], gt_jp6)
-        v6 = dL.copy()
-        if fwd["pixelIdxs"] is not None and fwd["refSteps"] > 0:
-            J_hyp, px, J_obj = self.dRefine(fwd["avgHyp"], fwd["pixelIdxs"], fwd["inlierMap"], max_inl=inlierCount, min_inl=minInliers,
-                                            thr=float(int(thr)), sub_sample=sub_sample)
-            for i, p in enumerate(px):
-                grad[p] += dL @ J_obj[i]
-            v6 = dL @ J_hyp
-        J = self.dPNP(fwd["sampledPoints"])
-        grad, g = self.path1AndSoftmaxBackward(v6, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], J, grad=grad)
+        N = len(fwd["sfScores"])
+        if fwd["pixelIdxs"] is not None:
+            # path I and the softmax backward as ONE device-side chain (dsac_backward_path1): dLossMax -> dRefine (12 + 6n replicas) ->
+            # contraction with dL -> dPNP -> support-point scatter + softmax backward; nothing but the results crosses to the host
+            J = np.zeros((N, 6, 12))
+            r = self.backwardPath1(fwd["hyps"], fwd["sampledPoints"], fwd["sfScores"], fwd["avgHyp"], fwd["refAvgHyp"], gt_jp6, fwd["pixelIdxs"],
+                                   fwd["inlierMap"], max_inl=inlierCount, min_inl=minInliers, thr=float(int(thr)), sub_sample=sub_sample, grad=grad,
+                                   out_dpnp=J)
+            dL, v6, g = r["dL"], r["v6"], r["g"]
+        else:  # no refinement stage: the loss gradient reaches the average pose directly
+            dL = self.dLossMax(fwd["refAvgHyp"], gt_jp6)
+            v6 = dL.copy()
+            J = self.dPNP(fwd["sampledPoints"])
+            grad, g = self.path1AndSoftmaxBackward(v6, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], J, grad=grad)
         if d_scores_fn is not None:
             d_err = np.ascontiguousarray(d_scores_fn(g), dtype=np.float32).reshape(len(g), self.P)
             grad = self.dScore(fwd["hyps"], fwd["sampledPoints"], d_err, dpnp=J, quirk_transpose=quirk_transpose, grad=grad)

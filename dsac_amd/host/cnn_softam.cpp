@@ -161,34 +161,19 @@ std::vector<double> Frame::backward(const ProcessImageResult& fwd, const Hypothe
     const size_t P = (size_t)H_ * W_;
     const int N = (int)fwd.hyps.size();
     std::vector<double> grad(P * 3, 0.0);
-    // --- path I: derivative of the loss wrt the refined average hypothesis (train_ransac_softam.cpp:301-304) ...
-    const std::array<double, 6> dL = dLossMax(fwd.refAvgHyp, poseGT);
-    std::array<double, 6> v6 = dL;
-    if (fwd.refStepsDone > 0) {
-        // ... times the refinement's Jacobians wrt the object coordinates (:307-312) and wrt the average hypothesis (:315-318)
-        std::array<double, 36> Jhyp;
-        std::vector<int32_t> px;
-        std::vector<double> Jobj;
-        dRefine(inlierCount, refSteps, (float)inlierThreshold2D, subSampleFactor, pixelIdxs, fwd.avgHyp, fwd.inlierMap, Jhyp, px, Jobj);
-        for (size_t i = 0; i < px.size(); i++)
-            for (int c = 0; c < 3; c++) {
-                double s = 0;
-                for (int k = 0; k < 6; k++) s += dL[k] * Jobj[i * 18 + k * 3 + c];
-                grad[(size_t)px[i] * 3 + c] += s;
-            }
-        for (int j = 0; j < 6; j++) {
-            double s = 0;
-            for (int k = 0; k < 6; k++) s += dL[k] * Jhyp[k * 6 + j];
-            v6[j] = s;
-        }
-    }
-    // ... the average is a weighted sum of hypotheses whose dPNP reaches the 4 support points of each (:344-357), and the softmax
-    // backward gives the score gradients of path II (:361-376): one call
-    const std::vector<double> J = dPNP(fwd.imgIdx);
+    // --- path I and the softmax backward (train_ransac_softam.cpp:294-376) as one device-side chain: dLossMax at the refined pose,
+    // dRefineObj / dRefineHyp (12 + 6n finite-difference replicas in one launch), their contraction with dL, dPNP of every minimal set,
+    // the scatter of v6 . w_h dPNP_h to the support points and the softmax backward
+    (void)refSteps;
     const std::vector<double> p = flatten(fwd.hyps);
-    std::vector<double> g(N);
-    check(dsac_path1_and_softmax_backward(ctx_, N, v6.data(), fwd.sfScores.data(), p.data(), &fwd.imgIdx[0][0], J.data(), grad.data(), g.data()),
-          "dsac_path1_and_softmax_backward");
+    const Pose6 avg = pack(fwd.avgHyp), ref = pack(fwd.refAvgHyp);
+    const std::vector<double> gt = poseGT.getRodVecAndTrans();
+    std::vector<double> J((size_t)N * 72), g(N);
+    const int steps = (int)(pixelIdxs.size() / P);
+    check(dsac_backward_path1(ctx_, N, p.data(), &fwd.imgIdx[0][0], fwd.sfScores.data(), avg.data(), ref.data(), gt.data(), pixelIdxs.data(), steps, inlierCount,
+                              50, (float)inlierThreshold2D, fwd.inlierMap.data(), subSampleFactor, 0.001f, 2.f, 1.0, J.data(), grad.data(), g.data(), nullptr,
+                              nullptr),
+          "dsac_backward_path1");
     // --- path II: score gradients -> error images -> object coordinates (dScore, :379-383); the score is alpha * soft-inlier count
     for (double& x : g) x *= alpha;
     if (!referenceIndexQuirk) {

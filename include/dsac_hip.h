@@ -261,6 +261,19 @@ int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double
 int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                     const double* dpnp, double* grad_xyz, double* g);
 
+/* The whole path-I half of the trainer's backward section, core/train_ransac_softam.cpp:294-376, enqueued as one chain with no host round
+ * trip: dLossMax at the refined pose (ref_cv6 vs gt_jp6) -> dRefineObj / dRefineHyp of the refinement that started at avg_cv6 (one batch
+ * of 12 + 6n finite-difference replicas; perm / steps / max_inl / min_inl / thr / inlier_map / sub_sample as dsac_refine_fd, eps_hyp 0.001f,
+ * eps_obj 2.f in the reference) -> grad_xyz[inlier cells] += dL . dRefineObj and v6 = dL . dRefineHyp -> dPNP of the N minimal sets ->
+ * grad_xyz[support cells of h] += v6 . w_h dPNP_h and the softmax backward g_j = g_scale * w_j (F_j - sum_h w_h F_h).  g (N) are the score
+ * gradients path II continues from (the score CNN's backward, or dsac_soft_score_backward with g_scale = the score scale alpha);
+ * dpnp_out_or_null (N x 72) can be handed on to dsac_score_backward.  grad_xyz (H*W x 3) is ACCUMULATED into.  dL_out / v6_out: the 1 x 6
+ * dLoss/dRef and dLoss/dAvg for logging.  The reference computes both refinement Jacobians unconditionally; so does this call. */
+int dsac_backward_path1(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* w, const double* avg_cv6, const double* ref_cv6,
+                        const double* gt_jp6, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const int32_t* inlier_map, float sub_sample,
+                        float eps_hyp, float eps_obj, double g_scale, double* dpnp_out_or_null, double* grad_xyz, double* g, double* dL_out_or_null,
+                        double* v6_out_or_null);
+
 /* ---- stream scheduling ---------------------------------------------------------------------------------- */
 /* Optional gate around the one bandwidth-bound kernel (K2): before launching it the context's stream waits for
  * `wait_before` (a hipEvent_t; a never-recorded event does not block), after it `record_after` is recorded.

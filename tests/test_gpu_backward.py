@@ -217,3 +217,35 @@ def test_quirk7_rot_writeback(engine, orc, frame40):
     assert e_fixed <= 2e-3
     if regular.all():
         assert e_quirk <= 2e-3
+
+
+def test_fused_path1_chain_equals_the_separate_calls(engine, orc, synth, frame40):
+    """dsac_backward_path1 (dLossMax -> dRefine -> contraction -> dPNP -> support scatter + softmax backward, one device-side chain) against the
+    same chain assembled on the host from the single calls, and against the oracle's functions."""
+    fr = frame40
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    perm = synth.fast_permutations(1600, 8)
+    gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    fwd = engine.processImage(N=128, seed=77, perm=perm, gt_jp6=gt)
+    r = engine.backwardPath1(fwd["hyps"], fwd["sampledPoints"], fwd["sfScores"], fwd["avgHyp"], fwd["refAvgHyp"], gt, perm, fwd["inlierMap"],
+                             g_scale=0.25, out_dpnp=np.zeros((128, 6, 12)))
+    # host assembly from the single calls
+    dL = engine.dLossMax(fwd["refAvgHyp"], gt)
+    J_hyp, px, J_obj = engine.dRefine(fwd["avgHyp"], perm, fwd["inlierMap"])
+    grad = np.zeros((1600, 3))
+    for i, p in enumerate(px):
+        grad[p] += dL @ J_obj[i]
+    J = engine.dPNP(fwd["sampledPoints"])
+    grad, g = engine.path1AndSoftmaxBackward(dL @ J_hyp, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], J, grad=grad)
+    assert np.array_equal(r["dL"], dL) and np.allclose(r["v6"], dL @ J_hyp, rtol=1e-12, atol=1e-15)
+    assert np.array_equal(r["dpnp"], J)
+    assert np.allclose(r["g"], 0.25 * g, rtol=1e-12, atol=1e-18)
+    assert np.allclose(r["grad"], grad, rtol=1e-10, atol=1e-12 * np.abs(grad).max())
+    # and the oracle's chain
+    Jo = orc.dRefineObj(fwd["avgHyp"], perm, fwd["inlierMap"], fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    Jh = orc.dRefineHyp(fwd["avgHyp"], perm, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    dLo = orc.dLossMax(orc.cv_to_jp6(fwd["refAvgHyp"]), gt)
+    go, g_o = orc.path1_pnp_and_softmax_bwd(dLo @ Jh, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], fr["xyz"], fr["uv"], 40, 40, fr["cam"],
+                                           grad=(dLo @ Jo).reshape(1600, 3))
+    assert np.abs(r["g"] - 0.25 * g_o).max() <= 1e-3 * np.abs(g_o).max() * 0.25 + 1e-12  # nearly one-hot weights: the score gradients are ~0
+    assert np.abs(r["grad"] - go).max() <= 1e-2 * np.abs(go).max()
