@@ -59,6 +59,7 @@ struct dsac_ctx {
     std::vector<Pending> pending;
     dk::K2Opts k2;  // launch knobs, read once in dsac_create (DSAC_K2_*) or set with dsac_set_option; no process-wide state
     dk::K1Opts k1;
+    int k1_cus = 0;       // > 0: the auxiliary stream of the pipelined pair (K1 of the next step) is confined to that many CUs (DSAC_K1_CUS / "k1_cus")
     int k4_variant = -1;  // K4 main-pass form (dk::backward_plan), DSAC_K4_VARIANT / dsac_set_option("k4_variant")
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
 
@@ -232,6 +233,7 @@ int dsac_create(dsac_ctx** out, int device) {
     if (const char* v = getenv("DSAC_K1_MINW")) c->k1.minw = atoi(v);
     if (const char* v = getenv("DSAC_K1_SHARE")) { const int sv = atoi(v); c->k1.share = sv < 0 ? -sv : sv; c->k1.share_always = sv < 0; }
     if (const char* v = getenv("DSAC_K4_VARIANT")) c->k4_variant = atoi(v);
+    if (const char* v = getenv("DSAC_K1_CUS")) c->k1_cus = atoi(v);
     *out = c;
     return DSAC_OK;
 }
@@ -494,6 +496,17 @@ int dsac_score_hypotheses_frames(dsac_ctx* c, int hyps_per_frame, uint64_t seed,
 
 static int pipeline_init(dsac_ctx* c) {
     if (c->aux) return DSAC_OK;
+    if (c->k1_cus > 0 && c->k1_cus < c->prop.multiProcessorCount) {
+        // Confine the latency-bound sampling kernel to a few CUs: 2048 one-wave solves then take about as long as the bandwidth-bound K2 of
+        // the previous step, which keeps (almost) the whole chip -- instead of K1's 288-register waves displacing K2's on every SIMD.
+        const int ncu = c->prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0u);
+        for (int k = 0; k < c->k1_cus; k++) {  // evenly spread over the CU index space (every XCD contributes)
+            const int cu = (int)(((long long)k * ncu) / c->k1_cus);
+            mask[cu >> 5] |= 1u << (cu & 31);
+        }
+        HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->aux, (uint32_t)words, mask.data()));
+    } else
     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(c, hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
     for (int k = 0; k < 2; k++) {
@@ -605,6 +618,7 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k1_minw") c->k1.minw = value;
     else if (k == "k1_share") { c->k1.share = value < 0 ? -value : value; c->k1.share_always = value < 0; }
     else if (k == "k4_variant") c->k4_variant = value;
+    else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
     return DSAC_OK;
 }

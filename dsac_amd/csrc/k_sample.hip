@@ -204,7 +204,8 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
 // function of the done-state at the start of the round, exchanged through LDS with two barriers per round).
 // Measured (profiles/r02_k1_share.txt, 640x480 synthetic frame): N = 256 34.8 -> 29.2 us, N = 1024 36.3 -> 30.3 us; but N = 2048 48.4 -> 51.6
 // and N = 4096 66.9 -> 83.8 us -- once there are more waves than SIMDs the launch is throughput-bound and 4-wave workgroups at one wave
-// per SIMD place worse than single waves.  The launcher therefore shares only up to 1024 hypotheses (one frame, or a small batch).
+// per SIMD place worse than single waves (and a register budget for two waves per SIMD costs scratch: 62.5 us at N = 2048).  The launcher
+// therefore shares only up to 1024 hypotheses (one frame, or a small batch).
 // --------------------------------------------------------------------------------------------------
 template <int SW>
 __global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
