@@ -24,9 +24,22 @@ def test_algorithmic_bytes_formula():
     assert b.algorithmic_bytes_k2(256, P, explicit_uv=False, write_err=False) == 12 * P + 48 * 256 + 4 * 256
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_default.json")).read().strip().splitlines()[-1]
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r01_bench_default.json", "r02_bench_driver_flags.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)
+    if name.startswith("r02"):
+        # round 2: the driver's own flags, every K2 launch of the timed region timed, the extra SURVEY 8(d) fields
+        assert d["steps"] == 20 and d["warmup"] == 5 and d["roofline"]["launches_timed"] == 20 and d["roofline"]["frac"] >= 0.60
+        s1 = d["single_frame"]
+        assert s1["roofline"]["algorithmic_bytes_per_launch"] == _bench().algorithmic_bytes_k2(256, 640 * 480, explicit_uv=False)
+        assert abs(s1["roofline"]["frac"] - s1["roofline"]["achieved"] / 8000.0) < 1e-9 and s1["value"] < d["value"]
+        r = d["rates"]
+        assert abs(r["per_image_hyp_s"] - d["value"]) < 1e-6 * d["value"] and r["kernel_only_k2_hyp_s"] > r["per_image_hyp_s"]
+        assert d["cpu_baseline"]["one_thread"]["cores"] == 1 and d["cpu_baseline"]["one_thread"]["value"] < d["cpu_baseline"]["value"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
