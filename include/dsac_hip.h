@@ -85,13 +85,19 @@ void* dsac_get_stream(dsac_ctx* ctx);
 int dsac_synchronize(dsac_ctx* ctx);
 /* device facts for reports: CU count, clock (kHz), total memory (bytes), gcnArchName into name[64] */
 int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64);
-/* Per-context launch knobs (the reference's GlobalProperties singleton, core/properties.h, made per-context and explicit).
- * Keys: "k2_variant" (-1 = auto policy; otherwise one fixed kernel form of K2, for A/B runs and tests), "k2_order" (1 = pixel tiles
- * innermost), "k2_flags" (bit0: cached instead of non-temporal stores), "k1_wpb" / "k1_prio" / "k1_hpw" (K1 waves per workgroup, wave
- * priority, hypotheses per wave), "k1_share" (4 or 8: the waves of a workgroup help each other's unfinished hypotheses -- same result, shorter
- * tail; used up to 1024 hypotheses, a negative value forces it always; 0 = off), "k1_minw", "k4_variant" (K4 main-pass form), "k1_horn" (1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P)
- * does -- parity mode, slower; 0 = orthonormal triad, equal to rounding).  The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER,
- * DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_HORN give the initial values at dsac_create. */
+/* Per-context launch knobs (what the reference keeps in its GlobalProperties singleton, core/properties.h, made per-context and explicit).
+ * None of them changes a result beyond rounding; -1 / the default is the measured policy.  Unknown keys are DSAC_ERR_INVALID.
+ *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
+ *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
+ *   "k2_flags"    bit0: cached instead of non-temporal stores; bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments)
+ *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
+ *   "k1_share"    4 or 8: the waves of a K1 workgroup evaluate the next attempts of their unfinished neighbours -- same first accepted attempt,
+ *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
+ *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
+ *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
+ *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 matrix-core form with 2 / 4 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
+ * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_SHARE,
+ * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
 int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
 
 /* ---- frame ------------------------------------------------------------------------------------ */
