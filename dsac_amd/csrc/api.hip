@@ -692,7 +692,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         d_dpnp = s.as<double>();
     }
     const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
-    HIP_TRY(c, c->bwd_staged.reserve((size_t)N * dk::BWD_STRIDE * sizeof(float)));
+    HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
     HIP_TRY(c, c->dRdH.reserve((size_t)N * 27 * sizeof(double)));
     HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * P * 3 * sizeof(float)));
     HIP_TRY(c, c->g12_part.reserve((size_t)plan.rows * N * 12 * sizeof(float)));

@@ -60,6 +60,21 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
     o[12] = r00; o[13] = r01; o[14] = -r10; o[15] = -r11;
     o[16] = -r20; o[17] = -r21; o[18] = r02; o[19] = -r12;
     o[20] = -r22; o[21] = 0.f; o[22] = 0.f; o[23] = 0.f;
+    // LDS image of the matrix-core main pass, per group of 16 hypotheses 384 floats behind the N records: the three MFMA B operands in lane
+    // order [comp][k][col] (x row, negated y row, z row) and the 16 x 12 gradient coefficients (r0, -r1, -r2 rows of R', 3 spare); the
+    // last hypothesis also fills the unused columns of its group (their contributions are masked in the kernel)
+    {
+        float* img = rec + (size_t)N * BWD_REC;
+        const int c_last = (h == N - 1) ? 15 : (h & 15);
+        for (int c = h & 15; c <= c_last; c++) {
+            float* gb = img + (size_t)(h >> 4) * 384;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { gb[k * 16 + c] = o[2 * k]; gb[64 + k * 16 + c] = o[2 * k + 1]; gb[128 + k * 16 + c] = o[8 + k]; }
+            float* gc = gb + 192 + c * 12;
+            gc[0] = o[12]; gc[1] = o[13]; gc[2] = o[18]; gc[3] = o[14]; gc[4] = o[15]; gc[5] = o[19]; gc[6] = o[16]; gc[7] = o[17]; gc[8] = o[20];
+            gc[9] = gc[10] = gc[11] = 0.f;
+        }
+    }
     // rod = Rodrigues(R'), dRdH = d Rodrigues(rod) / d rod   (core/cnn_softam.h:505-509)
     double rod[3], Rre[9], J[27];
     dm::rodrigues_m2v(R, rod);
@@ -326,29 +341,20 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
     // gradient accumulation, and the 12 sums of every (hypothesis, wave) accumulated over the workgroup's pixel tiles
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int HT16 = (HT + 15) >> 4;
-    float* s_B = s_dyn;                                  // [HT/16][3][64]
-    float* s_C = s_B + HT16 * 3 * 64;                    // [HT][12]: r0 (3), nr1 (3), nr2 (3), g, pad
-    float* s_G = s_C + HT16 * 16 * 12;                   // [HT/16][4 waves][16][12]
-    for (int i = tid; i < ngi * 3 * 64; i += K4_THREADS) {
-        const int l = i & 63, cg = i >> 6;
-        const int comp = cg % 3, gi = cg / 3;
-        const int hyp = min(16 * gi + (l & 15), nh - 1), k = l >> 4;  // ragged end: repeat the last record (its contributions are masked)
-        const float* o = rec + (size_t)(h0 + hyp) * BWD_REC;
-        // record (k_backward_prep): [0] (R'00,-R'10,R'01,-R'11) [1] (R'02,-R'12,t'0,-t'1) [2] (R'20,R'21,R'22,t'2)
-        s_B[i] = comp == 0 ? o[2 * k] : comp == 1 ? o[2 * k + 1] : o[8 + k];
+    float* s_img = s_dyn;                                // [HT/16][384]: B operands [3][64] + coefficients [16][12] (k_backward_prep's image)
+    float* s_G = s_img + HT16 * 384;                     // [HT/16][4 waves][16][12]
+    {
+        const f4* src = reinterpret_cast<const f4*>(rec + (size_t)N * BWD_REC + (size_t)(h0 >> 4) * 384);
+        f4* dst = reinterpret_cast<f4*>(s_img);
+        for (int i = tid; i < ngi * 96; i += K4_THREADS) dst[i] = src[i];
+        f4* gz4 = reinterpret_cast<f4*>(s_G);
+        for (int i = tid; i < ngi * 192; i += K4_THREADS) gz4[i] = f4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = tid; i < ngi * 16 * 12; i += K4_THREADS) {
-        const int hyp = i / 12, j = i - hyp * 12;
-        const float* o = rec + (size_t)(h0 + min(hyp, nh - 1)) * BWD_REC;
-        // r0 = (R'00,R'01,R'02) = o[12],o[13],o[18]; nr1 = -(R'10,R'11,R'12) = o[14],o[15],o[19]; nr2 = -(R'20,R'21,R'22) = o[16],o[17],o[20]
-        const int off = (int)((0x854732610ull >> (4 * j)) & 15ull);  // j -> {0,1,6,2,3,7,4,5,8} (+12)
-        float v = 0.f;
-        if (j < 9) v = o[12 + off];
-        else if (j == 9) v = (SOFTMODE && hyp < nh) ? (float)g[h0 + hyp] : 0.f;
-        s_C[i] = v;
-    }
-    for (int i = tid; i < ngi * 4 * 16 * 12; i += K4_THREADS) s_G[i] = 0.f;
     __syncthreads();
+    if (SOFTMODE) {  // dLoss/dscore of the tile's hypotheses into the spare coefficient slot
+        for (int i = tid; i < nh; i += K4_THREADS) s_img[(i >> 4) * 384 + 192 + (i & 15) * 12 + 9] = (float)g[h0 + i];
+        __syncthreads();
+    }
 
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f2 zero2 = {0.f, 0.f};
@@ -402,8 +408,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) wv[ch] = wn[ch];
             if (gi + 1 < ngi) load_w(gi + 1, wn);  // prefetch the next group's d_err under this group's arithmetic
-            const float bx = s_B[(gi * 3 + 0) * 64 + lane], by = s_B[(gi * 3 + 1) * 64 + lane], bz = s_B[(gi * 3 + 2) * 64 + lane];
-            const f4* cf = reinterpret_cast<const f4*>(s_C + (size_t)(16 * gi + c) * 12);
+            const float* simg = s_img + gi * 384;
+            const float bx = simg[lane], by = simg[64 + lane], bz = simg[128 + lane];
+            const f4* cf = reinterpret_cast<const f4*>(simg + 192 + c * 12);
             const f4 c0 = cf[0], c1 = cf[1], c2 = cf[2];  // (r0.x r0.y r0.z nr1.x) (nr1.y nr1.z nr2.x nr2.y) (nr2.z g - -)
             const bool hyp_ok = 16 * gi + c < nh;
             // S[j][m] = sum_p C_j * (E.x, -E.y, E.z, 1)_m with C_0 = C0, C_1 = -C1, C_2 = -C2; the two halves = the pixel pair's lanes
@@ -423,7 +430,9 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
                     const f2 ex = pp ? f2{ex4.z, ex4.w} : f2{ex4.x, ex4.y};
                     const f2 ny = pp ? f2{ny4.z, ny4.w} : f2{ny4.x, ny4.y};
                     const f2 ez = pp ? f2{ez4.z, ez4.w} : f2{ez4.x, ez4.y};
-                    const f2 iz = {__builtin_amdgcn_rcpf(ez.x), __builtin_amdgcn_rcpf(ez.y)};
+                    // guard |E.z| < 1e-8 -> 0 (cnn_softam.h:416,476) right at the reciprocal: a zero reciprocal keeps everything below finite
+                    const bool z0 = fabsf(ez.x) >= 1e-8f, z1 = fabsf(ez.y) >= 1e-8f;
+                    const f2 iz = {z0 ? __builtin_amdgcn_rcpf(ez.x) : 0.f, z1 ? __builtin_amdgcn_rcpf(ez.y) : 0.f};
                     const f2 fz = iz * f2{f, f};
                     // (u - px, v - py) with px = -f E.x/E.z + cx, py = f E.y/E.z + cy
                     const f2 du = __builtin_elementwise_fma(ex, fz, pu[ch][pp]);
@@ -443,14 +452,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
                     } else {
                         w = pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y};
                     }
-                    // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0, err > CNN_OBJ_MAXINPUT -> 0 (the comparison is false for
-                    // the NaN / inf a zero E.z produces), lanes beyond the map or the ragged hypothesis end -> 0
-                    const bool k0 = lane_ok && (fabsf(ez.x) >= 1e-8f) && (err.x <= clampv);
-                    const bool k1 = lane_ok && (fabsf(ez.y) >= 1e-8f) && (err.y <= clampv);
-                    f2 wfz = (w * fz) * ie;                               // w f / (E.z (err + eps))
+                    // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0, err > CNN_OBJ_MAXINPUT -> 0, lanes beyond the map or the
+                    // ragged hypothesis end -> 0
+                    const bool k0 = lane_ok && z0 && (err.x <= clampv);
+                    const bool k1 = lane_ok && z1 && (err.y <= clampv);
+                    f2 wfz = (w * fz) * ie;                               // w f / (E.z (err + eps)); finite: iz is 0 where E.z ~ 0
                     wfz.x = k0 ? wfz.x : 0.f;
                     wfz.y = k1 ? wfz.y : 0.f;
-                    const f2 wiz = {k0 ? wfz.x * iz.x : 0.f, k1 ? wfz.y * iz.y : 0.f};
+                    const f2 wiz = wfz * iz;
                     // a = -(du, dv)/(err+eps);  C0 = -a0 f/E.z ; C1 = a1 f/E.z ; C2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
                     const f2 C0 = du * wfz;                               //  C0
                     const f2 nC1 = dv * wfz;                              // -C1
@@ -503,21 +512,22 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
         }
     }
 
-    // G12 (E-based): sum over the 4 waves, one row per pixel workgroup
+    // G12 (E-based): sum over the 4 waves, one row per pixel workgroup.  [hyp][12] of a group is 192 consecutive floats in s_G as well:
+    // element i of the tile lives at i + 576 * (i / 192) + 192 * wave
     __syncthreads();
-    for (int i = tid; i < nh * 12; i += K4_THREADS) {
-        const int hyp = i / 12, j = i - hyp * 12;
-        const int gi = hyp >> 4, cc = hyp & 15;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; w++) v += s_G[((size_t)(gi * 4 + w) * 16 + cc) * 12 + j];
-        G12_part[((size_t)pw * N + h0 + hyp) * 12 + j] = v;
+    {
+        const f4* sg4 = reinterpret_cast<const f4*>(s_G);
+        f4* out4 = reinterpret_cast<f4*>(G12_part + ((size_t)pw * N + h0) * 12);
+        for (int i = tid; i < nh * 3; i += K4_THREADS) {
+            const int j = i + 144 * (i / 48);
+            out4[i] = (sg4[j] + sg4[j + 48]) + (sg4[j + 96] + sg4[j + 144]);
+        }
     }
 }
 
 static size_t k4m_lds_bytes(int HT) {
     const int ngi = (HT + 15) / 16;
-    return ((size_t)ngi * 3 * 64 + (size_t)ngi * 16 * 12 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
+    return ((size_t)ngi * 384 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
 }
 
 // Launch plan (see kernels.h).  VALU form: hypothesis tile 32 -- a round-counting model (workgroups / (2 per CU), cost ~ rounds x HT)
