@@ -396,6 +396,16 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_hp(const float* __rest
         for (int ch = 0; ch < KM_CH; ch++) {
             f4 ev[4];  // ev[r] = 4 consecutive pixels of hypothesis hyp0 + r
             f2 sloc[4];
+            if (kflags & 2) {  // measurement knob (k2_flags bit 1): the store schedule alone, no arithmetic -- the ceiling of this write pattern
+                if (ERR && valid[ch]) {
+                    f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp0) * P + p0[ch]);
+                    const size_t rs = (size_t)P / 4;
+                    const f4 o = {ax, ay, az, (float)gi};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (hyp0 + r < nh) __builtin_nontemporal_store(o, dst + r * rs);
+                }
+                continue;
+            }
             // projectPoints' "z = Z ? 1/Z : 1": one test for the 16 pairs, wave-uniform slow path (practically never) that redoes the chunk
             if (__builtin_expect(__any(hp_chunk<false, SOFT>(ax, ay, az, Bm[ch], ppix[ch], clampv, kA, kB, ev, sloc)), 0))
                 (void)hp_chunk<true, SOFT>(ax, ay, az, Bm[ch], ppix[ch], clampv, kA, kB, ev, sloc);
