@@ -402,7 +402,17 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_hp(const float* __rest
                     const size_t rs = (size_t)P / 4;
                     const f4 o = {ax, ay, az, (float)gi};
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (hyp0 + r < nh) __builtin_nontemporal_store(o, dst + r * rs);
+                    for (int r = 0; r < 4; r++) {
+                        if (hyp0 + r >= nh) continue;
+                        f4* q = dst + r * rs;
+                        const int mode = (kflags >> 2) & 7;  // cache policy of the store (measurement): 0 nt, 1 plain, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 sc0
+                        if (mode == 0) __builtin_nontemporal_store(o, q);
+                        else if (mode == 1) *q = o;
+                        else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(o) : "memory");
+                        else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(o) : "memory");
+                        else if (mode == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(q), "v"(o) : "memory");
+                        else asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(q), "v"(o) : "memory");
+                    }
                 }
                 continue;
             }

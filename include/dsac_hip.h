@@ -89,7 +89,7 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
  * None of them changes a result beyond rounding; -1 / the default is the measured policy.  Unknown keys are DSAC_ERR_INVALID.
  *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
  *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
- *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments)
+ *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments)
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_share"    4 or 8: the waves of a K1 workgroup evaluate the next attempts of their unfinished neighbours -- same first accepted attempt,
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
