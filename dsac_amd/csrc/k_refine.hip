@@ -23,46 +23,134 @@ constexpr int RF_MAX_INL = 256;  // LDS capacity for the collected correspondenc
 
 DM_INLINE dm::Cam make_cam_r(const FrameDev& F) { return dm::Cam{(double)F.fx, (double)F.fy, (double)F.cx, (double)F.cy}; }
 
-DM_INLINE double wave_allsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// ---- wave-wide sums of fp64 values without the LDS crossbar (round 1 used 6 ds_bpermute round trips per value) ----
+DM_INLINE void dsplit(double v, unsigned& lo, unsigned& hi) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    lo = (unsigned)u;
+    hi = (unsigned)(u >> 32);
+}
+DM_INLINE double djoin(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+// swap(a, b): the upper 32 lanes (odd 16-rows) of a trade places with the lower 32 lanes (even rows) of b
+DM_INLINE void dswap32(double& a, double& b) {
+    unsigned al, ah, bl, bh;
+    dsplit(a, al, ah);
+    dsplit(b, bl, bh);
+    auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+    a = djoin(l[0], h[0]);
+    b = djoin(l[1], h[1]);
+}
+DM_INLINE void dswap16(double& a, double& b) {
+    unsigned al, ah, bl, bh;
+    dsplit(a, al, ah);
+    dsplit(b, bl, bh);
+    auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+    a = djoin(l[0], h[0]);
+    b = djoin(l[1], h[1]);
+}
+template <int CTRL, int BANK = 0xf>
+DM_INLINE double ddpp(double old, double src) {
+    unsigned ol, oh, sl, sh;
+    dsplit(old, ol, oh);
+    dsplit(src, sl, sh);
+    const unsigned l = (unsigned)__builtin_amdgcn_update_dpp((int)ol, (int)sl, CTRL, 0xf, BANK, false);
+    const unsigned h = (unsigned)__builtin_amdgcn_update_dpp((int)oh, (int)sh, CTRL, 0xf, BANK, false);
+    return djoin(l, h);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128, DPP_SHL4 = 0x104, DPP_SHR4 = 0x114;
+// value of lane (l ^ 4): lanes with bit 2 clear read from l + 4, the others from l - 4 (bank masks pick the lanes that take each move)
+DM_INLINE double dxor4(double v) { return ddpp<DPP_SHR4, 0xA>(ddpp<DPP_SHL4, 0x5>(v, v), v); }
+
+DM_INLINE void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Cholesky solve of the symmetric positive definite 6x6 system A x = b (A given by its upper triangle,
-// row-major 6x6).  OpenCV uses an SVD pseudo-inverse here; identical for full-rank normal equations.
+// one value, result in every lane (the same bits everywhere: each stage adds the same two partial sums in both partners)
+DM_INLINE double wave_allsum(double v) {
+    v += ddpp<DPP_XOR1>(v, v);
+    v += ddpp<DPP_XOR2>(v, v);
+    v += ddpp<DPP_HALF_MIRROR>(v, v);
+    v += ddpp<DPP_MIRROR>(v, v);  // every lane of a 16-row holds the row's sum
+    double a = v, b = v;
+    dswap16(a, b);
+    v = a + b;
+    a = v;
+    b = v;
+    dswap32(a, b);
+    return a + b;
+}
+
+// 32 values per lane -> their 32 wave totals in s_out[0..31] (LDS), readable by every lane after the call.  Transpose-reduce: each
+// stage halves the values a lane still carries and the lanes that remain to be summed (31 adds and 62 lane moves in all instead of
+// 32 x 6 adds and 32 x 12 moves).  After stage k a lane holds the values whose index bits agree with its own lane bits:
+//   index = lane bit3 + 2 * bit1 + 4 * bit0 + 8 * bit4 + 16 * bit5;   lanes l and l ^ 4 end with the same index (summed last).
+DM_INLINE void wave_allsum32(double (&v)[32], double* s_out) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { dswap32(v[i], v[i + 16]); v[i] += v[i + 16]; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { dswap16(v[i], v[i + 8]); v[i] += v[i + 8]; }
+    const bool b0 = lane & 1, b1 = lane & 2, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // partner l ^ 1: keep v[i] (bit0 clear) or v[i + 4], send the other one
+        const double keep = b0 ? v[i + 4] : v[i], send = b0 ? v[i] : v[i + 4];
+        v[i] = keep + ddpp<DPP_XOR1>(send, send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double keep = b1 ? v[i + 2] : v[i], send = b1 ? v[i] : v[i + 2];
+        v[i] = keep + ddpp<DPP_XOR2>(send, send);
+    }
+    const double keep = b3 ? v[1] : v[0], send = b3 ? v[0] : v[1];
+    double r = keep + ddpp<DPP_ROR8>(send, send);
+    r += dxor4(r);
+    const int idx = ((lane >> 3) & 1) + 2 * ((lane >> 1) & 1) + 4 * (lane & 1) + 8 * ((lane >> 4) & 1) + 16 * ((lane >> 5) & 1);
+    // one wave per workgroup: its LDS operations execute in order, so a wave barrier (no counter wait: global loads may stay in
+    // flight) is all that separates the readers of the previous result, this write, and the readers of this one
+    wave_sync_lds();
+    s_out[idx] = r;
+    wave_sync_lds();
+}
+
+// Solve of the symmetric positive definite 6x6 system A x = b (upper triangle of A, row-major 6x6) by L D L^T: six reciprocals and no
+// square root on the dependent chain (a Cholesky factorisation has 6 square roots and 27 divisions there).  OpenCV uses an SVD
+// pseudo-inverse here; identical for full-rank normal equations.
 DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
-    double L[36];
+    double L[36], W[36], inv[6];  // W[i][j] = L[i][j] * D[j]
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
 #pragma unroll
-        for (int j = 0; j <= i; j++) {
-            double s = A[j * 6 + i];
+        for (int k = 0; k < j; k++) d -= L[j * 6 + k] * W[j * 6 + k];
+        ok = ok && (d > 0.0);
+        inv[j] = 1.0 / d;
 #pragma unroll
-            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-            if (i == j) {
-                ok = ok && (s > 0.0);
-                L[i * 6 + i] = sqrt(s);
-            } else {
-                L[i * 6 + j] = s / L[j * 6 + j];
-            }
+        for (int i = j + 1; i < 6; i++) {
+            double t = A[j * 6 + i];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= L[i * 6 + k] * W[j * 6 + k];
+            W[i * 6 + j] = t;
+            L[i * 6 + j] = t * inv[j];
         }
     }
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        double s = b[i];
+        double t = b[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        for (int k = 0; k < i; k++) t -= L[i * 6 + k] * y[k];
+        y[i] = t;
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
-        double s = y[i];
+        double t = y[i] * inv[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        for (int k = i + 1; k < 6; k++) t -= L[k * 6 + i] * x[k];
+        x[i] = t;
     }
     if (!ok) {
 #pragma unroll
@@ -74,13 +162,13 @@ DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
 // Residuals (and optionally the normal equations) of the n collected correspondences at pose `p`.
 // Returns the L2 norm of the 2n residuals; all lanes return the same bits.
 template <bool WITH_J>
-DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, const dm::Cam& K, const double p[6], double JtJ[21], double JtE[6]) {
+DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, const double p[6], double JtJ[21], double JtE[6]) {
     const int lane = threadIdx.x & 63;
     double R[9], dRdr[27];
     dm::rodrigues_v2m<WITH_J>(p, R, dRdr);
-    double acc[28];
+    double acc[32];  // 21 of J^T J, 6 of J^T e, |e|^2, 4 unused
 #pragma unroll
-    for (int i = 0; i < 28; i++) acc[i] = 0.0;
+    for (int i = 0; i < 32; i++) acc[i] = 0.0;
     for (int i = lane; i < n; i += 64) {
         const double Mx = s_X[i * 3], My = s_X[i * 3 + 1], Mz = s_X[i * 3 + 2];
         const double Xc = R[0] * Mx + R[1] * My + R[2] * Mz + p[3];
@@ -113,18 +201,21 @@ DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, const dm::C
             }
         }
     }
-    const double e2 = wave_allsum(acc[27]);
-    if (WITH_J) {
+    if (!WITH_J) return sqrt(wave_allsum(acc[27]));
+    wave_allsum32(acc, s_red);
 #pragma unroll
-        for (int i = 0; i < 21; i++) JtJ[i] = wave_allsum(acc[i]);
+    for (int i = 0; i < 21; i++) JtJ[i] = s_red[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) JtE[i] = wave_allsum(acc[21 + i]);
-    }
+    for (int i = 0; i < 6; i++) JtE[i] = s_red[21 + i];
+    const double e2 = s_red[27];
     return sqrt(e2);
 }
 
+__constant__ double c_pow10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0,
+                                   1e1,   1e2,   1e3,   1e4,   1e5,   1e6,   1e7,   1e8,  1e9,  1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
+
 DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10, const double prev[6], double param[6]) {
-    const double lambda = exp((double)lambdaLg10 * 2.302585092994046);  // exp(lambdaLg10 * log(10))
+    const double lambda = c_pow10[lambdaLg10 + 16];  // CvLevMarq: exp(lambdaLg10 * log(10)), lambdaLg10 in [-16, 16]
     double A[36];
     int q = 0;
 #pragma unroll
@@ -140,13 +231,13 @@ DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10
 }
 
 // solvePnP(CV_ITERATIVE, useExtrinsicGuess = true) on the wave; pose is updated in place.
-DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, const dm::Cam& K, double pose[6]) {
+DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, double pose[6]) {
     double param[6], prev[6], JtJ[21], JtE[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) param[i] = pose[i];
     int lambdaLg10 = -3, iters = 0;
     double prevErrNorm = 1.7976931348623157e308, errNorm = 0;
-    double e_at_param = lm_eval<true>(n, s_X, s_uv, K, param, JtJ, JtE);
+    double e_at_param = lm_eval<true>(n, s_X, s_uv, s_red, K, param, JtJ, JtE);
     bool done = false;
     for (int guard = 0; guard < 64 && !done; guard++) {
 #pragma unroll
@@ -154,7 +245,7 @@ DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, const dm::Cam&
         if (iters == 0) prevErrNorm = e_at_param;
         lm_step(JtJ, JtE, lambdaLg10, prev, param);
         for (int inner = 0; inner < 40; inner++) {
-            errNorm = lm_eval<false>(n, s_X, s_uv, K, param, nullptr, nullptr);
+            errNorm = lm_eval<false>(n, s_X, s_uv, s_red, K, param, nullptr, nullptr);
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) { lm_step(JtJ, JtE, lambdaLg10, prev, param); continue; }
             }
@@ -165,12 +256,39 @@ DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, const dm::Cam&
             const double change = sqrt(num) / (sqrt(den) + 2.220446049250313e-16);
             if (++iters >= 20 || change < 1.1920928955078125e-07) { done = true; break; }
             prevErrNorm = errNorm;
-            e_at_param = lm_eval<true>(n, s_X, s_uv, K, param, JtJ, JtE);
+            e_at_param = lm_eval<true>(n, s_X, s_uv, s_red, K, param, JtJ, JtE);
             break;
         }
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) pose[i] = param[i];
+}
+
+// The inlier walk reads the permuted cells 64 * WALK_AHEAD at a time: permutation entry -> coordinate is a chain of two dependent
+// loads, so one round trip now serves 256 cells (a walk that collects max_inl = 100 inliers rarely needs more).
+constexpr int WALK_AHEAD = 4;
+struct WalkCells {
+    int p[WALK_AHEAD];  // cell index, -1 past the end of the permutation
+    float X[WALK_AHEAD], Y[WALK_AHEAD], Z[WALK_AHEAD], u[WALK_AHEAD], v[WALK_AHEAD];
+};
+DM_INLINE void load_walk_cells(const int32_t* __restrict__ pidx, int base, int lane, const FrameDev& F, WalkCells& c) {
+    const int P = F.P;
+    int q[WALK_AHEAD];
+#pragma unroll
+    for (int s = 0; s < WALK_AHEAD; s++) {
+        const int idx = base + s * 64 + lane;
+        q[s] = idx < P ? min(max(pidx[idx], 0), P - 1) : -1;
+    }
+#pragma unroll
+    for (int s = 0; s < WALK_AHEAD; s++) {
+        const int p = max(q[s], 0);
+        c.p[s] = q[s];
+        c.X[s] = F.xyz[(size_t)p * 3];
+        c.Y[s] = F.xyz[(size_t)p * 3 + 1];
+        c.Z[s] = F.xyz[(size_t)p * 3 + 2];
+        if (F.uv) { c.u[s] = F.uv[(size_t)p * 2]; c.v[s] = F.uv[(size_t)p * 2 + 1]; }
+        else { const int y = p / F.W; c.u[s] = (float)(p - y * F.W); c.v[s] = (float)y; }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict__ n_live, int live_base, int live_mul,
@@ -188,6 +306,7 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
     const int lane = threadIdx.x;
     __shared__ float s_X[RF_MAX_INL * 3];
     __shared__ float s_uv[RF_MAX_INL * 2];
+    __shared__ double s_red[32];
     const dm::Cam K = make_cam_r(F);
     double pose[6];
 #pragma unroll
@@ -197,42 +316,46 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
     const float pval = pert_value ? pert_value[b] : 0.f;
     const int P = F.P;
     int done = 0;
+    WalkCells cells;
+    if (steps > 0) load_walk_cells(perm, 0, lane, F, cells);
     for (int step = 0; step < steps; step++) {
         double R[9];
         dm::rodrigues_v2m<false>(pose, R, nullptr);
         const int32_t* pidx = perm + (size_t)step * P;
         int cnt = 0;
-        for (int base = 0; base < P && cnt < max_inl; base += 64) {
-            const int idx = base + lane;
-            const bool in = idx < P;
-            int p = in ? pidx[idx] : 0;
-            p = min(max(p, 0), P - 1);
-            float X = F.xyz[(size_t)p * 3], Y = F.xyz[(size_t)p * 3 + 1], Z = F.xyz[(size_t)p * 3 + 2];
-            if (p == ppx) { if (pch == 0) X = pval; else if (pch == 1) Y = pval; else Z = pval; }
-            float pu, pv;
-            if (F.uv) { pu = F.uv[(size_t)p * 2]; pv = F.uv[(size_t)p * 2 + 1]; }
-            else { const int y = p / F.W; pu = (float)(p - y * F.W); pv = (float)y; }
-            const float e = dm::residual_f(R, pose + 3, K, X, Y, Z, pu, pv, 100.0);
-            const bool inl = in && (e < thr);
-            const unsigned long long m = __ballot(inl);
-            const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-            const bool take = inl && (cnt + prefix < max_inl);
-            if (take) {
-                const int slot = cnt + prefix;
-                s_X[slot * 3] = X; s_X[slot * 3 + 1] = Y; s_X[slot * 3 + 2] = Z;
-                s_uv[slot * 2] = pu; s_uv[slot * 2 + 1] = pv;
-                if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
+        for (int base = 0; base < P && cnt < max_inl; base += 64 * WALK_AHEAD) {
+            if (base > 0) load_walk_cells(pidx, base, lane, F, cells);
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                if (cnt >= max_inl) break;  // uniform: the walk stops at max_inl taken cells (core/cnn_softam.h:1121-1135)
+                const int p = cells.p[s];
+                const bool in = p >= 0;
+                float X = cells.X[s], Y = cells.Y[s], Z = cells.Z[s];
+                if (p == ppx) { if (pch == 0) X = pval; else if (pch == 1) Y = pval; else Z = pval; }
+                const float pu = cells.u[s], pv = cells.v[s];
+                const float e = dm::residual_f(R, pose + 3, K, X, Y, Z, pu, pv, 100.0);
+                const bool inl = in && (e < thr);
+                const unsigned long long m = __ballot(inl);
+                const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+                const bool take = inl && (cnt + prefix < max_inl);
+                if (take) {
+                    const int slot = cnt + prefix;
+                    s_X[slot * 3] = X; s_X[slot * 3 + 1] = Y; s_X[slot * 3 + 2] = Z;
+                    s_uv[slot * 2] = pu; s_uv[slot * 2 + 1] = pv;
+                    if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
+                }
+                cnt += __popcll(m);
             }
-            cnt += __popcll(m);
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        // the head of the next step's walk does not depend on the pose: its loads fly under the LM solve
+        if (step + 1 < steps) load_walk_cells(pidx + P, 0, lane, F, cells);
+        wave_sync_lds();
         const int n = min(cnt, max_inl);
         if (n < min_inl) break;  // abort for stability: too few inliers (core/cnn_softam.h:700, 1136)
         double upd[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) upd[i] = pose[i];
-        lm_pnp(n, s_X, s_uv, K, upd);
+        lm_pnp(n, s_X, s_uv, s_red, K, upd);
         bool nan = false;
 #pragma unroll
         for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
