@@ -26,46 +26,57 @@ DM_INLINE bool isnan_d(double x) { return x != x; }
 // ------------------------------------------------------------------------------------------------
 // Rodrigues: vector -> matrix (row-major R[9]); optional 3x9 derivative J[i*9+k] = dR_k / dr_i
 // ------------------------------------------------------------------------------------------------
-template <bool WITH_J>
-DM_INLINE void rodrigues_v2m(const double r[3], double R[9], double* J) {
+// Split in two so that a caller that already holds R(r) can add the derivative later without redoing sqrt / sincos / the division:
+// rodrigues_R fills R and the intermediates, rodrigues_J turns the intermediates into the derivative.
+// Both are branch-free (selects on the |r| < DBL_EPSILON case, which gives R = I and dR/dr = -[e_i]x exactly as OpenCV's special case).
+struct RodAux { double s, c, c1, it, k4, ax, ay, az; };
+
+DM_INLINE void rodrigues_R(const double r[3], double R[9], RodAux& a) {
     const double rx = r[0], ry = r[1], rz = r[2];
     const double theta = sqrt(rx * rx + ry * ry + rz * rz);
-    if (theta < 2.220446049250313e-16) {
-        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-        if (WITH_J) {
-#pragma unroll
-            for (int k = 0; k < 27; k++) J[k] = 0;
-            J[5] = -1; J[15] = -1; J[19] = -1;
-            J[7] = 1; J[11] = 1; J[21] = 1;
-        }
-        return;
-    }
+    const bool small = theta < 2.220446049250313e-16;
     double s, c;
-    sincos(theta, &s, &c);
-    const double c1 = 1.0 - c, it = 1.0 / theta;
+    sincos(small ? 1.0 : theta, &s, &c);
+    const double it = small ? 0.0 : 1.0 / theta;
+    s = small ? 0.0 : s;
+    c = small ? 1.0 : c;
+    a.s = s; a.c = c; a.c1 = 1.0 - c; a.it = it;
+    a.k4 = small ? 1.0 : s * it;  // sin(theta)/theta -> 1
     const double ax = rx * it, ay = ry * it, az = rz * it;
+    a.ax = ax; a.ay = ay; a.az = az;
     const double aat[9] = {ax * ax, ax * ay, ax * az, ax * ay, ay * ay, ay * az, ax * az, ay * az, az * az};
     const double skew[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * aat[k] + s * skew[k];
-    if (WITH_J) {
-        const double a[3] = {ax, ay, az};
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + a.c1 * aat[k] + s * skew[k];
+}
+
+DM_INLINE void rodrigues_J(const RodAux& q, double* J) {
+    const double s = q.s, c = q.c, c1 = q.c1, it = q.it, ax = q.ax, ay = q.ay, az = q.az;
+    const double aat[9] = {ax * ax, ax * ay, ax * az, ax * ay, ay * ay, ay * az, ax * az, ay * az, az * az};
+    const double skew[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+    const double a[3] = {ax, ay, az};
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const double ai = a[i];
-            const double k0 = -s * ai, k1 = (s - 2 * c1 * it) * ai, k2 = c1 * it, k3 = (c - s * it) * ai, k4 = s * it;
+    for (int i = 0; i < 3; i++) {
+        const double ai = a[i];
+        const double k0 = -s * ai, k1 = (s - 2 * c1 * it) * ai, k2 = c1 * it, k3 = (c - s * it) * ai, k4 = q.k4;
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const int row = k / 3, col = k % 3;
-                // d(a a^T)/d a_i  at (row, col):  delta(row,i) a_col + delta(col,i) a_row
-                const double daat = ((row == i) ? a[col] : 0.0) + ((col == i) ? a[row] : 0.0);
-                // d[a]x/d a_i at (row, col): -eps(row, col, i)
-                double dsk = 0.0;
-                if (row != col && row != i && col != i) dsk = (((col - row + 3) % 3) == 1) ? -1.0 : 1.0;
-                J[i * 9 + k] = k0 * ((k % 4 == 0) ? 1.0 : 0.0) + k1 * aat[k] + k2 * daat + k3 * skew[k] + k4 * dsk;
-            }
+        for (int k = 0; k < 9; k++) {
+            const int row = k / 3, col = k % 3;
+            // d(a a^T)/d a_i  at (row, col):  delta(row,i) a_col + delta(col,i) a_row
+            const double daat = ((row == i) ? a[col] : 0.0) + ((col == i) ? a[row] : 0.0);
+            // d[a]x/d a_i at (row, col): -eps(row, col, i)
+            double dsk = 0.0;
+            if (row != col && row != i && col != i) dsk = (((col - row + 3) % 3) == 1) ? -1.0 : 1.0;
+            J[i * 9 + k] = k0 * ((k % 4 == 0) ? 1.0 : 0.0) + k1 * aat[k] + k2 * daat + k3 * skew[k] + k4 * dsk;
         }
     }
+}
+
+template <bool WITH_J>
+DM_INLINE void rodrigues_v2m(const double r[3], double R[9], double* J) {
+    RodAux a;
+    rodrigues_R(r, R, a);
+    if (WITH_J) rodrigues_J(a, J);
 }
 
 // Rodrigues: matrix -> vector.  Inputs on this path are rotation matrices to rounding (outputs of P3P,

@@ -10,8 +10,13 @@
 // inliers in permutation order with ballot + popcount, so a refinement step touches O(max_inl) cells
 // instead of P.  The LM solve (CvLevMarq's state machine: Marquardt scaling 1+lambda, lambda0 = 1e-3,
 // x10 / /10, <= 20 iterations, eps = FLT_EPSILON on the relative parameter change) runs on the same wave:
-// lanes split the <= max_inl correspondences, J^T J / J^T e are reduced with a butterfly (bit-identical on
-// all lanes), and every lane solves the damped 6x6 system redundantly, which keeps control flow uniform.
+// lanes split the <= max_inl correspondences, J^T J / J^T e are summed over the wave by a transpose-reduce
+// (v_permlane32/16_swap + DPP, the totals broadcast through LDS: the same bits in all lanes), and every lane
+// solves the damped 6x6 system redundantly (L D L^T), which keeps control flow uniform.
+// The kernel is a latency chain on one wave (8 steps x ~3 LM iterations), so round 2 shortened the chain rather
+// than widening it: the walk's two dependent loads are issued 256 cells at a time and the next step's head is
+// fetched under the LM solve; R(r) and its intermediates are kept between evaluations of the same pose; an
+// accepted trial's residual and normal equations come from one pass (profiles/r02_k6_*.txt: 175 -> 90 us).
 // The 12 + 6*n finite-difference replicas of dRefineHyp/dRefineObj are just more waves of the same kernel:
 // a replica is (start pose, optionally one replaced coordinate), so the whole Jacobian is one launch.
 #include "kernels.h"
@@ -159,55 +164,105 @@ DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
     return ok;
 }
 
+// R(r) of the last rotation vector the wave evaluated, with the intermediates its derivative needs: the LM state machine evaluates the same
+// pose several times in a row (the walk, then the first Jacobian, at the start pose; residual-only, then Jacobian, at an accepted step)
+struct RodCache {
+    double r[3] = {__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
+    double R[9];
+    dm::RodAux aux;
+};
+DM_INLINE void rod_at(RodCache& rc, const double p[6]) {
+    if (p[0] == rc.r[0] && p[1] == rc.r[1] && p[2] == rc.r[2]) return;
+    rc.r[0] = p[0]; rc.r[1] = p[1]; rc.r[2] = p[2];
+    dm::rodrigues_R(p, rc.R, rc.aux);
+}
+
 // Residuals (and optionally the normal equations) of the n collected correspondences at pose `p`.
-// Returns the L2 norm of the 2n residuals; all lanes return the same bits.
+// Returns the L2 norm of the 2n residuals; all lanes return the same bits, and the same bits with or without the normal equations.
 template <bool WITH_J>
-DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, const double p[6], double JtJ[21], double JtE[6]) {
+DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, RodCache& rc, const double p[6], double JtJ[21],
+                         double JtE[6]) {
     const int lane = threadIdx.x & 63;
-    double R[9], dRdr[27];
-    dm::rodrigues_v2m<WITH_J>(p, R, dRdr);
-    double acc[32];  // 21 of J^T J, 6 of J^T e, |e|^2, 4 unused
+    double dRdr[27];
+    rod_at(rc, p);
+    if (WITH_J) dm::rodrigues_J(rc.aux, dRdr);
+    const double* R = rc.R;
+    double acc[32];  // 21 of J^T J, 6 of J^T e, 5 unused
+    double e2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 32; i++) acc[i] = 0.0;
-    for (int i = lane; i < n; i += 64) {
-        const double Mx = s_X[i * 3], My = s_X[i * 3 + 1], Mz = s_X[i * 3 + 2];
-        const double Xc = R[0] * Mx + R[1] * My + R[2] * Mz + p[3];
-        const double Yc = R[3] * Mx + R[4] * My + R[5] * Mz + p[4];
-        const double Zc = R[6] * Mx + R[7] * My + R[8] * Mz + p[5];
-        const double z = (Zc != 0.0) ? 1. / Zc : 1.;
-        const double x = Xc * z, y = Yc * z;
-        const double eu = x * K.fx + K.cx - (double)s_uv[i * 2];
-        const double ev = y * K.fy + K.cy - (double)s_uv[i * 2 + 1];
-        acc[27] += eu * eu + ev * ev;
-        if (WITH_J) {
-            double Ju[6], Jv[6];
+    // two correspondences per lane and trip (lane, lane + 64: the usual 100 inliers are one trip), written as one block so that the two
+    // dependent chains (the division, the Jacobian rows) interleave; a lane without a second correspondence adds exact zeros
+    for (int i0 = 0; i0 < n; i0 += 128) {
+        double eu[2], ev[2], x[2], y[2], zf[2], M[2][3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const double* dR = dRdr + j * 9;
-                const double dX = dR[0] * Mx + dR[1] * My + dR[2] * Mz;
-                const double dY = dR[3] * Mx + dR[4] * My + dR[5] * Mz;
-                const double dZ = dR[6] * Mx + dR[7] * My + dR[8] * Mz;
-                Ju[j] = K.fx * z * (dX - x * dZ);
-                Jv[j] = K.fy * z * (dY - y * dZ);
-            }
-            Ju[3] = K.fx * z; Ju[4] = 0; Ju[5] = -K.fx * x * z;
-            Jv[3] = 0; Jv[4] = K.fy * z; Jv[5] = -K.fy * y * z;
-            int q = 0;
+        for (int h = 0; h < 2; h++) {
+            const int i = i0 + h * 64 + lane;
+            const bool valid = i < n;
+            const int ic = valid ? i : 0;
+            M[h][0] = s_X[ic * 3]; M[h][1] = s_X[ic * 3 + 1]; M[h][2] = s_X[ic * 3 + 2];
+            const double Xc = R[0] * M[h][0] + R[1] * M[h][1] + R[2] * M[h][2] + p[3];
+            const double Yc = R[3] * M[h][0] + R[4] * M[h][1] + R[5] * M[h][2] + p[4];
+            const double Zc = R[6] * M[h][0] + R[7] * M[h][1] + R[8] * M[h][2] + p[5];
+            const double z = (Zc != 0.0) ? 1. / Zc : 1.;
+            const double xx = Xc * z, yy = Yc * z;
+            const double du = xx * K.fx + K.cx - (double)s_uv[ic * 2];
+            const double dv = yy * K.fy + K.cy - (double)s_uv[ic * 2 + 1];
+            x[h] = valid ? xx : 0.0;
+            y[h] = valid ? yy : 0.0;
+            eu[h] = valid ? du : 0.0;
+            ev[h] = valid ? dv : 0.0;
+            zf[h] = valid ? z : 0.0;
+        }
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
-                acc[21 + a] += Ju[a] * eu + Jv[a] * ev;
+        for (int h = 0; h < 2; h++) {
+            e2 += eu[h] * eu[h] + ev[h] * ev[h];
+            if (WITH_J) {
+                const double Mx = M[h][0], My = M[h][1], Mz = M[h][2], z = zf[h];
+                // rows of the 2 x 6 Jacobian: u-row (ju0 ju1 ju2 tu 0 wu), v-row (jv0 jv1 jv2 0 tv wv); the two structural zeros
+                // take 23 of the 54 products out of J^T J / J^T e (entry (3,4) is identically zero)
+                double ju[3], jv[3];
+                const double tu = K.fx * z, tv = K.fy * z;
 #pragma unroll
-                for (int b2 = a; b2 < 6; b2++) { acc[q] += Ju[a] * Ju[b2] + Jv[a] * Jv[b2]; q++; }
+                for (int j = 0; j < 3; j++) {
+                    const double* dR = dRdr + j * 9;
+                    const double dX = dR[0] * Mx + dR[1] * My + dR[2] * Mz;
+                    const double dY = dR[3] * Mx + dR[4] * My + dR[5] * Mz;
+                    const double dZ = dR[6] * Mx + dR[7] * My + dR[8] * Mz;
+                    ju[j] = tu * (dX - x[h] * dZ);
+                    jv[j] = tv * (dY - y[h] * dZ);
+                }
+                const double wu = -tu * x[h], wv = -tv * y[h];
+                // packed upper triangle, row a: index q(a, b) = a * 6 - a * (a - 1) / 2 + (b - a)
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+#pragma unroll
+                    for (int b2 = a; b2 < 3; b2++) { acc[q] = fma(ju[a], ju[b2], fma(jv[a], jv[b2], acc[q])); q++; }
+                    acc[q] = fma(ju[a], tu, acc[q]); q++;                        // (a, 3)
+                    acc[q] = fma(jv[a], tv, acc[q]); q++;                        // (a, 4)
+                    acc[q] = fma(ju[a], wu, fma(jv[a], wv, acc[q])); q++;        // (a, 5)
+                    acc[21 + a] = fma(ju[a], eu[h], fma(jv[a], ev[h], acc[21 + a]));
+                }
+                acc[15] = fma(tu, tu, acc[15]);                                  // (3, 3);  (3, 4) = acc[16] stays 0
+                acc[17] = fma(tu, wu, acc[17]);                                  // (3, 5)
+                acc[18] = fma(tv, tv, acc[18]);                                  // (4, 4)
+                acc[19] = fma(tv, wv, acc[19]);                                  // (4, 5)
+                acc[20] = fma(wu, wu, fma(wv, wv, acc[20]));                     // (5, 5)
+                acc[24] = fma(tu, eu[h], acc[24]);
+                acc[25] = fma(tv, ev[h], acc[25]);
+                acc[26] = fma(wu, eu[h], fma(wv, ev[h], acc[26]));
             }
         }
     }
-    if (!WITH_J) return sqrt(wave_allsum(acc[27]));
-    wave_allsum32(acc, s_red);
+    e2 = wave_allsum(e2);
+    if (WITH_J) {
+        wave_allsum32(acc, s_red);
 #pragma unroll
-    for (int i = 0; i < 21; i++) JtJ[i] = s_red[i];
+        for (int i = 0; i < 21; i++) JtJ[i] = s_red[i];
 #pragma unroll
-    for (int i = 0; i < 6; i++) JtE[i] = s_red[21 + i];
-    const double e2 = s_red[27];
+        for (int i = 0; i < 6; i++) JtE[i] = s_red[21 + i];
+    }
     return sqrt(e2);
 }
 
@@ -215,7 +270,8 @@ __constant__ double c_pow10[33] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-
                                    1e1,   1e2,   1e3,   1e4,   1e5,   1e6,   1e7,   1e8,  1e9,  1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16};
 
 DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10, const double prev[6], double param[6]) {
-    const double lambda = c_pow10[lambdaLg10 + 16];  // CvLevMarq: exp(lambdaLg10 * log(10)), lambdaLg10 in [-16, 16]
+    // CvLevMarq: exp(lambdaLg10 * log(10)), lambdaLg10 in [-16, 16] (the same in every lane: a scalar load)
+    const double lambda = c_pow10[__builtin_amdgcn_readfirstlane(lambdaLg10) + 16];
     double A[36];
     int q = 0;
 #pragma unroll
@@ -231,13 +287,16 @@ DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10
 }
 
 // solvePnP(CV_ITERATIVE, useExtrinsicGuess = true) on the wave; pose is updated in place.
-DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, double pose[6]) {
-    double param[6], prev[6], JtJ[21], JtE[6];
+// CvLevMarq's sequence per iteration is: solve -> residual at the trial pose -> (accepted) Jacobian at the same pose.  Whether an accepted
+// trial ends the iteration (20 iterations or a relative parameter change below FLT_EPSILON) is known before the residual is: unless it
+// does, residual and normal equations of the trial are computed in one pass and simply dropped if the trial is rejected.
+DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, RodCache& rc, double pose[6]) {
+    double param[6], prev[6], JtJ[21], JtE[6], JtJn[21], JtEn[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) param[i] = pose[i];
     int lambdaLg10 = -3, iters = 0;
     double prevErrNorm = 1.7976931348623157e308, errNorm = 0;
-    double e_at_param = lm_eval<true>(n, s_X, s_uv, s_red, K, param, JtJ, JtE);
+    double e_at_param = lm_eval<true>(n, s_X, s_uv, s_red, K, rc, param, JtJ, JtE);
     bool done = false;
     for (int guard = 0; guard < 64 && !done; guard++) {
 #pragma unroll
@@ -245,18 +304,26 @@ DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red,
         if (iters == 0) prevErrNorm = e_at_param;
         lm_step(JtJ, JtE, lambdaLg10, prev, param);
         for (int inner = 0; inner < 40; inner++) {
-            errNorm = lm_eval<false>(n, s_X, s_uv, s_red, K, param, nullptr, nullptr);
+            double num = 0, den = 0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { num += (param[i] - prev[i]) * (param[i] - prev[i]); den += prev[i] * prev[i]; }
+            // CvLevMarq: |param - prev| / (|prev| + DBL_EPSILON) < FLT_EPSILON, without the first square root and the division
+            const double lim = 1.1920928955078125e-07 * (sqrt(den) + 2.220446049250313e-16);
+            const bool last = (iters + 1 >= 20) || (num < lim * lim);
+            if (last) errNorm = lm_eval<false>(n, s_X, s_uv, s_red, K, rc, param, nullptr, nullptr);
+            else errNorm = lm_eval<true>(n, s_X, s_uv, s_red, K, rc, param, JtJn, JtEn);
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) { lm_step(JtJ, JtE, lambdaLg10, prev, param); continue; }
             }
             lambdaLg10 = max(lambdaLg10 - 1, -16);
-            double num = 0, den = 0;
-#pragma unroll
-            for (int i = 0; i < 6; i++) { num += (param[i] - prev[i]) * (param[i] - prev[i]); den += prev[i] * prev[i]; }
-            const double change = sqrt(num) / (sqrt(den) + 2.220446049250313e-16);
-            if (++iters >= 20 || change < 1.1920928955078125e-07) { done = true; break; }
+            iters++;
+            if (last) { done = true; break; }
             prevErrNorm = errNorm;
-            e_at_param = lm_eval<true>(n, s_X, s_uv, s_red, K, param, JtJ, JtE);
+            e_at_param = errNorm;
+#pragma unroll
+            for (int i = 0; i < 21; i++) JtJ[i] = JtJn[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) JtE[i] = JtEn[i];
             break;
         }
     }
@@ -273,22 +340,30 @@ struct WalkCells {
 };
 DM_INLINE void load_walk_cells(const int32_t* __restrict__ pidx, int base, int lane, const FrameDev& F, WalkCells& c) {
     const int P = F.P;
+    // branch-free: every load is issued before the first result is needed (clamped addresses instead of guarded loads)
     int q[WALK_AHEAD];
 #pragma unroll
-    for (int s = 0; s < WALK_AHEAD; s++) {
-        const int idx = base + s * 64 + lane;
-        q[s] = idx < P ? min(max(pidx[idx], 0), P - 1) : -1;
-    }
+    for (int s = 0; s < WALK_AHEAD; s++) q[s] = pidx[min(base + s * 64 + lane, P - 1)];
 #pragma unroll
     for (int s = 0; s < WALK_AHEAD; s++) {
-        const int p = max(q[s], 0);
-        c.p[s] = q[s];
+        const int p = min(max(q[s], 0), P - 1);
+        c.p[s] = (base + s * 64 + lane < P) ? p : -1;
         c.X[s] = F.xyz[(size_t)p * 3];
         c.Y[s] = F.xyz[(size_t)p * 3 + 1];
         c.Z[s] = F.xyz[(size_t)p * 3 + 2];
-        if (F.uv) { c.u[s] = F.uv[(size_t)p * 2]; c.v[s] = F.uv[(size_t)p * 2 + 1]; }
-        else { const int y = p / F.W; c.u[s] = (float)(p - y * F.W); c.v[s] = (float)y; }
+        q[s] = p;
     }
+    if (F.uv) {
+#pragma unroll
+        for (int s = 0; s < WALK_AHEAD; s++) { c.u[s] = F.uv[(size_t)q[s] * 2]; c.v[s] = F.uv[(size_t)q[s] * 2 + 1]; }
+    }
+}
+// pixel position of a walked cell: the sampled position when the frame has one, else the cell's grid position
+DM_INLINE void walk_cell_uv(const FrameDev& F, const WalkCells& c, int s, float& u, float& v) {
+    if (F.uv) { u = c.u[s]; v = c.v[s]; return; }
+    const int p = max(c.p[s], 0), y = p / F.W;
+    u = (float)(p - y * F.W);
+    v = (float)y;
 }
 
 __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict__ n_live, int live_base, int live_mul,
@@ -316,32 +391,37 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
     const float pval = pert_value ? pert_value[b] : 0.f;
     const int P = F.P;
     int done = 0;
+    RodCache rc;
     WalkCells cells;
     if (steps > 0) load_walk_cells(perm, 0, lane, F, cells);
     for (int step = 0; step < steps; step++) {
-        double R[9];
-        dm::rodrigues_v2m<false>(pose, R, nullptr);
+        rod_at(rc, pose);
+        const double* R = rc.R;
         const int32_t* pidx = perm + (size_t)step * P;
         int cnt = 0;
         for (int base = 0; base < P && cnt < max_inl; base += 64 * WALK_AHEAD) {
             if (base > 0) load_walk_cells(pidx, base, lane, F, cells);
+            // the residuals of the four sub-batches are independent of the running count: all four first (their divisions and
+            // square roots interleave), then the in-order compaction
+            float e[WALK_AHEAD], pu[WALK_AHEAD], pv[WALK_AHEAD];
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                if (ppx >= 0 && cells.p[s] == ppx) { if (pch == 0) cells.X[s] = pval; else if (pch == 1) cells.Y[s] = pval; else cells.Z[s] = pval; }
+                walk_cell_uv(F, cells, s, pu[s], pv[s]);
+                e[s] = dm::residual_f(R, pose + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
+            }
 #pragma unroll
             for (int s = 0; s < WALK_AHEAD; s++) {
                 if (cnt >= max_inl) break;  // uniform: the walk stops at max_inl taken cells (core/cnn_softam.h:1121-1135)
                 const int p = cells.p[s];
-                const bool in = p >= 0;
-                float X = cells.X[s], Y = cells.Y[s], Z = cells.Z[s];
-                if (p == ppx) { if (pch == 0) X = pval; else if (pch == 1) Y = pval; else Z = pval; }
-                const float pu = cells.u[s], pv = cells.v[s];
-                const float e = dm::residual_f(R, pose + 3, K, X, Y, Z, pu, pv, 100.0);
-                const bool inl = in && (e < thr);
+                const bool inl = (p >= 0) && (e[s] < thr);
                 const unsigned long long m = __ballot(inl);
                 const int prefix = __popcll(m & ((1ull << lane) - 1ull));
                 const bool take = inl && (cnt + prefix < max_inl);
                 if (take) {
                     const int slot = cnt + prefix;
-                    s_X[slot * 3] = X; s_X[slot * 3 + 1] = Y; s_X[slot * 3 + 2] = Z;
-                    s_uv[slot * 2] = pu; s_uv[slot * 2 + 1] = pv;
+                    s_X[slot * 3] = cells.X[s]; s_X[slot * 3 + 1] = cells.Y[s]; s_X[slot * 3 + 2] = cells.Z[s];
+                    s_uv[slot * 2] = pu[s]; s_uv[slot * 2 + 1] = pv[s];
                     if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
                 }
                 cnt += __popcll(m);
@@ -355,7 +435,7 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
         double upd[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) upd[i] = pose[i];
-        lm_pnp(n, s_X, s_uv, s_red, K, upd);
+        lm_pnp(n, s_X, s_uv, s_red, K, rc, upd);
         bool nan = false;
 #pragma unroll
         for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
