@@ -1,7 +1,7 @@
 """GPU parity of K6 (inlier refinement + finite-difference Jacobians) and K7 (pose loss) against the CPU oracle.
 
 Both sides run the same fp64 arithmetic (lazy getDiffMap residuals, CvLevMarq state machine); differences are
-libm-vs-ocml last bits and the 6x6 solve (Cholesky on the GPU, Gaussian elimination in the oracle).
+libm-vs-ocml last bits, the summation order of the normal equations and the 6x6 solve (L D L^T on the GPU, Gaussian elimination in the oracle).
   refined poses : 1e-7 relative          inlier maps / step counts : identical
   dRefineHyp/Obj: central differences divide LM outputs by 2e-3 / 4, so 1e-4 relative to the largest entry
   loss, dLossMax: 1e-9
@@ -75,6 +75,31 @@ def test_refine_too_few_inliers_and_short_perm(engine, orc, synth, frame40):
     # zero refinement steps requested
     got, sd = engine.refine(bad, perm[:0].reshape(0, 1600))
     assert np.array_equal(got[0], bad) and sd[0] == 0
+
+
+@pytest.mark.parametrize("max_inl,min_inl,outliers,full", [(100, 50, 0.93, False), (256, 50, 0.3, False), (130, 129, 0.3, False),
+                                                             (65, 1, 0.5, False), (100, 50, 0.9, True)])
+def test_refine_sparse_inliers_and_other_inlier_counts(engine, orc, synth, max_inl, min_inl, outliers, full):
+    """The walk reads the permutation 256 cells at a time and prefetches the next step's head; the LM loop takes two correspondences
+    per lane and trip.  Sparse inliers make the walk span many batches (and stop inside one); max_inl = 256 / 130 / 65 give the LM
+    loop 2 full trips / a ragged second trip / a second half with one lane.  `full`: 640x480 without sampled positions (the kernel
+    derives the pixel from the cell index)."""
+    H, W = (480, 640) if full else (120, 160)
+    fr = synth.chess_like_frame(H, W, seed=77, outlier_frac=outliers)
+    engine.set_frame(fr["xyz"], None if full else fr["uv"], H, W, fr["cam"])
+    perm = synth.fast_permutations(H * W, 8, seed=11)
+    rng = np.random.default_rng(3)
+    init = fr["gt_pose"][None, :] + rng.normal(size=(5, 6)) * np.array([0.004, 0.004, 0.004, 4.0, 4.0, 4.0])
+    kw = dict(inlier_count=max_inl, min_inliers=min_inl)
+    ref, sd_r = orc.refine(init, perm, fr["xyz"], fr["uv"], H, W, fr["cam"], **kw)
+    got, sd = engine.refine(init, perm, max_inl=max_inl, min_inl=min_inl)
+    assert np.array_equal(sd, sd_r) and sd.max() == 8
+    assert np.allclose(got, ref, rtol=1e-7, atol=1e-9)
+    _, imap_r, _ = orc.refine(init[0], perm, fr["xyz"], fr["uv"], H, W, fr["cam"], want_inlier_map=True, **kw)
+    _, _, imap = engine.refine(init[0], perm, max_inl=max_inl, min_inl=min_inl, want_inlier_map=True)
+    assert np.array_equal(imap, imap_r)
+    if sd[0] == 8:
+        assert imap.sum() == 8 * max_inl
 
 
 def test_drefine_parity(engine, orc, synth, frame40):
