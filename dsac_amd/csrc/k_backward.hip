@@ -324,7 +324,7 @@ DM_INLINE float row16_sum_f(float v) {  // sum over the 16 lanes of a DPP row, r
 }
 
 template <int CH, bool SOFTMODE, bool UV>
-__global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float* __restrict__ rec, const float* __restrict__ xyz,
+__global__ __launch_bounds__(K4_THREADS, 2) void k_score_backward_mfma(const float* __restrict__ rec, const float* __restrict__ xyz,
                                                                     const float* __restrict__ uv, const float* __restrict__ d_err,
                                                                     const double* __restrict__ g, float* __restrict__ grad_part,
                                                                     float* __restrict__ G12_part, int N, int P, int W, int PT, int NT, int G,
@@ -430,40 +430,38 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
                     const f2 ex = pp ? f2{ex4.z, ex4.w} : f2{ex4.x, ex4.y};
                     const f2 ny = pp ? f2{ny4.z, ny4.w} : f2{ny4.x, ny4.y};
                     const f2 ez = pp ? f2{ez4.z, ez4.w} : f2{ez4.x, ez4.y};
-                    // guard |E.z| < 1e-8 -> 0 (cnn_softam.h:416,476) right at the reciprocal: a zero reciprocal keeps everything below finite
-                    const bool z0 = fabsf(ez.x) >= 1e-8f, z1 = fabsf(ez.y) >= 1e-8f;
-                    const f2 iz = {z0 ? __builtin_amdgcn_rcpf(ez.x) : 0.f, z1 ? __builtin_amdgcn_rcpf(ez.y) : 0.f};
-                    const f2 fz = iz * f2{f, f};
-                    // (u - px, v - py) with px = -f E.x/E.z + cx, py = f E.y/E.z + cy
-                    const f2 du = __builtin_elementwise_fma(ex, fz, pu[ch][pp]);
-                    const f2 dv = __builtin_elementwise_fma(ny, fz, pv[ch][pp]);
-                    const f2 dq = __builtin_elementwise_fma(dv, dv, du * du);
-                    const f2 err = {__builtin_amdgcn_sqrtf(dq.x), __builtin_amdgcn_sqrtf(dq.y)};
-                    const f2 ee = err + f2{1e-8f, 1e-8f};
-                    const f2 ie = {__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
+                    // One transcendental per pair instead of three (rcp E.z, sqrt, rcp err; quarter-rate instructions were a third of the
+                    // pass).  With (u - px, v - py) = (A, B) / E.z,  A = (u - cx) E.z + f E.x,  B = (v - cy) E.z - f E.y,  S = A^2 + B^2:
+                    //   err = sqrt(S) / |E.z|,   m = rsq(E.z^2 S) = 1 / (|E.z| sqrt(S)),   1 / E.z = m^2 S E.z,
+                    //   C0 = w f A m,   -C1 = w f B m,   -C2 = w f m (A E.x - B E.y) / E.z          (px = -f E.x / E.z + cx, py = f E.y / E.z + cy)
+                    const f2 A = __builtin_elementwise_fma(pu[ch][pp], ez, ex * f2{f, f});
+                    const f2 B = __builtin_elementwise_fma(pv[ch][pp], ez, ny * f2{f, f});
+                    const f2 Sq = __builtin_elementwise_fma(B, B, A * A);
+                    const f2 zz = ez * ez;
+                    const f2 T = zz * Sq;
+                    // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0;  err > CNN_OBJ_MAXINPUT -> 0, i.e. S > clamp^2 E.z^2;  lanes beyond
+                    // the map or the ragged hypothesis end -> 0;  err == 0 -> 0 (the reference divides by err + 1e-8: -0 / 1e-8)
+                    const f2 lim = zz * f2{clampv * clampv, clampv * clampv};
+                    const bool k0 = lane_ok & (fabsf(ez.x) >= 1e-8f) & (Sq.x <= lim.x) & (T.x > 1e-30f);
+                    const bool k1 = lane_ok & (fabsf(ez.y) >= 1e-8f) & (Sq.y <= lim.y) & (T.y > 1e-30f);
+                    const f2 m = {k0 ? __builtin_amdgcn_rsqf(T.x) : 0.f, k1 ? __builtin_amdgcn_rsqf(T.y) : 0.f};  // 0 keeps everything below an exact 0
                     f2 w;
                     if (SOFTMODE) {
+                        const f2 err = Sq * m;  // guarded pairs: 0 -> a finite sigmoid, times m = 0 below
                         const f2 ec = {fminf(err.x, clampv), fminf(err.y, clampv)};
                         const f2 t = __builtin_elementwise_fma(f2{kA, kA}, ec, f2{kB, kB});
                         const f2 dd = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f2{1.f, 1.f};
                         const f2 sg = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
-                        const float gb = c2.y * (-beta);
+                        const float gb = c2.y * (-beta) * f;
                         w = (sg * f2{gb, gb}) * (f2{1.f, 1.f} - sg);
                     } else {
-                        w = pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y};
+                        w = (pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y}) * f2{f, f};
                     }
-                    // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0, err > CNN_OBJ_MAXINPUT -> 0, lanes beyond the map or the
-                    // ragged hypothesis end -> 0
-                    const bool k0 = lane_ok && z0 && (err.x <= clampv);
-                    const bool k1 = lane_ok && z1 && (err.y <= clampv);
-                    f2 wfz = (w * fz) * ie;                               // w f / (E.z (err + eps)); finite: iz is 0 where E.z ~ 0
-                    wfz.x = k0 ? wfz.x : 0.f;
-                    wfz.y = k1 ? wfz.y : 0.f;
-                    const f2 wiz = wfz * iz;
-                    // a = -(du, dv)/(err+eps);  C0 = -a0 f/E.z ; C1 = a1 f/E.z ; C2 = (a0 E.x - a1 E.y) f/E.z^2   (all times w)
-                    const f2 C0 = du * wfz;                               //  C0
-                    const f2 nC1 = dv * wfz;                              // -C1
-                    const f2 nC2 = __builtin_elementwise_fma(dv, ny, du * ex) * wiz;  // -C2
+                    const f2 q = w * m;                                   // w f / (|E.z| sqrt(S))
+                    const f2 iz = (m * m) * (Sq * ez);                    // 1 / E.z
+                    const f2 C0 = A * q;                                  //  C0
+                    const f2 nC1 = B * q;                                 // -C1
+                    const f2 nC2 = __builtin_elementwise_fma(B, ny, A * ex) * (q * iz);  // -C2
                     gx[ch][pp] = __builtin_elementwise_fma(f2{c0.x, c0.x}, C0, __builtin_elementwise_fma(f2{c0.w, c0.w}, nC1, __builtin_elementwise_fma(f2{c1.z, c1.z}, nC2, gx[ch][pp])));
                     gy[ch][pp] = __builtin_elementwise_fma(f2{c0.y, c0.y}, C0, __builtin_elementwise_fma(f2{c1.x, c1.x}, nC1, __builtin_elementwise_fma(f2{c1.w, c1.w}, nC2, gy[ch][pp])));
                     gz[ch][pp] = __builtin_elementwise_fma(f2{c0.z, c0.z}, C0, __builtin_elementwise_fma(f2{c1.y, c1.y}, nC1, __builtin_elementwise_fma(f2{c2.x, c2.x}, nC2, gz[ch][pp])));
@@ -476,6 +474,7 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
                     S[2][0] = __builtin_elementwise_fma(nC2, ex, S[2][0]); S[2][1] = __builtin_elementwise_fma(nC2, ny, S[2][1]);
                     S[2][2] = __builtin_elementwise_fma(nC2, ez, S[2][2]); S[2][3] += nC2;
                 }
+                __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: interleaved, their temporaries cost a wave of occupancy
             }
             // the 12 sums of hypothesis c over this lane's pixels (pair halves added), in the order a[3 j + m], a[9 + j] -> index
             // q = 0..11; then the transpose-reduce over the 4 lane groups: lane (g, c) ends with the totals of q = 3 g .. 3 g + 2
@@ -525,6 +524,17 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward_mfma(const float*
     }
 }
 
+// chunks of 16 pixels per wave and trip of the matrix-core form: variant 1..5 -> 2, 4, 5, 6, 3
+static int k4m_chunks(int variant) {
+    switch (variant) {
+        case 1: return 2;
+        case 3: return 5;
+        case 4: return 6;
+        case 5: return 3;
+        default: return 4;
+    }
+}
+
 static size_t k4m_lds_bytes(int HT) {
     const int ngi = (HT + 15) / 16;
     return ((size_t)ngi * 384 + (size_t)ngi * 4 * 16 * 12) * sizeof(float);
@@ -541,16 +551,20 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
     int ht_code = 0, wg_per_cu = 0;
     if (variant >= 10) { wg_per_cu = variant / 100; ht_code = (variant / 10) % 10; variant = variant % 10; }
-    if (variant < 0) variant = 2;  // 4 chunks per wave: 133 vs 147 us with 2 (N = 256, 640 x 480)
+    // Chunks per wave (measured, 640 x 480, profiles/r02_k4_chunks.txt): with the d_err stream 4 (N = 256: 131 us; 5: 134, 3: 140, 6 spills),
+    // without it 5 (N = 256: 144 vs 147 us, N = 1024: 485 vs 498).  A round-counting model (1200 tiles on 512 persistent workgroups =
+    // 3 rounds of 4 chunks where the mean is 2.34, against 960 tiles = 2 rounds of 5) predicted -20 % for 5 chunks; it is not there:
+    // a workgroup that runs out of tiles leaves its SIMDs to its neighbours.
+    if (variant < 0) variant = d_err ? 2 : 3;
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
-    if (!vec || variant > 2 || (!F.uv && F.W % 4 != 0)) variant = 0;
+    if (!vec || variant > 5 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
     if (variant == 0) {
         pl.HT = 32;
         const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
         pl.rows = ((F.P + tile - 1) / tile) * (K4_THREADS / 64);
     } else {
-        const int CH = variant == 1 ? 2 : 4;
+        const int CH = k4m_chunks(variant);
         // Persistent workgroups, 2 per CU (register- and LDS-limited: 2 waves per SIMD), shared between the hypothesis tiles.  The biggest
         // hypothesis tile wins: a round-counting model preferred HT = 128 for N = 256 on 640 x 480 (5 rounds of 128 instead of 3 of 256
         // for the 1200 pixel tiles on 512 workgroups), measured it loses (145 vs 133 us; N = 1024: 541 vs 506) -- a workgroup that runs out
@@ -576,7 +590,7 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
     const bool UV = F.uv != nullptr;
     if (plan.variant > 0) {
         if (HT < 16 || HT > K4M_HT_MAX || (reinterpret_cast<uintptr_t>(grad_part) & 15)) return hipErrorInvalidValue;
-        const int CH = plan.variant == 1 ? 2 : 4;
+        const int CH = k4m_chunks(plan.variant);
         const int PT = (F.P + 64 * CH - 1) / (64 * CH);
         const int G = plan.rows;
         const int grid = G * NT;
@@ -589,13 +603,19 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
         hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,       \
                            grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT);                            \
     } while (0)
-        if (CH == 2) {
-            if (soft) { if (UV) DSAC_K4M(2, true, true); else DSAC_K4M(2, true, false); }
-            else { if (UV) DSAC_K4M(2, false, true); else DSAC_K4M(2, false, false); }
-        } else {
-            if (soft) { if (UV) DSAC_K4M(4, true, true); else DSAC_K4M(4, true, false); }
-            else { if (UV) DSAC_K4M(4, false, true); else DSAC_K4M(4, false, false); }
+#define DSAC_K4M_CH(C_)                                                                                  \
+    do {                                                                                                 \
+        if (soft) { if (UV) DSAC_K4M(C_, true, true); else DSAC_K4M(C_, true, false); }                  \
+        else { if (UV) DSAC_K4M(C_, false, true); else DSAC_K4M(C_, false, false); }                     \
+    } while (0)
+        switch (CH) {
+            case 2: DSAC_K4M_CH(2); break;
+            case 3: DSAC_K4M_CH(3); break;
+            case 4: DSAC_K4M_CH(4); break;
+            case 5: DSAC_K4M_CH(5); break;
+            default: DSAC_K4M_CH(6); break;
         }
+#undef DSAC_K4M_CH
 #undef DSAC_K4M
         return hipGetLastError();
     }

@@ -66,7 +66,7 @@ hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, f
 // jp-convention staged records for the backward pass, BWD_STRIDE floats per hypothesis (see k_backward.hip).
 constexpr int BWD_STRIDE = 24;  // six float4 per hypothesis, already sign-folded and pair-packed for K4's packed-fp32 chains
 // Launch plan of the K4 main pass: which kernel form, its hypothesis tile and the sizes of the two partial-sum buffers.
-//   variant 0 = VALU form (lane = 8 pixels, wave reduction of the 12 sums per hypothesis), 1 / 2 = matrix-core form with 2 / 4 16-pixel
+//   variant 0 = VALU form (lane = 8 pixels, wave reduction of the 12 sums per hypothesis), 1 .. 5 = matrix-core form with 2 / 4 / 5 / 6 / 3 16-pixel
 //   chunks per wave (lane = one hypothesis x 4 consecutive pixels), -1 = auto.  Maps that cannot be read as 16-byte vectors use variant 0.
 struct K4Plan {
     int variant;  // resolved form

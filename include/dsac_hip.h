@@ -95,7 +95,7 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
  *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
- *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 matrix-core form with 2 / 4 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
+ *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
 int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
