@@ -543,9 +543,12 @@ DM_INLINE uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-DM_INLINE uint32_t draw_below(uint64_t key, uint32_t attempt, uint32_t k, uint32_t n) {
+// candidate cell k of attempt `attempt`: ONE 64-bit draw, x from its high half and y from its low half (multiply-shift into [0, W) x [0, H))
+DM_INLINE int draw_cell(uint64_t key, uint32_t attempt, uint32_t k, uint32_t W, uint32_t H) {
     const uint64_t v = mix64(key + (((uint64_t)attempt << 16) | k));
-    return (uint32_t)(((v >> 32) * (uint64_t)n) >> 32);
+    const uint32_t x = (uint32_t)(((v >> 32) * (uint64_t)W) >> 32);
+    const uint32_t y = (uint32_t)(((v & 0xffffffffull) * (uint64_t)H) >> 32);
+    return (int)(y * W + x);
 }
 DM_INLINE uint64_t hyp_key(uint64_t seed, uint32_t hyp) { return mix64(seed ^ mix64((uint64_t)hyp)); }
 

@@ -16,19 +16,29 @@ namespace dk {
 
 DM_INLINE dm::Cam make_cam(const FrameDev& F) { return dm::Cam{(double)F.fx, (double)F.fy, (double)F.cx, (double)F.cy}; }
 
-DM_INLINE void load_point(const FrameDev& F, int p, float X[3], float uv[2]) {
-    p = min(max(p, 0), F.P - 1);  // never fault on a bad index
-    X[0] = F.xyz[(size_t)p * 3]; X[1] = F.xyz[(size_t)p * 3 + 1]; X[2] = F.xyz[(size_t)p * 3 + 2];
-    if (F.uv) { uv[0] = F.uv[(size_t)p * 2]; uv[1] = F.uv[(size_t)p * 2 + 1]; }
-    else { const int y = p / F.W; uv[0] = (float)(p - y * F.W); uv[1] = (float)y; }
+// The four points of a minimal set: all coordinate loads first, then (one uniform branch) all position loads.  Written point by point
+// with the position branch inside, the compiler waits for every point before it issues the next: four memory round trips
+// per attempt instead of one -- about half of a K1 round.
+DM_INLINE void load_set(const FrameDev& F, const int32_t set4[4], float X[4][3], float uv[4][2]) {
+    int p[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) p[j] = min(max(set4[j], 0), F.P - 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { X[j][0] = F.xyz[(size_t)p[j] * 3]; X[j][1] = F.xyz[(size_t)p[j] * 3 + 1]; X[j][2] = F.xyz[(size_t)p[j] * 3 + 2]; }
+    if (F.uv) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { uv[j][0] = F.uv[(size_t)p[j] * 2]; uv[j][1] = F.uv[(size_t)p[j] * 2 + 1]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int y = p[j] / F.W; uv[j][0] = (float)(p[j] - y * F.W); uv[j][1] = (float)y; }
+    }
 }
 
 // P3P + the 4-point re-projection check of core/cnn_softam.h:1042-1059.
 template <bool HORN>
 DM_INLINE bool solve_and_check(const FrameDev& F, const int32_t set4[4], int thr_int, double cv6[6]) {
     float X[4][3], uv[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+    load_set(F, set4, X, uv);
     const dm::Cam K = make_cam(F);
     if (!dm::p3p<HORN>(X, uv, K, cv6)) return false;
     double R[9];
@@ -57,23 +67,49 @@ DM_INLINE void write_staged(const FrameDev& F, const double cv6[6], float* o) {
     write_staged_R(F, R, cv6, o);
 }
 
-// Draw the minimal set of attempt `attempt` (core/cnn_softam.h:1021-1039).  false: more than 32 candidate
-// draws were needed (degenerate tiny maps).
+// Draw the minimal set of attempt `attempt` (core/cnn_softam.h:1021-1039): candidate cells k = 0, 1, 2, ... until four distinct ones.
+// false: more than 32 candidates were needed (degenerate tiny maps).  The first four candidates are drawn as straight-line code (four
+// independent 64-bit mixes whose quarter-rate multiplies overlap); the loop with the reference's redraw-on-duplicate semantics only
+// runs when two of them coincide (probability ~6/P).
 DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32_t set4[4]) {
+    const uint32_t W = (uint32_t)F.W, H = (uint32_t)F.H;
+#pragma unroll
+    for (int j = 0; j < 4; j++) set4[j] = dm::draw_cell(key, attempt, (uint32_t)j, W, H);
+    const bool distinct = set4[0] != set4[1] && set4[0] != set4[2] && set4[0] != set4[3] && set4[1] != set4[2] && set4[1] != set4[3] && set4[2] != set4[3];
+    if (distinct) return true;
     uint32_t k = 0;
     int cnt = 0;
     set4[0] = set4[1] = set4[2] = set4[3] = 0;
     while (cnt < 4) {
-        if (k >= 64) return false;
-        const int x = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.W);
-        const int y = (int)dm::draw_below(key, attempt, k++, (uint32_t)F.H);
-        const int idx = y * F.W + x;
+        if (k >= 32) return false;
+        const int idx = dm::draw_cell(key, attempt, k++, W, H);
         const bool dup = (cnt > 0 && set4[0] == idx) || (cnt > 1 && set4[1] == idx) || (cnt > 2 && set4[2] == idx);
         if (dup) continue;
         if (cnt == 0) set4[0] = idx; else if (cnt == 1) set4[1] = idx; else if (cnt == 2) set4[2] = idx; else set4[3] = idx;
         cnt++;
     }
     return true;
+}
+
+// value of lane (lane & ~3) | I: the four root lanes of an attempt are one DPP quad
+template <int I>
+DM_INLINE int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, true); }
+template <int I>
+DM_INLINE double quad_bcast_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)quad_bcast_i<I>((int)(unsigned)u), hi = (unsigned)quad_bcast_i<I>((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// winner among the 4 roots of an attempt: smallest re-projection error of the 4th point, first on ties (-1: no candidate)
+DM_INLINE int best_root_of_quad(bool cand, double reproj) {
+    int win = -1;
+    double best = 0;
+    const int ci[4] = {quad_bcast_i<0>((int)cand), quad_bcast_i<1>((int)cand), quad_bcast_i<2>((int)cand), quad_bcast_i<3>((int)cand)};
+    const double ri[4] = {quad_bcast_d<0>(reproj), quad_bcast_d<1>(reproj), quad_bcast_d<2>(reproj), quad_bcast_d<3>(reproj)};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (ci[i] && (win < 0 || best > ri[i])) { win = i; best = ri[i]; }
+    return win;
 }
 
 // One wave per hypothesis.  Lane l evaluates quartic root (l & 3) of attempt base + (l >> 2): 16 attempts
@@ -126,23 +162,14 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
         double Rc[9], Tc[3], reproj = 0;
         bool cand = false;
         if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+            load_set(F, set4, X, uv);
             dm::P3PSetup S;
             if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
                 const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
                 cand = dm::p3p_eval_root<HORN>(S, X, uv, K, x, Rc, Tc, reproj);
             }
         }
-        // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
-        int win = -1;
-        double best = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool ci = __shfl((int)cand, (lane & ~3) | i, 64) != 0;
-            const double ri = __shfl(reproj, (lane & ~3) | i, 64);
-            if (ci && (win < 0 || best > ri)) { win = i; best = ri; }
-        }
+        const int win = best_root_of_quad(cand, reproj);
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -270,23 +297,14 @@ __global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed,
         double Rc[9], Tc[3], reproj = 0;
         bool cand = false;
         if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) load_point(F, set4[j], X[j], uv[j]);
+            load_set(F, set4, X, uv);
             dm::P3PSetup S;
             if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
                 const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
                 cand = dm::p3p_eval_root<false>(S, X, uv, K, x, Rc, Tc, reproj);
             }
         }
-        // winner among the 4 roots of this attempt: smallest re-projection error of the 4th point, first on ties
-        int win = -1;
-        double best = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool ci = __shfl((int)cand, (lane & ~3) | i, 64) != 0;
-            const double ri = __shfl(reproj, (lane & ~3) | i, 64);
-            if (ci && (win < 0 || best > ri)) { win = i; best = ri; }
-        }
+        const int win = best_root_of_quad(cand, reproj);
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -413,8 +431,10 @@ __global__ __launch_bounds__(64) void k_dpnp(int N, const int32_t* __restrict__ 
     double jp6[6] = {0, 0, 0, 0, 0, 0};
     if (active) {
         float X[4][3], uv[4][2];
+        int32_t set4[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) load_point(F, sets[(size_t)h * 4 + j], X[j], uv[j]);
+        for (int j = 0; j < 4; j++) set4[j] = sets[(size_t)h * 4 + j];
+        load_set(F, set4, X, uv);
         // replay the float round trips of coordinates 0..c-1, then apply this lane's own perturbation
 #pragma unroll
         for (int cc = 0; cc < 12; cc++) {

@@ -42,9 +42,10 @@
  *   mix64(z): z += 0x9E3779B97F4A7C15; z = (z ^ (z>>30)) * 0xBF58476D1CE4E5B9;
  *             z = (z ^ (z>>27)) * 0x94D049BB133111EB; return z ^ (z>>31);
  *   key(h)          = mix64(seed ^ mix64(h))                       h = hypothesis index
- *   draw(h,a,k,n)   = ((mix64(key(h) + ((a << 16) | k)) >> 32) * n) >> 32      in [0, n)
- *   attempt a of hypothesis h draws x = draw(.,k++,W) then y = draw(.,k++,H) until 4 distinct cells
- *   (core/cnn_softam.h:1021-1039: x before y, duplicates redrawn); the first accepted attempt in
+ *   v(h,a,k)        = mix64(key(h) + ((a << 16) | k))                       candidate k of attempt a
+ *   cell(h,a,k)     : x = ((v >> 32) * W) >> 32,  y = ((v & 0xffffffff) * H) >> 32   (one 64-bit draw per cell)
+ *   attempt a of hypothesis h takes the candidate cells k = 0, 1, 2, ... until 4 distinct ones (core/cnn_softam.h:1021-1039:
+ *   duplicates redrawn; more than 32 candidates: the attempt fails); the first accepted attempt in
  *   a = 0,1,2,... wins, which is the reference's while(true) loop made order-independent.
  */
 #ifndef DSAC_HIP_H

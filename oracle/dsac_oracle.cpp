@@ -321,9 +321,12 @@ inline uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-inline uint32_t draw_below(uint64_t key, uint32_t attempt, uint32_t k, uint32_t n) {
+// candidate cell k of an attempt: one 64-bit draw, x from its high half, y from its low half
+inline int draw_cell(uint64_t key, uint32_t attempt, uint32_t k, uint32_t W, uint32_t H) {
     uint64_t v = mix64(key + (((uint64_t)attempt << 16) | k));
-    return (uint32_t)(((v >> 32) * (uint64_t)n) >> 32);
+    uint32_t x = (uint32_t)(((v >> 32) * (uint64_t)W) >> 32);
+    uint32_t y = (uint32_t)(((v & 0xffffffffull) * (uint64_t)H) >> 32);
+    return (int)(y * W + x);
 }
 inline uint64_t hyp_key(uint64_t seed, uint32_t hyp) { return mix64(seed ^ mix64((uint64_t)hyp)); }
 
@@ -332,10 +335,8 @@ bool sample_attempt(const Frame& F, uint64_t key, uint32_t attempt, int thr_int,
     uint32_t k = 0;
     int cnt = 0;
     while (cnt < 4) {
-        if (k >= 64) return false;  // > 32 candidate draws: give up on this attempt (degenerate tiny maps)
-        int x = (int)draw_below(key, attempt, k++, (uint32_t)F.W);   // x before y (core/cnn_softam.h:1024-1025)
-        int y = (int)draw_below(key, attempt, k++, (uint32_t)F.H);
-        int idx = y * F.W + x;
+        if (k >= 32) return false;  // > 32 candidate cells: give up on this attempt (degenerate tiny maps)
+        int idx = draw_cell(key, attempt, k++, (uint32_t)F.W, (uint32_t)F.H);   // (x, y) of a candidate: core/cnn_softam.h:1024-1025
         bool dup = false;
         for (int j = 0; j < cnt; j++) if (set4[j] == idx) dup = true;
         if (dup) continue;

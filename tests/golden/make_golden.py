@@ -30,10 +30,13 @@ def mix64(z):
     return z ^ (z >> 31)
 
 
-def draw(seed, h, a, k, n):
+def cell(seed, h, a, k, W, H):
+    """candidate cell k of attempt a of hypothesis h: one 64-bit draw, x from the high half, y from the low half"""
     key = mix64(seed ^ mix64(h))
     v = mix64((key + ((a << 16) | k)) & M64)
-    return ((v >> 32) * n) >> 32
+    x = ((v >> 32) * W) >> 32
+    y = ((v & 0xFFFFFFFF) * H) >> 32
+    return y * W + x
 
 
 def main():
@@ -101,8 +104,8 @@ def main():
     w /= w.sum()
     out.update(sm_scores=s, sm_w=w, sm_entropy=-(w * np.log2(w)).sum())
 
-    # RNG stream: first 8 draws of attempts 0..2 of hypotheses 0..3 for seed 1305 on a 40 x 40 map
-    out["rng_draws"] = np.array([[[draw(1305, h, a, k, 40) for k in range(8)] for a in range(3)] for h in range(4)], dtype=np.int32)
+    # RNG stream: first 6 candidate cells of attempts 0..2 of hypotheses 0..3 for seed 1305 on a 40 x 40 map
+    out["rng_cells"] = np.array([[[cell(1305, h, a, k, 40, 40) for k in range(6)] for a in range(3)] for h in range(4)], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "golden_v1.npz"), **out)
     print("wrote", os.path.join(HERE, "golden_v1.npz"), {k: v.shape for k, v in out.items()})
 

@@ -38,22 +38,22 @@ def test_oracle_softmax(orc):
 
 
 def test_rng_stream_matches_the_spec(orc, synth):
-    """The first accepted minimal sets must be consistent with the golden integer draws: attempt a of hypothesis h
-    takes cells (x = draw 0, y = draw 1), (draw 2, draw 3), ... skipping duplicates."""
+    """The first accepted minimal sets must be consistent with the golden integer draws (an independent Python restatement of the
+    generator in include/dsac_hip.h): attempt a of hypothesis h takes candidate cells 0, 1, 2, ... skipping duplicates."""
     fr = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
     poses, sets, ok, tries = orc.sample(4, 1305, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    checked = 0
     for h in range(4):
         a = tries[h] - 1
         if a >= 3:
             continue
-        d = G["rng_draws"][h, a]
         cells = []
-        for k in range(0, 8, 2):
-            c = int(d[k + 1]) * 40 + int(d[k])
-            if c not in cells:
-                cells.append(c)
-        if len(cells) == 4:
-            assert list(sets[h]) == cells
+        for c in G["rng_cells"][h, a]:
+            if int(c) not in cells:
+                cells.append(int(c))
+        assert list(sets[h]) == cells[:4]
+        checked += 1
+    assert checked >= 1
 
 
 @pytest.mark.gpu

@@ -165,21 +165,31 @@ def test_sample_given_sets_and_failures(engine, orc, frame40):
 
 
 def test_dpnp_parity(engine, orc, frame40):
+    """dPNP = central differences (0.1 mm) of an fp64 P3P.  The closed-form quartic of Gao's P3P loses up to half of the double's
+    digits on unlucky minimal sets, so last-bit differences between libm / g++ and the GPU's math library / FMA contraction surface
+    at the size of a ONE-FLOAT-ULP change of an input coordinate.  The bound is therefore per hypothesis: the bulk must agree
+    tightly, and every hypothesis within 4x the oracle's own sensitivity to one float ulp of its inputs (measured ratio: 0.5-0.6 on
+    the worst sets of three seeds, scripts/diag_dpnp.py)."""
     fr = frame40
     _set(engine, fr)
-    poses, sets, ok, _ = orc.sample(64, 21, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
-    J = engine.dPNP(sets, eps=0.1)
-    rel = np.zeros(64)
-    for h in range(64):
-        Jr = orc.dPNP(fr["uv"][sets[h]], fr["xyz"][sets[h]], fr["cam"], eps=0.1)
-        rel[h] = np.abs(J[h] - Jr).max() / max(1.0, np.abs(Jr).max())
-    # central differences (eps = 0.1 mm) of an fp64 P3P: last-bit differences between libm and the GPU's
-    # math library are amplified by 1/(2 eps) and by the conditioning of the minimal set, so the bulk must
-    # agree tightly and the ill-conditioned tail loosely
-    print("dPNP rel err: median %.2e  p90 %.2e  max %.2e" % (np.median(rel), np.quantile(rel, 0.9), rel.max()))
-    assert np.median(rel) <= 1e-6
-    assert (rel <= 1e-4).mean() >= 0.9
-    assert rel.max() <= 1e-3  # measured 1.7e-4 (Horn alignment in K5 as in OpenCV)
+    for seed in (21, 23):
+        poses, sets, ok, _ = orc.sample(64, seed, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+        J = engine.dPNP(sets, eps=0.1)
+        rel, sens = np.zeros(64), np.zeros(64)
+        for h in range(64):
+            X0 = fr["xyz"][sets[h]]
+            Jr = orc.dPNP(fr["uv"][sets[h]], X0, fr["cam"], eps=0.1)
+            sc = max(1.0, np.abs(Jr).max())
+            rel[h] = np.abs(J[h] - Jr).max() / sc
+            for c in range(12):
+                X1 = X0.copy().reshape(-1)
+                X1[c] = np.nextafter(X1[c], np.float32(1e9))
+                sens[h] = max(sens[h], np.abs(orc.dPNP(fr["uv"][sets[h]], X1.reshape(4, 3), fr["cam"], eps=0.1) - Jr).max() / sc)
+        print("dPNP seed %d rel err: median %.2e  p90 %.2e  max %.2e;  max rel / one-ulp sensitivity %.2f" %
+              (seed, np.median(rel), np.quantile(rel, 0.9), rel.max(), (rel / np.maximum(sens, 1e-7)).max()))
+        assert np.median(rel) <= 1e-6
+        assert (rel <= 1e-4).mean() >= 0.9
+        assert np.all(rel <= np.maximum(1e-6, 4.0 * sens)), (seed, np.argmax(rel / np.maximum(sens, 1e-7)), rel.max())
 
 
 def test_device_pointers_through_torch(engine, orc, frame40):
