@@ -131,7 +131,10 @@ DM_INLINE int best_root_of_quad(bool cand, double reproj) {
 // the parity mode (poses equal the oracle's to rounding also on near-degenerate sets); several times slower, the triad is the default.
 // MINW: minimum waves per SIMD the register allocation must leave room for (1: 288 registers, no scratch; 2: 256 registers + 140 B of
 // scratch per lane, two waves share a SIMD and hide each other's fp64 dependency chains)
-template <int WPB, int HPW, bool HORN = false, int MINW = 1>
+// RL: lanes per attempt.  4 = one lane per quartic root (16 attempts per round and hypothesis); 1 = one lane per ATTEMPT, its roots in
+// sequence (64 attempts per round): a round is longer (set-up + up to 4 root evaluations instead of one) but four times as wide, so a
+// hypothesis rarely needs a second one -- the launch time is the slowest hypothesis' number of rounds.
+template <int WPB, int HPW, bool HORN = false, int MINW = 1, int RL = 4>
 __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
                                                      int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
                                                      int Nf) {
@@ -139,14 +142,14 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     constexpr int LPH = 64 / HPW;        // lanes per hypothesis
-    constexpr int APR = LPH / 4;         // attempts per round and hypothesis
+    constexpr int APR = LPH / RL;        // attempts per round and hypothesis
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPH, sl = lane % LPH;
     const int h = (blockIdx.x * WPB + (threadIdx.x >> 6)) * HPW + sub;
     const unsigned long long submask = (HPW == 1) ? ~0ull : (((1ull << LPH) - 1ull) << (sub * LPH));
     bool done = h >= N;                  // uniform over the lanes of a hypothesis
     const int hc = done ? 0 : h;
-    const int root = lane & 3;
+    const int root = lane & (RL - 1);
     const int frame = hc / Nf;           // Nf == N for a single frame
     F.xyz += (long long)frame * F.xyz_stride;
     if (F.uv) F.uv += (long long)frame * F.uv_stride;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
     const dm::Cam K = make_cam(F);
     for (int base = 0; base < max_tries; base += APR) {
         if (__ballot(!done) == 0ull) return;
-        const uint32_t attempt = (uint32_t)(base + (sl >> 2));
+        const uint32_t attempt = (uint32_t)(base + sl / RL);
         int32_t set4[4];
         bool live = !done && (int)attempt < max_tries;
         if (live) live = draw_set(F, key, attempt, set4);
@@ -164,12 +167,29 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
         if (live) {
             load_set(F, set4, X, uv);
             dm::P3PSetup S;
-            if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
-                const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
-                cand = dm::p3p_eval_root<HORN>(S, X, uv, K, x, Rc, Tc, reproj);
+            if (RL == 4) {
+                if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
+                    const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
+                    cand = dm::p3p_eval_root<HORN>(S, X, uv, K, x, Rc, Tc, reproj);
+                }
+            } else if (dm::p3p_setup(X, uv, K, S)) {
+                // the roots in sequence, the one whose pose re-projects the 4th point best wins, the first on ties (dm::p3p)
+                for (int i = 0; i < 4; i++) {
+                    if (i >= S.n) continue;
+                    double Rt[9], Tt[3], rp;
+                    const double x = (i == 0) ? S.roots[0] : (i == 1) ? S.roots[1] : (i == 2) ? S.roots[2] : S.roots[3];
+                    if (!dm::p3p_eval_root<HORN>(S, X, uv, K, x, Rt, Tt, rp)) continue;
+                    if (!cand || reproj > rp) {
+                        cand = true;
+                        reproj = rp;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Rc[k] = Rt[k];
+                        Tc[0] = Tt[0]; Tc[1] = Tt[1]; Tc[2] = Tt[2];
+                    }
+                }
             }
         }
-        const int win = best_root_of_quad(cand, reproj);
+        const int win = (RL == 4) ? best_root_of_quad(cand, reproj) : (cand ? 0 : -1);
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -401,7 +421,7 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
 #define DSAC_K1(W, G, HN) hipLaunchKernelGGL((k_sample<W, G, HN>), dim3((N + W * G - 1) / (W * G)), dim3(64 * W), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N)
         const int NfK = Nf > 0 ? Nf : N;
         if (o.horn) DSAC_K1(1, 1, true);
-        else if (o.share >= 2 && H2 == 1 && (N <= 1024 || o.share_always) && (F.frames <= 1 || NfK % o.share == 0)) {  // a workgroup's hypotheses must share a frame
+        else if (o.rl != 1 && o.share >= 2 && H2 == 1 && (N <= 1024 || o.share_always) && (F.frames <= 1 || NfK % o.share == 0)) {  // a workgroup's hypotheses must share a frame
             if (o.share >= 8) hipLaunchKernelGGL((k_sample_shared<8>), dim3((N + 7) / 8), dim3(512), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
             else hipLaunchKernelGGL((k_sample_shared<4>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         }
@@ -411,6 +431,7 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         }
         else if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4, false); else DSAC_K1(1, 4, false); }
         else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2, false); else if (wpb >= 4) DSAC_K1(4, 2, false); else DSAC_K1(1, 2, false); }
+        else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4) hipLaunchKernelGGL((k_sample<1, 1, false, 1, 1>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }
 #undef DSAC_K1
     }

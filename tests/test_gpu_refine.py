@@ -114,7 +114,7 @@ def test_drefine_parity(engine, orc, synth, frame40):
     for i, p in enumerate(px):
         dense[:, p * 3:p * 3 + 3] = Jo[i]
     nz = np.flatnonzero(np.abs(Jo_r).sum(0))
-    assert len(px) == len(set(nz // 3)) and len(px) >= 1
+    assert set(nz // 3) <= set(int(p) for p in px) and len(px) >= 1  # a selected cell may have an exactly zero column (never walked)
     assert np.abs(dense - Jo_r).max() <= 1e-4 * max(np.abs(Jo_r).max(), 1e-12)
     # denser sub-sampling exercises more replicas
     Jo_r2 = orc.dRefineObj(avg, perm, imap, fr["xyz"], fr["uv"], 40, 40, fr["cam"], sub_sample=0.1)
