@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/ref_frame_v1.npz from the REAL reference (oracle/_ref/libdsac_ref.so = /root/reference/core
+"""Generates tests/golden/ref_frame_v<K>.npz and refd_frame_v<K>.npz from the REAL reference (oracle/_ref/libdsac_ref.so = /root/reference/core
 compiled where it lies against OpenCV / Lua stand-ins, see oracle/refbuild/).  Needs /root/reference, so it runs in
 the build container only; the fixture it writes travels to the GPU box.
 
@@ -7,7 +7,8 @@ One synthetic 7-Scenes-like frame goes through the reference's processImage (40x
 hypotheses by P3P, soft-inlier score in place of the score CNN, soft-argmax, 8 refinement steps, loss) and through
 the backward section of its training loop (train_ransac_softam.cpp:288-394).  Stored: every input the product needs
 to replay the frame (scene coordinates, sampling grid, the reference's own minimal sets and shuffles, ground truth)
-and every output to compare against.  Run:  python tests/golden/make_golden_ref.py
+and every output to compare against.  Run:  python tests/golden/make_golden_ref.py [version]
+Version 1 (default): the frame of round 1.  Version 2: another scene, more noise and outliers, another draw seed and ground-truth offset.
 """
 import os
 import sys
@@ -24,18 +25,22 @@ from oracle import reference as ref  # noqa: E402
 TAU, BETA, ALPHA = 10.0, 0.5, 0.1
 N = 64
 SUB_SAMPLE = 0.05
+# version -> (frame seed, noise [mm], outlier fraction, the reference's draw seed, ground-truth offset)
+VERSIONS = {1: (20260925, 20.0, 0.3, 1305, (0.012, -0.02, 0.008, 6.0, -9.0, 14.0)),
+            2: (31337, 30.0, 0.45, 4242, (-0.02, 0.015, 0.01, -12.0, 7.0, 20.0))}
 
 
-def main():
+def main(version=1):
     assert os.path.isdir("/root/reference/core"), "the reference sources are needed to generate this fixture"
+    frame_seed, noise_mm, outliers, draw_seed, gt_off = VERSIONS[version]
     ref.build()
     ref.lib()
     ref.set_score_model(TAU, BETA, ALPHA)
-    fr = synth.chess_like_frame(40, 40, seed=20260925, quantise_int16=True)
+    fr = synth.chess_like_frame(40, 40, seed=frame_seed, noise_mm=noise_mm, outlier_frac=outliers, quantise_int16=True)
     # ground truth a little off the pose the scene was rendered with, so that loss and gradient are not zero
-    gt_cv = fr["gt_pose"] + np.array([0.012, -0.02, 0.008, 6.0, -9.0, 14.0])
+    gt_cv = fr["gt_pose"] + np.array(gt_off)
     gt_jp6 = ref.cv_to_jp6(gt_cv)
-    r = ref.processImage(1305, fr["xyz"], gt_jp6, hyps=N, backward=True, sub_sample=SUB_SAMPLE)
+    r = ref.processImage(draw_seed, fr["xyz"], gt_jp6, hyps=N, backward=True, sub_sample=SUB_SAMPLE)
     out = dict(cam=ref.cam(), tau=TAU, beta=BETA, alpha=ALPHA, sub_sample=SUB_SAMPLE, gt_jp6=gt_jp6, thr=10, inlier_count=100, ref_steps=8)
     for k in ("hyps", "sampledPoints", "sfScores", "avgHyp", "refAvgHyp", "sampling", "estObj", "inlierMap", "pixelIdxs", "dLoss_dObj"):
         out[k] = r[k]
@@ -64,7 +69,7 @@ def main():
             natural[h, x, y] = 0.0
     out["dScore_ddiff_natural"] = natural
     out["dScore_jac_sum"] = ref.dScore(r["sampledPoints"][:8], r["estObj"], uvi, ddiff=natural.reshape(8, -1)).sum(0).reshape(1600, 3)
-    path = os.path.join(HERE, "ref_frame_v1.npz")
+    path = os.path.join(HERE, "ref_frame_v%d.npz" % version)
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| loss %.4f rotErr %.4f tErr %.3f entropy %.4f" %
           (r["loss"], r["rotErr"], r["tErr"], r["sfEntropy"]))
@@ -73,7 +78,7 @@ def main():
     from oracle import reference_dsac as refd
     refd.lib(random_draw=False)
     refd.set_score_model(TAU, BETA, ALPHA)
-    d = refd.processImage(1305, fr["xyz"], gt_jp6, hyps=32, backward=True, sub_sample=SUB_SAMPLE)
+    d = refd.processImage(draw_seed, fr["xyz"], gt_jp6, hyps=32, backward=True, sub_sample=SUB_SAMPLE)
     o2 = dict(cam=ref.cam(), tau=TAU, beta=BETA, alpha=ALPHA, sub_sample=SUB_SAMPLE, gt_jp6=gt_jp6, thr=10, inlier_count=100, ref_steps=8)
     for k in ("hyps", "refHyps", "sampledPoints", "sfScores", "losses", "sampling", "estObj", "inlierMaps", "pixelIdxs", "dLoss_dObj"):
         o2[k] = d[k]
@@ -82,11 +87,11 @@ def main():
     best = int(np.argmax(d["sfScores"]))
     sets = d["sampledPoints"][:, :, 1] * 40 + d["sampledPoints"][:, :, 0]
     o2["dRefine_best"] = refd.dRefine(sets[best], d["pixelIdxs"], d["inlierMaps"][best], d["estObj"], d["sampling"], 40, 40, sub_sample=SUB_SAMPLE)
-    path = os.path.join(HERE, "refd_frame_v1.npz")
+    path = os.path.join(HERE, "refd_frame_v%d.npz" % version)
     np.savez_compressed(path, **o2)
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| expected loss %.4f hypIdx %d entropy %.4f" %
           (d["expectedLoss"], d["hypIdx"], d["sfEntropy"]))
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 1)

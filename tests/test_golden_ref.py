@@ -7,13 +7,14 @@ import os
 import numpy as np
 import pytest
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_frame_v1.npz")
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FRAMES = ["ref_frame_v1.npz", "ref_frame_v2.npz"]  # v2: another scene, more noise and outliers, another draw seed (make_golden_ref.py 2)
 H = W = 40
 
 
-@pytest.fixture(scope="module")
-def g():
-    d = dict(np.load(G))
+@pytest.fixture(scope="module", params=FRAMES)
+def g(request):
+    d = dict(np.load(os.path.join(GDIR, request.param)))
     d["uv"] = d["sampling"].astype(np.float32)
     d["sets"] = (d["sampledPoints"][:, :, 1] * W + d["sampledPoints"][:, :, 0]).astype(np.int32)
     return d
