@@ -104,3 +104,40 @@ def test_short_runs_time_every_k2_launch():
     b = _bench()
     assert b.event_stride_for(20, -1) == 1 and b.event_stride_for(64, -1) == 1   # the driver's --steps 20: 20 samples, not 3
     assert b.event_stride_for(200, -1) == 3 and b.event_stride_for(200, 8) == 8 and b.event_stride_for(20, 0) == 0
+
+
+_FALLBACK_RANK = r'''
+import importlib.util, os, sys, types
+rank = int(sys.argv[1])
+os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+import torch
+torch.cuda.device_count = lambda: 2          # pretend two GPUs are visible: the RCCL init then fails for real (there is none here)
+torch.cuda.set_device = lambda i: None
+spec = importlib.util.spec_from_file_location("bench_module", sys.argv[3])
+b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+args = types.SimpleNamespace(gpus=2, dry_run=False, workload="default")
+r, lr, world, backend, dist = b.init_distributed(args)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+print("RESULT", backend, world, t.item(), "|", b.BACKEND_NOTE)
+dist.destroy_process_group()
+'''
+
+
+def test_timing_collectives_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
+    """The default workload has no data-path collective; if RCCL cannot be initialised on a node the barrier / max of the timing
+    scalars go over gloo and the JSON says so (config3, which gathers results with the backend, refuses instead)."""
+    import subprocess
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text(_FALLBACK_RANK)
+    port = str(29600 + os.getpid() % 300)
+    env = dict(os.environ)
+    env.pop("DSAC_BENCH_BACKEND", None)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, os.path.join(ROOT, "bench.py")], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT")][0]
+        assert line.startswith("RESULT gloo 2 2.0") and "RCCL init failed" in line, line
