@@ -7,8 +7,8 @@
 // sequential loop would have stopped at, so the result does not depend on the wave width or on
 // scheduling.  P3P runs in fp64 in registers (dmath.h).
 //
-// K5 replaces dPNP (core/cnn_softam.h:101-146): one lane per (hypothesis, coordinate, +/-) P3P solve,
-// 24 lanes per hypothesis; central differences are formed after a wave-local exchange.
+// K5 replaces dPNP (core/cnn_softam.h:101-146): four lanes (one per quartic root) per (hypothesis, coordinate, +/-) P3P solve,
+// 96 lanes = one two-wave workgroup per hypothesis; central differences are formed after a wave-local exchange.
 #include "kernels.h"
 #include "dmath.h"
 
@@ -444,54 +444,86 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
 // (core/cnn_softam.h:115-135), so a lane first replays the float round trips of the coordinates before
 // its own.  32 lanes per hypothesis (24 active), two hypotheses per wave.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dpnp(int N, const int32_t* __restrict__ sets, FrameDev F, float eps, double* __restrict__ J) {
-    const int h = blockIdx.x * 2 + (threadIdx.x >> 5);
-    const int l = threadIdx.x & 31;
-    const bool active = (h < N) && (l < 24);
-    const int c = l >> 1;
+// One workgroup of two waves per hypothesis: 24 solves (coordinate c = 0..11, +/-) x 4 lanes per solve, one per quartic root -- the
+// roots' Horn/Jacobi alignments, the long pole of a solve, run side by side as in K1's four-lane form (round 1 ran them in sequence on
+// ONE lane per solve with two hypotheses per wave: 62 us for 256 hypotheses on 128 of the chip's 1024 SIMDs).
+// Thread t: solve s = t >> 2 (forward s = 2c, backward s = 2c + 1: neighbouring quads), root t & 3.
+__global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__ sets, FrameDev F, float eps, double* __restrict__ J) {
+    const int h = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
+    const int s = t >> 2, root = t & 3;
+    const bool active = s < 24;
+    const int c = s >> 1;
+    __shared__ int s_nan[2];
     double jp6[6] = {0, 0, 0, 0, 0, 0};
+    bool cand = false;
+    double Rc[9], Tc[3], reproj = 0;
     if (active) {
         float X[4][3], uv[4][2];
         int32_t set4[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) set4[j] = sets[(size_t)h * 4 + j];
         load_set(F, set4, X, uv);
-        // replay the float round trips of coordinates 0..c-1, then apply this lane's own perturbation
+        // replay the float round trips of coordinates 0..c-1, then apply this solve's own perturbation
 #pragma unroll
         for (int cc = 0; cc < 12; cc++) {
             float& v = X[cc / 3][cc % 3];
             if (cc < c) { v += eps; v -= 2 * eps; v += eps; }
-            else if (cc == c) { v += eps; if (l & 1) v -= 2 * eps; }
+            else if (cc == c) { v += eps; if (s & 1) v -= 2 * eps; }
         }
-        double cv6[6];
-        if (!dm::p3p<true>(X, uv, make_cam(F), cv6)) {  // Horn alignment as in OpenCV: the difference quotient amplifies the method's rounding
-#pragma unroll
-            for (int k = 0; k < 6; k++) cv6[k] = 0;  // safeSolvePnP's zero pose
+        const dm::Cam K = make_cam(F);
+        dm::P3PSetup S;
+        if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
+            const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
+            // Horn alignment as in OpenCV: the difference quotient amplifies the method's rounding
+            cand = dm::p3p_eval_root<true>(S, X, uv, K, x, Rc, Tc, reproj);
         }
-        dm::cv_to_jp6(cv6, jp6);
     }
-    // central difference: forward lane (even) minus backward lane (odd neighbour)
+    const int win = best_root_of_quad(cand, reproj);  // -1: no root -> safeSolvePnP's zero pose
+    {
+        double cv6[6] = {0, 0, 0, 0, 0, 0};
+        if (active && win == root) {
+            dm::rodrigues_m2v(Rc, cv6);
+            cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
+        }
+        // lanes other than the winner (and all four when there is none) carry the zero pose; the winner's is summed into root lane 0
+        double mine[6];
+        if (active && (win == root || (win < 0 && root == 0))) dm::cv_to_jp6(cv6, mine);
+        else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) mine[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double v0 = quad_bcast_d<0>(mine[k]), v1 = quad_bcast_d<1>(mine[k]), v2 = quad_bcast_d<2>(mine[k]), v3 = quad_bcast_d<3>(mine[k]);
+            jp6[k] = (win <= 0) ? v0 : (win == 1) ? v1 : (win == 2) ? v2 : v3;  // exactly one lane of the quad holds a pose
+        }
+    }
+    // central difference: forward quad minus the backward quad four lanes up
     const double inv = 1.0 / (double)(2 * eps);
     bool nan = false;
     double d[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const double other = __shfl_xor(jp6[k], 1, 64);
+        const double other = __shfl_xor(jp6[k], 4, 64);
         d[k] = (jp6[k] - other) * inv;
         nan = nan || (d[k] != d[k]);
     }
     // any NaN in any column -> whole Jacobian zero (core/cnn_softam.h:141-142)
-    const unsigned long long m = __ballot(nan && active && !(l & 1));
-    const unsigned long long mine = (threadIdx.x >> 5) ? (m >> 32) : (m & 0xffffffffull);
-    if (active && !(l & 1)) {
+    const bool writer = active && !(s & 1) && root == 0;
+    const unsigned long long m = __ballot(nan && writer);
+    if (lane == 0) s_nan[t >> 6] = m != 0ull;
+    __syncthreads();
+    const bool any_nan = s_nan[0] || s_nan[1];
+    if (writer) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) J[(size_t)h * 72 + k * 12 + c] = (mine != 0ull) ? 0.0 : d[k];
+        for (int k = 0; k < 6; k++) J[(size_t)h * 72 + k * 12 + c] = any_nan ? 0.0 : d[k];
     }
 }
 
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dpnp, dim3((N + 1) / 2), dim3(64), 0, st, N, sets, F, eps, J);
+    hipLaunchKernelGGL(k_dpnp, dim3(N), dim3(128), 0, st, N, sets, F, eps, J);
     return hipGetLastError();
 }
 
