@@ -536,6 +536,28 @@ DM_INLINE bool p3p(const float X[4][3], const float uv[4][2], const Cam& K, doub
     return true;
 }
 
+// ---- the four root lanes of a P3P solve (K1's four-lane form, K5, the DSAC variant's replica start poses) --------------------------
+// value of lane (lane & ~3) | I: the four root lanes of an attempt are one DPP quad
+template <int I>
+DM_INLINE int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, true); }
+template <int I>
+DM_INLINE double quad_bcast_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)quad_bcast_i<I>((int)(unsigned)u), hi = (unsigned)quad_bcast_i<I>((int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// winner among the 4 roots of an attempt: smallest re-projection error of the 4th point, first on ties (-1: no candidate)
+DM_INLINE int best_root_of_quad(bool cand, double reproj) {
+    int win = -1;
+    double best = 0;
+    const int ci[4] = {quad_bcast_i<0>((int)cand), quad_bcast_i<1>((int)cand), quad_bcast_i<2>((int)cand), quad_bcast_i<3>((int)cand)};
+    const double ri[4] = {quad_bcast_d<0>(reproj), quad_bcast_d<1>(reproj), quad_bcast_d<2>(reproj), quad_bcast_d<3>(reproj)};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (ci[i] && (win < 0 || best > ri[i])) { win = i; best = ri[i]; }
+    return win;
+}
+
 // ---- sampling RNG (include/dsac_hip.h) ------------------------------------------------------------
 DM_INLINE uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

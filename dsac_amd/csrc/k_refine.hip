@@ -627,26 +627,40 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; rep_px_c += m * R * 2; rep_value += m * R; rep_poses += m * R * 6; n_obj += m;
     }
-    const int r = blockIdx.x * 64 + threadIdx.x;
-    if (r >= 18 + 6 * min(n_obj[0], cap)) return;
-    const int ppx = rep_px_c[2 * r], pch = rep_px_c[2 * r + 1];
-    const float pval = rep_value[r];
-    float X[4][3], uv[4][2];
+    // four lanes per replica, one per quartic root (the Horn/Jacobi alignments side by side, as in K5)
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 2), root = threadIdx.x & 3;
+    const bool active = r < 18 + 6 * min(n_obj[0], cap);
+    bool cand = false;
+    double Rc[9], Tc[3], reproj = 0;
+    if (active) {
+        const int ppx = rep_px_c[2 * r], pch = rep_px_c[2 * r + 1];
+        const float pval = rep_value[r];
+        float X[4][3], uv[4][2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int p = min(max(set4[j], 0), F.P - 1);
+        for (int j = 0; j < 4; j++) {
+            const int p = min(max(set4[j], 0), F.P - 1);
 #pragma unroll
-        for (int c = 0; c < 3; c++) X[j][c] = (p == ppx && c == pch) ? pval : F.xyz[(size_t)p * 3 + c];
-        if (F.uv) { uv[j][0] = F.uv[(size_t)p * 2]; uv[j][1] = F.uv[(size_t)p * 2 + 1]; }
-        else { const int y = p / F.W; uv[j][0] = (float)(p - y * F.W); uv[j][1] = (float)y; }
+            for (int c = 0; c < 3; c++) X[j][c] = (p == ppx && c == pch) ? pval : F.xyz[(size_t)p * 3 + c];
+            if (F.uv) { uv[j][0] = F.uv[(size_t)p * 2]; uv[j][1] = F.uv[(size_t)p * 2 + 1]; }
+            else { const int y = p / F.W; uv[j][0] = (float)(p - y * F.W); uv[j][1] = (float)y; }
+        }
+        const dm::Cam K = make_cam_r(F);
+        dm::P3PSetup S;
+        if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
+            const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
+            cand = dm::p3p_eval_root<true>(S, X, uv, K, x, Rc, Tc, reproj);
+        }
     }
-    double cv6[6];
-    if (!dm::p3p<true>(X, uv, make_cam_r(F), cv6)) {
+    const int win = dm::best_root_of_quad(cand, reproj);
+    if (active && (win == root || (win < 0 && root == 0))) {
+        double cv6[6] = {0, 0, 0, 0, 0, 0};  // no root: safeSolvePnP's zero pose
+        if (win == root) {
+            dm::rodrigues_m2v(Rc, cv6);
+            cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
+        }
 #pragma unroll
-        for (int k = 0; k < 6; k++) cv6[k] = 0;  // safeSolvePnP's zero pose
+        for (int k = 0; k < 6; k++) rep_poses[(size_t)r * 6 + k] = cv6[k];
     }
-#pragma unroll
-    for (int k = 0; k < 6; k++) rep_poses[(size_t)r * 6 + k] = cv6[k];
 }
 
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
@@ -654,7 +668,7 @@ hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(PLAN_THREADS), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
     const int R = 18 + 6 * cap;
-    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 63) / 64, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
+    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 15) / 16, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
     return hipGetLastError();
 }
 

@@ -91,27 +91,6 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
     return true;
 }
 
-// value of lane (lane & ~3) | I: the four root lanes of an attempt are one DPP quad
-template <int I>
-DM_INLINE int quad_bcast_i(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, true); }
-template <int I>
-DM_INLINE double quad_bcast_d(double v) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)quad_bcast_i<I>((int)(unsigned)u), hi = (unsigned)quad_bcast_i<I>((int)(unsigned)(u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-// winner among the 4 roots of an attempt: smallest re-projection error of the 4th point, first on ties (-1: no candidate)
-DM_INLINE int best_root_of_quad(bool cand, double reproj) {
-    int win = -1;
-    double best = 0;
-    const int ci[4] = {quad_bcast_i<0>((int)cand), quad_bcast_i<1>((int)cand), quad_bcast_i<2>((int)cand), quad_bcast_i<3>((int)cand)};
-    const double ri[4] = {quad_bcast_d<0>(reproj), quad_bcast_d<1>(reproj), quad_bcast_d<2>(reproj), quad_bcast_d<3>(reproj)};
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (ci[i] && (win < 0 || best > ri[i])) { win = i; best = ri[i]; }
-    return win;
-}
-
 // One wave per hypothesis.  Lane l evaluates quartic root (l & 3) of attempt base + (l >> 2): 16 attempts
 // per round, the four candidate poses of an attempt side by side (their Jacobi eigen-solves, the long pole
 // of P3P, run in parallel instead of in sequence).
@@ -189,7 +168,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
                 }
             }
         }
-        const int win = (RL == 4) ? best_root_of_quad(cand, reproj) : (cand ? 0 : -1);
+        const int win = (RL == 4) ? dm::best_root_of_quad(cand, reproj) : (cand ? 0 : -1);
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -324,7 +303,7 @@ __global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed,
                 cand = dm::p3p_eval_root<false>(S, X, uv, K, x, Rc, Tc, reproj);
             }
         }
-        const int win = best_root_of_quad(cand, reproj);
+        const int win = dm::best_root_of_quad(cand, reproj);
         bool good = false;
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -479,7 +458,7 @@ __global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__
             cand = dm::p3p_eval_root<true>(S, X, uv, K, x, Rc, Tc, reproj);
         }
     }
-    const int win = best_root_of_quad(cand, reproj);  // -1: no root -> safeSolvePnP's zero pose
+    const int win = dm::best_root_of_quad(cand, reproj);  // -1: no root -> safeSolvePnP's zero pose
     {
         double cv6[6] = {0, 0, 0, 0, 0, 0};
         if (active && win == root) {
@@ -495,7 +474,7 @@ __global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            const double v0 = quad_bcast_d<0>(mine[k]), v1 = quad_bcast_d<1>(mine[k]), v2 = quad_bcast_d<2>(mine[k]), v3 = quad_bcast_d<3>(mine[k]);
+            const double v0 = dm::quad_bcast_d<0>(mine[k]), v1 = dm::quad_bcast_d<1>(mine[k]), v2 = dm::quad_bcast_d<2>(mine[k]), v3 = dm::quad_bcast_d<3>(mine[k]);
             jp6[k] = (win <= 0) ? v0 : (win == 1) ? v1 : (win == 2) ? v2 : v3;  // exactly one lane of the quad holds a pose
         }
     }
