@@ -797,7 +797,14 @@ int dsac_refine_fd(dsac_ctx* c, const double* init_pose, const int32_t* perm, in
     DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
     DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap + 1) * sizeof(int32_t)));
     int32_t* d_pxbuf = d_px ? d_px : px.as<int32_t>();
-    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_init, d_map, c->F, skip, eps_hyp, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n));
+    int32_t* plan_scratch = nullptr;
+    if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
+        DevBuf& ps = next_slot(c);
+        HIP_TRY(c, ps.reserve(ni * sizeof(int32_t)));
+        plan_scratch = ps.as<int32_t>();
+    }
+    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_init, d_map, c->F, skip, eps_hyp, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n,
+                                  plan_scratch));
     HIP_TRY(c, dk::refine_fd_run(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
     HIP_TRY(c, dk::refine_fd_finish(c->stream, ro.as<double>(), d_n, cap, skip, eps_hyp, eps_obj, d_Jh, d_Jo));
     return end_call(c);
@@ -1013,7 +1020,13 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
     // dLossMax at the refined pose (train_ransac_softam.cpp:301-304)
     HIP_TRY(c, dk::pose_loss(c->stream, 1, d_ref, d_gt, s_out4, s_dL));
     // dRefineObj / dRefineHyp as one batch of finite-difference replicas (:307-341)
-    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n));
+    int32_t* plan_scratch = nullptr;
+    if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
+        DevBuf& ps = next_slot(c);
+        HIP_TRY(c, ps.reserve(ni * sizeof(int32_t)));
+        plan_scratch = ps.as<int32_t>();
+    }
+    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n, plan_scratch));
     HIP_TRY(c, dk::refine_fd_run(c->stream, cap, s_n, s_rp, d_perm, steps, max_inl, min_inl, thr, s_rx, s_rv, c->F, s_ro));
     HIP_TRY(c, dk::refine_fd_finish(c->stream, s_ro, s_n, cap, skip, eps_hyp, eps_obj, s_Jh, s_Jo));
     HIP_TRY(c, dk::path1_assemble(c->stream, s_dL, s_Jh, s_px, s_Jo, s_n, cap, (int)P, d_grad, s_v6));

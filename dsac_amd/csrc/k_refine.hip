@@ -484,6 +484,7 @@ hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int
 // cell (1-based) is kept iff k % skip == 0 and then is selection number k / skip - 1 -- a closed form, so no second prefix is needed.
 // (Round 1 scanned with one wave, 64 cells per dependent step: 1.4 ms on a 640 x 480 map.)
 constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_TILED_MIN_CELLS = 16384;  // larger maps take the two-launch tiled plan (40 x 40: one workgroup, 5 us)
 
 DM_INLINE int plan_segment_prefix(const int32_t* __restrict__ inlier_map, const FrameDev& F, int t0, int t1, int* s_cnt, int* total) {
     const int tid = threadIdx.x;
@@ -553,8 +554,118 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan(const double* _
     if (lane == 0) n_obj[0] = min(total / skip, cap);
 }
 
+// ---- the same plan for large maps: two launches over tiles of 64 columns --------------------------------------------------------
+// A single workgroup scanning a 640 x 480 map column-major reads it with a 2.5 KB stride: 158 us, a quarter of that frame's training
+// geometry.  Tiled: workgroup b owns columns 64 b .. 64 b + 63; lane = column, so a wave reads a row segment of 256 contiguous bytes, and
+// the 16 waves split the rows.  Launch 1 counts the inliers per (column, row segment); launch 2 turns the counts into the column-major
+// rank of every inlier (columns before the tile, columns before it inside the tile, row segments above it in its column, then a walk down
+// its own segment) and emits the selected ones exactly as the one-workgroup form does.  scratch: PLAN_SEGS + 1 ints per column.
+constexpr int PLAN_SEGS = PLAN_THREADS / 64;  // row segments = waves per workgroup
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_count(const int32_t* __restrict__ inlier_map, FrameDev F, int32_t* __restrict__ scratch) {
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int rows = (F.H + PLAN_SEGS - 1) / PLAN_SEGS;
+    const int y0 = min(F.H, seg * rows), y1 = min(F.H, y0 + rows);
+    int cnt = 0;
+    if (x < F.W)
+        for (int y = y0; y < y1; y++) cnt += inlier_map[(size_t)y * F.W + x] != 0;
+    __shared__ int s_c[PLAN_SEGS][64];
+    s_c[seg][lane] = cnt;
+    __syncthreads();
+    if (x < F.W) {
+        scratch[(size_t)F.W + (size_t)x * PLAN_SEGS + seg] = cnt;          // per (column, segment)
+        if (seg == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int k = 0; k < PLAN_SEGS; k++) tot += s_c[k][lane];
+            scratch[x] = tot;                                                // per column
+        }
+    }
+}
+
+DM_INLINE void emit_obj_replicas(int slot, int p, const FrameDev& F, const double init[6], float eps_obj, double* __restrict__ rep_poses,
+                                 int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels) {
+    obj_pixels[slot] = p;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v0 = F.xyz[(size_t)p * 3 + c];
+        const float vf = v0 + eps_obj;
+        const float vb = vf - 2 * eps_obj;
+        const int r = 12 + slot * 6 + c * 2;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { rep_poses[(size_t)r * 6 + k] = init[k]; rep_poses[(size_t)(r + 1) * 6 + k] = init[k]; }
+        rep_px_c[2 * r] = p; rep_px_c[2 * r + 1] = c; rep_value[r] = vf;
+        rep_px_c[2 * (r + 1)] = p; rep_px_c[2 * (r + 1) + 1] = c; rep_value[r + 1] = vb;
+    }
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* __restrict__ init_pose, const int32_t* __restrict__ inlier_map, FrameDev F,
+                                                                 int skip, float eps_hyp, float eps_obj, int cap, const int32_t* __restrict__ scratch,
+                                                                 double* __restrict__ rep_poses, int32_t* __restrict__ rep_px_c,
+                                                                 float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels,
+                                                                 int32_t* __restrict__ n_obj) {
+    const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+    const int x0 = blockIdx.x * 64, x = x0 + lane;
+    double init[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) init[i] = init_pose[i];
+    if (blockIdx.x == 0 && tid < 12) {  // dRefineHyp: replica 2i = +step on parameter i, 2i+1 = (+step) - 2 step (as the one-workgroup form)
+        const int i = tid >> 1;
+        const double step = (i < 3) ? (double)eps_hyp : (double)(eps_hyp * 1000);
+        double v = init[i] + step;
+        if (tid & 1) v -= 2 * step;
+#pragma unroll
+        for (int k = 0; k < 6; k++) rep_poses[(size_t)tid * 6 + k] = (k == i) ? v : init[k];
+        rep_px_c[2 * tid] = -1; rep_px_c[2 * tid + 1] = 0; rep_value[tid] = 0.f;
+    }
+    // inliers in the columns before this tile (all threads), and in all columns (for n_obj)
+    __shared__ int s_part[PLAN_SEGS], s_tot[PLAN_SEGS], s_col[64];
+    int before = 0, total = 0;
+    for (int i = tid; i < F.W; i += PLAN_THREADS) { const int v = scratch[i]; total += v; if (i < x0) before += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); total += __shfl_xor(total, o, 64); }
+    if (lane == 0) { s_part[seg] = before; s_tot[seg] = total; }
+    if (seg == 0) {  // exclusive prefix over the tile's 64 columns
+        const int own = x < F.W ? scratch[x] : 0;
+        int incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        s_col[lane] = incl - own;
+    }
+    __syncthreads();
+    before = 0; total = 0;
+#pragma unroll
+    for (int k = 0; k < PLAN_SEGS; k++) { before += s_part[k]; total += s_tot[k]; }
+    if (blockIdx.x == 0 && tid == 0) n_obj[0] = min(total / skip, cap);
+    if (x >= F.W) return;
+    int inCount = before + s_col[lane];
+    for (int k = 0; k < seg; k++) inCount += scratch[(size_t)F.W + (size_t)x * PLAN_SEGS + k];
+    const int rows = (F.H + PLAN_SEGS - 1) / PLAN_SEGS;
+    const int y0 = min(F.H, seg * rows), y1 = min(F.H, y0 + rows);
+    for (int y = y0; y < y1; y++) {
+        const int p = y * F.W + x;
+        if (inlier_map[p] == 0) continue;
+        inCount++;
+        if (inCount % skip != 0) continue;
+        const int slot = inCount / skip - 1;
+        if (slot >= cap) continue;
+        emit_obj_replicas(slot, p, F, init, eps_obj, rep_poses, rep_px_c, rep_value, obj_pixels);
+    }
+}
+
+size_t refine_fd_plan_scratch_ints(const FrameDev& F) { return F.P > PLAN_TILED_MIN_CELLS ? (size_t)F.W * (PLAN_SEGS + 1) : 0; }
+
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
-                          float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj) {
+                          float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj,
+                          int32_t* scratch) {
+    if (scratch && F.P > PLAN_TILED_MIN_CELLS) {
+        const int tiles = (F.W + 63) / 64;
+        hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
+        hipLaunchKernelGGL(k_refine_fd_emit, dim3(tiles), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch, rep_poses,
+                           rep_px_c, rep_value, obj_pixels, n_obj);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_refine_fd_plan, dim3(1), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c, rep_value,
                        obj_pixels, n_obj);
     return hipGetLastError();

@@ -109,9 +109,11 @@ hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, cons
 hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set /*M x 6 x 9*/,
                                 double* J_obj, int M = 1);
 // builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
+// scratch: refine_fd_plan_scratch_ints(F) int32 of device memory (0: not needed, small map) -- large maps are planned by two tiled launches
+size_t refine_fd_plan_scratch_ints(const FrameDev& F);
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,
-                          int32_t* n_obj);
+                          int32_t* n_obj, int32_t* scratch = nullptr);
 // launches 12 + 6*cap replica waves; those beyond 12 + 6*n_obj[0] exit immediately
 hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
                          int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out);

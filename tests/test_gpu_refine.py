@@ -126,6 +126,33 @@ def test_drefine_parity(engine, orc, synth, frame40):
     assert np.abs(dense2 - Jo_r2).max() <= 1e-4 * max(np.abs(Jo_r2).max(), 1e-12)
 
 
+def test_drefine_large_map_uses_the_tiled_plan(engine, orc, synth):
+    """Maps above 16384 cells build the replica list with two tiled launches (64-column tiles, 16 row segments) instead of one workgroup:
+    the selected cells (every skip-th inlier in the reference's column-major order, cnn_softam.h:868-880) and their Jacobians must be the
+    oracle's.  160 columns = two full tiles and a half one, 120 rows = 15 used row segments of 8."""
+    H, W = 120, 160
+    fr = synth.chess_like_frame(H, W, seed=5)
+    engine.set_frame(fr["xyz"], fr["uv"], H, W, fr["cam"])
+    perm = synth.fast_permutations(H * W, 8, seed=3)
+    init = fr["gt_pose"] + np.array([0.003, -0.002, 0.001, 2.0, -3.0, 4.0])
+    ref, imap, sd = orc.refine(init, perm, fr["xyz"], fr["uv"], H, W, fr["cam"], want_inlier_map=True)
+    assert sd[0] == 8 and (imap > 0).sum() > 300
+    for sub in (0.05, 0.3):
+        Jh_r = orc.dRefineHyp(init, perm, fr["xyz"], fr["uv"], H, W, fr["cam"])
+        Jo_r = orc.dRefineObj(init, perm, imap, fr["xyz"], fr["uv"], H, W, fr["cam"], sub_sample=sub)
+        Jh, px, Jo = engine.dRefine(init, perm, imap, sub_sample=sub)
+        # the reference's selection: walk x outer / y inner, every skip-th inlier
+        skip = int(1 / sub)
+        order = [y * W + x for x in range(W) for y in range(H) if imap[y * W + x] > 0]
+        want = order[skip - 1::skip]
+        assert [int(p_) for p_ in px] == want
+        assert np.abs(Jh - Jh_r).max() <= 1e-4 * max(np.abs(Jh_r).max(), 1e-12)
+        dense = np.zeros((6, H * W * 3))
+        for i, p_ in enumerate(px):
+            dense[:, p_ * 3:p_ * 3 + 3] = Jo[i]
+        assert np.abs(dense - Jo_r).max() <= 1e-4 * max(np.abs(Jo_r).max(), 1e-12)
+
+
 def test_loss_and_gradient(engine, orc, synth):
     rng = np.random.default_rng(1)
     gt_cv = np.array([0.2, -0.1, 0.05, 120.0, -340.0, 2100.0])
