@@ -537,6 +537,42 @@ def main(argv=None):
             refsize["frames_per_step_%d" % nf] = {"value": nn * n40 / e40s, "unit": "hyp/s", "us_per_frame": e40s / n40 / nf * 1e6}
         eng.profile_read(0, reset=True)
 
+    # the reference's test-time unit of work (test_ransac_softam.cpp:97-157): processImage of ONE image -- K1 -> K2 -> K3, then the 8-step
+    # inlier refinement of the soft-argmax pose (K6) and the pose loss (K7) -- device-resident, at full and at reference size
+    procimg = None
+    if not args.no_single_frame and not args.kernel_only and not config3 and args.k2_mode == "both" and rank == 0:
+        from dsac_amd.capi import lib as _lib, ptr as _ptr, check as _check
+        eng, _ = engines[0]
+        b = bufs[0]
+        procimg = {"workload": "processImage of one image (core/cnn_softam.h:960-1179 with the soft-inlier score): sample + P3P, error images, softmax / "
+                               "soft-argmax, 8 refinement steps, pose loss; %d hypotheses, everything resident in HBM" % N}
+        f40 = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
+        for (hh, ww, xs, us, cam_) in ((H, W, xyz_batches[0][0] if batched else xyz_batches[0], None, fr["cam"]),
+                                       (40, 40, torch.from_numpy(f40["xyz"]).to(dev), torch.from_numpy(f40["uv"]).to(dev), f40["cam"])):
+            pp = hh * ww
+            eng.set_frame(xs, us, hh, ww, cam_, borrow=True)
+            perm_d = torch.from_numpy(synth.fast_permutations(pp, 8)).to(dev)
+            gt_d = torch.zeros(6, dtype=torch.float64, device=dev)
+            ref_d, out4_d, sd_d = torch.zeros(6, dtype=torch.float64, device=dev), torch.zeros(4, dtype=torch.float64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+            errp = b["err"][:N] if pp == P else torch.empty(N, pp, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+
+            def proc(i):
+                eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=errp,
+                                    out=(b["poses"][:N], b["sets"][:N], b["ok"][:N], b["soft"][:N], b["w"][:N], b["ent"][:1], b["avg"][0]))
+                _check(eng._ctx, _lib.dsac_refine(eng._ctx, 1, _ptr(b["avg"][0]), _ptr(perm_d), 8, 100, 50, 10.0, None, None, _ptr(ref_d), None, _ptr(sd_d)))
+                _check(eng._ctx, _lib.dsac_loss(eng._ctx, _ptr(ref_d), _ptr(gt_d), _ptr(out4_d), None))
+            for i in range(10):
+                proc(i)
+            eng.synchronize()
+            npi = 100
+            tp = time.perf_counter()
+            for i in range(npi):
+                proc(10 + i)
+            eng.synchronize()
+            procimg["%dx%d" % (ww, hh)] = {"us_per_image": (time.perf_counter() - tp) / npi * 1e6, "images": npi, "refine_steps_done": int(sd_d.item())}
+        eng.profile_read(0, reset=True)
+
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -599,6 +635,8 @@ def main(argv=None):
             out["single_frame"] = single
         if refsize is not None:
             out["reference_size"] = refsize
+        if procimg is not None:
+            out["process_image"] = procimg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
         print(json.dumps(out), flush=True)
