@@ -1,10 +1,11 @@
 // k_sample.hip -- K1 (minimal-set sampling + P3P) and K5 (dPNP) of the gfx950 DSAC engine.
 //
 // K1 replaces the rejection loop of processImage (core/cnn_softam.h:1010-1060).  The reference runs one
-// OpenMP thread per hypothesis and retries sequentially; here ONE WAVE owns a hypothesis and evaluates 16
-// consecutive attempts at once, 4 lanes per attempt (one per quartic root of P3P), each attempt with its
-// own counter-based draws.  A ballot picks the lowest accepted attempt, which is exactly the attempt the
-// sequential loop would have stopped at, so the result does not depend on the wave width or on
+// OpenMP thread per hypothesis and retries sequentially; here ONE WAVE owns a hypothesis and evaluates 64
+// consecutive attempts at once, one lane per attempt with the quartic's roots in sequence (the default since
+// round 2; the first form -- 16 attempts, 4 lanes per attempt, one per root -- is kept behind k1_rl = 4), each
+// attempt with its own counter-based draws.  A ballot picks the lowest accepted attempt, which is exactly the
+// attempt the sequential loop would have stopped at, so the result does not depend on the wave width or on
 // scheduling.  P3P runs in fp64 in registers (dmath.h).
 //
 // K5 replaces dPNP (core/cnn_softam.h:101-146): four lanes (one per quartic root) per (hypothesis, coordinate, +/-) P3P solve,
