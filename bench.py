@@ -2,7 +2,7 @@
 """bench.py -- hypotheses scored / s over a 640x480 scene-coordinate map (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of synthetic input of BASELINE.json configs[1]
-("chess"-like frame, 256 hypotheses, 640x480 coordinate map, one MI355X), by default 8 independent frames per step:
+("chess"-like frame, 256 hypotheses, 640x480 coordinate map, one MI355X), by default 16 independent frames per step:
     K1 sample 256 minimal sets + P3P   ->  K2 reproject all 307 200 points under all 256 poses
     (error images, the score-CNN input of the reference, + fused soft-inlier sums)  ->  K3 softmax.
 The frames are resident in HBM before the timed region; every output stays in HBM.
@@ -69,7 +69,7 @@ def parse_args(argv=None):
                          "one frame run under K2 of the other and K2 runs alone.  'frames' = the same without the serialisation.  'pipeline' = one context, "
                          "dsac_sample_ahead / dsac_score_sampled: K1 of step i+1 on the context's auxiliary stream under K2/K3 of step i, consecutive steps on DIFFERENT "
                          "frames.  'stages' = stream A samples frame i+1 while stream B scores frame i.  With one context and not 'pipeline': no overlap")
-    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSAC_BENCH_FRAMES", "8")),
+    ap.add_argument("--frames-per-step", type=int, default=int(os.environ.get("DSAC_BENCH_FRAMES", "16")),
                     help="independent 640x480 frames (each with --hyps hypotheses) batched into one step: dsac_set_frames / dsac_score_hypotheses_frames carry "
                          "them through K1, K2, K3 in three launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")

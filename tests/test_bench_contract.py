@@ -82,7 +82,7 @@ def test_gpus_flag_launches_the_ranks_itself():
     assert r.returncode == 0, r.stderr
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
-    assert d["config"]["frames_per_step_all_ranks"] == 16  # 8 frames per rank
+    assert d["config"]["frames_per_step_all_ranks"] == 32  # 16 frames per rank
 
 
 def test_config3_shards_64_images_and_gathers_them():

@@ -57,10 +57,11 @@ def _check_scores(orc, soft_gpu, w_gpu, poses, xyz, uv, cam, what, engine=None):
 
 
 def test_bench_shape_frame_batch_against_the_oracle(engine, orc, synth):
-    """bench.py's default step: 8 frames x 256 hypotheses x 640x480 through dsac_score_hypotheses_frames."""
+    """bench.py's default step: 16 frames x 256 hypotheses x 640x480 through dsac_score_hypotheses_frames (8 frames until late in round 2;
+    the same kernel instantiations)."""
     import torch
     dev = torch.device("cuda", 0)
-    F, N = 8, 256
+    F, N = 16, 256
     frames = [synth.chess_like_frame(H, W, seed=1305 + 1000 + f) for f in range(F)]
     xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
     cam = frames[0]["cam"]
@@ -78,7 +79,7 @@ def test_bench_shape_frame_batch_against_the_oracle(engine, orc, synth):
     engine.synchronize()
     ms, n = engine.profile_read(0, reset=True)
     engine.profile_enable(False)
-    assert n == 1  # one K2 launch carried the 8 frames
+    assert n == 1  # one K2 launch carried the 16 frames
     assert int(ok.sum().item()) == F * N
     ph, sh, wh, sf = poses.cpu().numpy(), sets.cpu().numpy(), w.cpu().numpy(), soft.cpu().numpy()
     rng = np.random.default_rng(0)
@@ -88,7 +89,7 @@ def test_bench_shape_frame_batch_against_the_oracle(engine, orc, synth):
         # minimal sets: what the oracle draws for seed + f on this frame
         pr, sr, okr, _ = orc.sample(N, 4711 + f, frames[f]["xyz"], uv, H, W, cam, thr=10.0, max_tries=1 << 16)
         assert np.array_equal(sh[sl], sr), "frame %d: minimal sets differ from the oracle's" % f
-        rows = f * N + rng.choice(N, 10, replace=False)  # 80 rows in total
+        rows = f * N + rng.choice(N, 6, replace=False)  # 96 rows in total
         worst = max(worst, _check_rows(orc, err, rows, ph, frames[f]["xyz"], uv, cam, "frame %d" % f))
         rel, dw = _check_scores(orc, sf[sl], wh[sl], ph[sl], frames[f]["xyz"], uv, cam, "frame %d" % f, engine=engine if f == 0 else None)
         aref = orc.avg_pose(wh[sl], ph[sl])
