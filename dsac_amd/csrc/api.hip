@@ -232,6 +232,7 @@ int dsac_create(dsac_ctx** out, int device) {
     if (const char* v = getenv("DSAC_K1_HORN")) c->k1.horn = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K1_MINW")) c->k1.minw = atoi(v);
     if (const char* v = getenv("DSAC_K1_RL")) c->k1.rl = atoi(v) == 1 ? 1 : 4;
+    if (const char* v = getenv("DSAC_K1_WIDE")) c->k1.wide = atoi(v);
     if (const char* v = getenv("DSAC_K1_SHARE")) { const int sv = atoi(v); c->k1.share = sv < 0 ? -sv : sv; c->k1.share_always = sv < 0; }
     if (const char* v = getenv("DSAC_K4_VARIANT")) c->k4_variant = atoi(v);
     if (const char* v = getenv("DSAC_K1_CUS")) c->k1_cus = atoi(v);
@@ -618,6 +619,7 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k1_horn") c->k1.horn = value != 0;
     else if (k == "k1_minw") c->k1.minw = value;
     else if (k == "k1_rl") c->k1.rl = value == 1 ? 1 : 4;
+    else if (k == "k1_wide") c->k1.wide = value;
     else if (k == "k1_share") { c->k1.share = value < 0 ? -value : value; c->k1.share_always = value < 0; }
     else if (k == "k4_variant") c->k4_variant = value;
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }

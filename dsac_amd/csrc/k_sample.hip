@@ -221,6 +221,108 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
 }
 
 // --------------------------------------------------------------------------------------------------
+// K1 for few hypotheses (one frame): WPH waves per hypothesis from the first round on, one lane per attempt, so a round is 64 * WPH
+// attempts wide.  With one wave (64 attempts, failure probability ~4 % on the synthetic frames) some of 256 hypotheses need a second
+// round in practically every launch, and the launch lasts as long as its slowest hypothesis; with four waves (256 attempts) a second
+// round is a 1e-6 event, and 256 x 4 waves are exactly the chip's 1024 SIMDs -- measured (profiles/r02_k1_wide.txt), two waves are the
+// better trade: N = 256 15.1 -> 11.4 us (four: 12.3), N = 512 16.3 -> 11.8 us; the launcher uses two up to 512 hypotheses.  Same result: wave w takes attempts base + 64 w + lane,
+// the lowest accepted attempt of the round wins (LDS exchange, two barriers per round), rounds are consumed in increasing order.
+// --------------------------------------------------------------------------------------------------
+template <int WPH>
+__global__ __launch_bounds__(64 * WPH) void k_sample_wide(int N, uint64_t seed, FrameDev F, int thr_int, int max_tries, double* __restrict__ poses,
+                                                         int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged, int prio,
+                                                         int Nf) {
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    __shared__ int s_win[WPH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x;  // grid = N
+    const int frame = h / Nf;
+    F.xyz += (long long)frame * F.xyz_stride;
+    if (F.uv) F.uv += (long long)frame * F.uv_stride;
+    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+    const dm::Cam K = make_cam(F);
+    const double thr_hi = (double)thr_int + 0.01;
+    bool done = false;
+    for (long long base = 0; base < (long long)max_tries && !done; base += 64 * WPH) {
+        const long long att = base + 64 * wave + lane;
+        const uint32_t attempt = (uint32_t)att;
+        int32_t set4[4];
+        bool live = att < (long long)max_tries;
+        if (live) live = draw_set(F, key, attempt, set4);
+        float X[4][3], uv[4][2];
+        double Rc[9], Tc[3], reproj = 0;
+        bool cand = false;
+        if (live) {
+            load_set(F, set4, X, uv);
+            dm::P3PSetup S;
+            if (dm::p3p_setup(X, uv, K, S)) {
+                for (int i = 0; i < 4; i++) {  // the roots in sequence, best 4th-point re-projection wins, the first on ties (dm::p3p)
+                    if (i >= S.n) continue;
+                    double Rt[9], Tt[3], rp;
+                    const double x = (i == 0) ? S.roots[0] : (i == 1) ? S.roots[1] : (i == 2) ? S.roots[2] : S.roots[3];
+                    if (!dm::p3p_eval_root<false>(S, X, uv, K, x, Rt, Tt, rp)) continue;
+                    if (!cand || reproj > rp) {
+                        cand = true;
+                        reproj = rp;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Rc[k] = Rt[k];
+                        Tc[0] = Tt[0]; Tc[1] = Tt[1]; Tc[2] = Tt[2];
+                    }
+                }
+            }
+        }
+        bool good = false;
+        double cv6[6] = {0, 0, 0, 0, 0, 0};
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (live && cand && !(reproj > thr_hi * thr_hi)) {  // early rejection as in k_sample
+            dm::rodrigues_m2v(Rc, cv6);
+            cv6[3] = Tc[0]; cv6[4] = Tc[1]; cv6[5] = Tc[2];
+            dm::rodrigues_v2m<false>(cv6, R, nullptr);
+            good = true;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float uu, vv;
+                dm::project_f(R, cv6 + 3, K, X[j][0], X[j][1], X[j][2], uu, vv);
+                const float dx = uv[j][0] - uu, dy = uv[j][1] - vv;
+                good = good && (sqrt((double)dx * dx + (double)dy * dy) < (double)thr_int);
+            }
+        }
+        const unsigned long long m = __ballot(good);
+        const int wl = m ? (__ffsll((long long)m) - 1) : -1;
+        if (lane == 0) s_win[wave] = m ? 64 * wave + wl : 0x7fffffff;
+        __syncthreads();
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < WPH; w++) best = min(best, s_win[w]);
+        if (best != 0x7fffffff) {
+            done = true;
+            if (best == 64 * wave + lane) {  // exactly one lane of the workgroup
+#pragma unroll
+                for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = cv6[k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = set4[k];
+                ok[h] = 1;
+                if (staged) write_staged_R(F, R, cv6, staged + (size_t)h * POSE_STRIDE);
+            }
+        }
+        __syncthreads();  // s_win is rewritten in the next round
+    }
+    // no accepted attempt: zero pose, ok = 0; sets_out reports the last attempt's set
+    if (!done && threadIdx.x == 0) {
+        int32_t set4[4];
+        draw_set(F, key, (uint32_t)(max_tries - 1), set4);
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) poses[(size_t)h * 6 + kk] = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) sets_out[(size_t)h * 4 + kk] = set4[kk];
+        ok[h] = 0;
+        if (staged) { const double z6[6] = {0, 0, 0, 0, 0, 0}; write_staged(F, z6, staged + (size_t)h * POSE_STRIDE); }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // K1 with work sharing inside a workgroup (round 2).  The launch time of k_sample is the time of its SLOWEST hypothesis: an attempt is
 // accepted with p ~ 0.05 on the synthetic frames, a round of 16 fails with 0.44, so the slowest of 2048 hypotheses needs ~9 rounds of
 // ~5.5 us while the average needs 1.8.  Here SW waves form a workgroup over SW consecutive hypotheses; a wave whose hypothesis is
@@ -411,6 +513,10 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         }
         else if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4, false); else DSAC_K1(1, 4, false); }
         else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2, false); else if (wpb >= 4) DSAC_K1(4, 2, false); else DSAC_K1(1, 2, false); }
+        else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4 && o.wide == 4 && N <= 256)
+            hipLaunchKernelGGL((k_sample_wide<4>), dim3(N), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
+        else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4 && o.wide != 0 && N <= 512 && (o.wide < 0 || o.wide == 2))
+            hipLaunchKernelGGL((k_sample_wide<2>), dim3(N), dim3(128), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4) hipLaunchKernelGGL((k_sample<1, 1, false, 1, 1>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }
 #undef DSAC_K1

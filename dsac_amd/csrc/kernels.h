@@ -56,6 +56,7 @@ struct K1Opts {
     bool share_always = false;  // share beyond 1024 hypotheses as well (DSAC_K1_SHARE < 0)
     int share = 4;  // waves of a workgroup that help each other's unfinished hypotheses (k_sample_shared; 0 / 1 = off, 4, 8; DSAC_K1_SHARE)
     bool horn = false;
+    int wide = -1;  // waves per hypothesis of the one-lane-per-attempt form for few hypotheses: -1 auto (2 up to 512 hypotheses), 0 off, 2, 4 (4: up to 256) (DSAC_K1_WIDE)
     int rl = 1;  // lanes per attempt: 4 = one per quartic root, 1 = one lane per attempt with its roots in sequence (DSAC_K1_RL)
 };
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,

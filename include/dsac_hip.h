@@ -94,12 +94,14 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_rl"       lanes per sampling attempt: 1 (default) = one lane per attempt, the quartic's roots in sequence, 64 attempts per round and
  *                 hypothesis; 4 = one lane per root, 16 attempts per round (the form the wpb / hpw / minw / share knobs below act on)
+ *   "k1_wide"     waves per hypothesis of the one-lane-per-attempt form when there are few hypotheses: -1 auto (2 up to 512 hypotheses,
+ *                 else 1), 0 = always 1, 2, 4 (4: up to 256 hypotheses) -- a round is 64 x waves attempts wide, the first accepted attempt is the same
  *   "k1_share"    4 or 8: the waves of a K1 workgroup evaluate the next attempts of their unfinished neighbours -- same first accepted attempt,
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
  *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
  *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
- * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_SHARE,
+ * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
 int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
 

@@ -447,15 +447,15 @@ def test_pipelined_calls_on_a_frame_batch(engine, synth):
 
 
 def test_k1_forms_give_the_same_first_accepted_attempt(engine, orc, frame_full, frame40):
-    """K1 exists with one lane per attempt (64 attempts per round, the default) and with one lane per quartic root (16 per round): as one
-    wave per hypothesis, as 2 / 4 hypotheses per wave and as the work-sharing form (finished waves of a workgroup help the unfinished
+    """K1 exists with one lane per attempt (64 attempts per round and wave, the default; 2 or 4 waves per hypothesis when there are few
+    hypotheses) and with one lane per quartic root (16 per round): as one wave per hypothesis, as 2 / 4 hypotheses per wave and as the work-sharing form (finished waves of a workgroup help the unfinished
     hypotheses): all must stop at the same attempt -- the first accepted one in index order, which is what the reference's sequential
     loop does (cnn_softam.h:1010-1060) -- including ragged counts and exhausted budgets."""
     for fr, N, tries in ((frame_full, 301, 1 << 16), (frame40, 130, 24), (frame40, 7, 1 << 16)):
         _set(engine, fr)
         ref = None
-        for knobs in (dict(k1_rl=1), dict(k1_share=0, k1_wpb=1), dict(k1_share=4), dict(k1_share=-8), dict(k1_share=0, k1_wpb=4), dict(k1_share=0, k1_hpw=2)):
-            for k, v in {**dict(k1_rl=4, k1_share=4, k1_wpb=1, k1_hpw=1), **knobs}.items():
+        for knobs in (dict(k1_rl=1, k1_wide=0), dict(k1_rl=1, k1_wide=2), dict(k1_rl=1, k1_wide=4), dict(k1_rl=1, k1_wide=-1), dict(k1_share=0, k1_wpb=1), dict(k1_share=4), dict(k1_share=-8), dict(k1_share=0, k1_wpb=4), dict(k1_share=0, k1_hpw=2)):
+            for k, v in {**dict(k1_rl=4, k1_wide=-1, k1_share=4, k1_wpb=1, k1_hpw=1), **knobs}.items():
                 engine.set_option(k, v)
             got = engine.sample(N, seed=4242, thr=10.0, max_tries=tries)
             if ref is None:
@@ -466,7 +466,7 @@ def test_k1_forms_give_the_same_first_accepted_attempt(engine, orc, frame_full, 
                     assert 0 < okr.sum() < N  # some hypotheses run out of attempts: zero pose, ok = 0
             else:
                 assert all(np.array_equal(a, b) for a, b in zip(ref, got)), knobs
-    for k, v in dict(k1_rl=1, k1_share=4, k1_wpb=1, k1_hpw=1).items():
+    for k, v in dict(k1_rl=1, k1_wide=-1, k1_share=4, k1_wpb=1, k1_hpw=1).items():
         engine.set_option(k, v)
 
 
