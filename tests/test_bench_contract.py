@@ -27,7 +27,7 @@ def test_algorithmic_bytes_formula():
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench_default.json", "r02_bench_driver_flags.json"])
+@pytest.mark.parametrize("name", ["r01_bench_default.json", "r02_bench_driver_flags.json", "r02_final_bench_driver_flags.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)
