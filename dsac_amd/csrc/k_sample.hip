@@ -511,6 +511,8 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
             if (wpb >= 4) hipLaunchKernelGGL((k_sample<4, 1, false, 2>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
             else hipLaunchKernelGGL((k_sample<1, 1, false, 2>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
         }
+        else if (o.rl == 1 && H2 == 2) hipLaunchKernelGGL((k_sample<1, 2, false, 1, 1>), dim3((N + 1) / 2), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
+        else if (o.rl == 1 && H2 == 4) hipLaunchKernelGGL((k_sample<1, 4, false, 1, 1>), dim3((N + 3) / 4), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else if (H2 >= 4) { if (wpb >= 4) DSAC_K1(4, 4, false); else DSAC_K1(1, 4, false); }
         else if (H2 == 2) { if (wpb >= 8) DSAC_K1(8, 2, false); else if (wpb >= 4) DSAC_K1(4, 2, false); else DSAC_K1(1, 2, false); }
         else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4 && o.wide == 4 && N <= 256)

@@ -454,7 +454,7 @@ def test_k1_forms_give_the_same_first_accepted_attempt(engine, orc, frame_full, 
     for fr, N, tries in ((frame_full, 301, 1 << 16), (frame40, 130, 24), (frame40, 7, 1 << 16)):
         _set(engine, fr)
         ref = None
-        for knobs in (dict(k1_rl=1, k1_wide=0), dict(k1_rl=1, k1_wide=2), dict(k1_rl=1, k1_wide=4), dict(k1_rl=1, k1_wide=-1), dict(k1_share=0, k1_wpb=1), dict(k1_share=4), dict(k1_share=-8), dict(k1_share=0, k1_wpb=4), dict(k1_share=0, k1_hpw=2)):
+        for knobs in (dict(k1_rl=1, k1_wide=0), dict(k1_rl=1, k1_wide=2), dict(k1_rl=1, k1_wide=4), dict(k1_rl=1, k1_wide=-1), dict(k1_rl=1, k1_wide=0, k1_hpw=2), dict(k1_rl=1, k1_wide=0, k1_hpw=4), dict(k1_share=0, k1_wpb=1), dict(k1_share=4), dict(k1_share=-8), dict(k1_share=0, k1_wpb=4), dict(k1_share=0, k1_hpw=2)):
             for k, v in {**dict(k1_rl=4, k1_wide=-1, k1_share=4, k1_wpb=1, k1_hpw=1), **knobs}.items():
                 engine.set_option(k, v)
             got = engine.sample(N, seed=4242, thr=10.0, max_tries=tries)
