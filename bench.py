@@ -460,6 +460,33 @@ def main(argv=None):
         k2_n += n
     ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
     wsum = float(bufs[0]["w"][:N].sum().item()) if not args.kernel_only else 1.0
+
+    # The ceiling of K2's own write pattern ON THIS BOX: the same launches with k2_flags bit 1 (the kernel issues its store schedule only, no
+    # arithmetic; include/dsac_hip.h).  The pool's boxes differ by several per cent for the same binary; this number moves with them.
+    store_only_us = None
+    if rank == 0 and not config3 and args.k2_mode != "soft" and not args.separate_calls:
+        try:
+            for eng, _ in engines:
+                eng.set_option("k2_flags", 2)
+                eng.profile_read(0, reset=True)
+            for i in range(6):
+                step(ctr)
+                ctr += 1
+            sync_all()
+            so_ms, so_n = 0.0, 0
+            for eng, _ in engines:
+                ms, n = eng.profile_read(0, reset=True)
+                so_ms += ms
+                so_n += n
+            store_only_us = so_ms / max(1, so_n) * 1e3 if so_n else None
+        finally:
+            for eng, _ in engines:
+                eng.set_option("k2_flags", 0)
+            step(ctr)  # leave real results in the buffers
+            ctr += 1
+            sync_all()
+            for eng, _ in engines:
+                eng.profile_read(0, reset=True)
     if config3 and rank == 0:
         ws = last[:, 6:].sum(1)
         assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
@@ -626,7 +653,8 @@ def main(argv=None):
                        "prewarm_steps_untimed": n_pre, "accepted_fraction": ok_frac, "softmax_sum": wsum},
             "roofline": {"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": abytes,
-                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n, "event_stride": stride},
+                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n, "event_stride": stride,
+                         "store_schedule_only_us": store_only_us},
             # kernel-only (K2) and per-image (K1 + K2 + K3) rates reported separately
             "rates": {"per_image_hyp_s": value, "kernel_only_k2_hyp_s": (N * frames_per_launch / k2_avg_s * world) if k2_avg_s > 0 else None,
                       "unit": "hyp/s", "note": "per_image = whole step (K1 sample+P3P, K2, soft reduce, K3); kernel_only = hypotheses per K2 launch / its duration"},
