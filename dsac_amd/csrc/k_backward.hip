@@ -555,6 +555,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     // without it 5 (N = 256: 144 vs 147 us, N = 1024: 485 vs 498).  A round-counting model (1200 tiles on 512 persistent workgroups =
     // 3 rounds of 4 chunks where the mean is 2.34, against 960 tiles = 2 rounds of 5) predicted -20 % for 5 chunks; it is not there:
     // a workgroup that runs out of tiles leaves its SIMDs to its neighbours.
+    const bool auto_form = variant < 0;
     if (variant < 0) variant = d_err ? 2 : 3;
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 5 || (!F.uv && F.W % 4 != 0)) variant = 0;
@@ -564,6 +565,21 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
         pl.rows = ((F.P + tile - 1) / tile) * (K4_THREADS / 64);
     } else {
+        // Small maps (the reference's 40 x 40 sub-sample: 1600 cells): with the big-map tiles the whole pass is 5 workgroups that each walk
+        // 16 hypothesis groups -- 37 us of pure latency for 0.4 M pairs.  When the tiles would not even give every CU a workgroup, take 2
+        // chunks per wave and the largest hypothesis tile that does (down to one 16-hypothesis group per workgroup).
+        int ht_small = 0;
+        if (auto_form && ht_code == 0) {
+            const int CHb = k4m_chunks(variant), PTb = (F.P + 64 * CHb - 1) / (64 * CHb);
+            const int HTb = min(K4M_HT_MAX, ((max(N, 1) + 15) / 16) * 16), NTb = (max(N, 1) + HTb - 1) / HTb;
+            if (PTb * NTb < 256) {
+                variant = 1;
+                pl.variant = 1;
+                const int PT2 = (F.P + 127) / 128;
+                for (ht_small = K4M_HT_MAX; ht_small > 16; ht_small >>= 1)
+                    if (PT2 * ((max(N, 1) + ht_small - 1) / ht_small) >= 256) break;
+            }
+        }
         const int CH = k4m_chunks(variant);
         // Persistent workgroups, 2 per CU (register- and LDS-limited: 2 waves per SIMD), shared between the hypothesis tiles.  The biggest
         // hypothesis tile wins: a round-counting model preferred HT = 128 for N = 256 on 640 x 480 (5 rounds of 128 instead of 3 of 256
@@ -571,7 +587,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // of tiles early leaves the VALU to its SIMD neighbours, so the imbalance costs far less than the extra set-up.
         const int PT = (F.P + 64 * CH - 1) / (64 * CH);
         const int ht_max = ht_code == 1 ? 64 : ht_code == 2 ? 128 : K4M_HT_MAX;
-        pl.HT = min(ht_max, ((max(N, 1) + 15) / 16) * 16);
+        pl.HT = min(ht_small > 0 ? ht_small : ht_max, ((max(N, 1) + 15) / 16) * 16);
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
         pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : 2) * 256 + pl.NT - 1) / pl.NT));
         return pl;
