@@ -40,6 +40,14 @@ def test_committed_bench_line_has_the_contract_fields(name):
         r = d["rates"]
         assert abs(r["per_image_hyp_s"] - d["value"]) < 1e-6 * d["value"] and r["kernel_only_k2_hyp_s"] > r["per_image_hyp_s"]
         assert d["cpu_baseline"]["one_thread"]["cores"] == 1 and d["cpu_baseline"]["one_thread"]["value"] < d["cpu_baseline"]["value"]
+    if name.startswith("r02_final"):
+        # the closing line of round 2: 16 frames per step, the store-only twin of the same launches, processImage of one image
+        assert d["config"]["frames_per_step"] == 16
+        so = d["roofline"]["store_schedule_only_us"]
+        assert so is not None and abs(so - d["roofline"]["avg_launch_us"]) < 0.1 * d["roofline"]["avg_launch_us"]  # K2 sits on its store schedule
+        pi = d["process_image"]
+        assert pi["640x480"]["refine_steps_done"] == 8 and pi["40x40"]["refine_steps_done"] == 8
+        assert 50.0 < pi["40x40"]["us_per_image"] < pi["640x480"]["us_per_image"] < 1000.0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
