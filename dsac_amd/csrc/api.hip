@@ -156,21 +156,29 @@ int end_call(dsac_ctx* c) {
 }
 
 // RAII-ish helper: records an event pair around a launch when profiling is on.
+// attached = true: the pair is handed to the launch (hipExtLaunchKernelGGL takes the kernel's own start / stop timestamps), nothing is recorded
+// on the stream here.
 struct ProfScope {
     dsac_ctx* c;
     int which;
     dsac_ctx::EvPair p{};
-    bool on = false;
-    ProfScope(dsac_ctx* c_, int which_) : c(c_), which(which_) {
+    bool on = false, attached = false;
+    ProfScope(dsac_ctx* c_, int which_, bool attached_ = false) : c(c_), which(which_), attached(attached_) {
         if (!c->profiling) return;
         if ((c->prof_count[which]++ % c->prof_stride) != 0) return;
         if (!c->ev_free.empty()) { p = c->ev_free.back(); c->ev_free.pop_back(); }
         else if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
-        on = hipEventRecord(p.a, c->stream) == hipSuccess;
+        on = attached ? true : hipEventRecord(p.a, c->stream) == hipSuccess;
+    }
+    // the K2 options of this call: the context's, plus the event pair when this launch is sampled
+    dk::K2Opts k2() const {
+        dk::K2Opts o = c->k2;
+        if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
+        return o;
     }
     ~ProfScope() {
         if (!on) return;
-        if (hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
+        if (attached || hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
     }
 };
 
@@ -402,8 +410,8 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
-        ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, c->k2, &used));
+        ProfScope ps(c, 0, true);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used));
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
@@ -467,8 +475,8 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
-        ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), c->k2, &used, Nf));
+        ProfScope ps(c, 0, true);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(), &used, Nf));
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
@@ -574,8 +582,8 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     if (c->slot_reduced_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_reduced[slot], 0));  // partials of frame i-2 consumed
     int used = 0;
     {
-        ProfScope ps(c, 0);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, c->k2, &used, Nf));
+        ProfScope ps(c, 0, true);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, ps.k2(), &used, Nf));
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
     c->slot_free_recorded[slot] = true;

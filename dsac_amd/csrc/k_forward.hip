@@ -15,6 +15,7 @@
 // decoded XCD-aware: blocks that share a pixel tile run on the same XCD (block b -> XCD b % 8) back to
 // back, so the xyz tile is fetched from HBM once and re-read from that XCD's L2.
 #include "kernels.h"
+#include <hip/hip_ext.h>
 #include "dmath.h"
 
 namespace dk {
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_hp(const float* __rest
 
 template <int HT, int KM_CH>
 static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA,
-                                      float kB, float* soft_part, int* tiles_used, int Nf, bool pixel_minor, int kflags) {
+                                      float kB, float* soft_part, int* tiles_used, int Nf, bool pixel_minor, int kflags, hipEvent_t evA, hipEvent_t evB) {
     const int tile = K2_THREADS * KM_CH;  // 64 pixels per wave-chunk
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
@@ -478,8 +479,8 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
     // experiment knob (k2_flags bits 8..15): that many 8-KiB units of unused dynamic LDS per workgroup cap the workgroups per CU
     const size_t lds_pad = (size_t)((kflags >> 8) & 0xff) * 8192;
 #define DSAC_K2H(E, S, U)                                                                                                             \
-    hipLaunchKernelGGL((k_reproject_hp<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), lds_pad, st, staged, F.xyz, F.uv, err, soft_part, N, F.P, \
-                       F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
+    hipExtLaunchKernelGGL((k_reproject_hp<HT, E, S, U, KM_CH>), dim3(grid), dim3(K2_THREADS), lds_pad, st, evA, evB, 0, staged, F.xyz, F.uv, err,   \
+                          soft_part, N, F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2H(true, true, true); else DSAC_K2H(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2H(true, false, true); else DSAC_K2H(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2H(false, true, true); else DSAC_K2H(false, true, false); }
@@ -491,7 +492,7 @@ int reproject_num_pixel_tiles(int P) { return (P + K2_THREADS - 1) / K2_THREADS;
 
 template <int PX, int HT, bool SPOSE>
 static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
-                                   float* soft_part, int Nf, bool pixel_minor, int kflags) {
+                                   float* soft_part, int Nf, bool pixel_minor, int kflags, hipEvent_t evA, hipEvent_t evB) {
     const int tile = K2_THREADS * PX;
     const int PT = (F.P + tile - 1) / tile;
     const int NTa = (N + HT - 1) / HT;
@@ -499,8 +500,8 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
     const int NT = pixel_minor ? -NTa : NTa;
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2(E, S, U)                                                                                                              \
-    hipLaunchKernelGGL((k_reproject<PX, HT, E, S, U, SPOSE>), dim3(grid), dim3(K2_THREADS), 0, st, staged, F.xyz, F.uv, err, soft_part, N, \
-                       F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
+    hipExtLaunchKernelGGL((k_reproject<PX, HT, E, S, U, SPOSE>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, soft_part, \
+                          N, F.P, F.W, PT, NT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
     if (ERR && SOFT) { if (UV) DSAC_K2(true, true, true); else DSAC_K2(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2(true, false, true); else DSAC_K2(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2(false, true, true); else DSAC_K2(false, true, false); }
@@ -523,10 +524,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0);
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
     const int kf = opts.flags;
-    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf);
+    // timing events (dsac_profile_enable): attached to the kernel's own dispatch (hipExtLaunchKernelGGL) instead of two event records on the
+    // stream, which cost ~7 us of bubble each (one 640x480 frame: 100 us per step with them, 86 without)
+    hipEvent_t evA = opts.ev_start, evB = opts.ev_stop;
+    if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
-#define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf)
-#define DSAC_HP(HT_, CH_) launch_reproject_hp<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf)
+#define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf, evA, evB)
+#define DSAC_HP(HT_, CH_) launch_reproject_hp<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf, evA, evB)
     int variant = opts.variant;
     if (variant < 0) {
         // auto (measured on MI355X, profiles/r02_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited: matrix-core

@@ -32,6 +32,7 @@ struct K2Opts {
     bool pixel_minor = true;  // block order: pixel tiles innermost (DSAC_K2_ORDER)
     int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
     int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // per call: timing events attached to the K2 dispatch itself (profiling), else null
 };
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
