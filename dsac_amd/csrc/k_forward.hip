@@ -488,7 +488,368 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
-int reproject_num_pixel_tiles(int P) { return (P + K2_THREADS - 1) / K2_THREADS; }  // the scalar path's (larger) count
+// --------------------------------------------------------------------------------------------------
+// K2, streaming small-tile form (round 3).  Same arithmetic as k_reproject_hp (hp_chunk), other schedule.
+// What decides the store rate of the N x P volume is how many error-image ROWS are open at once across the chip
+// (scripts/micro/store_sched.hip, profiles/r03_store_sched.txt: one row 6.9 TB/s, ~30 rows 6.6, ~110 rows 5.8, ~450 rows 5.5):
+//   open rows ~ hypotheses per workgroup x (resident waves x pixels a wave holds while it lives) / P.
+// So the tile is small (NG x 16 hypotheses, WAVES x CHW x 64 pixels) and its workgroups short-lived, and the per-workgroup set-up
+// that made round 2's small tiles lose is cut down: the MFMA A operands come straight from the staged records (one dword per lane and
+// component, L2-resident -- no LDS image, no barrier before the first MFMA), the pixel positions of the implicit grid from a
+// wave-uniform row / column (W % 64 == 0), and the only barrier is the one before the 16 NG partial soft sums leave the workgroup.
+// --------------------------------------------------------------------------------------------------
+template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* __restrict__ staged, const float* __restrict__ xyz,
+                                                             const float* __restrict__ uv, float* __restrict__ err,
+                                                             float* __restrict__ soft_part, int N, int P, int W, int PT, float cx, float cy,
+                                                             float clampv, float kA, float kB, int kflags, int Nf, long long xyz_stride,
+                                                             long long uv_stride) {
+    constexpr int HT = 16 * NG;
+    const int b = blockIdx.x;
+    int ht, pt;
+    if (kflags & 32) { pt = b % PT; ht = b / PT; }  // plain pixel-minor order
+    else if (WAVES == 1) {
+        // one-wave workgroups, XCD-aware: the four workgroups b, b + 8, b + 16, b + 24 (same XCD, dispatched back to back) take four ADJACENT
+        // 64-pixel chunks, so that an XCD still writes 1 KiB runs of every row
+        const int q = b >> 5, sub = (b >> 3) & 3, PTG = (PT + 31) >> 5;
+        ht = q / PTG;
+        pt = ((q % PTG) * 8 + (b & 7)) * 4 + sub;
+        if (pt >= PT) return;
+    } else {  // XCD-aware pixel-minor order (block b -> XCD b % 8 keeps its eighth of the pixel tiles)
+        const int q = b >> 3, PTG = (PT + 7) >> 3;
+        ht = q / PTG;
+        pt = (q % PTG) * 8 + (b & 7);
+        if (pt >= PT) return;
+    }
+    const int h0 = ht * HT;
+    const int nh = min(HT, N - h0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    {
+        const int frame = h0 / Nf;
+        xyz += (long long)frame * xyz_stride;
+        if (UV) uv += (long long)frame * uv_stride;
+    }
+    __shared__ float s_soft[(SOFT && !PW) ? WAVES * HT : 1];
+    // PW: every wave writes its own partial soft sums (row pt * WAVES + wave of soft_part), no LDS, no barrier
+
+    // B operands (coordinate g of pixel 4c + m of every chunk) and the MFMA A operands (x-, y-, z-row entry k = g of hypothesis c)
+    // G64 (implicit grid, W % 64 == 0: a 64-pixel chunk never straddles a row): the pixel positions are rebuilt from one (column, row) pair
+    // per chunk in front of every use instead of living in 8 registers per chunk
+    float Bm[CHW][4];
+    f2 ppix[G64 ? 1 : CHW][4];
+    f2 pbase[G64 ? CHW : 1];
+    int p0[CHW];
+    bool valid[CHW];
+    const int chunk0 = (pt * WAVES + wave) * CHW;
+#pragma unroll
+    for (int ch = 0; ch < CHW; ch++) {
+        p0[ch] = (chunk0 + ch) * 64 + 4 * c;
+        valid[ch] = p0[ch] < P;  // P % 4 == 0
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int pc = min(p0[ch] + m, P - 1);
+            Bm[ch][m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
+        }
+    }
+    float ax[NG], ay[NG], az[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+        const int hyp = min(16 * gi + c, nh - 1);  // beyond the ragged end: repeat the last valid hypothesis (never stored)
+        const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
+        ax[gi] = rec[0]; ay[gi] = rec[4]; az[gi] = rec[8];
+    }
+#pragma unroll
+    for (int ch = 0; ch < CHW; ch++) {
+        if (UV) {
+            constexpr int pc = G64 ? 0 : 1;
+            if (valid[ch]) {
+                const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0[ch] * 2);
+                const f4 u0 = su[0], u1 = su[1];
+                ppix[ch * pc][0] = f2{u0.x - cx, u0.y - cy}; ppix[ch * pc][1] = f2{u0.z - cx, u0.w - cy};
+                ppix[ch * pc][2] = f2{u1.x - cx, u1.y - cy}; ppix[ch * pc][3] = f2{u1.z - cx, u1.w - cy};
+            } else {
+                ppix[ch * pc][0] = ppix[ch * pc][1] = ppix[ch * pc][2] = ppix[ch * pc][3] = splat(0.f);
+            }
+        } else if (G64) {
+            // row and first column are wave-uniform (scalar division)
+            const int cpr = W >> 6;
+            const int y = (chunk0 + ch) / cpr, xc0 = ((chunk0 + ch) - y * cpr) * 64;
+            pbase[ch] = f2{(float)(xc0 + 4 * c) - cx, (float)y - cy};
+        } else {
+            constexpr int pc = G64 ? 0 : 1;
+            int y = p0[ch] / W, x = p0[ch] - y * W;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                ppix[ch * pc][m] = f2{(float)x - cx, (float)y - cy};
+                if (++x == W) { x = 0; y++; }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+        if (16 * gi >= nh) break;
+        const float nax = -ax[gi], nay = -ay[gi];  // x and y rows negated: the MFMA yields (-xc, -yc, zc)
+        const int hyp0 = 16 * gi + 4 * g;
+        f2 ssum[4] = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
+#pragma unroll
+        for (int ch = 0; ch < CHW; ch++) {
+            f4 ev[4];
+            f2 sloc[4];
+            if (G64) {
+                f2 pb = pbase[ch];
+                asm volatile("" : "+v"(pb));  // rebuilt per use: keeps the 8 position registers of a chunk from staying live across the whole kernel
+#pragma unroll
+                for (int m = 0; m < 4; m++) ppix[0][m] = f2{pb.x + (float)m, pb.y};
+            }
+            const f2 (&pp)[4] = ppix[G64 ? 0 : ch];
+            if (kflags & 2) {  // store schedule alone (measurement)
+                ev[0] = ev[1] = ev[2] = ev[3] = f4{nax, nay, az[gi], (float)ch};
+                sloc[0] = sloc[1] = sloc[2] = sloc[3] = splat(0.f);
+            } else if (__builtin_expect(__any(hp_chunk<false, SOFT>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
+                (void)hp_chunk<true, SOFT>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc);
+            }
+            if (SOFT) {
+                const f2 vf = splat(valid[ch] ? 1.0f : 0.0f);
+#pragma unroll
+                for (int r = 0; r < 4; r++) ssum[r] = pk_fma(sloc[r], vf, ssum[r]);
+            }
+            if (ERR && valid[ch]) {
+                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp0) * P + p0[ch]);
+                const size_t rs = (size_t)P / 4;
+                if (nh == HT) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (hyp0 + r < nh) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                }
+            }
+        }
+        if (SOFT) {
+            const float s0 = row16_sum(ssum[0].x + ssum[0].y), s1 = row16_sum(ssum[1].x + ssum[1].y);
+            const float s2 = row16_sum(ssum[2].x + ssum[2].y), s3 = row16_sum(ssum[3].x + ssum[3].y);
+            if (c == 0) {
+                float* dst = !PW ? s_soft + wave * HT + hyp0 : soft_part + (size_t)(pt * WAVES + wave) * N + h0 + hyp0;
+                if (hyp0 + 0 < nh) dst[0] = s0;
+                if (hyp0 + 1 < nh) dst[1] = s1;
+                if (hyp0 + 2 < nh) dst[2] = s2;
+                if (hyp0 + 3 < nh) dst[3] = s3;
+            }
+        }
+    }
+    if (SOFT && !PW) {
+        __syncthreads();
+        if (tid < nh) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) s += s_soft[w * HT + tid];
+            soft_part[(size_t)pt * N + h0 + tid] = s;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// K2, persistent pipelined form (round 3).  Small tiles (NG x 16 hypotheses x one 64-pixel chunk per wave) stream their stores best, but as
+// short-lived workgroups each of them starts with global loads that queue BEHIND the stores of the other waves of its CU in the CU's
+// in-order memory pipe, and a store-bound kernel keeps that pipe full (k2_lab: small tiles 774 us store-only, 846 arithmetic-only, 981
+// together).  Here the waves are persistent and software-pipelined: the operands of tile i + 2 (4 coordinate dwords + 3 NG pose dwords per
+// lane) are requested BEFORE the stores of tile i are issued, so -- the memory counter of a wave retires in order -- waiting for the operands
+// of tile i + 1 never waits for a store, and no wave ever waits for its stores at all until the kernel ends.  The tile sequence of the grid
+// follows the order the dispatcher would give short-lived workgroups: pixel units (4 adjacent chunks = the 4 waves of a workgroup) innermost,
+// XCD x owning the units u % 8 == x.
+// --------------------------------------------------------------------------------------------------
+template <int NG>
+struct K2Ops {
+    float B[4];
+    float A[NG][3];
+};
+
+template <int NG, int WAVES, bool ERR, bool SOFT, bool UV>
+__global__ __launch_bounds__(WAVES * 64) void k_reproject_ps(const float* __restrict__ staged, const float* __restrict__ xyz,
+                                                             const float* __restrict__ uv, float* __restrict__ err,
+                                                             float* __restrict__ soft_part, int N, int P, int W, float cx, float cy,
+                                                             float clampv, float kA, float kB, int kflags, int Nf, long long xyz_stride,
+                                                             long long uv_stride) {
+    constexpr int HT = 16 * NG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, lwg = blockIdx.x >> 3, GX = gridDim.x >> 3;  // gridDim.x is a multiple of 8
+    const int CR = (P + 63) >> 6;                   // 64-pixel chunks per row
+    const int UR = (CR + WAVES - 1) / WAVES;        // pixel units (WAVES adjacent chunks) per row
+    const int URX = (UR + 7) >> 3;                  // ... per XCD
+    const int NRG = (N + HT - 1) / HT;              // hypothesis groups
+    const int TT = NRG * URX;                       // tiles of this XCD's workgroup sequence
+
+    // tile tw of this workgroup -> (first hypothesis, chunk of this wave); chunk < 0: nothing to do
+    auto decode = [&](int tw, int& h0, int& chunk) {
+        const int rg = tw / URX, ux = tw - rg * URX;
+        const int unit = ux * 8 + xcd;
+        h0 = rg * HT;
+        chunk = (tw < TT && unit < UR) ? unit * WAVES + wave : -1;
+        if (chunk >= CR) chunk = -1;
+    };
+    // the loads of a tile are issued unconditionally (a tile beyond the end re-reads the last one's operands): the number of memory
+    // operations between a tile's loads and their first use is then the same on every path, and the wait in front of that use is never vmcnt(0)
+    auto issue = [&](int tw, K2Ops<NG>& o) {
+        int h0, chunk;
+        decode(min(tw, TT - 1), h0, chunk);
+        chunk = max(chunk, 0);
+        const int nh = min(HT, N - h0);
+        const float* fx = xyz + (long long)(h0 / Nf) * xyz_stride;
+        const int p0 = chunk * 64 + 4 * c;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int pc = min(p0 + m, P - 1);
+            o.B[m] = fx[(size_t)pc * 3 + min(g, 2)];
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            const int hyp = min(16 * gi + c, nh - 1);
+            const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
+            o.A[gi][0] = rec[0]; o.A[gi][1] = rec[4]; o.A[gi][2] = rec[8];
+        }
+    };
+    auto compute = [&](int tw, const K2Ops<NG>& o) {
+        int h0, chunk;
+        decode(tw, h0, chunk);
+        if (chunk < 0) return;
+        const int nh = min(HT, N - h0);
+        const int p0 = chunk * 64 + 4 * c;
+        const bool valid = p0 < P;
+        const float Bv[4] = {g < 3 ? o.B[0] : 1.0f, g < 3 ? o.B[1] : 1.0f, g < 3 ? o.B[2] : 1.0f, g < 3 ? o.B[3] : 1.0f};  // the k = 3 row of B is 1
+        f2 ppix[4];
+        if (UV) {
+            const float* fu = uv + (long long)(h0 / Nf) * uv_stride;
+            if (valid) {
+                const f4* su = reinterpret_cast<const f4*>(fu + (size_t)p0 * 2);
+                const f4 u0 = su[0], u1 = su[1];
+                ppix[0] = f2{u0.x - cx, u0.y - cy}; ppix[1] = f2{u0.z - cx, u0.w - cy};
+                ppix[2] = f2{u1.x - cx, u1.y - cy}; ppix[3] = f2{u1.z - cx, u1.w - cy};
+            } else {
+                ppix[0] = ppix[1] = ppix[2] = ppix[3] = splat(0.f);
+            }
+        } else if ((W & 63) == 0) {
+            const int cpr = W >> 6;
+            const int y = chunk / cpr, xc0 = (chunk - y * cpr) * 64;
+            const float fy_ = (float)y - cy, fx_ = (float)(xc0 + 4 * c) - cx;
+#pragma unroll
+            for (int m = 0; m < 4; m++) ppix[m] = f2{fx_ + (float)m, fy_};
+        } else {
+            int y = p0 / W, x = p0 - y * W;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                ppix[m] = f2{(float)x - cx, (float)y - cy};
+                if (++x == W) { x = 0; y++; }
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) {
+            if (16 * gi >= nh) break;
+            const float nax = -o.A[gi][0], nay = -o.A[gi][1], az = o.A[gi][2];
+            const int hyp0 = 16 * gi + 4 * g;
+            f4 ev[4];
+            f2 sloc[4];
+            if (kflags & 2) {
+                ev[0] = ev[1] = ev[2] = ev[3] = f4{nax, nay, az, Bv[0]};
+                sloc[0] = sloc[1] = sloc[2] = sloc[3] = splat(0.f);
+            } else if (__builtin_expect(__any(hp_chunk<false, SOFT>(nax, nay, az, Bv, ppix, clampv, kA, kB, ev, sloc)), 0)) {
+                (void)hp_chunk<true, SOFT>(nax, nay, az, Bv, ppix, clampv, kA, kB, ev, sloc);
+            }
+            if (ERR && valid) {
+                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp0) * P + p0);
+                const size_t rs = (size_t)P / 4;
+                if (nh == HT) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (hyp0 + r < nh) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                }
+            }
+            if (SOFT) {
+                const float vf = valid ? 1.0f : 0.0f;
+                const float s0 = row16_sum((sloc[0].x + sloc[0].y) * vf), s1 = row16_sum((sloc[1].x + sloc[1].y) * vf);
+                const float s2 = row16_sum((sloc[2].x + sloc[2].y) * vf), s3 = row16_sum((sloc[3].x + sloc[3].y) * vf);
+                if (c == 0) {  // one partial row per 64-pixel chunk
+                    float* dst = soft_part + (size_t)chunk * N + h0 + hyp0;
+                    if (nh == HT) {
+                        __builtin_nontemporal_store(f4{s0, s1, s2, s3}, reinterpret_cast<f4*>(dst));
+                    } else {
+                        if (hyp0 + 0 < nh) dst[0] = s0;
+                        if (hyp0 + 1 < nh) dst[1] = s1;
+                        if (hyp0 + 2 < nh) dst[2] = s2;
+                        if (hyp0 + 3 < nh) dst[3] = s3;
+                    }
+                }
+            }
+        }
+    };
+
+    // three operand sets in rotation (unrolled by hand: a register copy of a set whose loads are still in flight would have to wait for them)
+    K2Ops<NG> o0, o1, o2;
+    issue(lwg, o0);
+    issue(lwg + GX, o1);
+    for (int tw = lwg; tw < TT; tw += 3 * GX) {
+        issue(tw + 2 * GX, o2);
+        compute(tw, o0);
+        issue(tw + 3 * GX, o0);
+        compute(tw + GX, o1);
+        issue(tw + 4 * GX, o1);
+        compute(tw + 2 * GX, o2);
+    }
+}
+
+template <int NG, int WAVES>
+static hipError_t launch_reproject_ps(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
+                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB) {
+    if (N % 4 != 0 && soft_part) return hipErrorInvalidValue;  // the partial sums leave as 16-byte stores
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int per_cu = (kflags >> 8) & 0xff;  // k2_flags bits 8..15: persistent workgroups per CU (0 = default)
+    if (per_cu <= 0) per_cu = 3;
+    const int grid = ((cus * per_cu + 7) / 8) * 8;
+    if (tiles_used) *tiles_used = (F.P + 63) / 64;
+    const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
+#define DSAC_K2P(E, S, U)                                                                                                               \
+    hipExtLaunchKernelGGL((k_reproject_ps<NG, WAVES, E, S, U>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err,   \
+                          soft_part, N, F.P, F.W, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
+    if (ERR && SOFT) { if (UV) DSAC_K2P(true, true, true); else DSAC_K2P(true, true, false); }
+    else if (ERR) { if (UV) DSAC_K2P(true, false, true); else DSAC_K2P(true, false, false); }
+    else if (SOFT) { if (UV) DSAC_K2P(false, true, true); else DSAC_K2P(false, true, false); }
+#undef DSAC_K2P
+    return hipGetLastError();
+}
+
+template <int NG, int CHW, int WAVES, bool PW, int MINW = 1>
+static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
+                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB) {
+    constexpr int HT = 16 * NG;
+    const int tile = WAVES * CHW * 64;
+    static_assert(PW || WAVES > 1, "one-wave workgroups write per-wave partial sums");
+    const int PT = (F.P + tile - 1) / tile;
+    const int NTa = (N + HT - 1) / HT;
+    const int grid = (kflags & 32) ? PT * NTa : WAVES == 1 ? ((PT + 31) / 32) * 32 * NTa : ((PT + 7) / 8) * 8 * NTa;
+    if (tiles_used) *tiles_used = PW ? PT * WAVES : PT;
+    const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
+    const bool G64 = !UV && (F.W & 63) == 0;
+#define DSAC_K2S(E, S, U, G)                                                                                                               \
+    hipExtLaunchKernelGGL((k_reproject_st<NG, CHW, WAVES, PW, E, S, U, G, MINW>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, \
+                          soft_part, N, F.P, F.W, PT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
+    if (ERR && SOFT) { if (UV) DSAC_K2S(true, true, true, false); else if (G64) DSAC_K2S(true, true, false, true); else DSAC_K2S(true, true, false, false); }
+    else if (ERR) { if (UV) DSAC_K2S(true, false, true, false); else if (G64) DSAC_K2S(true, false, false, true); else DSAC_K2S(true, false, false, false); }
+    else if (SOFT) { if (UV) DSAC_K2S(false, true, true, false); else if (G64) DSAC_K2S(false, true, false, true); else DSAC_K2S(false, true, false, false); }
+#undef DSAC_K2S
+    return hipGetLastError();
+}
+
+int reproject_num_pixel_tiles(int P) { return (P + 63) / 64; }  // the largest count over all forms: one partial row per 64-pixel wave chunk
 
 template <int PX, int HT, bool SPOSE>
 static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
@@ -511,7 +872,10 @@ static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, c
 
 // variant: -1 = auto (default) ; VALU forms: 0 = LDS-staged poses, HT = 32 ; 1 = scalar-load poses (SGPR operands), HT = 32 ; 2 = HT 16 ;
 //          3 = HT 64 ; 10..13 = 1, 2, 4, 8 hypothesis rows per workgroup ; matrix-core forms <HT, 64-pixel chunks per wave>: 20 = <64,2>,
-//          21 = <64,4>, 22 = <128,2>, 23 = <32,2>, 24 = <64,1>, 25 = <128,4>, 26 = <32,4>, 27 = <128,1>.  Unknown values are an error.
+//          21 = <64,4>, 22 = <128,2>, 23 = <32,2>, 24 = <64,1>, 25 = <128,4>, 26 = <32,4>, 27 = <128,1> ; streaming small-tile forms
+//          <16-hypothesis groups, chunks per wave, waves per workgroup>: 40 = <1,1,4>, 41 = <2,1,4>, 42 = <4,1,4>, 43 = <2,2,4> (partial sums
+//          through LDS, one row per workgroup) ; per-wave partial sums, no barrier: 44-46 = <1|2|4,4,1>, 47-49 = <1|2|4,2,1>, 50-52 = <1|2|4,1,1>,
+//          53 = <2,1,4>, 54 = <2,2,4>, 55 = <4,1,4>, 56 = <2,4,4>, 57 = <4,2,4>.  Unknown values are an error.
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
                      float* soft_part, const K2Opts& opts, int* tiles_used, int Nf) {
     if (tiles_used) *tiles_used = 0;
@@ -523,7 +887,9 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0);
     if (tiles_used) *tiles_used = vec ? (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4) : (F.P + K2_THREADS - 1) / K2_THREADS;
-    const int kf = opts.flags;
+    // the streaming / persistent forms (variant >= 40) know two block orders: XCD-aware pixel-minor (k2_order 1) and plain pixel-minor (k2_order 0
+    // or k2_flags bit 5)
+    int kf = opts.flags | ((opts.variant >= 40 && !opts.pixel_minor) ? 32 : 0);
     // timing events (dsac_profile_enable): attached to the kernel's own dispatch (hipExtLaunchKernelGGL) instead of two event records on the
     // stream, which cost ~7 us of bubble each (one 640x480 frame: 100 us per step with them, 86 without)
     hipEvent_t evA = opts.ev_start, evB = opts.ev_stop;
@@ -531,14 +897,21 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
 #define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf, evA, evB)
 #define DSAC_HP(HT_, CH_) launch_reproject_hp<HT_, CH_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, pm, kf, evA, evB)
+#define DSAC_ST(NG_, CH_, WV_, PW_) launch_reproject_st<NG_, CH_, WV_, PW_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB)
     int variant = opts.variant;
     if (variant < 0) {
         // auto (measured on MI355X, profiles/r02_k2_variants.txt).  With the fused soft-inlier sums the kernel is VALU-limited: matrix-core
         // form; 1024 pixels per workgroup for big launches (> 1.5 GB of error images: N = 4096 or a batch of frames: 443 vs 460-508 us for
         // the 8-frame batch), 256 for a single frame of 256 hypotheses.  Error images only: store-limited, the VALU kernel with pixel
         // tiles innermost has the best store stream (N = 256: 56.6 vs 58.9 us; N = 4096: equal).
+        // Round 3 (A/B inside bench.py on five boxes, profiles/r03_k2_ab_bench*.txt -- a plain-HIP harness, scripts/micro/k2_lab, ranks the forms
+        // differently from the bench's process and is NOT what this policy follows): big launches take the streaming form <32 hypotheses, 256
+        // pixels> per one-wave workgroup (no LDS, no barrier, operands straight from the staged records, per-wave partial sums) in PLAIN
+        // pixel-minor block order: 842-870 us against 904-950 for round 2's <64,4> (0.73-0.75 of the HBM spec instead of 0.67-0.70); one frame
+        // of 256 hypotheses takes <64 hypotheses, 4 waves x 64 pixels>: 56.7-58.0 against 60.2-60.8 us.
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
-        variant = soft_part ? (big ? 21 : 24) : 0;
+        variant = soft_part ? (big ? 45 : 42) : 0;
+        if (soft_part && big) kf |= 32;
     }
     switch (variant) {
         case 0: return DSAC_VA(4, 32, false);
@@ -557,30 +930,74 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 25: return DSAC_HP(128, 4);
         case 26: return DSAC_HP(32, 4);
         case 27: return DSAC_HP(128, 1);
+        // streaming small-tile forms <16-hypothesis groups, 64-pixel chunks per wave, waves per workgroup>
+        case 40: return DSAC_ST(1, 1, 4, false);
+        case 41: return DSAC_ST(2, 1, 4, false);
+        case 42: return DSAC_ST(4, 1, 4, false);
+        case 43: return DSAC_ST(2, 2, 4, false);
+        case 44: return DSAC_ST(1, 4, 1, true);
+        case 45: return DSAC_ST(2, 4, 1, true);
+        case 46: return DSAC_ST(4, 4, 1, true);
+        case 47: return DSAC_ST(1, 2, 1, true);
+        case 48: return DSAC_ST(2, 2, 1, true);
+        case 49: return DSAC_ST(4, 2, 1, true);
+        case 50: return DSAC_ST(1, 1, 1, true);
+        case 51: return DSAC_ST(2, 1, 1, true);
+        case 52: return DSAC_ST(4, 1, 1, true);
+        case 53: return DSAC_ST(2, 1, 4, true);
+        case 54: return DSAC_ST(2, 2, 4, true);
+        case 55: return DSAC_ST(4, 1, 4, true);
+        case 56: return DSAC_ST(2, 4, 4, true);
+        case 57: return DSAC_ST(4, 2, 4, true);
+        case 58: return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
+        case 59: return launch_reproject_st<2, 4, 1, true, 5>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <2,4,1>, >= 5 waves per SIMD
+        case 65: return launch_reproject_st<4, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,4> per-wave sums
+        case 66: return launch_reproject_st<4, 4, 2, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,2>
+        case 67: return DSAC_ST(1, 4, 4, true);
+        case 68: return DSAC_ST(2, 4, 4, false);
+        case 69: return DSAC_ST(2, 4, 8, true);
+        case 70: return launch_reproject_st<2, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
+        case 71: return DSAC_ST(1, 4, 8, true);
+        case 72: return DSAC_ST(2, 4, 16, true);
+        // persistent pipelined forms <16-hypothesis groups, waves per workgroup>; k2_flags bits 8..15 = workgroups per CU
+        case 60: return launch_reproject_ps<1, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
+        case 61: return launch_reproject_ps<2, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
+        case 62: return launch_reproject_ps<4, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
         default: return hipErrorInvalidValue;
     }
 #undef DSAC_VA
 #undef DSAC_HP
+#undef DSAC_ST
 }
 
 // --------------------------------------------------------------------------------------------------
-// One wave per hypothesis, lanes stride over the pixel tiles (independent
-// loads in flight), fixed butterfly -> deterministic.
-__global__ __launch_bounds__(256) void k_reduce_soft(int N, int tiles, const float* __restrict__ part, double* __restrict__ soft) {
+// A workgroup of 16 waves per 64 hypotheses: lane = hypothesis (a wave reads 256 contiguous bytes of a partial row), wave w sums the rows
+// t = w, w + 16, ... in fp64, then a fixed-order sum over the 16 waves -> deterministic.  (Rounds 1-2 ran one wave per hypothesis with the
+// lanes striding over the rows: every lane touched its own 64-byte sector, fine for 300 rows, not for the 1200 of the one-wave tiles.)
+constexpr int KR_WAVES = 16;
+__global__ __launch_bounds__(KR_WAVES * 64) void k_reduce_soft(int N, int tiles, const float* __restrict__ part, double* __restrict__ soft) {
     __builtin_amdgcn_s_setprio(3);
-    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (h >= N) return;
+    __shared__ double s_acc[KR_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
     double s = 0;
-    for (int t = lane; t < tiles; t += 64) s += (double)part[(size_t)t * N + h];
+    if (h < N) {
+#pragma unroll 4
+        for (int t = wave; t < tiles; t += KR_WAVES) s += (double)part[(size_t)t * N + h];
+    }
+    s_acc[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && h < N) {
+        double tot = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) soft[h] = s;
+        for (int w = 0; w < KR_WAVES; w++) tot += s_acc[w][lane];
+        soft[h] = tot;
+    }
 }
 
 hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce_soft, dim3((N + 3) / 4), dim3(256), 0, st, N, tiles, soft_part, soft);
+    hipLaunchKernelGGL(k_reduce_soft, dim3((N + 63) / 64), dim3(KR_WAVES * 64), 0, st, N, tiles, soft_part, soft);
     return hipGetLastError();
 }
 

@@ -144,8 +144,9 @@ def variant_case(orc, synth):
     return dict(fr=fr, uv=uv, N=N, poses=poses, ref_err=ref_err, soft=orc.soft_inlier(ref_err, TAU, BETA))
 
 
-# every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 20-27 matrix-core forms
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24, 25, 26, 27])
+# every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 20-27 matrix-core forms, 40-59 streaming small-tile forms
+# (40-43 partial sums through LDS, 44-59 per-wave partial sums), 60-62 persistent pipelined forms
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24, 25, 26, 27] + list(range(40, 63)))
 @pytest.mark.parametrize("order", [1, 0])
 def test_every_k2_kernel_form_against_the_oracle(engine, variant_case, variant, order):
     import torch
