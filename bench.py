@@ -178,14 +178,15 @@ def init_distributed(args):
 
 
 def cpu_baseline(args, fr, N, H, W):
-    """The oracle (port of the reference path) on the host cores: all threads, and one thread."""
+    """The oracle (port of the reference path) on the host cores: as many threads as the box really grants (effective_cpus), and one thread."""
     from oracle import oracle as orc
     orc.build()
-    cores = orc.num_threads()
+    cores, cpu_desc = orc.effective_cpus()
+    orc.set_num_threads(cores)
     sec1, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=1)
     reps = int(max(1, min(64, round(args.cpu_seconds / max(sec1, 1e-3)))))
     sec, _ = orc.time_forward(N, 1305, fr["xyz"], fr["uv"], H, W, fr["cam"], reps=reps)
-    out = {"value": N * reps / sec, "unit": "hyp/s", "cores": cores, "kind": "port",
+    out = {"value": N * reps / sec, "unit": "hyp/s", "cores": cores, "cpus": cpu_desc, "kind": "port",
            "sample": "%d frame(s) x %d hypotheses x %dx%d, same workload (sample+P3P, error images, soft-inlier, softmax), "
                      "oracle built g++ -Ofast -fopenmp, %.1f s" % (reps, N, W, H, sec)}
     # one thread (deterministic RNG stream order, SURVEY.md 8(d)); bounded: a quarter of the hypotheses of one frame

@@ -162,7 +162,7 @@ struct ProfScope {
     dsac_ctx* c;
     int which;
     dsac_ctx::EvPair p{};
-    bool on = false, attached = false;
+    bool on = false, attached = false, launched = false;  // launched: set by commit() once the kernel the pair is attached to really went out
     ProfScope(dsac_ctx* c_, int which_, bool attached_ = false) : c(c_), which(which_), attached(attached_) {
         if (!c->profiling) return;
         if ((c->prof_count[which]++ % c->prof_stride) != 0) return;
@@ -176,9 +176,13 @@ struct ProfScope {
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
         return o;
     }
+    void commit() { launched = true; }
     ~ProfScope() {
         if (!on) return;
-        if (attached || hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
+        // an attached pair whose launch never happened (rejected variant, failed launch) was never recorded: reading it would fail every later
+        // dsac_profile_read -- it goes back to the free list instead
+        if (attached) { if (launched) c->ev[which].push_back(p); else c->ev_free.push_back(p); return; }
+        if (hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
     }
 };
 
@@ -412,6 +416,7 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     {
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used));
+        ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
@@ -477,6 +482,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     {
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(), &used, Nf));
+        ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
@@ -544,10 +550,11 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
     if (!is_device_ptr(poses) || !is_device_ptr(sets_out) || !is_device_ptr(ok) || (sets_or_null && !is_device_ptr(sets_or_null)))
         return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: the pipelined calls need device pointers");
     if (!sets_or_null && (max_tries <= 0 || c->F.P < 4)) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: max_tries > 0 and >= 4 cells needed");
+    // every rejection comes before anything is touched: a protocol-violating call must leave the slot (its staged poses, K1's output) as it was
+    if (c->slot_pending[slot]) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot %d is sampled but not yet scored", slot);
     HIP_TRY(c, hipSetDevice(c->device));
     ARG_TRY(pipeline_init(c));
     HIP_TRY(c, c->slot_staged[slot].reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
-    if (c->slot_pending[slot]) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot %d is sampled but not yet scored", slot);
     if (c->slot_free_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_free[slot], 0));  // K2 of the slot's previous use has read its staged poses
     // ... and the K3 tail of that use (second auxiliary stream) has read the caller's `poses` for the soft-argmax average
     if (c->slot_done_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->aux, c->slot_done[slot], 0));
@@ -584,6 +591,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     {
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, ps.k2(), &used, Nf));
+        ps.commit();
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
     c->slot_free_recorded[slot] = true;
@@ -618,7 +626,10 @@ int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
 int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     if (!c || !key) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: NULL argument");
     const std::string k = key;
-    if (k == "k2_variant") c->k2.variant = value;
+    if (k == "k2_variant") {
+        if (!dk::reproject_variant_known(value)) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown K2 kernel form %d", value);
+        c->k2.variant = value;
+    }
     else if (k == "k2_order") c->k2.pixel_minor = value != 0;
     else if (k == "k2_flags") c->k2.flags = value;
     else if (k == "k1_wpb") c->k1.wpb = value;
@@ -629,7 +640,10 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k1_rl") c->k1.rl = value == 1 ? 1 : 4;
     else if (k == "k1_wide") c->k1.wide = value;
     else if (k == "k1_share") { c->k1.share = value < 0 ? -value : value; c->k1.share_always = value < 0; }
-    else if (k == "k4_variant") c->k4_variant = value;
+    else if (k == "k4_variant") {
+        if (!dk::backward_variant_known(value)) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown K4 kernel form %d", value);
+        c->k4_variant = value;
+    }
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
     return DSAC_OK;

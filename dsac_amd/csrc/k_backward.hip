@@ -544,6 +544,13 @@ static size_t k4m_lds_bytes(int HT) {
 // suggested 86 for N = 256 on a 640 x 480 map and 103 for N = 1024; measured, 86 gains 3 % at N = 256 and 103 loses 5 % at N = 1024
 // (workgroups do not run in lock-step rounds, and long tiles have the longer tail).  Matrix-core form: all hypotheses of the frame in one
 // tile up to 256 (the d_err stream is read once either way; a single tile writes grad_part once).
+bool backward_variant_known(int v) {
+    if (v == -1) return true;
+    if (v < 0) return false;
+    const int form = v % 10, tile = (v / 10) % 10, wgs = v / 100;
+    return form <= 5 && tile <= 3 && wgs <= 8;
+}
+
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) {
     K4Plan pl{};
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&

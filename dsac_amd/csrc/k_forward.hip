@@ -849,6 +849,10 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
+bool reproject_variant_known(int v) {
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 72);
+}
+
 int reproject_num_pixel_tiles(int P) { return (P + 63) / 64; }  // the largest count over all forms: one partial row per 64-pixel wave chunk
 
 template <int PX, int HT, bool SPOSE>
@@ -881,7 +885,7 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     if (tiles_used) *tiles_used = 0;
     if (N <= 0 || F.P <= 0 || (!err && !soft_part)) return hipSuccess;
     if (Nf <= 0 || F.frames <= 1) Nf = N > 0 ? ((N + 127) / 128) * 128 : 128;  // one frame: every tile maps to frame 0
-    else if (Nf % 128 != 0) return hipErrorInvalidValue;                      // tiles (<= 128 hypotheses) must not straddle frames
+    else if (Nf % K2_NF_MULTIPLE != 0) return hipErrorInvalidValue;           // tiles (<= 128 hypotheses) must not straddle frames
     const float LOG2E = 1.4426950408889634f;
     const float kA = beta * LOG2E, kB = -beta * tau * LOG2E;
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&

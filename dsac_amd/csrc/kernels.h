@@ -36,7 +36,10 @@ struct K2Opts {
 };
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
-// Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of 64 then); 0 = one frame.
+// Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of K2_NF_MULTIPLE = 128 then: no
+// hypothesis tile of any kernel form may straddle two frames); 0 = one frame.
+constexpr int K2_NF_MULTIPLE = 128;
+bool reproject_variant_known(int variant);  // -1 (auto) or a value reproject() has a kernel form for
 hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float tau, float beta,
                      float* soft_part, const K2Opts& opts, int* tiles_used, int Nf = 0);
 // soft[h] = sum over pixel tiles of soft_part[tile][h]   (double, deterministic)
@@ -77,6 +80,7 @@ struct K4Plan {
     int rows;     // rows of G12_part the launch writes
 };
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant);
+bool backward_variant_known(int variant);  // -1 (auto), 0 .. 5, or a form + 10 * tile code + 100 * workgroups per CU (see backward_plan)
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [partial rows][N][12] floats

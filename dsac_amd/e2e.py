@@ -153,6 +153,7 @@ class TrainStep:
         eng.reproject(self.poses, N=N, err=self.err)
         err = self.err.detach().requires_grad_(True)  # same storage: the score CNN reads what K2 wrote
         scores = self.score_net(err)
+        self.scores = scores.detach()  # kept for inspection (tests feed the oracle's softmax with exactly these numbers)
         # ---- K3: softmax, entropy, soft-argmax pose ------------------------------------------------------------------
         eng.softMax(scores.detach().double().contiguous(), 1.0, self.poses, N=N, out=(self.w, self.ent, self.avg))
         # ---- K6, K7 forward, then path I + softmax backward: all enqueued on the stream, device buffers only (no host round trip) ---
@@ -176,7 +177,12 @@ class TrainStep:
                                            float(self.sub_sample), 0.001, 2.0, 1.0, ptr(dpnp), ptr(self.grad_xyz), ptr(g), None, None))
         # ---- backward, path II: score CNN (gradient clamp of train_score_softam.lua:97), then K4 -----------------------
         scores.backward(gradient=g.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
-        d_err = err.grad.reshape(N, S * S).contiguous()  # (n, y, x): already the layout K4 reads
+        if quirk_transpose:
+            # reference-exact seam: the Lua bridge reads the gradient images back TRANSPOSED (lua_calls.h:329-335: gradients[c](y, x) <- table entry
+            # c*P + x*S + y) and dScore then indexes its columns x*cols*3 + y*3 (cnn_softam.h:628,641) -- both quirks together or neither
+            d_err = err.grad.reshape(N, S, S).transpose(1, 2).reshape(N, S * S).contiguous()
+        else:
+            d_err = err.grad.reshape(N, S * S).contiguous()  # (n, y, x): already the layout K4 reads
         eng.dScore(self.poses, self.sets, d_err, dpnp=dpnp, quirk_transpose=quirk_transpose, grad=self.grad_xyz)
         # ---- CNN 1 backward (gradient clamp of train_obj_softam.lua:105) ---------------------------------------------
         pred_m.backward(gradient=self.grad_xyz.float().clamp_(-CLAMP_E2E, CLAMP_E2E))

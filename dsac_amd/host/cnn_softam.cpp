@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <random>
+#include <stdexcept>
 
 namespace dsac {
 
@@ -164,12 +165,16 @@ std::vector<double> Frame::backward(const ProcessImageResult& fwd, const Hypothe
     // --- path I and the softmax backward (train_ransac_softam.cpp:294-376) as one device-side chain: dLossMax at the refined pose,
     // dRefineObj / dRefineHyp (12 + 6n finite-difference replicas in one launch), their contraction with dL, dPNP of every minimal set,
     // the scatter of v6 . w_h dPNP_h to the support points and the softmax backward
-    (void)refSteps;
     const std::vector<double> p = flatten(fwd.hyps);
     const Pose6 avg = pack(fwd.avgHyp), ref = pack(fwd.refAvgHyp);
     const std::vector<double> gt = poseGT.getRodVecAndTrans();
     std::vector<double> J((size_t)N * 72), g(N);
-    const int steps = (int)(pixelIdxs.size() / P);
+    // the gradient must belong to the function the forward evaluated: the same refSteps steps of the same permutations (a replayed .perm file
+    // may hold more of them than the forward used)
+    if (refSteps < 0 || (size_t)refSteps * P > pixelIdxs.size())
+        throw std::invalid_argument("Frame::backward: pixelIdxs holds fewer than refSteps permutations");
+    if (fwd.refStepsDone > refSteps) throw std::invalid_argument("Frame::backward: the forward pass refined more steps than refSteps");
+    const int steps = refSteps;
     check(dsac_backward_path1(ctx_, N, p.data(), &fwd.imgIdx[0][0], fwd.sfScores.data(), avg.data(), ref.data(), gt.data(), pixelIdxs.data(), steps, inlierCount,
                               50, (float)inlierThreshold2D, fwd.inlierMap.data(), subSampleFactor, 0.001f, 2.f, 1.0, J.data(), grad.data(), g.data(), nullptr,
                               nullptr),

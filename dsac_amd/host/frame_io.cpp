@@ -196,7 +196,15 @@ std::vector<DriverFrame> loadFrames(const std::string& splitDir) {
         DriverFrame f;
         f.name = stemOf(coords[i]);
         if (!readCoordsFile(coords[i], f)) throw Error(DSAC_ERR_INVALID, "cannot read " + coords[i]);
-        if (i < poses.size()) f.havePose = readPose7Scenes(poses[i], f.poseGT);
+        // the pose belongs to the frame by NAME (7-Scenes: frame-000123.coords <-> frame-000123.pose.txt; the reference's dataset couples them by
+        // file stem, core/dataset.h): a missing or extra pose file must not shift every later ground truth onto the wrong frame
+        f.havePose = false;
+        for (const std::string& pf : poses) {
+            std::string ps = stemOf(pf);
+            const size_t dot = ps.find(".pose");
+            if (dot != std::string::npos) ps.erase(dot);
+            if (ps == f.name) { f.havePose = readPose7Scenes(pf, f.poseGT); break; }
+        }
         std::ifstream sets(scene + "replay/" + f.name + ".sets");
         if (sets.is_open()) {
             std::array<int32_t, 4> s;

@@ -36,12 +36,18 @@ int main(int argc, const char* argv[]) {
             testDataset = loadFrames("./test/");
         }
 
-        std::ofstream testFile;  // contains evaluation information for the whole test sequence
-        testFile.open("ransac_test_loss_" + modelFileRGB + "_rdraw" + intToString(gp->pP.randomDraw) + "_softam.txt");
-        std::ofstream testErrFile;  // contains evaluation information for each test image
-        testErrFile.open("ransac_test_errors_" + modelFileRGB + "_rdraw" + intToString(gp->pP.randomDraw) + "_softam.txt");
-        testFile.precision(10);
-        testErrFile.precision(10);
+        // The two result files keep the reference's names and column order (core/test_ransac_softam.cpp:161-263) so that runs can be diffed
+        // against anyone's reference run; the columns are data here: {file, position, quantity}.
+        //   per image:  loss | score-distribution entropy | translation error mm | rotation error deg | exported pose: 3 x Rodrigues, 3 x metres
+        //   per run:    fraction correct | loss mean, stddev | entropy mean, stddev | median rotation error deg | median translation error mm
+        const std::string suffix = modelFileRGB + "_rdraw" + intToString(gp->pP.randomDraw) + "_softam.txt";
+        std::ofstream perRun("ransac_test_loss_" + suffix), perImage("ransac_test_errors_" + suffix);
+        perRun.precision(10);
+        perImage.precision(10);
+        auto writeRow = [](std::ofstream& f, const std::vector<double>& cols, bool trailingBlank) {
+            for (size_t k = 0; k < cols.size(); k++) f << cols[k] << ((k + 1 < cols.size() || trailingBlank) ? " " : "");
+            f << std::endl;
+        };
 
         double avgCorrect = 0;
         std::vector<double> losses, sfEntropies, rotErrs, tErrs;
@@ -59,19 +65,8 @@ int main(int argc, const char* argv[]) {
             // convert back to 7-Scenes norm, Rodriguez vector + translation in m, optional translation.txt
             const std::vector<double> hypV = exportPose7Scenes(r.refAvgHyp);
 
-            testErrFile << r.loss << " "       // 0 - loss of the average hypothesis
-                        << r.sfEntropy << " "  // 1 - entropy of the hypothesis score distribution
-                        << r.tErr << " "       // 2 - translational error in mm
-                        << r.rotErr << " "     // 3 - rotational error in deg
-                        << hypV[0] << " "      // 4 - selected pose, rotation (1st component of Rodriguez vector)
-                        << hypV[1] << " "      // 5 - selected pose, rotation (2nd component of Rodriguez vector)
-                        << hypV[2] << " "      // 6 - selected pose, rotation (3th component of Rodriguez vector)
-                        << hypV[3] << " "      // 7 - selected pose, translation in m (x)
-                        << hypV[4] << " "      // 8 - selected pose, translation in m (y)
-                        << hypV[5] << " "      // 9 - selected pose, translation in m (z)
-                        << std::endl;
+            writeRow(perImage, {r.loss, r.sfEntropy, r.tErr, r.rotErr, hypV[0], hypV[1], hypV[2], hypV[3], hypV[4], hypV[5]}, true);
 
-            // store statistics for calculation of mean, median, stddev
             losses.push_back(r.loss);
             sfEntropies.push_back(r.sfEntropy);
             tErrs.push_back(r.tErr);
@@ -88,16 +83,7 @@ int main(int argc, const char* argv[]) {
         std::cout << "Avg. test loss: " << lossMean << ", accuracy: " << avgCorrect * 100 << "%" << std::endl;
         std::cout << "Median Rot. Error: " << medianRotErr << "deg, Median T. Error: " << medianTErr / 10 << "cm." << std::endl;
 
-        testFile << avgCorrect << " "     // 0 - percentage of correct poses
-                 << lossMean << " "       // 1 - mean loss of average hypotheses
-                 << lossStdDev << " "     // 2 - standard deviation of losses of average hypotheses
-                 << entropyMean << " "    // 3 - mean of the score distribution entropy
-                 << entropyStdDev << " "  // 4 - standard deviation of the score distribution entropy
-                 << medianRotErr << " "   // 5 - median rotational error of selected hypotheses
-                 << medianTErr            // 6 - median translational error (in mm) of selected hypotheses
-                 << std::endl;
-        testFile.close();
-        testErrFile.close();
+        writeRow(perRun, {avgCorrect, lossMean, lossStdDev, entropyMean, entropyStdDev, medianRotErr, medianTErr}, false);
     } catch (const Error& e) {
         std::cout << "dsac error " << e.code << ": " << e.what() << std::endl;
         return 1;

@@ -54,6 +54,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The only symbols libdsac_hip.so exports: the library is built with -fvisibility=hidden, its C++ internals (namespace dk) stay private. */
+#if defined(__GNUC__)
+#define DSAC_API __attribute__((visibility("default")))
+#else
+#define DSAC_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,15 +84,15 @@ typedef enum dsac_status {
 #define DSAC_BWD_QUIRK_TRANSPOSE 1u /* reproduce core/cnn_softam.h:628,641 (index x*W*3 + y*3); needs H == W */
 
 /* ---- context ---------------------------------------------------------------------------------- */
-const char* dsac_version(void);
-int dsac_create(dsac_ctx** out, int device);
-void dsac_destroy(dsac_ctx* ctx);
-const char* dsac_last_error(dsac_ctx* ctx_or_null);
-int dsac_set_stream(dsac_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (e.g. torch's) */
-void* dsac_get_stream(dsac_ctx* ctx);
-int dsac_synchronize(dsac_ctx* ctx);
+DSAC_API const char* dsac_version(void);
+DSAC_API int dsac_create(dsac_ctx** out, int device);
+DSAC_API void dsac_destroy(dsac_ctx* ctx);
+DSAC_API const char* dsac_last_error(dsac_ctx* ctx_or_null);
+DSAC_API int dsac_set_stream(dsac_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (e.g. torch's) */
+DSAC_API void* dsac_get_stream(dsac_ctx* ctx);
+DSAC_API int dsac_synchronize(dsac_ctx* ctx);
 /* device facts for reports: CU count, clock (kHz), total memory (bytes), gcnArchName into name[64] */
-int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64);
+DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_bytes, char* name64);
 /* Per-context launch knobs (what the reference keeps in its GlobalProperties singleton, core/properties.h, made per-context and explicit).
  * None of them changes a result beyond rounding; -1 / the default is the measured policy.  Unknown keys are DSAC_ERR_INVALID.
  *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
@@ -103,12 +110,12 @@ int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t* mem_byte
  *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
-int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
+DSAC_API int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
 
 /* ---- frame ------------------------------------------------------------------------------------ */
 /* Replaces the (estObj, sampling, camMat) triple every reference function takes
  * (core/cnn_softam.h:319-323, 564-570, 663-671, 960-988). */
-int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int H, int W, float fx, float fy, float cx, float cy,
+DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int H, int W, float fx, float fy, float cx, float cy,
                    unsigned flags);
 
 /* Frame batch: `frames` coordinate maps of the same H x W and camera, stored back to back (frame f at xyz + f*H*W*3); uv is one
@@ -116,13 +123,13 @@ int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_null, int
  * are the unit the path shards over (core/test_ransac_softam.cpp:97-230); batching them lets one launch carry several frames.
  * Only dsac_score_hypotheses_frames and the pipelined pair dsac_sample_ahead / dsac_score_sampled (N = frames x hypotheses per frame,
  * outputs frame-major) accept a batch; every other call reports DSAC_ERR_INVALID while one is set. */
-int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
+DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
                     float cx, float cy, unsigned flags);
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).
  * Frame f draws from the stream of seed + f, so the result equals `frames` single-frame calls with seeds seed, seed + 1, ...
  * hyps_per_frame must be a multiple of 128.  Outputs are frame-major: poses / sets_out / ok / scores / w [frames][hyps_per_frame],
  * err [frames*hyps_per_frame][H*W], entropy [frames], avg6 [frames][6]. */
-int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta,
+DSAC_API int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta,
                                  double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null, double* w,
                                  double* entropy_or_null, double* avg6_or_null);
 
@@ -133,7 +140,7 @@ int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * the counter RNG above; otherwise the given N x 4 pixel indices are evaluated once each (this is also the
  * "re-solve P3P from the stored minimal set" step of dScore, core/cnn_softam.h:583-598).
  * Outputs: poses N x 6, sets_out N x 4 (pixel index y*W+x, the reference's imgIdx), ok N. */
-int dsac_sample(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
+DSAC_API int dsac_sample(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
                 int32_t* sets_out, uint8_t* ok);
 
 /* ---- K2: batched reprojection -> error images and/or soft-inlier scores -------------------------- */
@@ -141,13 +148,13 @@ int dsac_sample(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null
  * err[h][p] = min(|uv_p - project(K, pose_h, xyz_p)|, clamp)  (clamp = CNN_OBJ_MAXINPUT = 100, lua_calls.h:36).
  * soft[h] = sum_p sigmoid(beta * (tau - err[h][p]))  is the DSAC++-style soft-inlier count named by
  * north_star (not in the reference).  Either output may be NULL. */
-int dsac_reproject(dsac_ctx* ctx, int N, const double* poses, float clamp, float* err_or_null, float tau, float beta,
+DSAC_API int dsac_reproject(dsac_ctx* ctx, int N, const double* poses, float clamp, float* err_or_null, float tau, float beta,
                    double* soft_or_null);
 
 /* ---- K3: softmax / entropy / soft-argmax pose --------------------------------------------------- */
 /* Replaces softMax core/cnn_softam.h:535-553, entropy :80-88 and the weighted pose average :1082-1094.
  * w = softmax(scale * scores); entropy in bits; avg6 = sum_h w_h * poses[h].  entropy/avg6/poses may be NULL. */
-int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, double* w, double* entropy_or_null,
+DSAC_API int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, double* w, double* entropy_or_null,
                  const double* poses_or_null, double* avg6_or_null);
 
 /* ---- K1 + K2 + K3 in one call: the hypothesis-scoring half of processImage ------------------------ */
@@ -155,7 +162,7 @@ int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, doubl
  * sample N hypotheses (dsac_sample), reproject (dsac_reproject: error images optional, soft-inlier sums always),
  * w = softmax(scale * soft), entropy, soft-argmax pose.  Same results as the three separate calls; the fused
  * form saves the pose-staging launch and the host round trips.  scores_or_null receives the soft-inlier sums. */
-int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clamp, float tau,
+DSAC_API int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clamp, float tau,
                           float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
                           double* w, double* entropy_or_null, double* avg6_or_null);
 
@@ -171,16 +178,16 @@ int dsac_score_hypotheses(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* se
  * a stream of different frames is pipelined by calling dsac_set_frame(..., DSAC_FRAME_BORROW) before each dsac_sample_ahead;
  * frames the library copies itself (no DSAC_FRAME_BORROW) cannot be replaced while a slot is sampled but not yet scored
  * (DSAC_ERR_INVALID).  Each slot alternates strictly: sample_ahead, score_sampled, sample_ahead, ... */
-int dsac_sample_ahead(dsac_ctx* ctx, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
+DSAC_API int dsac_sample_ahead(dsac_ctx* ctx, int slot, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
                       int32_t* sets_out, uint8_t* ok);
-int dsac_score_sampled(dsac_ctx* ctx, int slot, float clamp, float tau, float beta, double scale, const double* poses, float* err_or_null,
+DSAC_API int dsac_score_sampled(dsac_ctx* ctx, int slot, float clamp, float tau, float beta, double scale, const double* poses, float* err_or_null,
                        double* scores, double* w, double* entropy_or_null, double* avg6_or_null);
 
 /* ---- K5: dPNP ------------------------------------------------------------------------------------ */
 /* Replaces dPNP core/cnn_softam.h:101-146 for the minimal (4-point, CV_P3P) case: central differences
  * (float eps, sequential float perturbation of the object points) of the jp 6-vector of the P3P pose.
  * J is N x 6 x 12; all-zero for a hypothesis whose differences contain NaN (:141-142). */
-int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, double* J);
+DSAC_API int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, double* J);
 
 /* ---- K4: score backward -------------------------------------------------------------------------- */
 /* Replaces dScore part (iii), core/cnn_softam.h:609-645, plus the sum over hypotheses at
@@ -188,7 +195,7 @@ int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, double* J);
  * and, for the 4 support pixels of h, += (sum_p d_err[h][p] * dProjectdHyp(h,p)) * dPNP(h).
  * poses are the cv poses of the hypotheses (as re-solved at :597-598); dpnp N x 72 or NULL (computed
  * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into. */
-int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
+DSAC_API int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
                         unsigned flags, double* grad_xyz);
 /* The backward calls need fx == fy: the reference's Jacobians use the single focal length camMat(0,0) for both axes
  * (core/cnn_softam.h:406,466); a camera with two focal lengths is rejected with DSAC_ERR_INVALID rather than differentiated
@@ -198,13 +205,13 @@ int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t
  * switch, and tests/test_gpu_backward.py::test_quirk7_rot_writeback bounds the difference between the two.
  * Same with the soft-inlier score: d_err[h][p] = g[h] * d soft[h] / d err[h][p], formed in-kernel
  * (no N x P read).  g = dLoss/d soft[h]. */
-int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
+DSAC_API int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
                              float beta, const double* dpnp_or_null, unsigned flags, double* grad_xyz);
 
 /* The per-hypothesis 1 x 6 pose gradients of the most recent dsac_score_backward / dsac_soft_score_backward call on
  * this context: G6[h] = sum over cells of d_err[h][p] * dProjectdHyp(p) (the accumulation of core/cnn_softam.h:631-632
  * before its product with dPNP; columns = jp Rodrigues vector, translation in mm).  N must not exceed that call's N. */
-int dsac_last_pose_gradients(dsac_ctx* ctx, int N, double* G6);
+DSAC_API int dsac_last_pose_gradients(dsac_ctx* ctx, int N, double* G6);
 
 /* ---- K6: inlier refinement (LM-PnP) and its finite-difference Jacobians -------------------------- */
 /* Replaces the refinement loop of processImage core/cnn_softam.h:1099-1154 (B = 1, fills inlier_map) and
@@ -214,14 +221,14 @@ int dsac_last_pose_gradients(dsac_ctx* ctx, int N, double* G6);
  * pose.  pert_px_c (B x 2: pixel or -1, channel) / pert_value (B) replace one coordinate per replica, which
  * is dRefineObj's localEstObj (:887,901).  out_poses B x 6 (cv).  inlier_map (H*W int32, += 1 per
  * selection) is only written for replica 0 and only when non-NULL. */
-int dsac_refine(dsac_ctx* ctx, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+DSAC_API int dsac_refine(dsac_ctx* ctx, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                 const int32_t* pert_px_c_or_null, const float* pert_value_or_null, double* out_poses, int32_t* inlier_map_or_null,
                 int32_t* steps_done_or_null);
 /* Replaces dRefineHyp core/cnn_softam.h:738-836 (J_hyp 6 x 6; eps_hyp = 0.001f) and dRefineObj :853-923
  * (eps_obj = 2.f, every skip = (int)(1/sub_sample)-th cell of inlier_map > 0 in x-outer/y-inner order,
  * scaled by skip).  All 12 + 6*n_obj replicas run as one batch.  dRefineObj's 6 x 3P matrix is returned
  * sparse: obj_pixels[i] = pixel index, J_obj[i] = 6 x 3 block, i < *n_obj <= cap. */
-int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+DSAC_API int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                    const int32_t* inlier_map, float sub_sample, float eps_hyp, float eps_obj, double* J_hyp, int32_t* obj_pixels,
                    double* J_obj, int cap, int32_t* n_obj);
 
@@ -230,31 +237,31 @@ int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_t* perm, 
  * shared steps x H*W permutation (every hypothesis re-seeds the same default std::mt19937, :1169).  inlier_maps
  * (N x H*W int32, zeroed here) receives one hit-count map per hypothesis; with sets (N x 4) the cells of each
  * hypothesis' own minimal set are cleared afterwards (:1208-1214). */
-int dsac_refine_all(dsac_ctx* ctx, int N, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+DSAC_API int dsac_refine_all(dsac_ctx* ctx, int N, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                     const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null);
 /* Replaces dRefine core/cnn.h:854-990 for ONE hypothesis given by its minimal set: the refinement restarts from P3P of
  * the set (:797-800), so besides dRefineObj's inlier cells the first three set points are perturbed as well
  * (+-eps_obj = 2.f on the map and on the P3P input alike).  J_set is 6 x 9 (columns pt*3 + c, pt < 3), J_obj / obj_pixels /
  * n_obj as in dsac_refine_fd (scaled by skip; J_set is not, :923). */
-int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+DSAC_API int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                        const int32_t* inlier_map, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
                        int32_t* n_obj);
 /* dsac_refine_fd_set for M hypotheses in ONE batch of M * (18 + 6*cap) refinement problems -- the loop over hypotheses of
  * core/train_ransac.cpp:314-339 (the reference runs it under OpenMP).  sets M x 4, inlier_maps M x H*W; outputs J_set M x 6 x 9,
  * obj_pixels M x cap, J_obj M x cap x 6 x 3, n_obj M (entries beyond n_obj[m] are untouched). */
-int dsac_refine_fd_sets(dsac_ctx* ctx, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+DSAC_API int dsac_refine_fd_sets(dsac_ctx* ctx, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                         const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
                         int32_t* n_obj);
 /* maxLoss / dLossMax for B estimates against one ground truth: the losses[] of expectedMaxLoss core/cnn.h:137-150 and
  * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
-int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+DSAC_API int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
 
 /* ---- producer side: patch gather for the scene-coordinate CNN ----------------------------------------------------- */
 /* Replaces the patch assembly of getCoordImg core/cnn_softam.h:224-254 in the table layout of pushMaps core/lua_calls.h:63-80:
  * patches[i][c][y][x] = (float) bgr[(sy + y) * W + (sx + x)][c] with (sx, sy) = sampling_xy[i] - patch/2.  bgr is the H x W x 3
  * uint8 image (jp::img_bgr_t), sampling_xy n x (x, y) int32 (the reference's `sampling`), patch = CNN_RGB_PATCHSIZE (42).
  * A window that leaves the image (the reference skips such patches, :235-239) is written as zeros and counted in *skipped. */
-int dsac_gather_patches(dsac_ctx* ctx, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches,
+DSAC_API int dsac_gather_patches(dsac_ctx* ctx, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches,
                         int32_t* skipped_or_null);
 
 /* ---- K7: pose loss ---------------------------------------------------------------------------------- */
@@ -263,13 +270,13 @@ int dsac_gather_patches(dsac_ctx* ctx, const uint8_t* bgr, int H, int W, const i
  * as at cnn_softam.h:1160-1163 / train_ransac_softam.cpp:301-304); gt_jp6 is the ground truth as the jp
  * 6-vector poseGT.getRodVecAndTrans().  out4 = {loss, rotErr[deg], tErr[mm], correct(5deg/50mm)};
  * J6_or_null = dLossMax w.r.t. the jp 6-vector of est. */
-int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+DSAC_API int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
 
 /* ---- gradient assembly ------------------------------------------------------------------------------ */
 /* Replaces core/train_ransac_softam.cpp:344-376: with v6 = dLoss/dRef * dRef/dAvg (1 x 6),
  * grad_xyz[support px of h] += v6 * w_h * dPNP_h  (path I, second term) and the softmax backward
  * g_j = w_j * (F_j - sum_h w_h F_h),  F_h = v6 . [rvec_h ; tvec_h / 1000]  (written O(N^2) in the reference). */
-int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
+DSAC_API int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                     const double* dpnp, double* grad_xyz, double* g);
 
 /* The whole path-I half of the trainer's backward section, core/train_ransac_softam.cpp:294-376, enqueued as one chain with no host round
@@ -280,7 +287,7 @@ int dsac_path1_and_softmax_backward(dsac_ctx* ctx, int N, const double* v6, cons
  * gradients path II continues from (the score CNN's backward, or dsac_soft_score_backward with g_scale = the score scale alpha);
  * dpnp_out_or_null (N x 72) can be handed on to dsac_score_backward.  grad_xyz (H*W x 3) is ACCUMULATED into.  dL_out / v6_out: the 1 x 6
  * dLoss/dRef and dLoss/dAvg for logging.  The reference computes both refinement Jacobians unconditionally; so does this call. */
-int dsac_backward_path1(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* w, const double* avg_cv6, const double* ref_cv6,
+DSAC_API int dsac_backward_path1(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* w, const double* avg_cv6, const double* ref_cv6,
                         const double* gt_jp6, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const int32_t* inlier_map, float sub_sample,
                         float eps_hyp, float eps_obj, double g_scale, double* dpnp_out_or_null, double* grad_xyz, double* g, double* dL_out_or_null,
                         double* v6_out_or_null);
@@ -291,14 +298,14 @@ int dsac_backward_path1(dsac_ctx* ctx, int N, const double* poses, const int32_t
  * Two contexts working on alternate frames cross-wire their events so that their K2 launches run back to back
  * -- never competing for HBM -- while the latency-bound kernels (K1 sampling, K3) of one frame fill the bubbles of
  * the other.  NULL removes the gate. */
-int dsac_set_k2_events(dsac_ctx* ctx, void* wait_before_or_null, void* record_after_or_null);
+DSAC_API int dsac_set_k2_events(dsac_ctx* ctx, void* wait_before_or_null, void* record_after_or_null);
 
 /* ---- measurement hooks (bench.py's roofline leg) ----------------------------------------------------- */
 /* When enabled, a hipEvent pair is recorded on the context's stream immediately around every launch of the
  * dominant kernel (K2 k_reproject, and K4 k_score_backward).  dsac_profile_read waits for the recorded
  * events and returns the summed kernel time in ms and the launch count per kernel (which = 0: K2, 1: K4). */
-int dsac_profile_enable(dsac_ctx* ctx, int on);
-int dsac_profile_read(dsac_ctx* ctx, int which, double* ms_total, int* launches, int reset);
+DSAC_API int dsac_profile_enable(dsac_ctx* ctx, int on);
+DSAC_API int dsac_profile_read(dsac_ctx* ctx, int which, double* ms_total, int* launches, int reset);
 
 #ifdef __cplusplus
 }

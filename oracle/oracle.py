@@ -78,6 +78,38 @@ def _cam(cam):
     return _d(np.asarray(cam, dtype=np.float64).reshape(4))
 
 
+import os as _os
+
+
+def effective_cpus():
+    """(usable cores, description): min of the online CPUs, the scheduler affinity and the cgroup CPU quota (cpu.max) -- on the GPU boxes of this
+    pool nproc says 256 while the container's quota is 16 CPUs, and an OpenMP team of 256 threads on 16 CPUs' worth of quota is throttled to a
+    fraction of what 16 threads reach."""
+    n = _os.cpu_count() or 1
+    desc = ["online %d" % n]
+    try:
+        a = len(_os.sched_getaffinity(0))
+        desc.append("affinity %d" % a)
+        n = min(n, a)
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = float(quota) / period
+                desc.append("cgroup quota %.1f" % q)
+                n = max(1, min(n, int(q + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, ", ".join(desc)
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -18,6 +18,7 @@ def orc():
     """The CPU oracle (test infrastructure)."""
     from oracle import oracle as o
     o.build()
+    o.set_num_threads(o.effective_cpus()[0])  # an OpenMP team larger than the container's CPU quota only gets throttled
     return o
 
 

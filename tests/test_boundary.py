@@ -32,6 +32,17 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(_header_functions()), "exported C symbols differ from the header: %s" % (exported ^ set(_header_functions()))
 
 
+def test_nothing_but_the_c_abi_is_exported():
+    """-fvisibility=hidden + DSAC_API: the dynamic symbol table holds the 35 dsac_* functions and none of the library's C++ internals (namespace dk,
+    the kernels' host stubs, template instantiations).  Weak symbols the C++ runtime needs (typeinfo / vague-linkage std:: code) are not ours."""
+    from dsac_amd import capi
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
+    strong = [l.split() for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "TDBR"]
+    names = sorted(n for _, _, n in strong)
+    assert names == _header_functions(), [n for n in names if not n.startswith("dsac_")][:10]
+    assert not re.search(r"_ZN2dk", out), "namespace dk leaks out of libdsac_hip.so"
+
+
 def test_version_and_no_cpu_fallback():
     import torch
     import dsac_amd

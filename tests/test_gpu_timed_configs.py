@@ -145,8 +145,8 @@ def variant_case(orc, synth):
 
 
 # every value dk::reproject() accepts: -1 auto, 0-3 and 10-13 VALU forms, 20-27 matrix-core forms, 40-59 streaming small-tile forms
-# (40-43 partial sums through LDS, 44-59 per-wave partial sums), 60-62 persistent pipelined forms
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24, 25, 26, 27] + list(range(40, 63)))
+# (40-43, 68 partial sums through LDS, the others per-wave partial sums), 60-62 persistent pipelined forms
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 10, 11, 12, 13, 20, 21, 22, 23, 24, 25, 26, 27] + list(range(40, 63)) + list(range(65, 73)))
 @pytest.mark.parametrize("order", [1, 0])
 def test_every_k2_kernel_form_against_the_oracle(engine, variant_case, variant, order):
     import torch
