@@ -35,12 +35,24 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak: 256 CUs x 4 SIMDs x 64 flop/clk x 2.4 GHz (vendor figure)
+FLOP_PER_PAIR = 36        # SURVEY.md 8(d), fused soft-inlier mode: 9 FMA + rcp + 2 mul + 2 FMA + 2 sub + 3 + min + ~5 (sigmoid) per (hypothesis, pixel)
 CONFIG3_IMAGES = 64    # BASELINE.json configs[3]
 
 
 def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
     # B_fwd(N,P) = 12 P (xyz f32) + 8 P [explicit uv] + 48 N (R|t f32) + 4 N P (err f32 out) + 4 N (score out)
     return 12 * P + (8 * P if explicit_uv else 0) + 48 * N + (4 * N * P if write_err else 0) + 4 * N
+
+
+def soft_only_roofline(n_hyps, P, k2_s, launches):
+    """SURVEY.md 8(d) secondary measurement: the fused soft-inlier mode (scores without the error-image output) moves 12 P + 48 N + 4 N bytes
+    for N P x 36 flop -- it is priced against the fp32 VECTOR roof, never as an HBM fraction."""
+    flop = float(n_hyps) * float(P) * FLOP_PER_PAIR
+    ach = flop / k2_s / 1e12 if k2_s > 0 else 0.0
+    return {"kernel": "k_reproject (K2), soft-inlier sums only (no error-image output)", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "flop_per_launch": flop, "flop_per_pair": FLOP_PER_PAIR, "avg_launch_us": k2_s * 1e6,
+            "launches_timed": launches, "hyp_per_s": n_hyps / k2_s if k2_s > 0 else None}
 
 
 def event_stride_for(steps, requested):
@@ -488,6 +500,27 @@ def main(argv=None):
             sync_all()
             for eng, _ in engines:
                 eng.profile_read(0, reset=True)
+    # SURVEY.md 8(d) secondary line: the same launches WITHOUT the error-image output (fused soft-inlier mode): K2 is then VALU-bound
+    soft_only = None
+    if rank == 0 and batched and not config3 and not pipelined and args.k2_mode == "both":
+        eng, _ = engines[0]
+        b = bufs[0]
+        eng.profile_read(0, reset=True)
+        for i in range(12):
+            eng.scoreHypothesesFrames(N, seed=seed_of(ctr + i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=None,
+                                      out=(b["poses"], b["sets"], b["ok"], b["soft"], b["w"], b["ent"], b["avg"]))
+            if i == 1:
+                eng.synchronize()
+                eng.profile_read(0, reset=True)  # the first two launches settle
+        eng.synchronize()
+        ms_s, n_s = eng.profile_read(0, reset=True)
+        if n_s:
+            soft_only = soft_only_roofline(N * B, P, ms_s / n_s * 1e-3, n_s)
+        step(ctr)  # leave real error images in the buffers
+        ctr += 1
+        sync_all()
+        for e_, _ in engines:
+            e_.profile_read(0, reset=True)
     if config3 and rank == 0:
         ws = last[:, 6:].sum(1)
         assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
@@ -662,14 +695,21 @@ def main(argv=None):
                        "parallelism": "images sharded over %d GPU(s), no data-path collective%s%s" %
                                       (world, "; results gathered on rank 0" if config3 else "", ("; " + BACKEND_NOTE) if BACKEND_NOTE else ""),
                        "prewarm_steps_untimed": n_pre, "accepted_fraction": ok_frac, "softmax_sum": wsum},
-            "roofline": {"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": abytes,
-                         "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n, "event_stride": stride,
-                         "store_schedule_only_us": store_only_us},
+            "roofline": ({"kernel": "k_reproject (K2)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                          "traffic_source": ("constant from the committed PMC pass profiles/k2_traffic.json (rocprofv3 WRITE_SIZE + 2 x FETCH_SIZE of this "
+                                             "launch shape), not measured in this run") if traffic is not None else None,
+                          "algorithmic_bytes_per_launch": abytes, "avg_launch_us": k2_avg_s * 1e6, "launches_timed": k2_n, "event_stride": stride,
+                          "store_schedule_only_us": store_only_us}
+                         if args.k2_mode != "soft" else
+                         dict(soft_only_roofline(N * frames_per_launch, P, k2_avg_s, k2_n), traffic=None, event_stride=stride,
+                              algorithmic_bytes_per_launch=abytes)),
             # kernel-only (K2) and per-image (K1 + K2 + K3) rates reported separately
             "rates": {"per_image_hyp_s": value, "kernel_only_k2_hyp_s": (N * frames_per_launch / k2_avg_s * world) if k2_avg_s > 0 else None,
                       "unit": "hyp/s", "note": "per_image = whole step (K1 sample+P3P, K2, soft reduce, K3); kernel_only = hypotheses per K2 launch / its duration"},
         }
+        if soft_only is not None:
+            out["soft_only"] = soft_only
         if single is not None:
             out["single_frame"] = single
         if refsize is not None:

@@ -764,7 +764,10 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
                 const int32_t* pert_px_c, const float* pert_value, double* out_poses, int32_t* inlier_map, int32_t* steps_done) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (frames > 1 && (B % frames != 0 || pert_px_c))
+        return fail(c, DSAC_ERR_INVALID, "dsac_refine: with a frame batch B must be frames x problems per frame (problem b refines against frame b / (B / frames)), "
+                                         "without perturbations");
     if (B < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
     if ((pert_px_c != nullptr) != (pert_value != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_refine: pert_px_c and pert_value go together");
@@ -782,9 +785,11 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
     ARG_TRY(in_arg(c, pert_px_c, (size_t)B * 2, &d_px));
     ARG_TRY(in_arg(c, pert_value, (size_t)B, &d_pv));
     ARG_TRY(out_arg(c, out_poses, (size_t)B * 6, &d_out));
-    ARG_TRY(out_arg(c, inlier_map, P, &d_map, /*preload=*/true));
+    // one frame: the map of problem 0 (H*W counters, += 1 per selection); frame batch: one map per problem (B x H*W)
+    ARG_TRY(out_arg(c, inlier_map, frames > 1 ? (size_t)B * P : P, &d_map, /*preload=*/true));
     ARG_TRY(out_arg(c, steps_done, (size_t)B, &d_sd));
-    HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd));
+    HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
+                          frames > 1 ? B / frames : 0));
     return end_call(c);
 }
 
@@ -1057,6 +1062,91 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
     // sum_h w_h dPNP_h to the support points and the softmax backward (:344-376)
     HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp));
     HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale));
+    return end_call(c);
+}
+
+int dsac_loss_frames(dsac_ctx* c, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_loss_frames: ctx is NULL");
+    if (B < 0 || !est_cv6 || !gt_jp6 || (!out4 && !J6_or_null)) return fail(c, DSAC_ERR_INVALID, "dsac_loss_frames: NULL argument or negative count");
+    if (B == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const double *d_est, *d_gt;
+    double *d_out, *d_J;
+    ARG_TRY(in_arg(c, est_cv6, (size_t)B * 6, &d_est));
+    ARG_TRY(in_arg(c, gt_jp6, (size_t)B * 6, &d_gt));
+    ARG_TRY(out_arg(c, out4, (size_t)B * 4, &d_out));
+    ARG_TRY(out_arg(c, J6_or_null, (size_t)B * 6, &d_J));
+    HIP_TRY(c, dk::pose_loss(c->stream, B, d_est, d_gt, d_out, d_J, 6));
+    return end_call(c);
+}
+
+int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clampv, float tau, float beta, double scale,
+                        const int32_t* perm, int steps, int max_inl, int min_inl, const double* gt_jp6_or_null, double* poses, int32_t* sets_out, uint8_t* ok,
+                        float* err_or_null, double* scores_or_null, double* w, double* entropy, double* avg6, double* ref6, int32_t* steps_done,
+                        int32_t* inlier_maps_or_null, double* out4_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_process_images: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_process_images: no frame set");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (hyps_per_frame <= 0 || (frames > 1 && hyps_per_frame % dk::K2_NF_MULTIPLE != 0))
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images: hyps_per_frame must be positive (a multiple of %d for a frame batch), got %d", dk::K2_NF_MULTIPLE,
+                    hyps_per_frame);
+    if ((long long)hyps_per_frame * frames > (1ll << 24)) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: too many hypotheses");
+    if (!perm || !poses || !sets_out || !ok || !w || !entropy || !avg6 || !ref6 || !steps_done || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images: NULL argument or negative step count");
+    if ((out4_or_null != nullptr) != (gt_jp6_or_null != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: out4 and gt_jp6 go together");
+    if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
+    if (max_tries <= 0 || c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: max_tries > 0 and a frame of at least 4 cells needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const int N = hyps_per_frame * frames, Nf = frames > 1 ? hyps_per_frame : 0;
+    const int32_t* d_perm;
+    const double* d_gt;
+    double *d_poses, *d_scores, *d_w, *d_ent, *d_avg, *d_ref, *d_out4;
+    int32_t *d_sets, *d_sd, *d_maps;
+    uint8_t* d_ok;
+    float* d_err;
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, gt_jp6_or_null, (size_t)frames * 6, &d_gt));
+    ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets));
+    ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
+    ARG_TRY(out_arg(c, err_or_null, (size_t)N * P, &d_err));
+    ARG_TRY(out_arg(c, scores_or_null, (size_t)N, &d_scores));
+    ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(out_arg(c, entropy, (size_t)frames, &d_ent));
+    ARG_TRY(out_arg(c, avg6, (size_t)frames * 6, &d_avg));
+    ARG_TRY(out_arg(c, ref6, (size_t)frames * 6, &d_ref));
+    ARG_TRY(out_arg(c, steps_done, (size_t)frames, &d_sd));
+    ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)frames * P, &d_maps));
+    ARG_TRY(out_arg(c, out4_or_null, (size_t)frames * 4, &d_out4));
+    if (!d_scores) {
+        DevBuf& s = next_slot(c);
+        HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
+        d_scores = s.as<double>();
+    }
+    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+    // processImage (core/cnn_softam.h:960-1179) for every frame of the batch, one launch per stage:
+    //   K1 sample + P3P (:1010-1060)  ->  K2 error images + soft-inlier sums (:1067-1072)  ->  scores  ->  K3 softmax / entropy / soft-argmax
+    //   (:1078-1094)  ->  K6 the refinement loop, one wave per frame (:1099-1154)  ->  K7 maxLoss against each frame's ground truth (:1160-1179)
+    HIP_TRY(c, dk::sample(c->stream, N, seed, nullptr, c->F, (int)thr, max_tries, d_poses, d_sets, d_ok, c->staged.as<float>(), Nf, c->k1));
+    int used = 0;
+    if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
+    {
+        ProfScope ps(c, 0, true);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(), &used, Nf));
+        ps.commit();
+    }
+    if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
+    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
+    HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), c->stream));
+    HIP_TRY(c, dk::refine(c->stream, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
+                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0));
+    if (d_out4) HIP_TRY(c, dk::pose_loss(c->stream, frames, d_ref, d_gt, d_out4, nullptr, 6));
     return end_call(c);
 }
 

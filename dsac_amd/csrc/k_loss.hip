@@ -25,9 +25,10 @@ DM_INLINE void mul3(const double A[9], const double B[9], double C[9]) {
 // One lane per estimate (B = 1: maxLoss / dLossMax of the soft-argmax pipeline; B = N: the per-hypothesis losses of
 // expectedMaxLoss, core/cnn.h:137-150, and the per-hypothesis dLossMax of core/train_ransac.cpp:345-349).
 __global__ __launch_bounds__(64) void k_pose_loss(int B, const double* __restrict__ est_all, const double* __restrict__ gt_jp6,
-                                                  double* __restrict__ out4_all, double* __restrict__ J6_all) {
+                                                  double* __restrict__ out4_all, double* __restrict__ J6_all, int gt_stride) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
+    gt_jp6 += (size_t)b * gt_stride;  // 0: one ground truth for all estimates; 6: one per estimate (a frame batch)
     const double* est_cv6 = est_all + (size_t)b * 6;
     double* out4 = out4_all ? out4_all + (size_t)b * 4 : nullptr;
     double* J6 = J6_all ? J6_all + (size_t)b * 6 : nullptr;
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(64) void k_pose_loss(int B, const double* __restric
     for (int i = 0; i < 6; i++) J6[i] = J[i];
 }
 
-hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6) {
+hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6, int gt_stride) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pose_loss, dim3((B + 63) / 64), dim3(64), 0, st, B, est_cv6, gt_jp6, out4, J6);
+    hipLaunchKernelGGL(k_pose_loss, dim3((B + 63) / 64), dim3(64), 0, st, B, est_cv6, gt_jp6, out4, J6, gt_stride);
     return hipGetLastError();
 }
 

@@ -370,9 +370,14 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
-                                               int32_t* __restrict__ steps_done, int map_stride, int group) {
+                                               int32_t* __restrict__ steps_done, int map_stride, int group, int per_frame) {
     const int b = blockIdx.x;
     if (b >= B) return;
+    if (per_frame > 0) {  // frame batch: one wave per (frame, problem) -- the per-image refinement of test_ransac_softam.cpp:97-157 for F images at once
+        const int f = b / per_frame;
+        F.xyz += (long long)f * F.xyz_stride;
+        if (F.uv) F.uv += (long long)f * F.uv_stride;
+    }
     // replica lists shorter than the launch: `group` replicas per list (0: one list), list m holds live_base + live_mul * n_live[m]
     if (n_live) {
         const int m = group > 0 ? b / group : 0, local = group > 0 ? b - m * group : b;
@@ -454,11 +459,11 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
 
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride) {
+                  int32_t* steps_done, int map_stride, int per_frame) {
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0);
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame);
     return hipGetLastError();
 }
 
@@ -677,7 +682,7 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     const int B = 12 + 6 * cap;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0);
     return hipGetLastError();
 }
 
@@ -791,7 +796,7 @@ hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, cons
     const long long B = (long long)R * M;
     if (B > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
-                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R);
+                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0);
     return hipGetLastError();
 }
 

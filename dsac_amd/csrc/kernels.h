@@ -100,9 +100,10 @@ hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp,
 
 // ---- k_refine.hip ----------------------------------------------------------------------------------
 // inlier_map: map_stride == 0 -> H*W counters of problem 0 only; map_stride == H*W -> one map per problem
+// per_frame > 0 (frame batch): problem b refines against frame b / per_frame (F.xyz_stride / F.uv_stride)
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride = 0);
+                  int32_t* steps_done, int map_stride = 0, int per_frame = 0);
 // inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)
 hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps);
 // DSAC-variant replica plan (core/cnn.h:854-990 dRefine): 18 replicas perturb the first three points of the minimal set,
@@ -127,7 +128,9 @@ hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t
                             double* J_hyp, double* J_obj);
 
 // ---- k_loss.hip ------------------------------------------------------------------------------------
-hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6 /*B x 6*/, const double* gt_jp6, double* out4 /*B x 4*/, double* J6 /*B x 6*/);
+// gt_stride: 0 = one ground truth (6 doubles) for all estimates, 6 = one per estimate
+hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6 /*B x 6*/, const double* gt_jp6, double* out4 /*B x 4*/, double* J6 /*B x 6*/,
+                     int gt_stride = 0);
 
 // ---- k_patches.hip ---------------------------------------------------------------------------------
 // n patches of 3 x patch x patch floats (patch, channel, row, column) around sampling_xy[i] = (x, y) of an H x W x 3 BGR image

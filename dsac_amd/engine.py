@@ -143,6 +143,42 @@ class Engine:
                                                           ptr(ent), ptr(avg)))
         return out
 
+    def processImages(self, hyps_per_frame, perm, gt_jp6=None, seed=1305, thr=10.0, max_tries=1 << 20, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5,
+                      scale=0.1, max_inl=100, min_inl=50, err=None, want_inlier_maps=False, out=None):
+        """processImage (cnn_softam.h:960-1179) for every frame set with set_frame / set_frames in one call (dsac_process_images): K1, K2, K3, the
+        refinement loop (one wave per frame) and the loss against each frame's ground truth, one launch per stage.  perm: refSteps x H*W pixel
+        permutations (shared by the frames); gt_jp6: F x 6 or None.  Frame f uses the random stream of seed + f.
+        out = dict of preallocated buffers (numpy or torch) with the keys of the returned dict; returns dict(hyps, sampledPoints, ok, scores,
+        sfScores, sfEntropy F, avgHyp F x 6, refAvgHyp F x 6, refSteps F[, inlierMaps F x P][, out4 F x 4 = loss, rotErr, tErr, correct])."""
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        perm = _np(perm, np.int32)
+        steps = int(perm.shape[0])
+        o = dict(out) if out is not None else {}
+        def buf(key, shape, dtype=np.float64):
+            if key not in o or o[key] is None:
+                o[key] = np.zeros(shape, dtype)
+            return o[key]
+        hyps, sets, ok = buf("hyps", (F * N, 6)), buf("sampledPoints", (F * N, 4), np.int32), buf("ok", F * N, np.uint8)
+        scores, w, ent = buf("scores", F * N), buf("sfScores", F * N), buf("sfEntropy", F)
+        avg, ref, sd = buf("avgHyp", (F, 6)), buf("refAvgHyp", (F, 6)), buf("refSteps", F, np.int32)
+        maps = buf("inlierMaps", (F, self.P), np.int32) if (want_inlier_maps or o.get("inlierMaps") is not None) else None
+        gt = _np(np.asarray(gt_jp6, dtype=np.float64).reshape(F, 6), np.float64) if isinstance(gt_jp6, (np.ndarray, list, tuple)) else gt_jp6
+        out4 = buf("out4", (F, 4)) if gt is not None else None
+        check(self._ctx, lib.dsac_process_images(self._ctx, N, int(seed) & 0xFFFFFFFFFFFFFFFF, float(thr), int(max_tries), float(clamp), float(tau), float(beta),
+                                                 float(scale), ptr(perm), steps, int(max_inl), int(min_inl), ptr(gt), ptr(hyps), ptr(sets), ptr(ok), ptr(err),
+                                                 ptr(scores), ptr(w), ptr(ent), ptr(avg), ptr(ref), ptr(sd), ptr(maps), ptr(out4)))
+        return o
+
+    def maxLossFrames(self, est_cv6, gt_jp6, want_grad=False):
+        """maxLoss (and dLossMax) of B estimates, each against its own ground truth (dsac_loss_frames).  Returns dict(out4 B x 4[, grad B x 6])."""
+        est = _np(np.asarray(est_cv6, dtype=np.float64).reshape(-1, 6), np.float64)
+        gt = _np(np.asarray(gt_jp6, dtype=np.float64).reshape(-1, 6), np.float64)
+        B = int(est.shape[0])
+        out4 = np.zeros((B, 4))
+        J = np.zeros((B, 6)) if want_grad else None
+        check(self._ctx, lib.dsac_loss_frames(self._ctx, B, ptr(est), ptr(gt), ptr(out4), ptr(J)))
+        return dict(out4=out4, grad=J) if want_grad else dict(out4=out4)
+
     # ---- K1 ---------------------------------------------------------------------------------------
     def sample(self, N, seed=1305, thr=10.0, max_tries=1 << 20, sets=None, out=None):
         """Sampling loop of processImage (cnn_softam.h:1010-1060).  Returns (poses N x 6, sets N x 4, ok N)."""

@@ -220,7 +220,8 @@ DSAC_API int dsac_last_pose_gradients(dsac_ctx* ctx, int N, double* G6);
  * fewer than min_inl (50), otherwise solvePnP(CV_ITERATIVE, useExtrinsicGuess) restarts from the current
  * pose.  pert_px_c (B x 2: pixel or -1, channel) / pert_value (B) replace one coordinate per replica, which
  * is dRefineObj's localEstObj (:887,901).  out_poses B x 6 (cv).  inlier_map (H*W int32, += 1 per
- * selection) is only written for replica 0 and only when non-NULL. */
+ * selection) is only written for replica 0 and only when non-NULL.  With a frame batch (dsac_set_frames) B = frames x k problems, problem b
+ * refines against frame b / k, no perturbations, and inlier_map (if given) is B x H*W, one map per problem. */
 DSAC_API int dsac_refine(dsac_ctx* ctx, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                 const int32_t* pert_px_c_or_null, const float* pert_value_or_null, double* out_poses, int32_t* inlier_map_or_null,
                 int32_t* steps_done_or_null);
@@ -271,6 +272,23 @@ DSAC_API int dsac_gather_patches(dsac_ctx* ctx, const uint8_t* bgr, int H, int W
  * 6-vector poseGT.getRodVecAndTrans().  out4 = {loss, rotErr[deg], tErr[mm], correct(5deg/50mm)};
  * J6_or_null = dLossMax w.r.t. the jp 6-vector of est. */
 DSAC_API int dsac_loss(dsac_ctx* ctx, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+/* maxLoss / dLossMax of B estimates, each against ITS OWN ground truth (est_cv6, gt_jp6 B x 6): the per-image evaluation of
+ * core/test_ransac_softam.cpp:129-157 for a batch of images. */
+DSAC_API int dsac_loss_frames(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+
+/* ---- the whole test-time unit of work ------------------------------------------------------------------ */
+/* processImage (core/cnn_softam.h:960-1179, called per image by core/test_ransac_softam.cpp:97-157) for EVERY frame set with dsac_set_frame /
+ * dsac_set_frames, one launch per stage for all frames: K1 sample + P3P, K2 error images + soft-inlier sums (the score-CNN seam; scores are
+ * scale * soft-inlier count), K3 softmax / entropy / soft-argmax pose, K6 the refinement loop (one wave per frame; perm = steps x H*W pixel
+ * permutations shared by all frames -- the reference re-seeds a default mt19937 per image, :1104), K7 maxLoss against each frame's ground truth
+ * (gt_jp6 frames x 6; NULL with out4 NULL: no loss).  Frame f draws from the random stream of seed + f, i.e. the result equals F single-frame
+ * calls with seeds seed, seed + 1, ... bit for bit.  Outputs: poses / sets_out / ok / w (frames * hyps_per_frame), entropy (frames),
+ * avg6 / ref6 (frames x 6, cv), steps_done (frames), inlier_maps (frames x H*W, zeroed here, or NULL), out4 (frames x 4: loss, rotErr deg,
+ * tErr mm, correct), err_or_null (frames * hyps_per_frame x H*W), scores_or_null. */
+DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta, double scale,
+                        const int32_t* perm, int steps, int max_inl, int min_inl, const double* gt_jp6_or_null, double* poses, int32_t* sets_out,
+                        uint8_t* ok, float* err_or_null, double* scores_or_null, double* w, double* entropy, double* avg6, double* ref6,
+                        int32_t* steps_done, int32_t* inlier_maps_or_null, double* out4_or_null);
 
 /* ---- gradient assembly ------------------------------------------------------------------------------ */
 /* Replaces core/train_ransac_softam.cpp:344-376: with v6 = dLoss/dRef * dRef/dAvg (1 x 6),

@@ -24,6 +24,16 @@ def test_algorithmic_bytes_formula():
     assert b.algorithmic_bytes_k2(256, P, explicit_uv=False, write_err=False) == 12 * P + 48 * 256 + 4 * 256
 
 
+def test_soft_only_mode_is_priced_against_the_valu_roof():
+    """the fused soft-inlier mode is VALU-bound (36 flop per pair, 12 B per pixel); its roofline object names the fp32 vector
+    peak and never an HBM fraction."""
+    b = _bench()
+    r = b.soft_only_roofline(2048, 640 * 480, 384e-6, 10)  # round 2's measurement: 384 us per 8-frame launch
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == b.VALU_PEAK_TFLOPS == 157.3
+    assert r["flop_per_launch"] == 2048 * 640 * 480 * 36 and abs(r["achieved"] - 58.98) < 0.01 and abs(r["frac"] - 0.375) < 1e-3
+    assert "GB/s" not in json.dumps(r) and "hbm" not in json.dumps(r).lower()
+
+
 import pytest
 
 

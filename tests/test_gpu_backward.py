@@ -2,8 +2,8 @@
 
 Tolerances: the oracle differentiates in fp64 like the reference; K4 projects in fp32 and accumulates in
 fp32 per tile / fp64 across tiles.  Gradients are compared on the scale of the largest entry:
-  max |grad_gpu - grad_oracle| <= 2e-3 * max |grad_oracle|     (1e-3 "fp32 fast mode"; the
-  extra factor covers cells whose error sits within fp32 rounding of the clamp / inlier guards)
+  max |grad_gpu - grad_oracle| <= 1e-3 * max |grad_oracle|     (1e-3 "fp32 fast mode"; round 2 allowed 2e-3 here,
+  measured 1e-5 .. 2e-4 with the one-transcendental pair arithmetic; tests/test_gpu_backward_big.py has the benchmarked shapes)
 and the relative l2 error must be <= 5e-4.
 """
 import numpy as np
@@ -39,7 +39,7 @@ def test_dscore_parity_reference_size(engine, orc, frame40, quirk):
     ref, G6, S = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], 40, 40, fr["cam"], quirk_transpose=quirk)
     emax, el2 = _rel(engine.dScore(poses, sets, d_err, dpnp=_oracle_dpnp(orc, fr, sets), quirk_transpose=quirk), ref)
     print("dScore 40x40 quirk=%s: max-rel %.3e l2-rel %.3e" % (quirk, emax, el2))
-    assert emax <= 2e-3 and el2 <= 5e-4
+    assert emax <= 1e-3 and el2 <= 5e-4
     # the internally computed dPNP (K5) gives the same result as K5's output supplied by the caller
     got = engine.dScore(poses, sets, d_err, quirk_transpose=quirk)
     got2 = engine.dScore(poses, sets, d_err, dpnp=engine.dPNP(sets), quirk_transpose=quirk)
@@ -86,7 +86,7 @@ def test_dscore_parity_full_resolution(engine, orc, frame_full):
     got = engine.dScore(poses, sets, d_err)
     emax, el2 = _rel(got, ref)
     print("dScore 640x480: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 2e-3 and el2 <= 5e-4
+    assert emax <= 1e-3 and el2 <= 5e-4
 
 
 @pytest.mark.parametrize("H,W", [(37, 41), (5, 3)])
@@ -103,7 +103,7 @@ def test_dscore_ragged(engine, orc, synth, H, W):
     ref, _, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], H, W, fr["cam"])
     got = engine.dScore(poses, sets, d_err)
     emax, el2 = _rel(got, ref)
-    assert emax <= 2e-3 and el2 <= 1e-3
+    assert emax <= 1e-3 and el2 <= 1e-3
 
 
 def test_soft_score_backward(engine, orc, frame40):
@@ -120,7 +120,7 @@ def test_soft_score_backward(engine, orc, frame40):
     got = engine.dSoftScore(poses, sets, g, tau=tau, beta=beta)
     emax, el2 = _rel(got, ref)
     print("soft score backward: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 2e-3 and el2 <= 5e-4
+    assert emax <= 1e-3 and el2 <= 5e-4
 
 
 def test_path1_and_softmax_backward(engine, orc, frame40):
@@ -158,7 +158,7 @@ def test_every_k4_form_against_the_oracle(engine, orc, synth, frame40, frame_ful
             ref, G6, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], 40, 40, fr["cam"], quirk_transpose=quirk)
             got = engine.dScore(poses, sets, d_err, dpnp=J, quirk_transpose=quirk)
             emax, el2 = _rel(got, ref)
-            assert emax <= 2e-3 and el2 <= 5e-4, (variant, quirk, emax, el2)
+            assert emax <= 1e-3 and el2 <= 5e-4, (variant, quirk, emax, el2)
         pg = engine.lastPoseGradients(N)
         rel = np.abs(pg - G6).max(1) / np.abs(G6).max(1)
         assert np.median(rel) <= 1e-4 and rel.max() <= 1e-3
@@ -172,14 +172,14 @@ def test_every_k4_form_against_the_oracle(engine, orc, synth, frame40, frame_ful
         # differences then amplifies the last-bit differences between the CPU's and the GPU's P3P far beyond K4's own error, see test_dpnp_parity)
         J = np.stack([orc.dPNP(fr["uv"][s_], fr["xyz"][s_], fr["cam"]) for s_ in sets])
         emax, el2 = _rel(engine.dScore(poses, sets, d_err, dpnp=J), ref)
-        assert emax <= 2e-3 and el2 <= 5e-4, (variant, "N=300", emax, el2)
+        assert emax <= 1e-3 and el2 <= 5e-4, (variant, "N=300", emax, el2)
         # fused soft-inlier form
         g = rng.normal(size=N)
         err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], 40, 40, fr["cam"]).astype(np.float64)
         s = 1.0 / (1.0 + np.exp(-0.5 * (10.0 - err)))
         ref, _, _ = orc.dScore(sets, g[:, None] * (-0.5) * s * (1 - s), fr["xyz"], fr["uv"], 40, 40, fr["cam"])
         emax, el2 = _rel(engine.dSoftScore(poses, sets, g, tau=10.0, beta=0.5, dpnp=J), ref)
-        assert emax <= 2e-3 and el2 <= 5e-4, (variant, "soft", emax, el2)
+        assert emax <= 1e-3 and el2 <= 5e-4, (variant, "soft", emax, el2)
         # 640 x 480, implicit pixel grid, ragged hypothesis count, zero-weight and zero-depth cells
         fr = dict(frame_full)
         xyz = fr["xyz"].copy()
@@ -194,7 +194,7 @@ def test_every_k4_form_against_the_oracle(engine, orc, synth, frame40, frame_ful
         got = engine.dScore(poses, sets, d_err)
         emax, el2 = _rel(got, ref)
         print("k4 variant %d, 640x480: max-rel %.3e l2-rel %.3e" % (variant, emax, el2))
-        assert np.isfinite(got).all() and emax <= 2e-3 and el2 <= 5e-4
+        assert np.isfinite(got).all() and emax <= 1e-3 and el2 <= 5e-4
     finally:
         engine.set_option("k4_variant", -1)
 
@@ -221,9 +221,9 @@ def test_quirk7_rot_writeback(engine, orc, frame40):
     e_fixed, _ = _rel(got, fixed)
     e_quirk, _ = _rel(got, quirk)
     print("engine vs fixed mode %.2e, vs parity mode %.2e" % (e_fixed, e_quirk))
-    assert e_fixed <= 2e-3
+    assert e_fixed <= 1e-3
     if regular.all():
-        assert e_quirk <= 2e-3
+        assert e_quirk <= 1e-3
 
 
 def test_fused_path1_chain_equals_the_separate_calls(engine, orc, synth, frame40):
@@ -254,5 +254,10 @@ def test_fused_path1_chain_equals_the_separate_calls(engine, orc, synth, frame40
     dLo = orc.dLossMax(orc.cv_to_jp6(fwd["refAvgHyp"]), gt)
     go, g_o = orc.path1_pnp_and_softmax_bwd(dLo @ Jh, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], fr["xyz"], fr["uv"], 40, 40, fr["cam"],
                                            grad=(dLo @ Jo).reshape(1600, 3))
-    assert np.abs(r["g"] - 0.25 * g_o).max() <= 1e-3 * np.abs(g_o).max() * 0.25 + 1e-12  # nearly one-hot weights: the score gradients are ~0
-    assert np.abs(r["grad"] - go).max() <= 1e-2 * np.abs(go).max()
+    print("fused path-I chain vs the oracle: score gradients %.2e, gradient %.2e (relative to the largest entry)" %
+          (np.abs(r["g"] - 0.25 * g_o).max() / max(np.abs(g_o).max() * 0.25, 1e-300), np.abs(r["grad"] - go).max() / np.abs(go).max()))
+    assert np.abs(r["g"] - 0.25 * g_o).max() <= 1e-6 * np.abs(g_o).max() * 0.25 + 1e-12  # nearly one-hot weights: the score gradients are ~0
+    # stated tolerance of the fp64 chain (measured 5e-8 where the gradient is a gradient); on this frame the weights are nearly one-hot and
+    # the refinement converges to the same optimum from every start: the whole gradient (2.6e-8) is the round-off of the central differences, on
+    # both sides, hence the absolute floor (as in tests/test_gpu_pipeline.py)
+    assert np.abs(r["grad"] - go).max() <= 1e-6 * np.abs(go).max() + 1e-10 * max(1.0, np.abs(dLo).max())

@@ -66,7 +66,7 @@ def test_process_image_and_backward_reference_size(engine, orc, synth, frame40):
     print("end-to-end gradient: max-rel %.3e l2-rel %.3e, nonzero rows %d, max |grad| %.3e (|dLoss/dRef| max %.3e)" %
           (emax, el2, (np.abs(ref_grad).sum(1) > 0).sum(), np.abs(ref_grad).max(), np.abs(dL).max()))
     assert np.abs(ref_grad).max() >= 1e-6 * np.abs(dL).max()  # a real gradient, not the finite differences' round-off
-    assert emax <= 1e-2 and el2 <= 1e-2
+    assert emax <= 1e-5 and el2 <= 1e-5  # measured 5e-8 (the chain is fp64 except K4's fp32 projection)
 
 
 def test_process_image_full_resolution_with_score_fn(engine, orc, synth, frame_full):

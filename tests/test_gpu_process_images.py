@@ -1,0 +1,94 @@
+"""dsac_process_images: the reference's whole test-time unit of work -- processImage of core/cnn_softam.h:960-1179 as
+core/test_ransac_softam.cpp:97-157 calls it per image -- for a batch of frames, one launch per stage (K1, K2, K3, K6 with one wave per frame,
+K7).  Parity: a batch equals F single-frame processImage calls (seeds seed + f) bit for bit, and the single-frame call is the one the oracle /
+golden tests pin (tests/test_gpu_pipeline.py, tests/test_gpu_reference_golden.py); the refinement and the loss of every frame are also compared
+with the oracle directly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,F,N", [(40, 40, 5, 128), (48, 64, 3, 256)])
+def test_batch_equals_single_frame_process_image(engine, orc, synth, H, W, F, N):
+    frames = [synth.chess_like_frame(H, W, seed=500 + f, quantise_int16=(H == 40)) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv = frames[0]["uv"]
+    cam = frames[0]["cam"]
+    perm = synth.fast_permutations(H * W, 8)
+    gts = np.stack([orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for fr in frames])
+    engine.set_frames(xyz, uv, H, W, cam)
+    err = np.zeros((F * N, H * W), np.float32)
+    b = engine.processImages(N, perm, gt_jp6=gts, seed=77, err=err, want_inlier_maps=True)
+    assert b["ok"].all() and (b["refSteps"] == 8).all()
+    for f in range(F):
+        engine.set_frame(xyz[f], uv, H, W, cam)
+        e1 = np.zeros((N, H * W), np.float32)
+        s = engine.processImages(N, perm, gt_jp6=gts[f:f + 1], seed=77 + f, err=e1, want_inlier_maps=True)  # the same export on ONE frame
+        sl = slice(f * N, (f + 1) * N)
+        assert np.array_equal(b["sampledPoints"][sl], s["sampledPoints"]) and np.array_equal(b["hyps"][sl], s["hyps"])
+        assert np.array_equal(err[sl], e1)
+        assert np.array_equal(b["sfScores"][sl], s["sfScores"]) and b["sfEntropy"][f] == s["sfEntropy"][0]
+        assert np.array_equal(b["avgHyp"][f], s["avgHyp"][0]) and np.array_equal(b["refAvgHyp"][f], s["refAvgHyp"][0])
+        assert np.array_equal(b["inlierMaps"][f], s["inlierMaps"][0]) and b["refSteps"][f] == s["refSteps"][0]
+        assert np.array_equal(b["out4"][f], s["out4"][0])
+        # ... and the host-orchestrated mirror of processImage (Engine.processImage: separate C-ABI calls, poses re-staged through fp64 Rodrigues)
+        m = engine.processImage(N=N, seed=77 + f, perm=perm, gt_jp6=gts[f])
+        assert np.array_equal(m["sampledPoints"], s["sampledPoints"]) and np.array_equal(m["hyps"], s["hyps"])
+        assert np.abs(m["sfScores"] - s["sfScores"]).max() <= 1e-6 and np.abs(m["refAvgHyp"] - s["refAvgHyp"][0]).max() <= 1e-5 * max(1.0, np.abs(m["refAvgHyp"]).max())
+        assert abs(m["loss"] - s["out4"][0][0]) <= 1e-5 * max(1.0, m["loss"]) and m["correct"] == bool(s["out4"][0][3])
+        # the oracle on the same soft-argmax pose: refinement (core/cnn_softam.h:1099-1154) and loss (core/maxloss.h:69-79)
+        ref_o, imap_o, sd_o = orc.refine(b["avgHyp"][f], perm, xyz[f], uv, H, W, cam, want_inlier_map=True)
+        assert np.abs(ref_o[0] - b["refAvgHyp"][f]).max() <= 1e-7 * max(1.0, np.abs(ref_o).max()) and np.array_equal(imap_o, b["inlierMaps"][f])
+        R1, t1 = orc.cv2our(b["refAvgHyp"][f])
+        R2 = orc.rodrigues_vec2mat(gts[f][:3])
+        loss_o = orc.maxLoss(R1, t1, R2, gts[f][3:])
+        assert abs(loss_o - b["out4"][f][0]) <= 1e-9 * max(1.0, loss_o)
+    # the batched refinement / loss exports on their own
+    engine.set_frames(xyz, uv, H, W, cam)
+    from dsac_amd.capi import lib, ptr, check
+    ref2, sd2, maps2 = np.zeros((F, 6)), np.zeros(F, np.int32), np.zeros((F, H * W), np.int32)
+    check(engine._ctx, lib.dsac_refine(engine._ctx, F, ptr(np.ascontiguousarray(b["avgHyp"])), ptr(perm), 8, 100, 50, 10.0, None, None, ptr(ref2), ptr(maps2), ptr(sd2)))
+    assert np.array_equal(ref2, b["refAvgHyp"]) and np.array_equal(maps2, b["inlierMaps"]) and np.array_equal(sd2, b["refSteps"])
+    assert np.array_equal(engine.maxLossFrames(ref2, gts)["out4"], b["out4"])
+    with pytest.raises(Exception):
+        engine.processImages(100, perm)  # not a multiple of 128 on a frame batch
+
+
+def test_process_images_at_baseline_size_on_device(engine, synth):
+    """640 x 480, 4 frames x 256 hypotheses, every buffer on the GPU: the batch reproduces the single-frame calls bit for bit."""
+    import torch
+    H, W, F, N = 480, 640, 4, 256
+    P = H * W
+    dev = torch.device("cuda", 0)
+    frames = [synth.chess_like_frame(H, W, seed=1305 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    perm = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    gts = torch.zeros(F, 6, dtype=torch.float64, device=dev)
+
+    def bufs(nf):
+        n = nf * N
+        return dict(hyps=torch.zeros(n, 6, dtype=torch.float64, device=dev), sampledPoints=torch.zeros(n, 4, dtype=torch.int32, device=dev),
+                    ok=torch.zeros(n, dtype=torch.uint8, device=dev), scores=torch.zeros(n, dtype=torch.float64, device=dev),
+                    sfScores=torch.zeros(n, dtype=torch.float64, device=dev), sfEntropy=torch.zeros(nf, dtype=torch.float64, device=dev),
+                    avgHyp=torch.zeros(nf, 6, dtype=torch.float64, device=dev), refAvgHyp=torch.zeros(nf, 6, dtype=torch.float64, device=dev),
+                    refSteps=torch.zeros(nf, dtype=torch.int32, device=dev), out4=torch.zeros(nf, 4, dtype=torch.float64, device=dev))
+    b = bufs(F)
+    err = torch.empty(F * N, P, dtype=torch.float32, device=dev)
+    engine.set_frames(xyz, None, H, W, frames[0]["cam"], borrow=True)
+    engine.processImages(N, perm, gt_jp6=gts, seed=9, err=err, out=b)
+    engine.synchronize()
+    assert int(b["ok"].sum().item()) == F * N and bool((b["refSteps"] == 8).all())
+    for f in range(F):
+        s = bufs(1)
+        e1 = torch.empty(N, P, dtype=torch.float32, device=dev)
+        engine.set_frame(xyz[f], None, H, W, frames[0]["cam"], borrow=True)
+        engine.processImages(N, perm, gt_jp6=gts[f:f + 1], seed=9 + f, err=e1, out=s)
+        engine.synchronize()
+        sl = slice(f * N, (f + 1) * N)
+        assert torch.equal(b["hyps"][sl], s["hyps"]) and torch.equal(err[sl], e1)
+        # a batch of 4 x 256 x 640x480 takes the big-launch K2 form, one frame the single-frame form: same error images, scores summed in another order
+        assert torch.allclose(b["sfScores"][sl], s["sfScores"], rtol=1e-6, atol=1e-12)
+        assert torch.allclose(b["refAvgHyp"][f], s["refAvgHyp"][0], rtol=1e-6, atol=1e-6) and torch.allclose(b["out4"][f], s["out4"][0], rtol=1e-6, atol=1e-6)
+    del err
+    torch.cuda.empty_cache()

@@ -4,7 +4,7 @@ synthetic frame: processImage forward, per-function Jacobians and the training l
 The engine replays the frame from the reference's own draws (sampling grid, minimal sets, shuffles).
 
 Tolerances (fp32 projection in K2/K4, fp64 elsewhere; see tests/test_gpu_forward.py for the P3P note):
-  error images 1e-3 px (clamp edge excluded) | softmax weights 2e-4 abs | averaged pose 1e-4 rad / 0.05 mm |
+  error images 1e-3 px (clamp edge excluded) | softmax weights 1e-4 abs | averaged pose 1e-4 rad / 0.05 mm |
   refined pose 1e-5 rel | loss 1e-4 | dScore and end-to-end gradient 1e-4 of the largest entry and in l2 (measured
   1e-6; the reference's own rotation drift, quirk 7, is not reproduced by the product).
 """
@@ -59,12 +59,12 @@ def test_error_images_scores_and_soft_argmax(eng, g):
     soft = np.zeros(64)
     eng.reproject(g["hyps"], soft=soft, tau=float(g["tau"]), beta=float(g["beta"]))
     w, ent, avg = eng.softMax(soft, float(g["alpha"]), g["hyps"])
-    assert np.abs(w - g["sfScores"]).max() <= 2e-4
+    assert np.abs(w - g["sfScores"]).max() <= 1e-4  # softmax weights 1e-4 end to end
     assert abs(ent[0] - float(g["sfEntropy"])) <= 2e-3
     assert np.abs(avg[:3] - g["avgHyp"][:3]).max() <= 1e-4 and np.abs(avg[3:] - g["avgHyp"][3:]).max() <= 5e-2
     # the fused call (K1 -> K2 -> K3) on the reference's sets gives the same distribution
     out = eng.scoreHypotheses(64, sets=g["sets"], thr=float(g["thr"]), tau=float(g["tau"]), beta=float(g["beta"]), scale=float(g["alpha"]))
-    assert np.abs(out[4] - g["sfScores"]).max() <= 2e-4
+    assert np.abs(out[4] - g["sfScores"]).max() <= 1e-4
 
 
 def test_refinement_and_loss(eng, g):
@@ -91,7 +91,7 @@ def test_jacobians(eng, g):
     want = g["dScore_jac_sum"]
     emax, el2 = np.abs(grad - want).max() / np.abs(want).max(), np.linalg.norm(grad - want) / np.linalg.norm(want)
     print("dScore vs the reference: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 1e-4 and el2 <= 1e-4  # measured 1.2e-6
+    assert emax <= 1e-5 and el2 <= 1e-5  # measured 1.2e-6
 
 
 def test_training_backward_end_to_end(eng, g):
@@ -111,4 +111,4 @@ def test_training_backward_end_to_end(eng, g):
     emax = np.abs(bwd["grad"] - want).max() / np.abs(want).max()
     el2 = np.linalg.norm(bwd["grad"] - want) / np.linalg.norm(want)
     print("end-to-end gradient vs the reference: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 1e-4 and el2 <= 1e-4  # measured 7e-7
+    assert emax <= 1e-5 and el2 <= 1e-5  # measured 7e-7

@@ -26,7 +26,7 @@ def test_forward_selection_refinement_expected_loss(engine, g):
     fwd = engine.processImageDSAC(N=N, sets=g["sets"], perm=g["pixelIdxs"], gt_jp6=g["gt_jp6"], thr=float(g["thr"]), inlierCount=int(g["inlier_count"]),
                                   tau=float(g["tau"]), beta=float(g["beta"]), alpha=float(g["alpha"]), draw_u=None)
     assert fwd["ok"].all()
-    assert np.abs(fwd["sfScores"] - g["sfScores"]).max() <= 2e-4 and abs(fwd["sfEntropy"] - float(g["sfEntropy"])) <= 2e-3
+    assert np.abs(fwd["sfScores"] - g["sfScores"]).max() <= 1e-4 and abs(fwd["sfEntropy"] - float(g["sfEntropy"])) <= 2e-3
     assert fwd["hypIdx"] == int(g["hypIdx"])
     # refinement restarts from the engine's own P3P poses (triad alignment): compare where LM converged from both starts
     close = np.isclose(fwd["refHyps"], g["refHyps"], rtol=1e-5, atol=1e-6).all(1)

@@ -235,11 +235,14 @@ def test_two_contexts_on_two_host_threads(orc, synth):
 def test_unknown_k2_variant_is_an_error(engine, frame40):
     import dsac_amd
     engine.set_frame(frame40["xyz"], frame40["uv"], 40, 40, frame40["cam"])
-    engine.set_option("k2_variant", 99)
-    try:
+    # rejected where it is set (round 2 accepted it and failed at the next launch, leaving the profiling hooks with a never-recorded event pair)
+    for key, bad in (("k2_variant", 99), ("k2_variant", 63), ("k4_variant", 7), ("k4_variant", -2)):
         with pytest.raises(dsac_amd.capi.DsacError):
-            engine.getDiffMap(np.zeros((2, 6)))
-    finally:
-        engine.set_option("k2_variant", -1)
+            engine.set_option(key, bad)
+    engine.profile_enable(True)
+    engine.getDiffMap(np.zeros((2, 6)))  # the context still works and still profiles
+    ms, n = engine.profile_read(0)
+    engine.profile_enable(False)
+    assert n == 1 and ms > 0
     with pytest.raises(dsac_amd.capi.DsacError):
         engine.set_option("no_such_knob", 1)
