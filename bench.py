@@ -71,9 +71,14 @@ def parse_args(argv=None):
     ap.add_argument("--hyps", type=int, default=256)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--workload", choices=("frames", "config3"), default="frames",
+    ap.add_argument("--workload", choices=("frames", "config3", "config5"), default="frames",
                     help="frames: BASELINE.json configs[1] frames, --frames-per-step per step and rank (weak scaling).  config3: configs[3], 64 images x "
-                         "--hyps hypotheses sharded over the ranks, results gathered on rank 0 (strong scaling); a step is one pass over the 64 images")
+                         "--hyps hypotheses sharded over the ranks, every image through the whole processImage (sample, score, soft-argmax, 8 refinement "
+                         "steps, loss), refined poses + losses + weights gathered (strong scaling); a step is one pass over the 64 images.  config5: "
+                         "configs[4], one end-to-end training step per rank and step (one frame per GPU, both CNNs, geometry forward + backward, the "
+                         "gradient exchange of ~157 MB over RCCL), weak scaling")
+    ap.add_argument("--reduce-mode", choices=("all_reduce", "reduce_scatter"), default="all_reduce",
+                    help="config5: how a gradient bucket travels (reduce_scatter = reduce-scatter + all-gather over all xGMI links, RCCL only)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DSAC_BENCH_STREAMS", "1")),
                     help="engine contexts (HIP streams) per GPU")
     ap.add_argument("--overlap", choices=("none", "pipeline", "gated", "stages", "frames"), default=os.environ.get("DSAC_BENCH_OVERLAP", "gated"),
@@ -168,8 +173,8 @@ def init_distributed(args):
             if int(probe.item()) != world:
                 raise RuntimeError("RCCL probe all-reduce returned %r for %d ranks" % (probe.item(), world))
         except Exception as e:  # noqa: BLE001 -- RCCL unusable on this node
-            if os.environ.get("DSAC_BENCH_NO_FALLBACK") or args.workload == "config3":
-                raise  # configs[3] gathers its results with the backend: no silent change there
+            if os.environ.get("DSAC_BENCH_NO_FALLBACK") or args.workload in ("config3", "config5"):
+                raise  # configs[3] gathers its results and configs[4] exchanges its gradients with the backend: no silent change there
             # The default workload has NO data-path collective (images shard, every rank scores its own): RCCL only carries the barrier
             # and the max of the timing scalars.  Rather than lose the scaling line, carry those over gloo and say so in the JSON.
             global BACKEND_NOTE
@@ -224,9 +229,11 @@ def run_dry(args, rank, world, dist):
     from dsac_amd import dist as ddist
     N = args.hyps
     K = args.steps
+    if args.workload == "config5":
+        return run_config5(args, rank, 0, world, "gloo", dist)
     if args.workload == "config3":
         mine = ddist.shard_images(CONFIG3_IMAGES, rank, world)
-        res = torch.tensor([[float(i)] * (6 + N) for i in mine], dtype=torch.float64).reshape(len(mine), 6 + N)
+        res = torch.tensor([[float(i)] * (10 + N) for i in mine], dtype=torch.float64).reshape(len(mine), 10 + N)
         t0 = time.perf_counter()
         for _ in range(K):
             allres = ddist.gather_frame_results(mine, res, CONFIG3_IMAGES)
@@ -251,6 +258,138 @@ def run_dry(args, rank, world, dist):
                           "config": {"workload": "DRY RUN (no GPU work): %s" % args.workload, "frames_per_step_all_ranks": per_step}}), flush=True)
 
 
+def run_config5(args, rank, local_rank, world, backend, dist):
+    """BASELINE.json configs[4] / SURVEY.md 8(d) config 5: one end-to-end training step per rank and step -- one frame per GPU
+    (core/train_ransac_softam.cpp:227-235 trains on one image per step), scene-coordinate CNN and score CNN with the reference's architectures and
+    random weights, the geometry forward + backward on the engine (K1 ... K7, K4), the gradient exchange of both CNNs (~157 MB fp32) launched from
+    inside the backward passes (dsac_amd.dist.GradientReducer) and waited for at the optimizer step.  Reports the step, its geometry share, the
+    stand-alone cost of the exchange and how much of it the step still shows.  --dry-run: small CPU networks over gloo (launcher / reducer /
+    reporting test), no GPU."""
+    import torch
+    from dsac_amd import dist as ddist
+    K, Wm, N = args.steps, args.warmup, args.hyps
+    distributed = world > 1
+
+    def barrier(devsync=None):
+        if devsync is not None:
+            torch.cuda.synchronize(devsync)
+        if distributed:
+            dist.barrier()
+
+    def rmax(x, cdev):
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.dry_run:
+        torch.manual_seed(rank)
+        nets = [torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 3)),
+                torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 1))]
+        reds = [ddist.GradientReducer(n.parameters(), bucket_bytes=16 << 10, mode=args.reduce_mode) for n in nets]
+        x = [torch.randn(16, 64), torch.randn(16, 32)]
+        cdev = torch.device("cpu")
+        barrier()
+        t0 = time.perf_counter()
+        ncoll = 0
+        for _ in range(K):
+            for n_, x_ in zip(nets, x):
+                for p in n_.parameters():
+                    p.grad = None if p.grad is None else p.grad.zero_()
+                n_(x_).sum().backward()
+            ncoll = sum(r.wait() for r in reds)
+        barrier()
+        step_s = rmax((time.perf_counter() - t0) / K, cdev)
+        grads = [p.grad for n_ in nets for p in n_.parameters()]
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ddist.all_reduce_gradients(grads, bucket_bytes=16 << 10)
+        coll_s = rmax((time.perf_counter() - t0) / K, cdev)
+        nparam = sum(g.numel() for g in grads)
+        line = dict(step_ms=step_s * 1e3, geometry_ms=None, cnn_ms=None, collective_ms=coll_s * 1e3 if distributed else 0.0, collectives_per_step=ncoll,
+                    grad_bytes=4 * nparam, dry_run=True)
+        value = N * world / step_s
+        dev_name = "cpu"
+    else:
+        from dsac_amd import e2e, synth
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        di = local_rank % ndev
+        torch.cuda.set_device(di)
+        ts = e2e.TrainStep(di, hyps=N, sub_sample=0.01, reduce_mode=args.reduce_mode)
+        dev = ts.dev
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        fr = synth.chess_like_frame(40, 40, seed=1305 + rank, quantise_int16=True)  # the reference's 40 x 40 stratified sub-sample (core/lua_calls.h:33)
+        patches = torch.rand(1600, 3, 42, 42, device=dev) * 255
+        uv = torch.as_tensor(fr["uv"], device=dev)
+        off = torch.as_tensor(fr["xyz"], device=dev)  # random-weight CNN predicts ~0: the synthetic scene rides on an offset, the gradient path is the real one
+        perm = synth.fast_permutations(1600, 8)
+        gt = synth.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+        for i in range(Wm):
+            ts.step(patches, uv, gt, perm, seed=1000 + i, xyz_offset_mm=off)
+        barrier(dev)
+        t0 = time.perf_counter()
+        for i in range(K):
+            out = ts.step(patches, uv, gt, perm, seed=2000 + i, xyz_offset_mm=off)
+        barrier(dev)
+        step_s = rmax((time.perf_counter() - t0) / K, cdev)
+        # the same steps with the segment events on: geometry vs CNN time on the stream (events cost a few us each; not part of step_ms)
+        ts.timing = True
+        geo = cnn = 0.0
+        for i in range(5):
+            ts.step(patches, uv, gt, perm, seed=3000 + i, xyz_offset_mm=off)
+            torch.cuda.synchronize(dev)
+            geo += ts.last_segments_ms["geometry"] / 5
+            cnn += ts.last_segments_ms["cnn"] / 5
+        ts.timing = False
+        # the exchange alone (no overlap): launch + wait of the same buckets on the gradients that are there
+        coll_s = 0.0
+        if distributed:
+            grads = [p.grad for p in ts.params()]
+            for _ in range(2):
+                ddist.all_reduce_gradients(grads, mode=args.reduce_mode)
+            barrier(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ddist.all_reduce_gradients(grads, mode=args.reduce_mode)
+            barrier(dev)
+            coll_s = rmax((time.perf_counter() - t0) / 10, cdev)
+        # ... and the step without any exchange (what the exchange adds to the step = what is NOT hidden under the backward)
+        local_s = step_s
+        if distributed:
+            ts.reducer_score.enabled = ts.reducer_obj.enabled = False
+            for h in ts.reducer_score._hooks + ts.reducer_obj._hooks:
+                h.remove()
+            barrier(dev)
+            t0 = time.perf_counter()
+            for i in range(K):
+                ts.step(patches, uv, gt, perm, seed=4000 + i, xyz_offset_mm=off)
+            barrier(dev)
+            local_s = rmax((time.perf_counter() - t0) / K, cdev)
+        nparam = sum(p.numel() for p in ts.params())
+        line = dict(step_ms=step_s * 1e3, geometry_ms=geo, cnn_ms=cnn, collective_ms=coll_s * 1e3, collective_exposed_ms=max(0.0, (step_s - local_s) * 1e3),
+                    step_without_exchange_ms=local_s * 1e3, collectives_per_step=out["collectives"], grad_bytes=4 * nparam, last_loss=out["loss"],
+                    accepted=out["accepted"], refine_steps_done=out["ref_steps"])
+        value = N * world / step_s
+        dev_name = torch.cuda.get_device_name(di)
+        ts.engine.close()
+    if rank == 0:
+        out = {"metric": "hypotheses scored/sec over 640x480 coord map", "value": value, "unit": "hyp/s", "n_gpus": world, "steps": K, "warmup": Wm,
+               "ms_per_step": line["step_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[4]: end-to-end training step, ONE frame per GPU and step (40x40 sub-sampled map, %d hypotheses), "
+                                      "scene-coordinate CNN + score CNN (reference architectures, random weights), geometry forward + backward, gradient "
+                                      "exchange over %s" % (N, "RCCL" if backend == "nccl" else backend),
+                          "frames_per_step_all_ranks": world, "frames_per_s": world / (line["step_ms"] * 1e-3), "ranks_joined": world, "backend": backend,
+                          "reduce_mode": args.reduce_mode, "device": dev_name,
+                          "parallelism": "data parallel over %d GPU(s): one image per rank, CNN gradients averaged (buckets launched from autograd hooks, "
+                                         "waited for at the optimizer step)%s" % (world, ("; " + BACKEND_NOTE) if BACKEND_NOTE else "")},
+               "train_step": line}
+        if args.dry_run:
+            out["dry_run"] = True
+        print(json.dumps(out), flush=True)
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -260,6 +399,13 @@ def main(argv=None):
     rank, local_rank, world, backend, dist = init_distributed(args)
     if args.dry_run:
         run_dry(args, rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "config5":
+        run_config5(args, rank, local_rank, world, backend, dist)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -350,7 +496,11 @@ def main(argv=None):
         for b in bufs:
             b["poses"].copy_(torch.from_numpy(rp))
     if config3:
-        results = torch.zeros(len(mine), 6 + N, dtype=torch.float64, device=dev)  # per image: soft-argmax pose (6) + softmax weights (N)
+        # per image: refined pose (6) + loss, rotErr, tErr, correct (4) + softmax weights (N) -- what core/test_ransac_softam.cpp:129-263 logs per image
+        results = torch.zeros(len(mine), 10 + N, dtype=torch.float64, device=dev)
+        perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+        gt3 = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+        ref3, sd3, out43 = torch.zeros(B, 6, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, 4, dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)
 
     staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
@@ -394,11 +544,14 @@ def main(argv=None):
                 nb_ = len(idx)
                 eng.set_frames(xyz_batches[bi], None, H, W, fr["cam"], borrow=True)
                 n_ = nb_ * N
-                eng.scoreHypothesesFrames(N, seed=1305 + 64 * i + mine[idx[0]], thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
-                                          err=b["err"][:n_], out=(b["poses"][:n_], b["sets"][:n_], b["ok"][:n_], b["soft"][:n_], b["w"][:n_],
-                                                                  b["ent"][:nb_], b["avg"][:nb_]))
-                results[idx[0]:idx[0] + nb_, :6] = b["avg"][:nb_]
-                results[idx[0]:idx[0] + nb_, 6:] = b["w"][:n_].view(nb_, N)
+                # the reference's whole per-image unit (test_ransac_softam.cpp:97-157 -> processImage): K1, K2, K3, 8 refinement steps, loss
+                eng.processImages(N, perm3, gt_jp6=gt3[:nb_], seed=1305 + 64 * i + mine[idx[0]], thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5,
+                                  scale=0.1, err=b["err"][:n_],
+                                  out=dict(hyps=b["poses"][:n_], sampledPoints=b["sets"][:n_], ok=b["ok"][:n_], scores=b["soft"][:n_], sfScores=b["w"][:n_],
+                                           sfEntropy=b["ent"][:nb_], avgHyp=b["avg"][:nb_], refAvgHyp=ref3[:nb_], refSteps=sd3[:nb_], out4=out43[:nb_]))
+                results[idx[0]:idx[0] + nb_, :6] = ref3[:nb_]
+                results[idx[0]:idx[0] + nb_, 6:10] = out43[:nb_]
+                results[idx[0]:idx[0] + nb_, 10:] = b["w"][:n_].view(nb_, N)
         st.synchronize()
         return ddist.gather_frame_results(mine, results if backend == "nccl" else results.cpu(), CONFIG3_IMAGES)
 
@@ -522,8 +675,9 @@ def main(argv=None):
         for e_, _ in engines:
             e_.profile_read(0, reset=True)
     if config3 and rank == 0:
-        ws = last[:, 6:].sum(1)
+        ws = last[:, 10:].sum(1)
         assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
+        assert bool((last[:, 6] > 0).all()) and bool(torch.isfinite(last[:, :10]).all()), "config3: gathered refined poses / losses are not finite"
 
     # literal configs[1]: ONE frame per step on the same context (fused call), its own K2 timing
     single = None
@@ -642,6 +796,28 @@ def main(argv=None):
                 proc(10 + i)
             eng.synchronize()
             procimg["%dx%d" % (ww, hh)] = {"us_per_image": (time.perf_counter() - tp) / npi * 1e6, "images": npi, "refine_steps_done": int(sd_d.item())}
+        if batched:
+            # the same unit for the %d frames of a step in ONE call (dsac_process_images: one launch per stage, K6 one wave per frame)
+            Bf = B
+            eng.set_frames(xyz_batches[0], None, H, W, fr["cam"], borrow=True)
+            permB = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+            gtB = torch.zeros(Bf, 6, dtype=torch.float64, device=dev)
+            refB, sdB, o4B = torch.zeros(Bf, 6, dtype=torch.float64, device=dev), torch.zeros(Bf, dtype=torch.int32, device=dev), torch.zeros(Bf, 4, dtype=torch.float64, device=dev)
+            outB = dict(hyps=b["poses"], sampledPoints=b["sets"], ok=b["ok"], scores=b["soft"], sfScores=b["w"], sfEntropy=b["ent"], avgHyp=b["avg"],
+                        refAvgHyp=refB, refSteps=sdB, out4=o4B)
+
+            def procB(i):
+                eng.processImages(N, permB, gt_jp6=gtB, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"], out=outB)
+            for i in range(5):
+                procB(i)
+            eng.synchronize()
+            nb_ = 30
+            tp = time.perf_counter()
+            for i in range(nb_):
+                procB(5 + i)
+            eng.synchronize()
+            procimg["%dx%d_batch_of_%d" % (W, H, Bf)] = {"us_per_image": (time.perf_counter() - tp) / nb_ / Bf * 1e6, "images": nb_ * Bf,
+                                                        "refine_steps_done_min": int(sdB.min().item())}
         eng.profile_read(0, reset=True)
 
     if distributed:
@@ -674,7 +850,8 @@ def main(argv=None):
                 traffic = None
         if config3:
             cfg_name = ("BASELINE.json configs[3]: %d 'chess'-like images x %d hypotheses, %dx%d coord maps, sharded round-robin over %d rank(s) "
-                        "(%d images per launch), results (6 + N per image) gathered" % (CONFIG3_IMAGES, N, W, H, world, B))
+                        "(%d images per launch), every image through the whole processImage (K1 sample+P3P, K2, K3, 8 refinement steps K6, loss K7), "
+                        "results (refined pose 6 + loss / errors 4 + N weights per image) gathered" % (CONFIG3_IMAGES, N, W, H, world, B))
         elif args.kernel_only:
             cfg_name = ("BASELINE.json configs[2]: %d random poses over a %dx%d coord map, K2 only" % (N, W, H) if N >= 1024 else
                         "K2 only on %d random poses over a %dx%d coord map (BASELINE.json configs[2] style at configs[1]'s hypothesis count)" % (N, W, H))

@@ -28,6 +28,8 @@ DSAC_ERR_ALLOC = -5
 DSAC_FRAME_QUANTISE_INT16 = 1
 DSAC_FRAME_BORROW = 2
 DSAC_BWD_QUIRK_TRANSPOSE = 1
+DSAC_BWD_PARITY_FP64 = 2
+DSAC_BWD_QUIRK_ROT_WRITEBACK = 4
 
 # every symbol include/dsac_hip.h declares (tests/test_boundary.py checks the header against this list
 # and the library against both)

@@ -697,6 +697,11 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     if (N < 0 || !poses || !sets || !grad_xyz || (!d_err && !g)) return fail(c, DSAC_ERR_INVALID, "%s: NULL argument", who);
     if ((flags & DSAC_BWD_QUIRK_TRANSPOSE) && c->F.H != c->F.W)
         return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_QUIRK_TRANSPOSE needs a square map (H=%d W=%d)", who, c->F.H, c->F.W);
+    const bool parity = (flags & DSAC_BWD_PARITY_FP64) != 0;
+    if ((flags & DSAC_BWD_QUIRK_ROT_WRITEBACK) && !parity)
+        return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_QUIRK_ROT_WRITEBACK needs DSAC_BWD_PARITY_FP64 (the write-back is a sequential recurrence)", who);
+    if (parity && (!d_err || (long long)N * c->F.P > (1ll << 26)))
+        return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_PARITY_FP64 takes a d_err volume with N*H*W <= 2^26 (reference-sized maps)", who);
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     begin_call(c);
@@ -716,6 +721,15 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         HIP_TRY(c, s.reserve((size_t)N * 72 * sizeof(double)));
         HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>()));
         d_dpnp = s.as<double>();
+    }
+    if (parity) {
+        // fp64 parity mode: the reference's evaluation order, optional rotation write-back (quirk 7)
+        DevBuf& jac = next_slot(c);
+        HIP_TRY(c, jac.reserve((size_t)N * P * 3 * sizeof(double)));
+        HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
+        HIP_TRY(c, dk::score_backward_parity(c->stream, N, d_poses, c->F, d_derr, d_dpnp, d_sets, flags, jac.as<double>(), d_grad, c->g6.as<double>()));
+        c->g6_n = N;
+        return end_call(c);
     }
     const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
     HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image

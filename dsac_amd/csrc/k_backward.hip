@@ -323,8 +323,8 @@ DM_INLINE float row16_sum_f(float v) {  // sum over the 16 lanes of a DPP row, r
     return v;
 }
 
-template <int CH, bool SOFTMODE, bool UV>
-__global__ __launch_bounds__(K4_THREADS, 2) void k_score_backward_mfma(const float* __restrict__ rec, const float* __restrict__ xyz,
+template <int CH, bool SOFTMODE, bool UV, int MINW>
+__global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const float* __restrict__ rec, const float* __restrict__ xyz,
                                                                     const float* __restrict__ uv, const float* __restrict__ d_err,
                                                                     const double* __restrict__ g, float* __restrict__ grad_part,
                                                                     float* __restrict__ G12_part, int N, int P, int W, int PT, int NT, int G,
@@ -524,16 +524,18 @@ __global__ __launch_bounds__(K4_THREADS, 2) void k_score_backward_mfma(const flo
     }
 }
 
-// chunks of 16 pixels per wave and trip of the matrix-core form: variant 1..5 -> 2, 4, 5, 6, 3
+// chunks of 16 pixels per wave and trip of the matrix-core form: variant 1..5 -> 2, 4, 5, 6, 3; the high-occupancy forms 6 -> 2 chunks at >= 4
+// waves per SIMD (<= 128 VGPRs), 7 -> 3 chunks at >= 3 waves per SIMD (<= 168 VGPRs), both with 128-hypothesis tiles (37 KB of LDS: 4 workgroups per CU)
 static int k4m_chunks(int variant) {
     switch (variant) {
-        case 1: return 2;
+        case 1: case 6: return 2;
         case 3: return 5;
         case 4: return 6;
-        case 5: return 3;
+        case 5: case 7: return 3;
         default: return 4;
     }
 }
+static int k4m_min_waves(int variant) { return variant == 6 ? 4 : variant == 7 ? 3 : 2; }
 
 static size_t k4m_lds_bytes(int HT) {
     const int ngi = (HT + 15) / 16;
@@ -548,7 +550,7 @@ bool backward_variant_known(int v) {
     if (v == -1) return true;
     if (v < 0) return false;
     const int form = v % 10, tile = (v / 10) % 10, wgs = v / 100;
-    return form <= 5 && tile <= 3 && wgs <= 8;
+    return form <= 7 && tile <= 3 && wgs <= 8;
 }
 
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) {
@@ -565,7 +567,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     const bool auto_form = variant < 0;
     if (variant < 0) variant = d_err ? 2 : 3;
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
-    if (!vec || variant > 5 || (!F.uv && F.W % 4 != 0)) variant = 0;
+    if (!vec || variant > 7 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
     if (variant == 0) {
         pl.HT = 32;
@@ -593,10 +595,11 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // for the 1200 pixel tiles on 512 workgroups), measured it loses (145 vs 133 us; N = 1024: 541 vs 506) -- a workgroup that runs out
         // of tiles early leaves the VALU to its SIMD neighbours, so the imbalance costs far less than the extra set-up.
         const int PT = (F.P + 64 * CH - 1) / (64 * CH);
-        const int ht_max = ht_code == 1 ? 64 : ht_code == 2 ? 128 : K4M_HT_MAX;
+        const bool hi_occ = variant >= 6;
+        const int ht_max = ht_code == 1 ? 64 : (ht_code == 2 || (hi_occ && ht_code == 0)) ? 128 : K4M_HT_MAX;
         pl.HT = min(ht_small > 0 ? ht_small : ht_max, ((max(N, 1) + 15) / 16) * 16);
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
-        pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : 2) * 256 + pl.NT - 1) / pl.NT));
+        pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : hi_occ ? k4m_min_waves(variant) : 2) * 256 + pl.NT - 1) / pl.NT));
         return pl;
     }
     pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
@@ -618,25 +621,27 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
         const int G = plan.rows;
         const int grid = G * NT;
         const size_t lds = k4m_lds_bytes(HT);
-#define DSAC_K4M(C_, S_, U_)                                                                                                               \
+#define DSAC_K4M(C_, S_, U_, W_)                                                                                                           \
     do {                                                                                                                                    \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_backward_mfma<C_, S_, U_>),                                \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score_backward_mfma<C_, S_, U_, W_>),                            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
         if (e_ != hipSuccess) return e_;                                                                                                    \
-        hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,       \
+        hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_, W_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,   \
                            grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT);                            \
     } while (0)
-#define DSAC_K4M_CH(C_)                                                                                  \
+#define DSAC_K4M_CH(C_, W_)                                                                              \
     do {                                                                                                 \
-        if (soft) { if (UV) DSAC_K4M(C_, true, true); else DSAC_K4M(C_, true, false); }                  \
-        else { if (UV) DSAC_K4M(C_, false, true); else DSAC_K4M(C_, false, false); }                     \
+        if (soft) { if (UV) DSAC_K4M(C_, true, true, W_); else DSAC_K4M(C_, true, false, W_); }          \
+        else { if (UV) DSAC_K4M(C_, false, true, W_); else DSAC_K4M(C_, false, false, W_); }             \
     } while (0)
-        switch (CH) {
-            case 2: DSAC_K4M_CH(2); break;
-            case 3: DSAC_K4M_CH(3); break;
-            case 4: DSAC_K4M_CH(4); break;
-            case 5: DSAC_K4M_CH(5); break;
-            default: DSAC_K4M_CH(6); break;
+        if (plan.variant == 6) DSAC_K4M_CH(2, 4);
+        else if (plan.variant == 7) DSAC_K4M_CH(3, 3);
+        else switch (CH) {
+            case 2: DSAC_K4M_CH(2, 2); break;
+            case 3: DSAC_K4M_CH(3, 2); break;
+            case 4: DSAC_K4M_CH(4, 2); break;
+            case 5: DSAC_K4M_CH(5, 2); break;
+            default: DSAC_K4M_CH(6, 2); break;
         }
 #undef DSAC_K4M_CH
 #undef DSAC_K4M
@@ -771,6 +776,132 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
     hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
                        G6_scratch, rec_if_e_based);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// K4 PARITY MODE (fp64, the reference's own evaluation order): dScore part (iii) exactly as core/cnn_softam.h:609-645 runs it -- one hypothesis
+// after the other, cells in the reference's loop order (x outer, y inner), dProjectdObj (:404-453) and dProjectdHyp (:464-528) in double, the
+// per-hypothesis Jacobian kept (copyTo semantics: a cell's direct term overwrites, the support term is added after the loop) and summed over the
+// hypotheses in index order.  With DSAC_BWD_QUIRK_ROT_WRITEBACK the rotation matrix is re-derived from its own Rodrigues vector and WRITTEN BACK on
+// every dProjectdHyp call (quirk 7: the reference does that through a const reference, :506-508), so it drifts by round-off from cell to cell --
+// a sequential recurrence, which is why this mode runs one LANE per hypothesis.  It exists for parity (tests against the real reference's golden
+// vectors to 1e-9), not for speed: reference-sized maps only (N * H * W bounded by the caller).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_score_backward_parity(int N, int H, int W, const double* __restrict__ poses, const float* __restrict__ xyz,
+                                                              const float* __restrict__ uv, const float* __restrict__ d_err,
+                                                              const double* __restrict__ dpnp, const int32_t* __restrict__ sets, double f, double cx,
+                                                              double cy, unsigned flags, double* __restrict__ jac /* N x P*3 */,
+                                                              double* __restrict__ G6_out) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= N) return;
+    const int P = H * W;
+    const bool transpose = flags & 1u, writeback = flags & 4u;
+    double cv6[6], R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cv6[k] = poses[(size_t)h * 6 + k];
+    dm::cv2our(cv6, R, t);
+    double* J = jac + (size_t)h * P * 3;
+    for (int i = 0; i < P * 3; i++) J[i] = 0.0;
+    double G6[6] = {0, 0, 0, 0, 0, 0};
+    const double EPS = 1e-8, MAXE = 100.0;  // core/cnn_softam.h:43 EPS, core/lua_calls.h:36 CNN_OBJ_MAXINPUT
+    for (int x = 0; x < W; x++)
+        for (int y = 0; y < H; y++) {
+            const int p = y * W + x;
+            const double X0 = xyz[(size_t)p * 3], X1 = xyz[(size_t)p * 3 + 1], X2 = xyz[(size_t)p * 3 + 2];
+            const double u = uv ? (double)uv[(size_t)p * 2] : (double)x, v = uv ? (double)uv[(size_t)p * 2 + 1] : (double)y;
+            const double w = (double)d_err[(size_t)h * P + p];
+            const int col = transpose ? (x * W * 3 + y * 3) : (p * 3);
+            // ---- dProjectdObj with the CURRENT rotation (the write-back of the previous cell's dProjectdHyp is in effect)
+            {
+                const double E0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0], E1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1],
+                             E2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
+                double d[3] = {0, 0, 0};
+                if (!(fabs(E2) < EPS)) {
+                    const double px = -f * E0 / E2 + cx, py = f * E1 / E2 + cy;
+                    double err = sqrt((u - px) * (u - px) + (v - py) * (v - py));
+                    if (!(err > MAXE)) {
+                        err += EPS;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const double pxd = -f * R[c] / E2 + f * E0 / E2 / E2 * R[6 + c];
+                            const double pyd = f * R[3 + c] / E2 - f * E1 / E2 / E2 * R[6 + c];
+                            d[c] = 0.5 / err * (2 * (u - px) * -pxd + 2 * (v - py) * -pyd);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) J[col + c] = w * d[c];  // copyTo: overwrite
+            }
+            // ---- dProjectdHyp
+            {
+                const double E0 = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0], E1 = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1],
+                             E2 = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
+                if (fabs(E2) < EPS) continue;
+                const double px = -f * E0 / E2 + cx, py = f * E1 / E2 + cy;
+                double err = sqrt((u - px) * (u - px) + (v - py) * (v - py));
+                if (err > MAXE) continue;
+                err += EPS;
+                const double n0 = -1 / err * (u - px), n1 = -1 / err * (v - py);
+                const double Xv[3] = {X0, X1, X2};
+                double q9[9];  // dNdP . dPdR  (1 x 9)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    q9[c] = n0 * (-f * Xv[c] / E2);
+                    q9[3 + c] = n1 * (f * Xv[c] / E2);
+                    q9[6 + c] = n0 * (f * E0 / E2 / E2 * Xv[c]) + n1 * (-f * E1 / E2 / E2 * Xv[c]);
+                }
+                double rod[3], Rre[9], Jr[27];
+                dm::rodrigues_m2v(R, rod);
+                dm::rodrigues_v2m<true>(rod, Rre, Jr);
+                if (writeback) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) R[k] = Rre[k];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += q9[k] * Jr[i * 9 + k];
+                    G6[i] += w * s;
+                }
+                G6[3] += w * (n0 * (-f / E2));
+                G6[4] += w * (n1 * (f / E2));
+                G6[5] += w * (n0 * (f * E0 / E2 / E2) + n1 * (-f * E1 / E2 / E2));
+            }
+        }
+    // support term: S = G6 . dPNP_h added to the 4 cells of the minimal set (:636-642)
+    for (int i = 0; i < 4; i++) {
+        int p = sets[(size_t)h * 4 + i];
+        p = min(max(p, 0), P - 1);
+        const int y = p / W, x = p - y * W;
+        const int col = transpose ? (x * W * 3 + y * 3) : (p * 3);
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += G6[k] * dpnp[(size_t)h * 72 + k * 12 + i * 3 + c];
+            J[col + c] += s;
+        }
+    }
+    if (G6_out)
+        for (int k = 0; k < 6; k++) G6_out[(size_t)h * 6 + k] = G6[k];
+}
+
+// grad_xyz += sum over hypotheses, in index order (core/train_ransac_softam.cpp:382-383)
+__global__ __launch_bounds__(256) void k_parity_sum(int N, size_t n3, const double* __restrict__ jac, double* __restrict__ grad_xyz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    double s = 0;
+    for (int h = 0; h < N; h++) s += jac[(size_t)h * n3 + i];
+    grad_xyz[i] += s;
+}
+
+hipError_t score_backward_parity(hipStream_t st, int N, const double* poses, const FrameDev& F, const float* d_err, const double* dpnp, const int32_t* sets,
+                                 unsigned flags, double* jac_scratch, double* grad_xyz, double* G6_out) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_score_backward_parity, dim3((N + 63) / 64), dim3(64), 0, st, N, F.H, F.W, poses, F.xyz, F.uv, d_err, dpnp, sets, (double)F.fx,
+                       (double)F.cx, (double)F.cy, flags, jac_scratch, G6_out);
+    const size_t n3 = (size_t)F.P * 3;
+    hipLaunchKernelGGL(k_parity_sum, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, N, n3, jac_scratch, grad_xyz);
     return hipGetLastError();
 }
 

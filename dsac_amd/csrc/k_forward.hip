@@ -850,7 +850,7 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
 }
 
 bool reproject_variant_known(int v) {
-    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 72);
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77);
 }
 
 int reproject_num_pixel_tiles(int P) { return (P + 63) / 64; }  // the largest count over all forms: one partial row per 64-pixel wave chunk
@@ -963,6 +963,11 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 70: return launch_reproject_st<2, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
         case 71: return DSAC_ST(1, 4, 8, true);
         case 72: return DSAC_ST(2, 4, 16, true);
+        case 73: return DSAC_ST(2, 8, 1, true);
+        case 74: return DSAC_ST(1, 8, 1, true);
+        case 75: return DSAC_ST(2, 6, 1, true);
+        case 76: return DSAC_ST(2, 3, 1, true);
+        case 77: return DSAC_ST(1, 6, 1, true);
         // persistent pipelined forms <16-hypothesis groups, waves per workgroup>; k2_flags bits 8..15 = workgroups per CU
         case 60: return launch_reproject_ps<1, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);
         case 61: return launch_reproject_ps<2, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);

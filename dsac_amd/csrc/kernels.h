@@ -92,6 +92,9 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
                                  double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr);
 // rec_if_e_based: the BWD records when G12_part holds the matrix-core form's E-based sums (K4Plan.variant > 0), else nullptr
+// K4 parity mode (fp64, the reference's evaluation order; flags bit 0 = transposed columns, bit 2 = rotation write-back); jac_scratch: N x P*3 doubles
+hipError_t score_backward_parity(hipStream_t st, int N, const double* poses, const FrameDev& F, const float* d_err, const double* dpnp, const int32_t* sets,
+                                 unsigned flags, double* jac_scratch, double* grad_xyz, double* G6_out);
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
                                   const double* dpnp, double* grad_xyz, double* g, double g_scale = 1.0);
 // grad[obj_pixels[i]] += dL . J_obj[i] for i < min(*n_obj, cap), v6 = dL . J_hyp

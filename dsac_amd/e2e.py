@@ -106,7 +106,7 @@ class TrainStep:
     buffers; the step synchronises once, for the scalars it logs."""
 
     def __init__(self, device=0, hyps=256, ref_steps=8, inlier_count=100, thr=10.0, sub_sample=0.01, cam=(525.0, 525.0, 320.0, 240.0),
-                 coord_net=None, score_net=None, lr_obj=1e-5, lr_score=1e-7, momentum=0.9):
+                 coord_net=None, score_net=None, lr_obj=1e-5, lr_score=1e-7, momentum=0.9, reduce_mode="all_reduce", bucket_bytes=64 << 20):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.N, self.ref_steps, self.inlier_count, self.thr, self.sub_sample, self.cam = hyps, ref_steps, inlier_count, thr, sub_sample, cam
@@ -115,6 +115,9 @@ class TrainStep:
         self.opt_obj = torch.optim.SGD(self.coord_net.parameters(), lr=lr_obj, momentum=momentum)
         self.opt_score = torch.optim.SGD(self.score_net.parameters(), lr=lr_score, momentum=momentum)
         self.engine = Engine(device, stream=torch.cuda.current_stream(self.dev))
+        # gradient exchange of config 5: buckets launched from autograd hooks while the backward still runs, waited for at the optimizer step
+        self.reducer_score = ddist.GradientReducer(self.score_net.parameters(), bucket_bytes=bucket_bytes, mode=reduce_mode)
+        self.reducer_obj = ddist.GradientReducer(self.coord_net.parameters(), bucket_bytes=bucket_bytes, mode=reduce_mode)
         S, N = CNN_OBJ_PATCHSIZE, hyps
         self.poses = torch.zeros(N, 6, dtype=torch.float64, device=self.dev)
         self.sets = torch.zeros(N, 4, dtype=torch.int32, device=self.dev)
@@ -141,19 +144,30 @@ class TrainStep:
         predicts ~0, the offset then carries a synthetic scene so that the geometry has something to solve.
         Leaves parameter gradients in .grad and returns a dict of scalars / small arrays for logging."""
         eng, N, S = self.engine, self.N, CNN_OBJ_PATCHSIZE
+        marks = [] if getattr(self, "timing", False) else None  # (label, event): the geometry segments between the CNN passes (bench config 5)
+
+        def mark(label):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.dev))
+                marks.append((label, ev))
+        mark("start")
         # ---- CNN 1: scene coordinates (metres -> mm, cnn_softam.h:265) -------------------------------------------------
         pred_m = self.coord_net(patches)
         xyz = pred_m.detach() * 1000.0
         if xyz_offset_mm is not None:
             xyz = xyz + xyz_offset_mm
         xyz = xyz.float().contiguous()
+        mark("cnn")
         eng.set_frame(xyz, sampling_uv, S, S, self.cam, borrow=True)
         # ---- K1, K2: hypotheses and their error images, written into the tensor the score CNN reads ---------------------
         eng.sample(N, seed=seed, thr=self.thr, out=(self.poses, self.sets, self.ok))
         eng.reproject(self.poses, N=N, err=self.err)
         err = self.err.detach().requires_grad_(True)  # same storage: the score CNN reads what K2 wrote
+        mark("geometry")
         scores = self.score_net(err)
         self.scores = scores.detach()  # kept for inspection (tests feed the oracle's softmax with exactly these numbers)
+        mark("cnn")
         # ---- K3: softmax, entropy, soft-argmax pose ------------------------------------------------------------------
         eng.softMax(scores.detach().double().contiguous(), 1.0, self.poses, N=N, out=(self.w, self.ent, self.avg))
         # ---- K6, K7 forward, then path I + softmax backward: all enqueued on the stream, device buffers only (no host round trip) ---
@@ -176,6 +190,7 @@ class TrainStep:
                                            ptr(self._perm_dev), steps, int(self.inlier_count), 50, float(int(self.thr)), ptr(self.imap),
                                            float(self.sub_sample), 0.001, 2.0, 1.0, ptr(dpnp), ptr(self.grad_xyz), ptr(g), None, None))
         # ---- backward, path II: score CNN (gradient clamp of train_score_softam.lua:97), then K4 -----------------------
+        mark("geometry")
         scores.backward(gradient=g.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
         if quirk_transpose:
             # reference-exact seam: the Lua bridge reads the gradient images back TRANSPOSED (lua_calls.h:329-335: gradients[c](y, x) <- table entry
@@ -183,19 +198,29 @@ class TrainStep:
             d_err = err.grad.reshape(N, S, S).transpose(1, 2).reshape(N, S * S).contiguous()
         else:
             d_err = err.grad.reshape(N, S * S).contiguous()  # (n, y, x): already the layout K4 reads
+        mark("cnn")
         eng.dScore(self.poses, self.sets, d_err, dpnp=dpnp, quirk_transpose=quirk_transpose, grad=self.grad_xyz)
+        mark("geometry")
         # ---- CNN 1 backward (gradient clamp of train_obj_softam.lua:105) ---------------------------------------------
         pred_m.backward(gradient=self.grad_xyz.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
+        mark("cnn")
         out4 = self.out4.cpu().numpy()  # the only synchronisation of the step: the scalars for the log
+        if marks is not None:
+            seg = {"geometry": 0.0, "cnn": 0.0}
+            for (_, a), (lb, b) in zip(marks[:-1], marks[1:]):
+                seg[lb] += a.elapsed_time(b)
+            self.last_segments_ms = seg
         return dict(loss=float(out4[0]), rotErr=float(out4[1]), tErr=float(out4[2]), entropy=float(self.ent.item()), ref_steps=int(self.sd.item()),
                     accepted=int(self.ok.sum().item()), refAvgHyp=self.ref.cpu().numpy(), avgHyp=self.avg.cpu().numpy())
 
     def step(self, *a, **kw):
-        """forward_backward + gradient all-reduce over the ranks (RCCL on GPUs, a few flat buckets) + SGD update."""
+        """forward_backward + gradient exchange over the ranks (RCCL on GPUs) + SGD update.  The exchange is launched bucket by bucket from
+        inside the backward passes (dist.GradientReducer): the score CNN's gradients travel under K4 and the scene-coordinate CNN's backward, the
+        scene-coordinate CNN's own buckets under the rest of its backward; only the wait sits in front of the optimizer."""
         self.opt_obj.zero_grad(set_to_none=False)
         self.opt_score.zero_grad(set_to_none=False)
         out = self.forward_backward(*a, **kw)
-        out["collectives"] = ddist.all_reduce_gradients([p.grad for p in self.params() if p.grad is not None])
+        out["collectives"] = self.reducer_score.wait() + self.reducer_obj.wait()
         self.opt_obj.step()
         self.opt_score.step()
         return out

@@ -259,16 +259,18 @@ class Engine:
         return J
 
     # ---- K4 ---------------------------------------------------------------------------------------
-    def dScore(self, poses, sets, d_err, dpnp=None, quirk_transpose=False, grad=None):
+    def dScore(self, poses, sets, d_err, dpnp=None, quirk_transpose=False, grad=None, parity_fp64=False, quirk_rot_writeback=False):
         """dScore part (iii) (cnn_softam.h:609-645) summed over hypotheses (train_ransac_softam.cpp:382-383).
-        grad (H*W x 3 float64) is accumulated into and returned."""
+        grad (H*W x 3 float64) is accumulated into and returned.  parity_fp64: the fp64 parity mode (the reference's evaluation order, one lane
+        per hypothesis; reference-sized maps), quirk_rot_writeback: with it, quirk 7 (cnn_softam.h:506-508)."""
         poses = _np(poses, np.float64)
         sets = _np(sets, np.int32)
         d_err = _np(d_err, np.float32)
         N = int(sets.shape[0])
         if grad is None:
             grad = np.zeros((self.P, 3))
-        flags = capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0
+        flags = (capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0) | (capi.DSAC_BWD_PARITY_FP64 if (parity_fp64 or quirk_rot_writeback) else 0) | \
+                (capi.DSAC_BWD_QUIRK_ROT_WRITEBACK if quirk_rot_writeback else 0)
         check(self._ctx, lib.dsac_score_backward(self._ctx, N, ptr(poses), ptr(sets), ptr(d_err), ptr(_np(dpnp, np.float64) if dpnp is not None else None),
                                                  flags, ptr(grad)))
         return grad

@@ -22,6 +22,19 @@ def rodrigues(r):
     return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(a, a) + np.sin(th) * K
 
 
+def cv_to_jp6(cv6):
+    """A pose in OpenCV's convention (Rodrigues vector, translation mm) as the jp 6-vector Hypothesis::getRodVecAndTrans returns
+    (core/types.h:186-214 cv2our: R' = diag(1,-1,-1) R, t' = diag(1,-1,-1) t; core/Hypothesis.cpp:274-289) -- the form ground truths are handed
+    over in.  Synthetic-data helper (rotation angles well below pi)."""
+    cv6 = np.asarray(cv6, dtype=np.float64)
+    F = np.diag([1.0, -1.0, -1.0])
+    Rj, tj = F @ rodrigues(cv6[:3]), F @ cv6[3:]
+    th = np.arccos(np.clip((np.trace(Rj) - 1) / 2, -1, 1))
+    ax = np.array([Rj[2, 1] - Rj[1, 2], Rj[0, 2] - Rj[2, 0], Rj[1, 0] - Rj[0, 1]])
+    r = ax / (2 * np.sin(th)) * th if th > 1e-12 else np.zeros(3)
+    return np.concatenate([r, tj])
+
+
 def pixel_grid(H, W, full_h=480, full_w=640, stratified_rng=None, patch=42):
     """(u, v) of every cell.  H x W == full frame -> u = x, v = y.  Otherwise a stratified sub-sample in
     the manner of the reference's stochasticSubSample (core/cnn_softam.h:283-309): one integer pixel per

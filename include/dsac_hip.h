@@ -81,6 +81,10 @@ typedef enum dsac_status {
 #define DSAC_FRAME_BORROW 2u         /* xyz/uv are device pointers that outlive the frame: use in place, no copy */
 
 /* backward flags */
+#define DSAC_BWD_PARITY_FP64 2u        /* dsac_score_backward only: the fp64 parity mode -- the reference's own evaluation order in double (one lane per
+                                          hypothesis, cells x outer / y inner, per-hypothesis Jacobians summed in index order); N*H*W <= 2^26 */
+#define DSAC_BWD_QUIRK_ROT_WRITEBACK 4u /* with DSAC_BWD_PARITY_FP64: quirk 7 -- dProjectdHyp writes the re-derived rotation back into the hypothesis
+                                          (core/cnn_softam.h:506-508), which then drifts by round-off from cell to cell; reproduces the reference to 1e-9 */
 #define DSAC_BWD_QUIRK_TRANSPOSE 1u /* reproduce core/cnn_softam.h:628,641 (index x*W*3 + y*3); needs H == W */
 
 /* ---- context ---------------------------------------------------------------------------------- */

@@ -113,6 +113,22 @@ def test_config3_shards_64_images_and_gathers_them():
         assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["frames_per_step_all_ranks"] == 64
 
 
+def test_config5_reports_the_gradient_exchange():
+    """BASELINE.json configs[4]: one training step per rank with the gradient exchange of both networks; the dry run trains two small CPU networks
+    over gloo through the real launcher, the hook-driven GradientReducer and the reporting code."""
+    for world in (1, 2):
+        r = _run_bench("--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "config5", "--dry-run", "--hyps", "64")
+        assert r.returncode == 0, r.stderr
+        d = _json_line(r.stdout)
+        ts = d["train_step"]
+        assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["ranks_joined"] == world and d["config"]["backend"] == "gloo"
+        assert d["config"]["frames_per_step_all_ranks"] == world and ts["step_ms"] > 0 and ts["grad_bytes"] > 0
+        if world == 1:
+            assert ts["collective_ms"] == 0.0 and ts["collectives_per_step"] == 0
+        else:
+            assert ts["collective_ms"] > 0 and ts["collectives_per_step"] >= 2
+
+
 def test_rank_count_mismatch_is_refused():
     r = _run_bench("--gpus", "4", "--steps", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -31,7 +31,28 @@ def _worker(rank, world, port, q):
     # CNN gradient all-reduce: two params, one small bucket size to force several buckets
     g = [torch.full((1000,), float(rank + 1)), torch.full((3, 5), float(10 * (rank + 1)))]
     nb = ddist.all_reduce_gradients(g, average=True, bucket_bytes=2048)
-    q.put((rank, mine, allres.numpy(), [t.numpy().copy() for t in g], nb))
+    # the launch / wait split: nothing is waited for at launch, the tensors hold the averages after wait()
+    g2 = [torch.full((600,), float(rank + 1)), torch.full((7,), float(3 * (rank + 1)))]
+    h = ddist.launch_gradient_reduce(g2, bucket_bytes=1 << 20, mode="reduce_scatter")  # gloo: falls back to all-reduce, one bucket
+    other = torch.ones(3) * 2  # work enqueued between launch and wait
+    nb2 = h.wait()
+    # hook-driven reducer: the buckets of a small network leave during its backward, back to front
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    red = ddist.GradientReducer(net.parameters(), bucket_bytes=64)  # 64 B buckets: several collectives
+    x = torch.full((5, 4), float(rank + 1))
+    net(x).sum().backward()
+    launched_before_wait = red.handle.collectives
+    nb3 = red.wait()
+    grads = [p.grad.numpy().copy() for p in net.parameters()]
+    # second step: hooks re-armed
+    for p in net.parameters():
+        p.grad.zero_()
+    net(x).sum().backward()
+    nb4 = red.wait()
+    red.close()
+    q.put((rank, mine, allres.numpy(), [t.numpy().copy() for t in g], nb, [t.numpy().copy() for t in g2], nb2, launched_before_wait, nb3, grads, nb4,
+           float(other.sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +77,21 @@ def test_image_sharding_and_gradient_allreduce_gloo():
         assert np.array_equal(o[2], expect)
         assert np.allclose(o[3][0], 1.5) and np.allclose(o[3][1], 15.0)  # mean over ranks of (1,2) and (10,20)
         assert o[4] == 2  # 4000 B + 60 B with a 2 KiB bucket limit -> two collectives
+        assert np.allclose(o[5][0], 1.5) and np.allclose(o[5][1], 4.5) and o[6] == 1 and o[11] == 6.0
+        assert o[7] >= 2 and o[8] == o[7] and o[10] == o[8]  # every bucket left from a hook, before wait(); the same again on the second step
+    # both ranks hold the same, averaged gradients: the mean of the two ranks' local gradients (inputs 1 and 2, same weights)
+    for a_, b_ in zip(out[0][9], out[1][9]):
+        assert np.array_equal(a_, b_)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    want = []
+    for r in (1.0, 2.0):
+        for p in net.parameters():
+            p.grad = None
+        net(torch.full((5, 4), r)).sum().backward()
+        want.append([p.grad.numpy().copy() for p in net.parameters()])
+    for k, g_ in enumerate(out[0][9]):
+        assert np.allclose(g_, 0.5 * (want[0][k] + want[1][k]), rtol=1e-6, atol=1e-7)
 
 
 def test_single_process_is_a_no_op():

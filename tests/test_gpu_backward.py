@@ -226,6 +226,41 @@ def test_quirk7_rot_writeback(engine, orc, frame40):
         assert e_quirk <= 1e-3
 
 
+@pytest.mark.parametrize("writeback", [False, True])
+@pytest.mark.parametrize("quirk", [False, True])
+def test_parity_mode_fp64(engine, orc, frame40, writeback, quirk):
+    """DSAC_BWD_PARITY_FP64 (+ DSAC_BWD_QUIRK_ROT_WRITEBACK): dScore part (iii) in double, in the reference's own evaluation order, with quirk 7
+    (core/cnn_softam.h:506-508: dProjectdHyp writes the re-derived rotation back, it drifts from cell to cell) switchable -- against the oracle
+    in the same mode to 1e-9 of the largest entry ("float64 in parity mode"; the oracle's write-back mode is what reproduces the
+    real reference to 1e-9, tests/test_reference_pinning.py)."""
+    fr = frame40
+    N = 64
+    poses, sets = _setup(engine, orc, fr, N, 5)
+    d_err = np.random.default_rng(8).normal(size=(N, 1600)).astype(np.float32)
+    ref, G6, _ = orc.dScore(sets, d_err.astype(np.float64), fr["xyz"], fr["uv"], 40, 40, fr["cam"], quirk_transpose=quirk, quirk_rot_writeback=writeback)
+    got = engine.dScore(poses, sets, d_err, dpnp=_oracle_dpnp(orc, fr, sets), quirk_transpose=quirk, parity_fp64=True, quirk_rot_writeback=writeback)
+    G6g = engine.lastPoseGradients(N)
+    theta = np.linalg.norm(poses[:, :3], axis=1)
+    regular = np.abs(theta - np.pi) > 1e-2  # at theta = pi the Rodrigues vector of a hypothesis flips sign between implementations
+    relp = np.abs(G6g - G6).max(1) / np.abs(G6).max(1)
+    emax, el2 = _rel(got, ref)
+    print("parity mode (write-back %s, transposed %s): gradient max-rel %.2e l2-rel %.2e, pose sums max %.2e (regular hypotheses)" %
+          (writeback, quirk, emax, el2, relp[regular].max()))
+    # the gradient (what the mode is for): measured 4e-14 without / 6e-12 with the write-back.  The per-hypothesis pose sums are sums with
+    # cancellation, and with the write-back the rotation's round-off drift is chaotic (two implementations' Rodrigues round trips differ in the
+    # last bit): their median agrees to 1e-9, single hypotheses to 1e-5 of their own largest component (measured 4e-9 / 3e-6)
+    assert np.median(relp[regular]) <= 1e-9 and relp[regular].max() <= 1e-5
+    if regular.all():
+        assert emax <= 1e-9 and el2 <= 1e-9
+    else:
+        assert emax <= 1e-6
+    # the write-back flag without the fp64 mode is refused (the recurrence is sequential)
+    from dsac_amd import capi
+    rc = capi.lib.dsac_score_backward(engine._ctx, N, capi.ptr(np.ascontiguousarray(poses)), capi.ptr(np.ascontiguousarray(sets)), capi.ptr(d_err), None,
+                                      capi.DSAC_BWD_QUIRK_ROT_WRITEBACK, capi.ptr(np.zeros((1600, 3))))
+    assert rc == capi.DSAC_ERR_INVALID
+
+
 def test_fused_path1_chain_equals_the_separate_calls(engine, orc, synth, frame40):
     """dsac_backward_path1 (dLossMax -> dRefine -> contraction -> dPNP -> support scatter + softmax backward, one device-side chain) against the
     same chain assembled on the host from the single calls, and against the oracle's functions."""

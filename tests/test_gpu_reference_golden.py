@@ -92,6 +92,13 @@ def test_jacobians(eng, g):
     emax, el2 = np.abs(grad - want).max() / np.abs(want).max(), np.linalg.norm(grad - want) / np.linalg.norm(want)
     print("dScore vs the reference: max-rel %.3e l2-rel %.3e" % (emax, el2))
     assert emax <= 1e-5 and el2 <= 1e-5  # measured 1.2e-6
+    # the fp64 parity mode with the rotation write-back (quirk 7) on the same input: what is left is the float32 rounding of the d_err volume
+    # the C ABI takes (6e-8 relative per entry) -- against the oracle in double on the float32-valued input the mode agrees to 1e-9
+    # (tests/test_gpu_backward.py::test_parity_mode_fp64)
+    gp = eng.dScore(g["hyps"][:8], g["sets"][:8], as_read, quirk_transpose=True, quirk_rot_writeback=True)
+    emax_p = np.abs(gp - want).max() / np.abs(want).max()
+    print("dScore, fp64 parity mode with write-back, vs the reference: max-rel %.3e" % emax_p)
+    assert emax_p <= 1e-6
 
 
 def test_training_backward_end_to_end(eng, g):
