@@ -900,7 +900,14 @@ int dsac_refine_fd_sets(dsac_ctx* c, int M, const int32_t* sets, const int32_t* 
     DevBuf& rx = next_slot(c); HIP_TRY(c, rx.reserve(B * 2 * sizeof(int32_t)));
     DevBuf& rv = next_slot(c); HIP_TRY(c, rv.reserve(B * sizeof(float)));
     DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
-    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_sets, d_maps, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_px, d_n, M));
+    int32_t* plan_scratch = nullptr;
+    if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
+        DevBuf& ps = next_slot(c);
+        HIP_TRY(c, ps.reserve(ni * (size_t)M * sizeof(int32_t)));
+        plan_scratch = ps.as<int32_t>();
+    }
+    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_sets, d_maps, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_px, d_n, M,
+                                      plan_scratch));
     HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F,
                                      ro.as<double>(), M));
     HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo, M));
@@ -1002,7 +1009,14 @@ int dsac_refine_fd_set(dsac_ctx* c, const int32_t* set4, const int32_t* perm, in
     DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
     DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap + 1) * sizeof(int32_t)));
     int32_t* d_pxbuf = d_px ? d_px : px.as<int32_t>();
-    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_set, d_map, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n));
+    int32_t* plan_scratch = nullptr;
+    if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
+        DevBuf& ps = next_slot(c);
+        HIP_TRY(c, ps.reserve(ni * sizeof(int32_t)));
+        plan_scratch = ps.as<int32_t>();
+    }
+    HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_set, d_map, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n, 1,
+                                      plan_scratch));
     HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
     HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo));
     return end_call(c);
@@ -1076,6 +1090,24 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
     // sum_h w_h dPNP_h to the support points and the softmax backward (:344-376)
     HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp));
     HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale));
+    return end_call(c);
+}
+
+int dsac_select(dsac_ctx* c, int N, const double* probs, const double* losses, int loss_stride, double u, int32_t* hyp_idx_or_null, double* expected_loss_or_null,
+                double* score_gradients_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_select: ctx is NULL");
+    if (N <= 0 || !probs || !losses || loss_stride < 1 || !(u < 1.0)) return fail(c, DSAC_ERR_INVALID, "dsac_select: need N > 0, probs, losses, loss_stride >= 1 and u < 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const double *d_w, *d_l;
+    int32_t* d_idx;
+    double *d_e, *d_g;
+    ARG_TRY(in_arg(c, probs, (size_t)N, &d_w));
+    ARG_TRY(in_arg(c, losses, (size_t)N * loss_stride, &d_l));
+    ARG_TRY(out_arg(c, hyp_idx_or_null, 1, &d_idx));
+    ARG_TRY(out_arg(c, expected_loss_or_null, 1, &d_e));
+    ARG_TRY(out_arg(c, score_gradients_or_null, (size_t)N, &d_g));
+    HIP_TRY(c, dk::dsac_select(c->stream, N, d_w, d_l, loss_stride, u, 1e-8, d_idx, d_e, d_g));
     return end_call(c);
 }
 

@@ -147,4 +147,71 @@ hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double*
     return hipGetLastError();
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// DSAC variant (core/cnn.h): probabilistic selection, expected loss and the softmax-expectation gradient on the device.
+//   draw            core/cnn.h:102-127   entries below EPS skipped; cumulative sums in index order are the keys of a std::map (a later entry
+//                                        that leaves the sum unchanged overwrites the earlier one), upper_bound(u * sum); argmax when u < 0
+//   expectedMaxLoss core/cnn.h:137-150   sum_i probs[i] * losses[i] in index order
+//   dSMScore        core/cnn.h:737-742   g[i] = w_i L_i - sum_j w_i w_j L_j, subtracted term by term in index order
+// One workgroup; the two scalar scans run on one lane (N sequential fp64 additions, the reference's own order), the N x N subtraction on all lanes.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dsac_select(int N, const double* __restrict__ w, const double* __restrict__ losses, int loss_stride, double u,
+                                                     double eps, int32_t* __restrict__ hyp_idx, double* __restrict__ expected, double* __restrict__ g) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double sum = 0;
+        for (int i = 0; i < N; i++)
+            if (!(w[i] < eps)) sum += w[i];
+        int pick = -1;
+        if (u < 0) {  // randomDraw == false: the first entry with the largest probability
+            double best = -1;
+            for (int i = 0; i < N; i++) {
+                if (w[i] < eps) continue;
+                if (best < 0 || w[i] > best) { best = w[i]; pick = i; }
+            }
+            if (pick < 0) pick = 0;  // maxIdx is initialised to 0
+        } else {
+            const double r = u * sum;  // drand(0, probSum)
+            double s = 0, key = 0;
+            bool found = false;
+            int last = 0;
+            for (int i = 0; i < N; i++) {
+                if (w[i] < eps) continue;
+                s += w[i];
+                last = i;
+                if (!found) {
+                    if (s > r) { found = true; key = s; pick = i; }
+                } else if (s == key) {
+                    pick = i;  // same map key: the later index replaces the earlier one
+                } else {
+                    break;
+                }
+            }
+            if (!found) pick = last;  // u * sum >= the last key: upper_bound would be end(); the last entry stands in
+        }
+        if (hyp_idx) *hyp_idx = pick;
+        if (expected) {
+            double e = 0;
+            for (int i = 0; i < N; i++) e = __dadd_rn(e, __dmul_rn(w[i], losses[(size_t)i * loss_stride]));  // product rounded, then added: no fused multiply-add
+            *expected = e;
+        }
+    }
+    if (g) {
+        for (int i = tid; i < N; i += blockDim.x) {
+            const double wi = w[i];
+            double v = __dmul_rn(wi, losses[(size_t)i * loss_stride]);
+            for (int j = 0; j < N; j++) v = __dsub_rn(v, __dmul_rn(__dmul_rn(wi, w[j]), losses[(size_t)j * loss_stride]));  // (w_i w_j) L_j as the reference groups it
+            g[i] = v;
+        }
+    }
+}
+
+hipError_t dsac_select(hipStream_t st, int N, const double* w, const double* losses, int loss_stride, double u, double eps, int32_t* hyp_idx, double* expected,
+                       double* g) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dsac_select, dim3(1), dim3(256), 0, st, N, w, losses, loss_stride, u, eps, hyp_idx, expected, g);
+    return hipGetLastError();
+}
+
 }  // namespace dk

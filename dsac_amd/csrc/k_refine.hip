@@ -568,6 +568,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan(const double* _
 constexpr int PLAN_SEGS = PLAN_THREADS / 64;  // row segments = waves per workgroup
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_count(const int32_t* __restrict__ inlier_map, FrameDev F, int32_t* __restrict__ scratch) {
+    inlier_map += (size_t)blockIdx.y * F.P;                       // map m of a batch (DSAC variant: one inlier map per hypothesis)
+    scratch += (size_t)blockIdx.y * F.W * (PLAN_SEGS + 1);
     const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
     const int rows = (F.H + PLAN_SEGS - 1) / PLAN_SEGS;
@@ -589,6 +591,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_count(const int32_t*
     }
 }
 
+// SET: the DSAC variant's replica list (18 set perturbations first, start poses written later by k_refine_fd_init_set)
+template <bool SET>
 DM_INLINE void emit_obj_replicas(int slot, int p, const FrameDev& F, const double init[6], float eps_obj, double* __restrict__ rep_poses,
                                  int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels) {
     obj_pixels[slot] = p;
@@ -597,25 +601,40 @@ DM_INLINE void emit_obj_replicas(int slot, int p, const FrameDev& F, const doubl
         const float v0 = F.xyz[(size_t)p * 3 + c];
         const float vf = v0 + eps_obj;
         const float vb = vf - 2 * eps_obj;
-        const int r = 12 + slot * 6 + c * 2;
+        const int r = (SET ? 18 : 12) + slot * 6 + c * 2;
+        if (!SET) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { rep_poses[(size_t)r * 6 + k] = init[k]; rep_poses[(size_t)(r + 1) * 6 + k] = init[k]; }
+            for (int k = 0; k < 6; k++) { rep_poses[(size_t)r * 6 + k] = init[k]; rep_poses[(size_t)(r + 1) * 6 + k] = init[k]; }
+        }
         rep_px_c[2 * r] = p; rep_px_c[2 * r + 1] = c; rep_value[r] = vf;
         rep_px_c[2 * (r + 1)] = p; rep_px_c[2 * (r + 1) + 1] = c; rep_value[r + 1] = vb;
     }
 }
 
+template <bool SET>
 __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* __restrict__ init_pose, const int32_t* __restrict__ inlier_map, FrameDev F,
                                                                  int skip, float eps_hyp, float eps_obj, int cap, const int32_t* __restrict__ scratch,
                                                                  double* __restrict__ rep_poses, int32_t* __restrict__ rep_px_c,
                                                                  float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels,
-                                                                 int32_t* __restrict__ n_obj) {
+                                                                 int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4) {
     const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
     const int x0 = blockIdx.x * 64, x = x0 + lane;
-    double init[6];
+    double init[6] = {0, 0, 0, 0, 0, 0};
+    if (SET) {  // hypothesis m of a batch (blockIdx.y): its set, inlier map, counts and slice of the replica arrays (18 + 6*cap replicas each)
+        const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
+        set4 += 4 * m; inlier_map += m * F.P; scratch += m * F.W * (PLAN_SEGS + 1); rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
+        if (blockIdx.x == 0 && tid < 18) {
+            const int pt = tid / 6, c = (tid % 6) >> 1;
+            const int p = min(max(set4[pt], 0), F.P - 1);
+            const float vf = F.xyz[(size_t)p * 3 + c] + eps_obj;
+            rep_px_c[2 * tid] = p; rep_px_c[2 * tid + 1] = c;
+            rep_value[tid] = (tid & 1) ? vf - 2 * eps_obj : vf;
+        }
+    } else {
 #pragma unroll
-    for (int i = 0; i < 6; i++) init[i] = init_pose[i];
-    if (blockIdx.x == 0 && tid < 12) {  // dRefineHyp: replica 2i = +step on parameter i, 2i+1 = (+step) - 2 step (as the one-workgroup form)
+        for (int i = 0; i < 6; i++) init[i] = init_pose[i];
+    }
+    if (!SET && blockIdx.x == 0 && tid < 12) {  // dRefineHyp: replica 2i = +step on parameter i, 2i+1 = (+step) - 2 step (as the one-workgroup form)
         const int i = tid >> 1;
         const double step = (i < 3) ? (double)eps_hyp : (double)(eps_hyp * 1000);
         double v = init[i] + step;
@@ -655,7 +674,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* _
         if (inCount % skip != 0) continue;
         const int slot = inCount / skip - 1;
         if (slot >= cap) continue;
-        emit_obj_replicas(slot, p, F, init, eps_obj, rep_poses, rep_px_c, rep_value, obj_pixels);
+        emit_obj_replicas<SET>(slot, p, F, init, eps_obj, rep_poses, rep_px_c, rep_value, obj_pixels);
     }
 }
 
@@ -667,8 +686,8 @@ hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t
     if (scratch && F.P > PLAN_TILED_MIN_CELLS) {
         const int tiles = (F.W + 63) / 64;
         hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
-        hipLaunchKernelGGL(k_refine_fd_emit, dim3(tiles), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch, rep_poses,
-                           rep_px_c, rep_value, obj_pixels, n_obj);
+        hipLaunchKernelGGL(k_refine_fd_emit<false>, dim3(tiles), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch, rep_poses,
+                           rep_px_c, rep_value, obj_pixels, n_obj, (const int32_t*)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_refine_fd_plan, dim3(1), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c, rep_value,
@@ -780,8 +799,16 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
 }
 
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
-                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M) {
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M, int32_t* scratch) {
     if (M <= 0) return hipSuccess;
+    if (scratch && F.P > PLAN_TILED_MIN_CELLS) {
+        // large maps: the tiled two-launch plan of the soft-argmax path, one grid row per hypothesis (round 2 scanned each map with one workgroup, column-major
+        // with a 2.5 KB stride: 158 us per 640 x 480 map)
+        const int tiles = (F.W + 63) / 64;
+        hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
+        hipLaunchKernelGGL(k_refine_fd_emit<true>, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, (const double*)nullptr, inlier_map, F, skip, 0.f, eps_obj, cap, scratch,
+                           (double*)nullptr, rep_px_c, rep_value, obj_pixels, n_obj, set4);
+    } else
     hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(PLAN_THREADS), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
     const int R = 18 + 6 * cap;
     hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 15) / 16, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);

@@ -456,6 +456,16 @@ class Engine:
         cum = np.cumsum(probs[keep])
         return int(keep[min(np.searchsorted(cum, u * cum[-1], side="right"), len(keep) - 1)])
 
+    def selectDSAC(self, probs, losses, u=None, want_gradients=True):
+        """draw + expectedMaxLoss + dSMScore's score gradients in one device launch (dsac_select).  Returns (hyp_idx, expected_loss, g or None)."""
+        probs = _np(np.asarray(probs, dtype=np.float64), np.float64)
+        losses = _np(np.asarray(losses, dtype=np.float64), np.float64)
+        N = int(probs.shape[0])
+        idx, e = np.zeros(1, np.int32), np.zeros(1)
+        g = np.zeros(N) if want_gradients else None
+        check(self._ctx, lib.dsac_select(self._ctx, N, ptr(probs), ptr(losses), 1, -1.0 if u is None else float(u), ptr(idx), ptr(e), ptr(g)))
+        return int(idx[0]), float(e[0]), g
+
     def processImageDSAC(self, N=256, seed=1305, perm=None, gt_jp6=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, alpha=0.1,
                          score_fn=None, draw_u=None, sets=None, max_tries=1 << 20):
         """Forward pass of the DSAC variant's processImage (core/cnn.h:1000-1240): N hypotheses, scores (soft-inlier count or
@@ -466,14 +476,14 @@ class Engine:
         self.reproject(poses, err=err, soft=soft, tau=tau, beta=beta)
         scores, scale = (np.ascontiguousarray(score_fn(err.reshape(N, self.H, self.W)), dtype=np.float64), 1.0) if score_fn is not None else (soft, alpha)
         w, ent, _ = self.softMax(scores, scale)
-        hyp_idx = self.draw(w, draw_u)
         ref, sd, maps = self.refineAll(poses, perm, sets=sets_out, max_inl=inlierCount, min_inl=minInliers, thr=float(int(thr)), want_inlier_maps=True)
-        out = dict(hyps=poses, sampledPoints=sets_out, ok=ok, scores=scores, score_scale=scale, sfScores=w, sfEntropy=float(ent[0]), hypIdx=hyp_idx,
+        out = dict(hyps=poses, sampledPoints=sets_out, ok=ok, scores=scores, score_scale=scale, sfScores=w, sfEntropy=float(ent[0]), hypIdx=self.selectDSAC(w, np.zeros(N), draw_u, want_gradients=False)[0],
                    refHyps=ref, refSteps=sd, inlierMaps=maps, pixelIdxs=np.ascontiguousarray(perm, dtype=np.int32), diffMaps=err)
         if gt_jp6 is not None:
             L = self.maxLossBatch(ref, gt_jp6)
-            out.update(losses=L["loss"], expectedLoss=float(np.dot(w, L["loss"])), rotErr=float(L["rotErr"][hyp_idx]), tErr=float(L["tErr"][hyp_idx]),
-                       correct=bool(L["correct"][hyp_idx]))
+            hyp_idx, e_loss, g = self.selectDSAC(w, L["loss"], draw_u)  # selection, expected loss and the score gradients: one device launch
+            out.update(hypIdx=hyp_idx, losses=L["loss"], expectedLoss=e_loss, scoreOutputGradients=g, rotErr=float(L["rotErr"][hyp_idx]),
+                       tErr=float(L["tErr"][hyp_idx]), correct=bool(L["correct"][hyp_idx]))
         return out
 
     def backwardDSAC(self, fwd, gt_jp6, d_scores_fn=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, sub_sample=0.01, min_prob=1e-4):
@@ -495,7 +505,7 @@ class Engine:
                 if k:
                     np.add.at(grad, px[i][:k], w[h] * np.einsum("k,ikc->ic", dL[h], J_obj[i][:k]))
         losses = fwd["losses"]
-        g = w * (losses - np.dot(w, losses))  # core/cnn.h:737-742
+        _, _, g = self.selectDSAC(w, losses)  # core/cnn.h:737-742, on the device
         if d_scores_fn is not None:
             d_err = np.ascontiguousarray(d_scores_fn(g), dtype=np.float32).reshape(N, self.P)
             grad = self.dScore(fwd["hyps"], sets, d_err, grad=grad)

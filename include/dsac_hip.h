@@ -260,6 +260,15 @@ DSAC_API int dsac_refine_fd_sets(dsac_ctx* ctx, int M, const int32_t* sets, cons
 /* maxLoss / dLossMax for B estimates against one ground truth: the losses[] of expectedMaxLoss core/cnn.h:137-150 and
  * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
 DSAC_API int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+/* DSAC variant, the three small reductions over the N hypotheses of an image on the device (one launch, no host round trip):
+ *   hyp_idx        = draw(probs)                 core/cnn.h:102-127: entries below EPS = 1e-8 skipped, the entry whose cumulative probability
+ *                                                first exceeds u * sum (u in [0, 1) supplied by the caller in place of drand); u < 0: the most
+ *                                                probable entry (randomDraw = false)
+ *   expected_loss  = sum_i probs[i] losses[i]    expectedMaxLoss core/cnn.h:137-150 (index order)
+ *   score_gradients[i] = probs[i] losses[i] - sum_j probs[i] probs[j] losses[j]      dSMScore core/cnn.h:737-742 (term by term, index order)
+ * losses[i * loss_stride]: loss_stride = 4 reads the first column of dsac_loss_batch's out4 in place. */
+DSAC_API int dsac_select(dsac_ctx* ctx, int N, const double* probs, const double* losses, int loss_stride, double u, int32_t* hyp_idx_or_null,
+                double* expected_loss_or_null, double* score_gradients_or_null);
 
 /* ---- producer side: patch gather for the scene-coordinate CNN ----------------------------------------------------- */
 /* Replaces the patch assembly of getCoordImg core/cnn_softam.h:224-254 in the table layout of pushMaps core/lua_calls.h:63-80:

@@ -105,3 +105,77 @@ def test_batched_drefine_equals_per_hypothesis_calls(engine, fwd_state):
     assert z[0].shape == (0, 6, 9)
     J0, n0, _, _ = engine.dRefineSets(fwd["sampledPoints"][:2], perm, np.zeros_like(fwd["inlierMaps"][:2]), sub_sample=0.05)
     assert not n0.any() and J0.shape == (2, 6, 9)
+
+
+def test_selection_expected_loss_and_score_gradients_on_the_device(engine):
+    """dsac_select against a literal restatement of the reference: draw (core/cnn.h:102-127: std::map of cumulative sums, upper_bound),
+    expectedMaxLoss (:137-150), the score gradients of dSMScore (:737-742)."""
+    rng = np.random.default_rng(3)
+    for N in (1, 7, 256, 1000):
+        w = rng.random(N) ** 6
+        w[rng.random(N) < 0.2] = 1e-12  # below EPS: skipped by draw, still part of the expectation
+        if N > 3:
+            w[3] = 0.0
+        w /= w.sum()
+        L = rng.random(N) * 50
+
+        def ref_draw(u):
+            cum, s, best, bi = {}, 0.0, -1.0, 0
+            for i, p in enumerate(w):
+                if p < 1e-8:
+                    continue
+                s += p
+                cum[s] = i
+                if best < 0 or p > best:
+                    best, bi = p, i
+            if u is None:
+                return bi
+            keys = sorted(cum)
+            r = u * s
+            for k in keys:
+                if k > r:
+                    return cum[k]
+            return cum[keys[-1]]
+        for u in [None, 0.0, 0.25, 0.5, 0.999999, float(np.nextafter(1.0, 0.0))] + list(rng.random(5)):
+            idx, e, g = engine.selectDSAC(w, L, u)
+            assert idx == ref_draw(u), (N, u)
+            assert idx == engine.draw(w, u)
+        e_ref = 0.0
+        for i in range(N):
+            e_ref += w[i] * L[i]
+        assert e == e_ref
+        g_ref = np.array([w[i] * L[i] - sum(w[i] * w[j] * L[j] for j in range(N)) for i in range(N)]) if N <= 256 else w * (L - e_ref)
+        assert np.allclose(g, g_ref, rtol=1e-10, atol=1e-15)
+        assert np.allclose(g, w * (L - np.dot(w, L)), rtol=1e-9, atol=1e-13)
+
+
+def test_dsac_variant_replica_plan_on_a_large_map(engine, orc, synth):
+    """dsac_refine_fd_sets on a map above 16384 cells: the replica lists come from the tiled two-launch plan (one grid row per hypothesis) instead of
+    one workgroup per hypothesis; selected cells = every skip-th inlier of each hypothesis' own map in the reference's column-major order
+    (core/cnn.h:935-945), Jacobians = the oracle's dRefine (core/cnn.h:854-990)."""
+    H, W = 120, 160
+    fr = synth.chess_like_frame(H, W, seed=5)
+    engine.set_frame(fr["xyz"], fr["uv"], H, W, fr["cam"])
+    perm = synth.fast_permutations(H * W, 8, seed=3)
+    poses, sets, ok, _ = orc.sample(3, 4, fr["xyz"], fr["uv"], H, W, fr["cam"])
+    ref, sd, maps = engine.refineAll(poses, perm, sets=sets, want_inlier_maps=True)
+    assert (maps > 0).sum(1).min() > 100
+    sub = 0.05
+    skip = int(1 / sub)
+    J_set, n_obj, px, J_obj = engine.dRefineSets(sets, perm, maps, sub_sample=sub)
+    for m in range(3):
+        order = [y * W + x for x in range(W) for y in range(H) if maps[m][y * W + x] > 0]
+        want = order[skip - 1::skip]
+        assert [int(p_) for p_ in px[m][:n_obj[m]]] == want
+        Jr = orc.dRefineDSAC(sets[m], perm, maps[m], fr["xyz"], fr["uv"], H, W, fr["cam"], sub_sample=sub)
+        got = np.zeros_like(Jr)
+        for pt in range(3):
+            got[:, sets[m][pt] * 3:sets[m][pt] * 3 + 3] = J_set[m][:, pt * 3:pt * 3 + 3]
+        for i in range(n_obj[m]):
+            p_ = px[m][i]
+            got[:, p_ * 3:p_ * 3 + 3] = J_obj[m][i]
+        scale = max(np.abs(Jr).max(), 1e-12)
+        assert np.abs(got - Jr).max() <= 2e-3 * scale, (m, np.abs(got - Jr).max(), scale)
+    # one hypothesis through dsac_refine_fd_set: the same lists
+    J1, px1, Jo1 = engine.dRefineSet(sets[1], perm, maps[1], sub_sample=sub)
+    assert np.array_equal(px1, px[1][:n_obj[1]]) and np.allclose(J1, J_set[1], rtol=1e-12, atol=1e-15)
