@@ -16,7 +16,8 @@ except ImportError:  # pure C-ABI use without torch is fine: the library then bi
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsac_hip.so")
+# DSAC_HIP_LIB: an alternative build of the same library (kernel A/B experiments, scripts/r03_k4_ab.sh); never a different implementation
+LIB_PATH = os.environ.get("DSAC_HIP_LIB") or os.path.join(_HERE, "libdsac_hip.so")
 
 DSAC_OK = 0
 DSAC_ERR_INVALID = -1

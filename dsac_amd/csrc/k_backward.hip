@@ -43,7 +43,7 @@ constexpr int BWD_REC = BWD_STRIDE;
 // per hypothesis: jp pose (cv2our), its float record, and dR'/drod (3x9) for the finish kernel
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __restrict__ poses, float* __restrict__ rec,
-                                                      double* __restrict__ dRdH) {
+                                                      double* __restrict__ dRdH, float f) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= N) return;
     double cv6[6];
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
         for (int c = h & 15; c <= c_last; c++) {
             float* gb = img + (size_t)(h >> 4) * 384;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { gb[k * 16 + c] = o[2 * k]; gb[64 + k * 16 + c] = o[2 * k + 1]; gb[128 + k * 16 + c] = o[8 + k]; }
+            // the x and negated-y rows carry the focal length (round 3): the MFMA then yields f E.x and -f E.y, which is what the residual uses
+            for (int k = 0; k < 4; k++) { gb[k * 16 + c] = f * o[2 * k]; gb[64 + k * 16 + c] = f * o[2 * k + 1]; gb[128 + k * 16 + c] = o[8 + k]; }
             float* gc = gb + 192 + c * 12;
             gc[0] = o[12]; gc[1] = o[13]; gc[2] = o[18]; gc[3] = o[14]; gc[4] = o[15]; gc[5] = o[19]; gc[6] = o[16]; gc[7] = o[17]; gc[8] = o[20];
             gc[9] = gc[10] = gc[11] = 0.f;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
 
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_backward_prep, dim3((N + 63) / 64), dim3(64), 0, st, N, poses, staged_bwd, dRdH);
+    hipLaunchKernelGGL(k_backward_prep, dim3((N + 63) / 64), dim3(64), 0, st, N, poses, staged_bwd, dRdH, F.fx);
     return hipGetLastError();
 }
 
@@ -403,11 +404,10 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
         };
         load_w(0, wn);
 
-        for (int gi = 0; gi < ngi; gi++) {
-            f4 wv[CH];
-#pragma unroll
-            for (int ch = 0; ch < CH; ch++) wv[ch] = wn[ch];
-            if (gi + 1 < ngi) load_w(gi + 1, wn);  // prefetch the next group's d_err under this group's arithmetic
+        // one group of 16 hypotheses; `wv` = this group's d_err, `wnext` receives the next group's (prefetched under this group's arithmetic).  The
+        // two register sets alternate roles (no copy: round 2 moved the prefetched set into place with 8 v_mov_b64 per group)
+        auto group = [&](int gi, const f4 (&wv)[CH], f4 (&wnext)[CH]) {
+            if (gi + 1 < ngi) load_w(gi + 1, wnext);
             const float* simg = s_img + gi * 384;
             const float bx = simg[lane], by = simg[64 + lane], bz = simg[128 + lane];
             const f4* cf = reinterpret_cast<const f4*>(simg + 192 + c * 12);
@@ -434,16 +434,17 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                     // pass).  With (u - px, v - py) = (A, B) / E.z,  A = (u - cx) E.z + f E.x,  B = (v - cy) E.z - f E.y,  S = A^2 + B^2:
                     //   err = sqrt(S) / |E.z|,   m = rsq(E.z^2 S) = 1 / (|E.z| sqrt(S)),   1 / E.z = m^2 S E.z,
                     //   C0 = w f A m,   -C1 = w f B m,   -C2 = w f m (A E.x - B E.y) / E.z          (px = -f E.x / E.z + cx, py = f E.y / E.z + cy)
-                    const f2 A = __builtin_elementwise_fma(pu[ch][pp], ez, ex * f2{f, f});
-                    const f2 B = __builtin_elementwise_fma(pv[ch][pp], ez, ny * f2{f, f});
+                    const f2 A = pu[ch][pp] * ez + ex;  // ex = f E.x, ny = -f E.y (the MFMA operands carry f)
+                    const f2 B = pv[ch][pp] * ez + ny;
                     const f2 Sq = __builtin_elementwise_fma(B, B, A * A);
                     const f2 zz = ez * ez;
                     const f2 T = zz * Sq;
                     // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0;  err > CNN_OBJ_MAXINPUT -> 0, i.e. S > clamp^2 E.z^2;  lanes beyond
                     // the map or the ragged hypothesis end -> 0;  err == 0 -> 0 (the reference divides by err + 1e-8: -0 / 1e-8)
                     const f2 lim = zz * f2{clampv * clampv, clampv * clampv};
-                    const bool k0 = lane_ok & (fabsf(ez.x) >= 1e-8f) & (Sq.x <= lim.x) & (T.x > 1e-30f);
-                    const bool k1 = lane_ok & (fabsf(ez.y) >= 1e-8f) & (Sq.y <= lim.y) & (T.y > 1e-30f);
+                    // |E.z| >= 1e-8 is implied: T = E.z^2 S > 1e-28 with S <= 1e4 E.z^2 gives E.z^4 > 1e-32
+                    const bool k0 = lane_ok & (Sq.x <= lim.x) & (T.x > 1e-28f);
+                    const bool k1 = lane_ok & (Sq.y <= lim.y) & (T.y > 1e-28f);
                     const f2 m = {k0 ? __builtin_amdgcn_rsqf(T.x) : 0.f, k1 ? __builtin_amdgcn_rsqf(T.y) : 0.f};  // 0 keeps everything below an exact 0
                     f2 w;
                     if (SOFTMODE) {
@@ -452,16 +453,17 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                         const f2 t = __builtin_elementwise_fma(f2{kA, kA}, ec, f2{kB, kB});
                         const f2 dd = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f2{1.f, 1.f};
                         const f2 sg = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
-                        const float gb = c2.y * (-beta) * f;
+                        const float gb = c2.y * (-beta);
                         w = (sg * f2{gb, gb}) * (f2{1.f, 1.f} - sg);
                     } else {
-                        w = (pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y}) * f2{f, f};
+                        w = pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y};
                     }
-                    const f2 q = w * m;                                   // w f / (|E.z| sqrt(S))
+                    const f2 q0 = w * m;                                  // w / (|E.z| sqrt(S))
+                    const f2 q = q0 * f2{f, f};                           // w f / (|E.z| sqrt(S))
                     const f2 iz = (m * m) * (Sq * ez);                    // 1 / E.z
                     const f2 C0 = A * q;                                  //  C0
                     const f2 nC1 = B * q;                                 // -C1
-                    const f2 nC2 = __builtin_elementwise_fma(B, ny, A * ex) * (q * iz);  // -C2
+                    const f2 nC2 = __builtin_elementwise_fma(B, ny, A * ex) * (q0 * iz);  // -C2: ex, ny carry the factor f that q0 leaves out
                     gx[ch][pp] = __builtin_elementwise_fma(f2{c0.x, c0.x}, C0, __builtin_elementwise_fma(f2{c0.w, c0.w}, nC1, __builtin_elementwise_fma(f2{c1.z, c1.z}, nC2, gx[ch][pp])));
                     gy[ch][pp] = __builtin_elementwise_fma(f2{c0.y, c0.y}, C0, __builtin_elementwise_fma(f2{c1.x, c1.x}, nC1, __builtin_elementwise_fma(f2{c1.w, c1.w}, nC2, gy[ch][pp])));
                     gz[ch][pp] = __builtin_elementwise_fma(f2{c0.z, c0.z}, C0, __builtin_elementwise_fma(f2{c1.y, c1.y}, nC1, __builtin_elementwise_fma(f2{c2.x, c2.x}, nC2, gz[ch][pp])));
@@ -474,7 +476,9 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                     S[2][0] = __builtin_elementwise_fma(nC2, ex, S[2][0]); S[2][1] = __builtin_elementwise_fma(nC2, ny, S[2][1]);
                     S[2][2] = __builtin_elementwise_fma(nC2, ez, S[2][2]); S[2][3] += nC2;
                 }
+#ifndef K4_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: interleaved, their temporaries cost a wave of occupancy
+#endif
             }
             // the 12 sums of hypothesis c over this lane's pixels (pair halves added), in the order a[3 j + m], a[9 + j] -> index
             // q = 0..11; then the transpose-reduce over the 4 lane groups: lane (g, c) ends with the totals of q = 3 g .. 3 g + 2
@@ -491,6 +495,11 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
             for (int k = 0; k < 3; k++) { lane_swap16(a[k], a[3 + k]); a[k] += a[3 + k]; }
             float* dst = s_G + ((size_t)(gi * 4 + wave) * 16 + c) * 12 + 3 * gq;  // private to this lane: plain read-modify-write
             dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2];
+        };
+        f4 wm[CH];
+        for (int gi = 0; gi < ngi; gi += 2) {
+            group(gi, wn, wm);
+            if (gi + 1 < ngi) group(gi + 1, wm, wn);
         }
 
         // grad: sum over the 16 hypothesis lanes of the row, lane c == 0 of every row stores its 4 pixels (12 consecutive floats)
@@ -565,7 +574,8 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     // 3 rounds of 4 chunks where the mean is 2.34, against 960 tiles = 2 rounds of 5) predicted -20 % for 5 chunks; it is not there:
     // a workgroup that runs out of tiles leaves its SIMDs to its neighbours.
     const bool auto_form = variant < 0;
-    if (variant < 0) variant = d_err ? 2 : 3;
+    // round 3: 4 chunks for both inputs (the ping-pong d_err registers put the 5-chunk form over the register file: 124-276 B of scratch)
+    if (variant < 0) variant = 2;
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 7 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(int P, int W, int H, int hy
 __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel_tiles, const float* __restrict__ G12_part,
                                                          const double* __restrict__ dRdH, const double* __restrict__ dpnp,
                                                          const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
-                                                         double* __restrict__ G6_out, const float* __restrict__ rec_e) {
+                                                         double* __restrict__ G6_out, const float* __restrict__ rec_e, float f_e) {
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
         const float* o = rec_e + (size_t)h * BWD_REC;
         const double Rp[3][3] = {{o[0], o[2], o[4]}, {-(double)o[1], -(double)o[3], -(double)o[5]}, {o[8], o[9], o[10]}};
         const double tp[3] = {o[6], -(double)o[7], o[11]};
-        const double sj[3] = {1, -1, -1}, sm[3] = {1, -1, 1};
+        const double sj[3] = {1, -1, -1}, sm[3] = {1.0 / (double)f_e, -1.0 / (double)f_e, 1};  // the kernel summed against (f E.x, -f E.y, E.z)
         double A[3][3], B[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -775,7 +785,7 @@ hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const
     const size_t n3 = (size_t)F.P * 3;
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
     hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
-                       G6_scratch, rec_if_e_based);
+                       G6_scratch, rec_if_e_based, F.fx);
     return hipGetLastError();
 }
 
