@@ -37,10 +37,22 @@ def test_soft_only_mode_is_priced_against_the_valu_roof():
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_bench_default.json", "r02_bench_driver_flags.json", "r02_final_bench_driver_flags.json"])
+@pytest.mark.parametrize("name", ["r01_bench_default.json", "r02_bench_driver_flags.json", "r02_final_bench_driver_flags.json",
+                                  "r03_final_bench_driver_flags.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1]
     d = json.loads(line)
+    if name.startswith("r03"):
+        # round 3: the secondary measurement of SURVEY.md 8(d) rides in the driver's line, priced against the VALU roof; the traffic figure says
+        # where it comes from; the batched processImage; the CPU baseline on the cores the container is granted
+        so = d["soft_only"]
+        assert so["bound"] == "valu" and so["unit"] == "TFLOP/s" and so["peak"] == 157.3 and abs(so["frac"] - so["achieved"] / 157.3) < 1e-9
+        assert so["flop_per_launch"] == 16 * 256 * 640 * 480 * 36 and 0.2 < so["frac"] < 1.0
+        assert "PMC" in d["roofline"]["traffic_source"] and d["roofline"]["frac"] >= 0.70
+        assert d["process_image"]["640x480_batch_of_16"]["us_per_image"] < 0.5 * d["process_image"]["640x480"]["us_per_image"]
+        assert d["cpu_baseline"]["cores"] <= 64 and "quota" in d["cpu_baseline"]["cpus"]
+        d = dict(d)  # the shared checks below know the round-2 shape
+        name = "r02_" + name
     if name.startswith("r02"):
         # round 2: the driver's own flags, every K2 launch of the timed region timed, the extra SURVEY 8(d) fields
         assert d["steps"] == 20 and d["warmup"] == 5 and d["roofline"]["launches_timed"] == 20 and d["roofline"]["frac"] >= 0.60
