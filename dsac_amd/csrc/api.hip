@@ -733,8 +733,8 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     }
     const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
     HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
-    HIP_TRY(c, c->dRdH.reserve((size_t)N * 27 * sizeof(double)));
-    HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * P * 3 * sizeof(float)));
+    HIP_TRY(c, c->dRdH.reserve((size_t)N * dk::BWD_DRDH * sizeof(double)));
+    HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * plan.glayers * P * 3 * sizeof(float)));
     HIP_TRY(c, c->g12_part.reserve((size_t)plan.rows * N * 12 * sizeof(float)));
     HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
     HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
@@ -743,7 +743,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
                                       c->g12_part.as<float>(), plan));
     }
-    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.NT, c->g12_part.as<float>(), plan.rows, c->dRdH.as<double>(),
+    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.NT * plan.glayers, c->g12_part.as<float>(), plan.rows, c->dRdH.as<double>(),
                                          d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(), plan.variant > 0 ? c->bwd_staged.as<float>() : nullptr));
     c->g6_n = N;
     return end_call(c);

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
             // the x and negated-y rows carry the focal length (round 3): the MFMA then yields f E.x and -f E.y, which is what the residual uses
             for (int k = 0; k < 4; k++) { gb[k * 16 + c] = f * o[2 * k]; gb[64 + k * 16 + c] = f * o[2 * k + 1]; gb[128 + k * 16 + c] = o[8 + k]; }
             float* gc = gb + 192 + c * 12;
-            gc[0] = o[12]; gc[1] = o[13]; gc[2] = o[18]; gc[3] = o[14]; gc[4] = o[15]; gc[5] = o[19]; gc[6] = o[16]; gc[7] = o[17]; gc[8] = o[20];
+            // r0 and -r1 rows carry the focal length as well: the kernel forms C0 / f and -C1 / f (one multiply per pair less, round 3)
+            gc[0] = f * o[12]; gc[1] = f * o[13]; gc[2] = f * o[18]; gc[3] = f * o[14]; gc[4] = f * o[15]; gc[5] = f * o[19];
+            gc[6] = o[16]; gc[7] = o[17]; gc[8] = o[20];
             gc[9] = gc[10] = gc[11] = 0.f;
         }
     }
@@ -81,7 +83,21 @@ __global__ __launch_bounds__(64) void k_backward_prep(int N, const double* __res
     dm::rodrigues_m2v(R, rod);
     dm::rodrigues_v2m<true>(rod, Rre, J);
 #pragma unroll
-    for (int k = 0; k < 27; k++) dRdH[(size_t)h * 27 + k] = J[k];
+    for (int k = 0; k < 27; k++) dRdH[(size_t)h * BWD_DRDH + k] = J[k];
+    // Omega_i = (dR / d rod_i) R^T, skew-symmetric because R(rod) is a rotation for every rod.  The matrix-core main pass sums C (x) (E - t) instead
+    // of C (x) X (X = R^T (E - t)): dLoss / d rod_i = sum_jm S[j][m] Omega_i[j][m], and only the antisymmetric part of S survives -- the kernel
+    // does not accumulate its diagonal (3 of 12 accumulations per pixel pair, round 3)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                double v = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) v += J[i * 9 + 3 * j + k] * Rre[3 * m + k];
+                dRdH[(size_t)h * BWD_DRDH + 27 + i * 9 + 3 * j + m] = v;
+            }
 }
 
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH) {
@@ -315,6 +331,11 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
 //   grad_part : [hyp tile][P*3]        G12_part : [G pixel workgroups][N][12]  (E-based sums, see k_support_scatter)
 // --------------------------------------------------------------------------------------------------
 constexpr int K4M_HT_MAX = 256;
+// K4_ABLATE (experiments only, scripts/r03_k4_ablate.sh; results are WRONG with any bit set): 1 no pose-sum accumulation, 2 no gradient
+// accumulation, 4 no transpose-reduce, 8 products instead of the MFMAs, 16 no d_err stream, 32 a multiply instead of the rsq
+#ifndef K4_ABLATE
+#define K4_ABLATE 0
+#endif
 
 DM_INLINE float row16_sum_f(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
     v += dpp_merge<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
@@ -359,7 +380,19 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
 
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f2 zero2 = {0.f, 0.f};
-    for (int pt = pw; pt < PT; pt += G) {
+    // Work of this workgroup (round 3): a CONTIGUOUS range of (pixel tile, hypothesis group) items, the same number for every workgroup of the
+    // hypothesis tile.  Round 2 gave whole tiles round-robin: 1200 tiles on 512 workgroups = 2.34 tiles each, and since the pass is bound by each
+    // wave's own latency chain (a workgroup whose neighbour has finished runs no faster) the launch took the time of THREE tiles.  A tile whose
+    // groups are split between two workgroups gets its gradient from both: the part that starts at group 0 writes layer 0 of grad_part, the part
+    // that starts later writes layer 1 (a workgroup that covers a whole tile zeroes layer 1 for it), k_grad_reduce sums the layers.
+    const long long items = (long long)PT * ngi;
+    long long it = items * pw / G;
+    const long long it_end = items * (pw + 1) / G;
+    while (it < it_end) {
+        const int pt = (int)(it / ngi);
+        const int g_begin = (int)(it - (long long)pt * ngi);
+        const int g_end = (int)min((long long)ngi, g_begin + (it_end - it));
+        it += g_end - g_begin;
         // per chunk: the MFMA A operand (coordinate gq of pixel base + c) and the position of this lane's own 4 pixels (base + 4 gq + 0..3)
         float Aop[CH];
         f2 pu[CH][2], pv[CH][2];
@@ -371,7 +404,8 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
             p0[ch] = base + 4 * gq;
             valid[ch] = p0[ch] < P;  // P % 4 == 0
             const int pa = min(base + c, P - 1);
-            Aop[ch] = (gq < 3) ? xyz[(size_t)pa * 3 + gq] : 1.0f;
+            const float xa = xyz[(size_t)pa * 3 + min(gq, 2)];  // unconditional: a load under a lane mask makes hipcc wait vmcnt(0) at the next use of ANY load
+            Aop[ch] = (gq < 3) ? xa : 1.0f;
             const int pl = min(p0[ch], P - 4);
             if (UV) {
                 const f4* su = reinterpret_cast<const f4*>(uv + (size_t)pl * 2);
@@ -394,20 +428,22 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
 
         // d_err of the first group (one dwordx4 per chunk: 4 consecutive pixels of hypothesis c)
         f4 wn[CH];
+        // Every lane loads, from a clamped address (ragged hypothesis end -> the tile's last row, pixels beyond the map -> the last 4): a load under a
+        // lane mask is a branch around the instruction, hipcc's wait-count pass then no longer knows how many loads are in flight and waits vmcnt(0) at
+        // the first use -- which also waited for the prefetch issued just before it (every second group paid a full memory round trip; round 3,
+        // profiles/r03_k4_ablate.txt: 14 us of 124).  Lanes that must not contribute are switched off through `okscale` below.
         auto load_w = [&](int gi, f4 (&dst)[CH]) {
-            const int hyp = 16 * gi + c;
+            const int hyp = min(16 * gi + c, nh - 1);
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
-                if (!SOFTMODE && hyp < nh && valid[ch]) dst[ch] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(d_err + (size_t)(h0 + hyp) * P + p0[ch]));
+                if (!(K4_ABLATE & 16) && !SOFTMODE) dst[ch] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(d_err + (size_t)(h0 + hyp) * P + min(p0[ch], P - 4)));
                 else dst[ch] = z4;
             }
         };
-        load_w(0, wn);
+        load_w(g_begin, wn);
 
-        // one group of 16 hypotheses; `wv` = this group's d_err, `wnext` receives the next group's (prefetched under this group's arithmetic).  The
-        // two register sets alternate roles (no copy: round 2 moved the prefetched set into place with 8 v_mov_b64 per group)
-        auto group = [&](int gi, const f4 (&wv)[CH], f4 (&wnext)[CH]) {
-            if (gi + 1 < ngi) load_w(gi + 1, wnext);
+        // one group of 16 hypotheses; `wv` = this group's d_err (the next group's is prefetched by the loop below)
+        auto group = [&](int gi, const f4 (&wv)[CH]) {
             const float* simg = s_img + gi * 384;
             const float bx = simg[lane], by = simg[64 + lane], bz = simg[128 + lane];
             const f4* cf = reinterpret_cast<const f4*>(simg + 192 + c * 12);
@@ -421,10 +457,15 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                 for (int k = 0; k < 4; k++) S[j][k] = zero2;
 #pragma unroll
             for (int ch = 0; ch < CH; ch++) {
+#if K4_ABLATE & 8
+                const f4 ex4 = f4{bx, by, bz, bx} * Aop[ch], ny4 = f4{by, bz, bx, by} * Aop[ch], ez4 = f4{bz, bx, by, bz} * Aop[ch] + f4{900.f, 900.f, 900.f, 900.f};
+#else
                 const f4 ex4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], bx, z4, 0, 0, 0);   // E.x   of pixels p0 .. p0+3, hypothesis c
                 const f4 ny4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], by, z4, 0, 0, 0);   // -E.y
                 const f4 ez4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Aop[ch], bz, z4, 0, 0, 0);   // E.z
+#endif
                 const bool lane_ok = hyp_ok && valid[ch];
+                const float okscale = lane_ok ? 1e30f : 0.f;  // keep = 0 on lanes beyond the map / the ragged hypothesis end (their d_err is a clamped re-read)
 #pragma unroll
                 for (int pp = 0; pp < 2; pp++) {
                     const f2 ex = pp ? f2{ex4.z, ex4.w} : f2{ex4.x, ex4.y};
@@ -438,14 +479,22 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                     const f2 B = pv[ch][pp] * ez + ny;
                     const f2 Sq = __builtin_elementwise_fma(B, B, A * A);
                     const f2 zz = ez * ez;
-                    const f2 T = zz * Sq;
                     // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0;  err > CNN_OBJ_MAXINPUT -> 0, i.e. S > clamp^2 E.z^2;  lanes beyond
                     // the map or the ragged hypothesis end -> 0;  err == 0 -> 0 (the reference divides by err + 1e-8: -0 / 1e-8)
-                    const f2 lim = zz * f2{clampv * clampv, clampv * clampv};
-                    // |E.z| >= 1e-8 is implied: T = E.z^2 S > 1e-28 with S <= 1e4 E.z^2 gives E.z^4 > 1e-32
-                    const bool k0 = lane_ok & (Sq.x <= lim.x) & (T.x > 1e-28f);
-                    const bool k1 = lane_ok & (Sq.y <= lim.y) & (T.y > 1e-28f);
-                    const f2 m = {k0 ? __builtin_amdgcn_rsqf(T.x) : 0.f, k1 ? __builtin_amdgcn_rsqf(T.y) : 0.f};  // 0 keeps everything below an exact 0
+                    // Round 3: the guards as ARITHMETIC, no compare -> scalar mask -> select chain (the pass is bound by the latency of each wave's own
+                    // dependent chain, and that chain crossed to the scalar unit and back four times per pixel pair):
+                    //   keep = clamp((clamp^2 E.z^2 - S) * 1e30, 0, 1) is exactly 1 where err <= clamp (the difference of two numbers ~1e10 is either <= 0 or
+                    //   >= one ulp ~ 1e3), exactly 0 where err > clamp -- and where |E.z| < 1e-8 (then clamp^2 E.z^2 <= 1e-12 << S = f^2 (E.x^2 + E.y^2));
+                    //   m = rsq(T + 1e-30) stays finite at err == 0 (A = B = 0 there: every C is an exact 0, as the reference's 0 / 1e-8);
+                    //   lanes beyond the map or the ragged hypothesis end: keep = 0 through okscale (their d_err is a clamped re-read of valid cells).
+                    const f2 tk = __builtin_elementwise_fma(zz, f2{clampv * clampv, clampv * clampv}, -Sq);
+                    const f2 keep = {__builtin_amdgcn_fmed3f(tk.x * okscale, 0.f, 1.f), __builtin_amdgcn_fmed3f(tk.y * okscale, 0.f, 1.f)};
+                    const f2 Tp = __builtin_elementwise_fma(zz, Sq, f2{1e-30f, 1e-30f});  // E.z^2 S, kept away from 0
+#if K4_ABLATE & 32
+                    const f2 m = Tp * f2{1e-12f, 1e-12f};
+#else
+                    const f2 m = {__builtin_amdgcn_rsqf(Tp.x), __builtin_amdgcn_rsqf(Tp.y)};
+#endif
                     f2 w;
                     if (SOFTMODE) {
                         const f2 err = Sq * m;  // guarded pairs: 0 -> a finite sigmoid, times m = 0 below
@@ -457,24 +506,34 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                         w = (sg * f2{gb, gb}) * (f2{1.f, 1.f} - sg);
                     } else {
                         w = pp ? f2{wv[ch].z, wv[ch].w} : f2{wv[ch].x, wv[ch].y};
+                        if (K4_ABLATE & 16) w = f2{c2.y, c2.z} + ex;
                     }
+                    w = w * keep;
                     const f2 q0 = w * m;                                  // w / (|E.z| sqrt(S))
-                    const f2 q = q0 * f2{f, f};                           // w f / (|E.z| sqrt(S))
                     const f2 iz = (m * m) * (Sq * ez);                    // 1 / E.z
-                    const f2 C0 = A * q;                                  //  C0
-                    const f2 nC1 = B * q;                                 // -C1
-                    const f2 nC2 = __builtin_elementwise_fma(B, ny, A * ex) * (q0 * iz);  // -C2: ex, ny carry the factor f that q0 leaves out
+                    const f2 C0 = A * q0;                                 //  C0 / f   (the factor f sits in the r0 / -r1 coefficient rows and in the finish kernel)
+                    const f2 nC1 = B * q0;                                // -C1 / f
+                    const f2 nC2 = __builtin_elementwise_fma(nC1, ny, C0 * ex) * iz;      // -C2 = (C0 E.x + C1 E.y) / E.z: C is orthogonal to the ray (ex, ny carry the f that C0, nC1 lack)
+#if K4_ABLATE & 2
+                    gx[ch][pp] += C0; gy[ch][pp] += nC1; gz[ch][pp] += nC2;
+#else
                     gx[ch][pp] = __builtin_elementwise_fma(f2{c0.x, c0.x}, C0, __builtin_elementwise_fma(f2{c0.w, c0.w}, nC1, __builtin_elementwise_fma(f2{c1.z, c1.z}, nC2, gx[ch][pp])));
                     gy[ch][pp] = __builtin_elementwise_fma(f2{c0.y, c0.y}, C0, __builtin_elementwise_fma(f2{c1.x, c1.x}, nC1, __builtin_elementwise_fma(f2{c1.w, c1.w}, nC2, gy[ch][pp])));
                     gz[ch][pp] = __builtin_elementwise_fma(f2{c0.z, c0.z}, C0, __builtin_elementwise_fma(f2{c1.y, c1.y}, nC1, __builtin_elementwise_fma(f2{c2.x, c2.x}, nC2, gz[ch][pp])));
+#endif
                     // E is exactly 0 where a guard fired with a NaN / inf intermediate?  No: C_j are exactly 0 there and E is finite
                     // (an MFMA of finite inputs), so the products below are exact zeros.
-                    S[0][0] = __builtin_elementwise_fma(C0, ex, S[0][0]); S[0][1] = __builtin_elementwise_fma(C0, ny, S[0][1]);
+#if K4_ABLATE & 1
+                    S[0][3] += C0; S[1][3] += nC1; S[2][3] += nC2;
+#else
+                    // off-diagonal sums only (the finish kernel contracts with skew-symmetric matrices, see k_backward_prep)
+                    S[0][1] = __builtin_elementwise_fma(C0, ny, S[0][1]);
                     S[0][2] = __builtin_elementwise_fma(C0, ez, S[0][2]); S[0][3] += C0;
-                    S[1][0] = __builtin_elementwise_fma(nC1, ex, S[1][0]); S[1][1] = __builtin_elementwise_fma(nC1, ny, S[1][1]);
+                    S[1][0] = __builtin_elementwise_fma(nC1, ex, S[1][0]);
                     S[1][2] = __builtin_elementwise_fma(nC1, ez, S[1][2]); S[1][3] += nC1;
                     S[2][0] = __builtin_elementwise_fma(nC2, ex, S[2][0]); S[2][1] = __builtin_elementwise_fma(nC2, ny, S[2][1]);
-                    S[2][2] = __builtin_elementwise_fma(nC2, ez, S[2][2]); S[2][3] += nC2;
+                    S[2][3] += nC2;
+#endif
                 }
 #ifndef K4_INTERLEAVE
                 __builtin_amdgcn_sched_barrier(0);  // keep the chunks apart: interleaved, their temporaries cost a wave of occupancy
@@ -489,17 +548,29 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                 for (int k = 0; k < 3; k++) a[3 * j + k] = S[j][k].x + S[j][k].y;
                 a[9 + j] = S[j][3].x + S[j][3].y;
             }
+#if K4_ABLATE & 4
+            a[0] += a[3] + a[6] + a[9]; a[1] += a[4] + a[7] + a[10]; a[2] += a[5] + a[8] + a[11];
+#else
 #pragma unroll
             for (int k = 0; k < 6; k++) { lane_swap32(a[k], a[6 + k]); a[k] += a[6 + k]; }
 #pragma unroll
             for (int k = 0; k < 3; k++) { lane_swap16(a[k], a[3 + k]); a[k] += a[3 + k]; }
+#endif
             float* dst = s_G + ((size_t)(gi * 4 + wave) * 16 + c) * 12 + 3 * gq;  // private to this lane: plain read-modify-write
             dst[0] += a[0]; dst[1] += a[1]; dst[2] += a[2];
         };
-        f4 wm[CH];
-        for (int gi = 0; gi < ngi; gi += 2) {
-            group(gi, wn, wm);
-            if (gi + 1 < ngi) group(gi + 1, wm, wn);
+        // Software pipeline, distance one group: this group's d_err moves out of the landing registers (4 v_mov_b64 per chunk... the wait for the loads
+        // issued a whole group ago sits here), the next group's loads are issued, then the arithmetic.  The prefetch is unconditional (the last group
+        // of the range re-reads its own rows: 1 / 16 of the stream, from L2) and pinned: round 3 tried two register sets that swap roles through a
+        // pair of calls -- the second call sits behind a branch, LLVM then sinks the first call's loads in front of their use and every other group
+        // paid the memory round trip.
+        for (int gi = g_begin; gi < g_end; gi++) {
+            f4 wv[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ch++) wv[ch] = wn[ch];
+            load_w(min(gi + 1, g_end - 1), wn);
+            __builtin_amdgcn_sched_barrier(0);
+            group(gi, wv);
         }
 
         // grad: sum over the 16 hypothesis lanes of the row, lane c == 0 of every row stores its 4 pixels (12 consecutive floats)
@@ -512,10 +583,15 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                 o[6 * pp + 3] = row16_sum_f(gx[ch][pp].y); o[6 * pp + 4] = row16_sum_f(gy[ch][pp].y); o[6 * pp + 5] = row16_sum_f(gz[ch][pp].y);
             }
             if (c == 0 && valid[ch]) {
-                f4* dstg = reinterpret_cast<f4*>(grad_part + (size_t)ht * P * 3 + (size_t)p0[ch] * 3);
+                const int layer = g_begin > 0 ? 1 : 0;
+                f4* dstg = reinterpret_cast<f4*>(grad_part + ((size_t)ht * 2 + layer) * P * 3 + (size_t)p0[ch] * 3);
                 dstg[0] = f4{o[0], o[1], o[2], o[3]};
                 dstg[1] = f4{o[4], o[5], o[6], o[7]};
                 dstg[2] = f4{o[8], o[9], o[10], o[11]};
+                if (g_begin == 0 && g_end == ngi) {  // the whole tile is this workgroup's: nobody writes its layer 1
+                    f4* dz = reinterpret_cast<f4*>(grad_part + ((size_t)ht * 2 + 1) * P * 3 + (size_t)p0[ch] * 3);
+                    dz[0] = z4; dz[1] = z4; dz[2] = z4;
+                }
             }
         }
     }
@@ -564,6 +640,7 @@ bool backward_variant_known(int v) {
 
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) {
     K4Plan pl{};
+    pl.glayers = 1;
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
     // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
@@ -574,8 +651,9 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     // 3 rounds of 4 chunks where the mean is 2.34, against 960 tiles = 2 rounds of 5) predicted -20 % for 5 chunks; it is not there:
     // a workgroup that runs out of tiles leaves its SIMDs to its neighbours.
     const bool auto_form = variant < 0;
-    // round 3: 4 chunks for both inputs (the ping-pong d_err registers put the 5-chunk form over the register file: 124-276 B of scratch)
-    if (variant < 0) variant = 2;
+    // round 3: 4 chunks with the d_err stream (its landing registers put the 5-chunk form over the register file: 116-152 B of scratch, 164 vs 102 us);
+    // without the stream and with the implicit pixel grid 5 chunks fit exactly (256 VGPRs, no scratch): N = 256: 108 vs 115 us, N = 1024: 388 vs 400
+    if (variant < 0) variant = (d_err == nullptr && F.uv == nullptr) ? 3 : 2;
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 7 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
@@ -610,6 +688,9 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         pl.HT = min(ht_small > 0 ? ht_small : ht_max, ((max(N, 1) + 15) / 16) * 16);
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
         pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : hi_occ ? k4m_min_waves(variant) : 2) * 256 + pl.NT - 1) / pl.NT));
+        // every workgroup takes the same number of (tile, 16-hypothesis group) items: at least one group each
+        pl.rows = (int)max(1ll, min((long long)pl.rows, (long long)PT * ((pl.HT + 15) / 16)));
+        pl.glayers = 2;
         return pl;
     }
     pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
@@ -723,11 +804,12 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
     if (rec_e) {
         // matrix-core main pass: the sums were taken against E = R'X + t' (signed as the kernel held them):
         //   a[3j + m] = sum C~_j E~_m, a[9 + j] = sum C~_j  with C~ = (C0, -C1, -C2), E~ = (E.x, -E.y, E.z)
-        // sum_p C_j X_k = sum_m R'[m][k] (sum C_j E_m - t'_m sum C_j); R', t' as the fp32 record the kernel computed E from
+        // sum_p C_j (E - t')_m = sum C_j E_m - t'_m sum C_j  (t' as the fp32 record the kernel computed E from); X = R^T (E - t) is applied through
+        // Omega below
         const float* o = rec_e + (size_t)h * BWD_REC;
-        const double Rp[3][3] = {{o[0], o[2], o[4]}, {-(double)o[1], -(double)o[3], -(double)o[5]}, {o[8], o[9], o[10]}};
         const double tp[3] = {o[6], -(double)o[7], o[11]};
-        const double sj[3] = {1, -1, -1}, sm[3] = {1.0 / (double)f_e, -1.0 / (double)f_e, 1};  // the kernel summed against (f E.x, -f E.y, E.z)
+        // the kernel summed (C0 / f, -C1 / f, -C2) against (f E.x, -f E.y, E.z), off-diagonal pairs only
+        const double sj[3] = {(double)f_e, -(double)f_e, -1}, sm[3] = {1.0 / (double)f_e, -1.0 / (double)f_e, 1};
         double A[3][3], B[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -738,21 +820,18 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 #pragma unroll
         for (int j = 0; j < 3; j++) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                double v = 0;
-#pragma unroll
-                for (int m = 0; m < 3; m++) v += Rp[m][k] * (A[j][m] - tp[m] * B[j]);
-                G[3 * j + k] = v;
-            }
+            for (int m = 0; m < 3; m++) G[3 * j + m] = (j == m) ? 0.0 : A[j][m] - tp[m] * B[j];   // sum_p C_j (E - t)_m, j != m
             G[9 + j] = B[j];
         }
     }
+    // rotation part: sum C_j X_k against dR/drod (VALU form), or sum C_j (E - t)_m against Omega = dR/drod R^T (matrix-core form)
+    const double* D = dRdH + (size_t)h * BWD_DRDH + (rec_e ? 27 : 0);
     double G6[6];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) s += G[k] * dRdH[(size_t)h * 27 + i * 9 + k];
+        for (int k = 0; k < 9; k++) s += G[k] * D[i * 9 + k];
         G6[i] = s;
         G6[3 + i] = G[9 + i];
     }

@@ -78,10 +78,12 @@ struct K4Plan {
     int variant;  // resolved form
     int HT, NT;   // hypotheses per workgroup, number of hypothesis tiles (rows of grad_part)
     int rows;     // rows of G12_part the launch writes
+    int glayers;  // layers of grad_part per hypothesis tile (matrix-core form: 2 -- a pixel tile's hypothesis groups may be split between two workgroups)
 };
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant);
 bool backward_variant_known(int variant);  // -1 (auto), 0 .. 5, or a form + 10 * tile code + 100 * workgroups per CU (see backward_plan)
-hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x 27*/);
+constexpr int BWD_DRDH = 54;  // per hypothesis: dR/drod (27) and Omega_i = (dR/drod_i) R^T (27)
+hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x BWD_DRDH*/);
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [partial rows][N][12] floats
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
