@@ -381,8 +381,9 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f2 zero2 = {0.f, 0.f};
     // Work of this workgroup (round 3): a CONTIGUOUS range of (pixel tile, hypothesis group) items, the same number for every workgroup of the
-    // hypothesis tile.  Round 2 gave whole tiles round-robin: 1200 tiles on 512 workgroups = 2.34 tiles each, and since the pass is bound by each
-    // wave's own latency chain (a workgroup whose neighbour has finished runs no faster) the launch took the time of THREE tiles.  A tile whose
+    // hypothesis tile (round 2 gave whole tiles round-robin: 1200 tiles on 512 workgroups = 2 or 3 tiles each).  Measured, the balance is worth
+    // nothing -- the pass is bound by the VALU issue rate of the SIMD, a workgroup that finishes early leaves its issue slots to its neighbour
+    //  -- but it costs nothing either and keeps the launch time independent of how the tile count divides.  A tile whose
     // groups are split between two workgroups gets its gradient from both: the part that starts at group 0 writes layer 0 of grad_part, the part
     // that starts later writes layer 1 (a workgroup that covers a whole tile zeroes layer 1 for it), k_grad_reduce sums the layers.
     const long long items = (long long)PT * ngi;
@@ -481,8 +482,8 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                     const f2 zz = ez * ez;
                     // guards (cnn_softam.h:416,430,476,490): |E.z| < 1e-8 -> 0;  err > CNN_OBJ_MAXINPUT -> 0, i.e. S > clamp^2 E.z^2;  lanes beyond
                     // the map or the ragged hypothesis end -> 0;  err == 0 -> 0 (the reference divides by err + 1e-8: -0 / 1e-8)
-                    // Round 3: the guards as ARITHMETIC, no compare -> scalar mask -> select chain (the pass is bound by the latency of each wave's own
-                    // dependent chain, and that chain crossed to the scalar unit and back four times per pixel pair):
+                    // Round 3: the guards as ARITHMETIC, no compare -> scalar mask -> select chain (same instruction count, no scalar round trips;
+                    // it also lets lanes beyond the map / the ragged end be switched off through the scale factor, so that their loads are unconditional):
                     //   keep = clamp((clamp^2 E.z^2 - S) * 1e30, 0, 1) is exactly 1 where err <= clamp (the difference of two numbers ~1e10 is either <= 0 or
                     //   >= one ulp ~ 1e3), exactly 0 where err > clamp -- and where |E.z| < 1e-8 (then clamp^2 E.z^2 <= 1e-12 << S = f^2 (E.x^2 + E.y^2));
                     //   m = rsq(T + 1e-30) stays finite at err == 0 (A = B = 0 there: every C is an exact 0, as the reference's 0 / 1e-8);

@@ -12,12 +12,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t ev_ = (x); if (ev_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(ev_)); exit(1); } } while (0)
 
 enum { K_FMA, K_PKFMA, K_PKMUL, K_PKADD, K_PKFMA_BCAST, K_PKFMA_SGPR, K_MUL, K_RSQ, K_PKFMA_DEP, K_FMA_DEP, K_MIX_PK_FMA, K_PKFMA_ILP4, K_PKFMA_ILP2,
-       K_FMA_ILP4, K_PKFMA_MFMA, K_FMA_MFMA, K_PKFMA_3SRC, K_NKINDS };
+       K_FMA_ILP4, K_PKFMA_MFMA, K_FMA_MFMA, K_PKFMA_3SRC, K_MFMA_F32, K_MFMA_BF16, K_PKFMA_MFMA_BF16, K_PKFMA4_MFMA_BF16, K_RSQ_MFMA_BF16, K_NKINDS };
 static const char* names[] = {"v_fma_f32 x16 indep", "v_pk_fma_f32 x16 indep", "v_pk_mul_f32 x16 indep", "v_pk_add_f32 x16 indep",
                               "v_pk_fma_f32 bcast(op_sel_hi 0) x16", "v_pk_fma_f32 sgpr src0 x16", "v_mul_f32 x16 indep", "v_rsq_f32 x16 indep",
                               "v_pk_fma_f32 dependent chain", "v_fma_f32 dependent chain", "pk_fma + fma alternating x16", "v_pk_fma_f32 ILP 4",
                               "v_pk_fma_f32 ILP 2", "v_fma_f32 ILP 4", "8 pk_fma per mfma16x16x4 (x16 indep)", "16 fma per mfma16x16x4",
-                              "v_pk_fma_f32 3 distinct vgpr srcs x16"};
+                              "v_pk_fma_f32 3 distinct vgpr srcs x16", "v_mfma_f32_16x16x4_f32 alone (4 accumulators)",
+                              "v_mfma_f32_16x16x32_bf16 alone (4 accumulators)", "8 pk_fma per mfma16x16x32_bf16", "4 pk_fma per mfma16x16x32_bf16",
+                              "4 rsq per mfma16x16x32_bf16"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, int iters, float s) {
@@ -28,6 +30,8 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, int it
     f2 b = {1.0000001f + s, 0.9999999f + s}, c = {1e-9f + s, -1e-9f + s}, d = {0.5f + s, 0.25f + s};
     float bs = 1.0000001f + s, cs = 1e-9f + s;
     f4 acc = {0.f, 0.f, 0.f, 0.f};
+    f4 accs[4] = {acc, acc, acc, acc};
+    f4 a4 = {s, s + 1.f, s, s}, b4 = {s + 2.f, s, s, s + 3.f};
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -59,12 +63,27 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, int it
                     asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(bs), "v"(cs));
                     if (i == 15) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(bs), "v"(cs));
                 }
+                if (KIND == K_MFMA_F32) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accs[i & 3]) : "v"(bs), "v"(cs));
+                if (KIND == K_MFMA_BF16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accs[i & 3]) : "v"(a4), "v"(b4));
+                if (KIND == K_PKFMA_MFMA_BF16) {
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                    if ((i & 7) == 7) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accs[(i >> 3) + 2 * r]) : "v"(a4), "v"(b4));
+                }
+                if (KIND == K_PKFMA4_MFMA_BF16) {
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                    if ((i & 3) == 3) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accs[(i >> 2) & 3]) : "v"(a4), "v"(b4));
+                }
+                if (KIND == K_RSQ_MFMA_BF16) {
+                    asm volatile("v_rsq_f32 %0, %0" : "+v"(q[i]));
+                    if ((i & 3) == 3) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accs[(i >> 2) & 3]) : "v"(a4), "v"(b4));
+                }
                 if (KIND == K_PKFMA_3SRC) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(d));
             }
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     float sum = acc.x + acc.y + acc.z + acc.w;
+    for (int i = 0; i < 4; i++) sum += accs[i].x + accs[i].y + accs[i].z + accs[i].w;
 #pragma unroll
     for (int i = 0; i < 16; i++) sum += a[i].x + a[i].y + q[i];
     if (sum == 1234.5678f) out[threadIdx.x] = sum;
@@ -105,6 +124,15 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     float* out; long long* cyc;
     CK(hipMalloc(&out, 4096)); CK(hipMalloc(&cyc, 256 * 8 * 4 * sizeof(long long)));
+    if (argc > 2) {  // second round: the matrix pipe beside the VALU
+        sweep<K_MFMA_F32>(iters, out, cyc);
+        sweep<K_MFMA_BF16>(iters, out, cyc);
+        sweep<K_PKFMA_MFMA>(iters, out, cyc);
+        sweep<K_PKFMA_MFMA_BF16>(iters, out, cyc);
+        sweep<K_PKFMA4_MFMA_BF16>(iters, out, cyc);
+        sweep<K_RSQ_MFMA_BF16>(iters, out, cyc);
+        return 0;
+    }
     sweep<K_FMA>(iters, out, cyc);
     sweep<K_MUL>(iters, out, cyc);
     sweep<K_PKFMA>(iters, out, cyc);
