@@ -50,9 +50,16 @@ def soft_only_roofline(n_hyps, P, k2_s, launches):
     for N P x 36 flop -- it is priced against the fp32 VECTOR roof, never as an HBM fraction."""
     flop = float(n_hyps) * float(P) * FLOP_PER_PAIR
     ach = flop / k2_s / 1e12 if k2_s > 0 else 0.0
+    # issue_model: the kernel's own instruction mix per 16 hypotheses x 64 pixels (61 packed fp32, 64 quarter-rate transcendentals, 57 plain, 12 exact-fp32
+    # MFMAs; ISA of k_reproject_st<2,4,1,...,soft only>) priced with the issue rates measured on this chip (profiles/r03_valu_rate*.txt: 5.3 / 8.8 / 2.9 / 38
+    # cycles at a nominal 2.4 GHz, MFMAs do not overlap the VALU stream): a constant, like `traffic` -- the time the arithmetic cannot go below
+    cyc_per_1024_pairs = 61 * 5.3 + 64 * 8.8 + 57 * 2.9 + 12 * 38.0
+    priced_s = float(n_hyps) * float(P) / 1024.0 * cyc_per_1024_pairs / (1024 * 2.4e9)
     return {"kernel": "k_reproject (K2), soft-inlier sums only (no error-image output)", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "flop_per_launch": flop, "flop_per_pair": FLOP_PER_PAIR, "avg_launch_us": k2_s * 1e6,
-            "launches_timed": launches, "hyp_per_s": n_hyps / k2_s if k2_s > 0 else None}
+            "launches_timed": launches, "hyp_per_s": n_hyps / k2_s if k2_s > 0 else None,
+            "issue_model": {"cycles_per_1024_pairs": cyc_per_1024_pairs, "priced_us": priced_s * 1e6, "frac": priced_s / k2_s if k2_s > 0 else None,
+                            "source": "constant: instruction mix of the kernel's ISA x issue rates of profiles/r03_valu_rate.txt, r03_valu_rate_mfma.txt"}}
 
 
 def event_stride_for(steps, requested):
