@@ -30,15 +30,20 @@ for N in (256, 1024):
                 eng.dScore(poses, sets, d_err, dpnp=dpnp, grad=grad)
             else:
                 eng.dSoftScore(poses, sets, g, dpnp=dpnp, grad=grad)
-        for _ in range(3): run()
-        eng.synchronize(); eng.profile_read(1)
-        # the whole K4 stage (prep + main pass + grad reduce + support scatter) on the engine's stream: device pointers only, so the
-        # calls just enqueue; wall time over 10 back-to-back calls
+        # settle the clocks first (as bench.py's prewarm does for K2): ten launches of 0.1-0.5 ms straight out of an idle GPU are timed at the idle
+        # clock -- the same binary reads 112 us cold and 102 us after 50 ms of work (in the trainer K4 follows the score CNN's backward: warm)
         import time
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.25:
+            for _ in range(20): run()
+            eng.synchronize()
+        eng.profile_read(1)
+        # the whole K4 stage (prep + main pass + grad reduce + support scatter) on the engine's stream: device pointers only, so the
+        # calls just enqueue; wall time over 40 back-to-back calls
         t0 = time.perf_counter()
-        for _ in range(10): run()
+        for _ in range(40): run()
         eng.synchronize()
-        stage_us = (time.perf_counter() - t0) / 10 * 1e6
+        stage_us = (time.perf_counter() - t0) / 40 * 1e6
         ms, n = eng.profile_read(1)
         us = ms / n * 1e3
         ab = (4 * N * P if mode == "d_err" else 0) + 12 * P + 48 * N + 48 * N + 12 * P
