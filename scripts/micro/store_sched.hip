@@ -42,6 +42,29 @@ __global__ void k_tile(float* out, int N, int P, int R, int CHW, int order, int 
         }
 }
 
+// the same tiles with ROW-CONTIGUOUS store instructions: a wave store covers ONE row x 1 KiB (lane l writes pixels 4l .. 4l+3 of a 256-pixel span) instead
+// of 4 rows x 256 B -- what an LDS transpose of K2's tile would give.  tile_px must be a multiple of 256; the R x (tile_px / 256) spans of the tile are
+// dealt round-robin to the waves.
+__global__ void k_tile_rows(float* out, int N, int P, int R, int CHW, int order, int work, float seedv) {
+    const int waves = blockDim.x >> 6;
+    const int tile_px = waves * CHW * 64;
+    const int PT = (P + tile_px - 1) / tile_px;
+    const int b = blockIdx.x;
+    int rt, pt;
+    if (order == 0) { pt = b % PT; rt = b / PT; }
+    else { const int q = b >> 3, PTG = (PT + 7) >> 3; rt = q / PTG; pt = (q % PTG) * 8 + (b & 7); }
+    if (pt >= PT) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc = seedv + (float)tid;
+    for (int i = 0; i < work; i++) acc = __builtin_fmaf(acc, 1.0000001f, 0.5f);
+    const f4 v = {acc, (float)b, 2.f, 3.f};
+    const int spans = tile_px / 256;
+    for (int i = wave; i < R * spans; i += waves) {
+        const int row = rt * R + i / spans, col = pt * tile_px + (i % spans) * 256 + 4 * lane;
+        if (row < N && col < P) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (size_t)row * P + col));
+    }
+}
+
 // one row x 4 KiB per workgroup, sequential (the fastest pattern of round 1's table) with the same dummy work
 __global__ __launch_bounds__(256) void k_seq(float* out, size_t chunks, int work, float seedv) {
     const size_t b = blockIdx.x;
@@ -90,17 +113,37 @@ int main(int argc, char** argv) {
         return best;
     };
     const size_t chunks = (size_t)N * P / 1024;
+    const bool rows_only = argc > 1 && argv[1][0] == 'r';
     for (int work : {0, 200, 800}) {
+        if (rows_only) break;
         const float ms = timeit([&] { hipLaunchKernelGGL(k_seq, dim3((unsigned)chunks), dim3(256), 0, 0, out, chunks, work, 1.f); });
         printf("seq 1 row x 4 KiB per workgroup, work %4d : %7.1f us  %6.0f GB/s\n", work, ms * 1e3, (double)N * P * 4 / ms / 1e6);
     }
     for (int work : {0, 100, 300})
-        for (int ppw : {60, 64, 120, 128, 240, 256, 300})
+        for (int ppw : {60, 64, 120, 128, 240, 256, 300}) if (!rows_only)
             for (int waves : {1, 4}) {
                 const int nw = (P + ppw - 1) / ppw, grid = (nw + waves - 1) / waves;
                 const float ms = timeit([&] { hipLaunchKernelGGL(k_sweep, dim3(grid), dim3(waves * 64), 0, 0, out, N, P, ppw, work, 1.f); });
                 printf("sweep px/wave %3d waves/wg %d (%5d waves) work %3d : %7.1f us  %6.0f GB/s\n", ppw, waves, nw, work, ms * 1e3, (double)N * P * 4 / ms / 1e6);
             }
+    if (argc > 1 && argv[1][0] == 'r') {  // store-instruction shape A/B on K2's tiles
+        struct C2 { int R, CHW, WAVES; };
+        for (int work : {0, 300})
+            for (C2 c : {C2{32, 4, 1}, C2{16, 4, 1}, C2{64, 4, 1}, C2{64, 1, 4}, C2{16, 1, 4}, C2{32, 1, 4}, C2{16, 4, 4}, C2{64, 4, 4}})
+                for (int order : {0, 2})
+                    for (int shape : {0, 1}) {
+                        const int tile_px = c.WAVES * c.CHW * 64;
+                        const int PT = (P + tile_px - 1) / tile_px, RT = (N + c.R - 1) / c.R;
+                        const long long grid = order == 0 ? (long long)PT * RT : (long long)((PT + 7) / 8) * 8 * RT;
+                        const float ms = timeit([&] {
+                            if (shape == 0) hipLaunchKernelGGL(k_tile, dim3((unsigned)grid), dim3(c.WAVES * 64), 0, 0, out, N, P, c.R, c.CHW, order, work, 1.f);
+                            else hipLaunchKernelGGL(k_tile_rows, dim3((unsigned)grid), dim3(c.WAVES * 64), 0, 0, out, N, P, c.R, c.CHW, order, work, 1.f);
+                        });
+                        printf("R %2d CHW %d WAVES %2d order %d work %3d store = %s : %7.1f us  %6.0f GB/s\n", c.R, c.CHW, c.WAVES, order, work,
+                               shape ? "1 row x 1 KiB " : "4 rows x 256 B", ms * 1e3, (double)N * P * 4 / ms / 1e6);
+                    }
+        return 0;
+    }
     if (argc > 1) return 0;
     struct Cfg { int R, CHW, WAVES, order, work, lds; };
     std::vector<Cfg> cfgs;

@@ -12,14 +12,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t ev_ = (x); if (ev_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(ev_)); exit(1); } } while (0)
 
 enum { K_FMA, K_PKFMA, K_PKMUL, K_PKADD, K_PKFMA_BCAST, K_PKFMA_SGPR, K_MUL, K_RSQ, K_PKFMA_DEP, K_FMA_DEP, K_MIX_PK_FMA, K_PKFMA_ILP4, K_PKFMA_ILP2,
-       K_FMA_ILP4, K_PKFMA_MFMA, K_FMA_MFMA, K_PKFMA_3SRC, K_MFMA_F32, K_MFMA_BF16, K_PKFMA_MFMA_BF16, K_PKFMA4_MFMA_BF16, K_RSQ_MFMA_BF16, K_NKINDS };
+       K_FMA_ILP4, K_PKFMA_MFMA, K_FMA_MFMA, K_PKFMA_3SRC, K_MFMA_F32, K_MFMA_BF16, K_PKFMA_MFMA_BF16, K_PKFMA4_MFMA_BF16, K_RSQ_MFMA_BF16, K_SQRT, K_RCP, K_EXP, K_MIN, K_RSQ_PK, K_NKINDS };
 static const char* names[] = {"v_fma_f32 x16 indep", "v_pk_fma_f32 x16 indep", "v_pk_mul_f32 x16 indep", "v_pk_add_f32 x16 indep",
                               "v_pk_fma_f32 bcast(op_sel_hi 0) x16", "v_pk_fma_f32 sgpr src0 x16", "v_mul_f32 x16 indep", "v_rsq_f32 x16 indep",
                               "v_pk_fma_f32 dependent chain", "v_fma_f32 dependent chain", "pk_fma + fma alternating x16", "v_pk_fma_f32 ILP 4",
                               "v_pk_fma_f32 ILP 2", "v_fma_f32 ILP 4", "8 pk_fma per mfma16x16x4 (x16 indep)", "16 fma per mfma16x16x4",
                               "v_pk_fma_f32 3 distinct vgpr srcs x16", "v_mfma_f32_16x16x4_f32 alone (4 accumulators)",
                               "v_mfma_f32_16x16x32_bf16 alone (4 accumulators)", "8 pk_fma per mfma16x16x32_bf16", "4 pk_fma per mfma16x16x32_bf16",
-                              "4 rsq per mfma16x16x32_bf16"};
+                              "4 rsq per mfma16x16x32_bf16", "v_sqrt_f32 x16 indep", "v_rcp_f32 x16 indep", "v_exp_f32 x16 indep", "v_min_f32 x16 indep",
+                              "v_rsq_f32 + v_pk_fma_f32 alternating"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, int iters, float s) {
@@ -77,6 +78,14 @@ __global__ __launch_bounds__(256) void k_rate(float* out, long long* cyc, int it
                     asm volatile("v_rsq_f32 %0, %0" : "+v"(q[i]));
                     if ((i & 3) == 3) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accs[(i >> 2) & 3]) : "v"(a4), "v"(b4));
                 }
+                if (KIND == K_SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(q[i]));
+                if (KIND == K_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(q[i]));
+                if (KIND == K_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(q[i]));
+                if (KIND == K_MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(q[i]) : "v"(bs));
+                if (KIND == K_RSQ_PK) {
+                    if (i & 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                    else asm volatile("v_rsq_f32 %0, %0" : "+v"(q[i]));
+                }
                 if (KIND == K_PKFMA_3SRC) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(d));
             }
         }
@@ -124,6 +133,15 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     float* out; long long* cyc;
     CK(hipMalloc(&out, 4096)); CK(hipMalloc(&cyc, 256 * 8 * 4 * sizeof(long long)));
+    if (argc > 2 && argv[2][0] == 't') {  // third round: the transcendental unit
+        sweep<K_RSQ>(iters, out, cyc);
+        sweep<K_SQRT>(iters, out, cyc);
+        sweep<K_RCP>(iters, out, cyc);
+        sweep<K_EXP>(iters, out, cyc);
+        sweep<K_MIN>(iters, out, cyc);
+        sweep<K_RSQ_PK>(iters, out, cyc);
+        return 0;
+    }
     if (argc > 2) {  // second round: the matrix pipe beside the VALU
         sweep<K_MFMA_F32>(iters, out, cyc);
         sweep<K_MFMA_BF16>(iters, out, cyc);
