@@ -124,6 +124,76 @@ static void run(int wg_per_cu, int iters, float* out, long long* cyc) {
     fflush(stdout);
 }
 
+
+// K2's instruction mix per 16 hypotheses x 16 pixels (one m of hp_chunk): 3 exact-fp32 MFMAs, 16 transcendentals, 15 packed, 14 plain -- in three orders
+//   0: MFMAs, then transcendentals, then the rest (what the compiler emits today)      1: every MFMA followed by a third of the transcendentals
+//   2: MFMAs spread among the packed instructions, transcendentals last
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_mix(float* out, long long* cyc, int iters, float s) {
+    f2 a[16]; float q[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { a[i] = f2{s + (float)i + (float)threadIdx.x, s - (float)i}; q[i] = s + (float)i * 0.5f + (float)threadIdx.x + 1.f; }
+    f2 b = {1.0000001f + s, 0.9999999f + s}, c = {1e-9f + s, -1e-9f + s};
+    float bs = 1.0000001f + s, cs = 1e-9f + s;
+    f4 acc[3] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+#define MF(j) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(bs), "v"(cs))
+#define TR(i) asm volatile("v_rsq_f32 %0, %0" : "+v"(q[i]))
+#define PK(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c))
+#define PL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(q[i]) : "v"(bs))
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if (ORDER == 0) {
+            MF(0); MF(1); MF(2);
+#pragma unroll
+            for (int i = 0; i < 16; i++) TR(i);
+#pragma unroll
+            for (int i = 0; i < 15; i++) PK(i);
+#pragma unroll
+            for (int i = 0; i < 14; i++) PL(i);
+        } else if (ORDER == 1) {
+            MF(0); TR(0); TR(1); TR(2); TR(3); TR(4);
+            MF(1); TR(5); TR(6); TR(7); TR(8); TR(9);
+            MF(2); TR(10); TR(11); TR(12); TR(13); TR(14); TR(15);
+#pragma unroll
+            for (int i = 0; i < 15; i++) PK(i);
+#pragma unroll
+            for (int i = 0; i < 14; i++) PL(i);
+        } else {
+            PK(0); PK(1); MF(0); PK(2); PK(3); PK(4); PK(5); PK(6); MF(1); PK(7); PK(8); PK(9); PK(10); PK(11); MF(2); PK(12); PK(13); PK(14);
+#pragma unroll
+            for (int i = 0; i < 14; i++) PL(i);
+#pragma unroll
+            for (int i = 0; i < 16; i++) TR(i);
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float sum = 0;
+    for (int j = 0; j < 3; j++) sum += acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += a[i].x + a[i].y + q[i];
+    if (sum == 1234.5678f) out[threadIdx.x] = sum;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int ORDER>
+static void run_mix(int wg_per_cu, int iters, float* out, long long* cyc) {
+    const int grid = 256 * wg_per_cu;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mix<ORDER>, dim3(grid), dim3(256), 0, 0, out, cyc, iters / 10, 0.f);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_mix<ORDER>, dim3(grid), dim3(256), 0, 0, out, cyc, iters, 0.f);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    static const char* nm[] = {"MFMAs, transcendentals, rest", "each MFMA followed by 5-6 transcendentals", "MFMAs among the packed instructions"};
+    printf("K2 mix (3 MFMA f32 + 16 rsq + 15 pk_fma + 14 mul), order %d (%s), waves/SIMD %d: %7.1f cycles per block and SIMD at 2.4 GHz by wall (sum of parts: 3x38 + 16x8.8 + 15x5.3 + 14x2.9 = 375)\n",
+           ORDER, nm[ORDER], wg_per_cu, ms * 1e-3 * 2.4e9 / ((double)iters * wg_per_cu));
+    fflush(stdout);
+}
+
 template <int KIND>
 static void sweep(int iters, float* out, long long* cyc) {
     for (int w : {1, 2, 4}) run<KIND>(w, iters, out, cyc);
@@ -133,6 +203,10 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     float* out; long long* cyc;
     CK(hipMalloc(&out, 4096)); CK(hipMalloc(&cyc, 256 * 8 * 4 * sizeof(long long)));
+    if (argc > 2 && argv[2][0] == 'x') {  // K2's mix in three orders
+        for (int w : {1, 2, 4, 5}) { run_mix<0>(w, iters, out, cyc); run_mix<1>(w, iters, out, cyc); run_mix<2>(w, iters, out, cyc); }
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 't') {  // third round: the transcendental unit
         sweep<K_RSQ>(iters, out, cyc);
         sweep<K_SQRT>(iters, out, cyc);
