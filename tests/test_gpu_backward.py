@@ -138,10 +138,10 @@ def test_path1_and_softmax_backward(engine, orc, frame40):
     assert abs(g.sum()) < 1e-12  # softmax gradients sum to zero
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_every_k4_form_against_the_oracle(engine, orc, synth, frame40, frame_full, variant):
-    """K4's main pass exists in six forms (dsac_set_option "k4_variant": 0 = VALU form with the per-hypothesis wave reduction, 1 .. 5 =
-    matrix-core form with per-lane hypothesis ownership, 2 / 4 / 5 / 6 / 3 chunks per wave); each against dScore part (iii) of the oracle
+    """K4's main pass exists in eight forms (dsac_set_option "k4_variant": 0 = VALU form with the per-hypothesis wave reduction, 1 .. 5 =
+    matrix-core form with per-lane hypothesis ownership, 2 / 4 / 5 / 6 / 3 chunks per wave, 6 / 7 = its high-occupancy builds with 2 / 3 chunks); each against dScore part (iii) of the oracle
     (core/cnn_softam.h:609-645): reference-sized map with both index conventions, 640x480 with a ragged hypothesis count, more
     hypotheses than one tile holds, implicit pixel grid, and the fused soft-inlier form."""
     engine.set_option("k4_variant", variant)

@@ -19,7 +19,10 @@ pytestmark = pytest.mark.gpu
 H, W = 480, 640
 P = H * W
 TAU, BETA = 10.0, 0.5
-K4_FORMS = [-1, 0, 1, 2, 3, 4, 5]  # auto, the VALU form, the matrix-core forms with 2 / 4 / 5 / 6 / 3 chunks per wave
+# auto, the VALU form, the matrix-core forms with 2 / 4 / 5 / 6 / 3 chunks per wave, the two high-occupancy forms (6: 2 chunks at >= 4 waves per SIMD,
+# 7: 3 chunks at >= 3, both with 128-hypothesis tiles), and the launch knobs folded into the value (+10 x tile code: 12 = 64-hypothesis tiles, 22 = 128;
+# +100 x workgroups per CU: 102 = one per CU, 402 = four)
+K4_FORMS = [-1, 0, 1, 2, 3, 4, 5, 6, 7, 12, 22, 102, 402]
 
 
 def _rel(a, b):
