@@ -507,7 +507,14 @@ def main(argv=None):
         results = torch.zeros(len(mine), 10 + N, dtype=torch.float64, device=dev)
         perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
         gt3 = torch.zeros(B, 6, dtype=torch.float64, device=dev)
-        ref3, sd3, out43 = torch.zeros(B, 6, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B, 4, dtype=torch.float64, device=dev)
+        # per batch of the step: what the deferred refinement tail writes (and the weights the gather reads) -- the tail of batch b runs under K1 / K2 of
+        # batch b + 1 (dsac_set_option "pi_defer_tail"), so its outputs are collected after the loop, behind joinTail
+        nbat3 = (len(mine) + B - 1) // B
+        ref3 = [torch.zeros(B, 6, dtype=torch.float64, device=dev) for _ in range(nbat3)]
+        sd3 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbat3)]
+        out43 = [torch.zeros(B, 4, dtype=torch.float64, device=dev) for _ in range(nbat3)]
+        w3 = [torch.zeros(B * N, dtype=torch.float64, device=dev) for _ in range(nbat3)]
+        engines[0][0].set_option("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)
     torch.cuda.synchronize(dev)
 
     staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
@@ -554,11 +561,15 @@ def main(argv=None):
                 # the reference's whole per-image unit (test_ransac_softam.cpp:97-157 -> processImage): K1, K2, K3, 8 refinement steps, loss
                 eng.processImages(N, perm3, gt_jp6=gt3[:nb_], seed=1305 + 64 * i + mine[idx[0]], thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5,
                                   scale=0.1, err=b["err"][:n_],
-                                  out=dict(hyps=b["poses"][:n_], sampledPoints=b["sets"][:n_], ok=b["ok"][:n_], scores=b["soft"][:n_], sfScores=b["w"][:n_],
-                                           sfEntropy=b["ent"][:nb_], avgHyp=b["avg"][:nb_], refAvgHyp=ref3[:nb_], refSteps=sd3[:nb_], out4=out43[:nb_]))
-                results[idx[0]:idx[0] + nb_, :6] = ref3[:nb_]
-                results[idx[0]:idx[0] + nb_, 6:10] = out43[:nb_]
-                results[idx[0]:idx[0] + nb_, 10:] = b["w"][:n_].view(nb_, N)
+                                  out=dict(hyps=b["poses"][:n_], sampledPoints=b["sets"][:n_], ok=b["ok"][:n_], scores=b["soft"][:n_], sfScores=w3[bi][:n_],
+                                           sfEntropy=b["ent"][:nb_], avgHyp=b["avg"][:nb_], refAvgHyp=ref3[bi][:nb_], refSteps=sd3[bi][:nb_],
+                                           out4=out43[bi][:nb_]))
+            eng.joinTail()  # the stream now waits for the last batch's refinement; everything below is in stream order
+            for bi, idx in enumerate(batches):
+                nb_ = len(idx)
+                results[idx[0]:idx[0] + nb_, :6] = ref3[bi][:nb_]
+                results[idx[0]:idx[0] + nb_, 6:10] = out43[bi][:nb_]
+                results[idx[0]:idx[0] + nb_, 10:] = w3[bi][:nb_ * N].view(nb_, N)
         st.synchronize()
         return ddist.gather_frame_results(mine, results if backend == "nccl" else results.cpu(), CONFIG3_IMAGES)
 
@@ -815,16 +826,19 @@ def main(argv=None):
 
             def procB(i):
                 eng.processImages(N, permB, gt_jp6=gtB, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"], out=outB)
-            for i in range(5):
-                procB(i)
-            eng.synchronize()
-            nb_ = 30
-            tp = time.perf_counter()
-            for i in range(nb_):
-                procB(5 + i)
-            eng.synchronize()
-            procimg["%dx%d_batch_of_%d" % (W, H, Bf)] = {"us_per_image": (time.perf_counter() - tp) / nb_ / Bf * 1e6, "images": nb_ * Bf,
-                                                        "refine_steps_done_min": int(sdB.min().item())}
+            for key, defer in (("%dx%d_batch_of_%d" % (W, H, Bf), 0), ("%dx%d_batch_of_%d_refinement_under_the_next_batch" % (W, H, Bf), 1)):
+                # defer = 1: dsac_set_option("pi_defer_tail"): K6 / K7 of a batch run on their own stream under K1 / K2 of the next one
+                eng.set_option("pi_defer_tail", defer)
+                for i in range(5):
+                    procB(i)
+                eng.synchronize()
+                nb_ = 30
+                tp = time.perf_counter()
+                for i in range(nb_):
+                    procB(5 + i)
+                eng.synchronize()
+                procimg[key] = {"us_per_image": (time.perf_counter() - tp) / nb_ / Bf * 1e6, "images": nb_ * Bf, "refine_steps_done_min": int(sdB.min().item())}
+            eng.set_option("pi_defer_tail", 0)
         eng.profile_read(0, reset=True)
 
     if distributed:

@@ -74,6 +74,12 @@ struct dsac_ctx {
     dk::FrameDev slot_F[2]{};               // the frame a slot was sampled from (its score call reprojects against the same one)
     hipEvent_t frame_ready = nullptr;       // recorded on `stream` after a frame copy; the auxiliary stream waits for it before K1
 
+    // deferred refinement tail of dsac_process_images ("pi_defer_tail"): K6 / K7 of batch i on `tail` under K1 / K2 of batch i + 1
+    int pi_defer_tail = 0;
+    hipStream_t tail = nullptr;
+    hipEvent_t tail_go = nullptr, tail_done = nullptr;  // go: K3 of the batch done (main stream); done: its K6 / K7 done (tail stream)
+    bool tail_pending = false;                          // a tail is in flight that the main stream has not been ordered behind yet
+
     // measurement hooks: event pairs around the dominant kernels
     bool profiling = false;
     int prof_stride = 1, prof_count[2] = {0, 0};  // record every prof_stride-th launch
@@ -109,10 +115,19 @@ bool is_device_ptr(const void* p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
 }
 
-// Begin a call: reset the staging slots.
-void begin_call(dsac_ctx* c) {
+// Order the main stream behind a deferred refinement tail that is still in flight (no-op otherwise).
+void join_tail(dsac_ctx* c) {
+    if (!c->tail_pending) return;
+    c->tail_pending = false;
+    if (hipStreamWaitEvent(c->stream, c->tail_done, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->tail); }
+}
+
+// Begin a call: reset the staging slots.  Every call that enqueues work sees the results of a deferred tail in stream order; dsac_process_images
+// itself keeps the tail in flight (keep_tail) and joins it right before the stage that would overwrite what the tail reads.
+void begin_call(dsac_ctx* c, bool keep_tail = false) {
     c->slot_next = 0;
     c->pending.clear();
+    if (!keep_tail) join_tail(c);
 }
 
 DevBuf& next_slot(dsac_ctx* c) {
@@ -271,6 +286,9 @@ void dsac_destroy(dsac_ctx* c) {
         if (c->slot_done[k]) (void)hipEventDestroy(c->slot_done[k]);
     }
     if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
+    if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
+    if (c->tail_go) (void)hipEventDestroy(c->tail_go);
+    if (c->tail_done) (void)hipEventDestroy(c->tail_done);
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -281,6 +299,7 @@ int dsac_set_stream(dsac_ctx* c, void* hip_stream) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_stream: ctx is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->tail) { HIP_TRY(c, hipStreamSynchronize(c->tail)); c->tail_pending = false; }
     if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->own_stream = false;
@@ -294,6 +313,7 @@ int dsac_synchronize(dsac_ctx* c) {
     if (c->aux) HIP_TRY(c, hipStreamSynchronize(c->aux));
     if (c->aux2) HIP_TRY(c, hipStreamSynchronize(c->aux2));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->tail) { HIP_TRY(c, hipStreamSynchronize(c->tail)); c->tail_pending = false; }
     return DSAC_OK;
 }
 
@@ -326,6 +346,7 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
         c->F.xyz = xyz;
         c->F.uv = uv;
     } else {
+        join_tail(c);  // ... and so may a deferred refinement tail
         // K1 of an earlier pipelined slot (auxiliary stream) may still be reading the library's copy: order the overwrite behind it
         for (int k = 0; k < 2; k++)
             if (c->aux && c->slot_N[k] > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_ready[k], 0));
@@ -552,6 +573,7 @@ int dsac_sample_ahead(dsac_ctx* c, int slot, int N, uint64_t seed, const int32_t
     if (!sets_or_null && (max_tries <= 0 || c->F.P < 4)) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: max_tries > 0 and >= 4 cells needed");
     // every rejection comes before anything is touched: a protocol-violating call must leave the slot (its staged poses, K1's output) as it was
     if (c->slot_pending[slot]) return fail(c, DSAC_ERR_INVALID, "dsac_sample_ahead: slot %d is sampled but not yet scored", slot);
+    join_tail(c);
     HIP_TRY(c, hipSetDevice(c->device));
     ARG_TRY(pipeline_init(c));
     HIP_TRY(c, c->slot_staged[slot].reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
@@ -576,6 +598,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     if (!is_device_ptr(scores) || !is_device_ptr(w) || (err_or_null && !is_device_ptr(err_or_null)) || (poses && !is_device_ptr(poses)) ||
         (entropy_or_null && !is_device_ptr(entropy_or_null)) || (avg6_or_null && !is_device_ptr(avg6_or_null)))
         return fail(c, DSAC_ERR_INVALID, "dsac_score_sampled: the pipelined calls need device pointers");
+    join_tail(c);
     HIP_TRY(c, hipSetDevice(c->device));
     const int N = c->slot_N[slot];
     const dk::FrameDev& SF = c->slot_F[slot];
@@ -644,6 +667,7 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
         if (!dk::backward_variant_known(value)) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown K4 kernel form %d", value);
         c->k4_variant = value;
     }
+    else if (k == "pi_defer_tail") { join_tail(c); c->pi_defer_tail = value != 0; }
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
     return DSAC_OK;
@@ -1144,7 +1168,7 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
     if (max_tries <= 0 || c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_process_images: max_tries > 0 and a frame of at least 4 cells needed");
     HIP_TRY(c, hipSetDevice(c->device));
-    begin_call(c);
+    begin_call(c, /*keep_tail=*/c->pi_defer_tail != 0);
     const size_t P = (size_t)c->F.P;
     const int N = hyps_per_frame * frames, Nf = frames > 1 ? hyps_per_frame : 0;
     const int32_t* d_perm;
@@ -1188,12 +1212,40 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
+    // "pi_defer_tail": the refinement tail (K6, a 90 us latency chain on one wave per frame, and K7) goes to its own stream and runs under K1 / K2 of the
+    // NEXT dsac_process_images call.  Its outputs (ref6, steps_done, inlier maps, out4) are complete in the order of the context's stream only after
+    // the next call of any other entry point, dsac_join_tail or dsac_synchronize.  Only with device-resident arguments: a host destination is copied
+    // back at the end of this call, and a host `perm` / `gt` lives in a staging slot that the next call reuses.
+    const bool defer = c->pi_defer_tail && c->pending.empty() && is_device_ptr(perm) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null));
+    join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
     HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
-    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), c->stream));
-    HIP_TRY(c, dk::refine(c->stream, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
+    hipStream_t ts = c->stream;
+    if (defer) {
+        if (!c->tail) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
+        ts = c->tail;
+    }
+    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
+    HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
                           d_maps ? (int)P : 0, frames > 1 ? 1 : 0));
-    if (d_out4) HIP_TRY(c, dk::pose_loss(c->stream, frames, d_ref, d_gt, d_out4, nullptr, 6));
+    if (d_out4) HIP_TRY(c, dk::pose_loss(ts, frames, d_ref, d_gt, d_out4, nullptr, 6));
+    if (defer) {
+        HIP_TRY(c, hipEventRecord(c->tail_done, c->tail));
+        c->tail_pending = true;
+    }
     return end_call(c);
+}
+
+int dsac_join_tail(dsac_ctx* c) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_join_tail: ctx is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    join_tail(c);
+    return DSAC_OK;
 }
 
 int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const double* w, const double* poses, const int32_t* sets,

@@ -83,7 +83,7 @@ class Engine:
         return dict(cus=cus.value, clock_khz=clk.value, mem_bytes=mem.value, arch=name.value.decode())
 
     def set_option(self, key, value):
-        """Per-context launch knob (dsac_set_option): k2_variant, k2_order, k2_flags, k1_wpb, k1_prio, k1_hpw, k1_horn."""
+        """Per-context launch knob (dsac_set_option): k2_variant, k2_order, k2_flags, k1_wpb, k1_prio, k1_hpw, k1_horn, k4_variant, pi_defer_tail."""
         check(self._ctx, lib.dsac_set_option(self._ctx, str(key).encode(), int(value)))
 
     def set_k2_events(self, wait_before=None, record_after=None):
@@ -168,6 +168,11 @@ class Engine:
                                                  float(scale), ptr(perm), steps, int(max_inl), int(min_inl), ptr(gt), ptr(hyps), ptr(sets), ptr(ok), ptr(err),
                                                  ptr(scores), ptr(w), ptr(ent), ptr(avg), ptr(ref), ptr(sd), ptr(maps), ptr(out4)))
         return o
+
+    def joinTail(self):
+        """Order the engine's stream behind a deferred refinement tail (set_option("pi_defer_tail", 1)): after this call the refined poses, step
+        counts, inlier maps and losses of the last processImages are complete in stream order.  Does not block the host."""
+        check(self._ctx, lib.dsac_join_tail(self._ctx))
 
     def maxLossFrames(self, est_cv6, gt_jp6, want_grad=False):
         """maxLoss (and dLossMax) of B estimates, each against its own ground truth (dsac_loss_frames).  Returns dict(out4 B x 4[, grad B x 6])."""

@@ -111,7 +111,8 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
  *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
- *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave (+ 10 x tile code + 100 x workgroups per CU)
+ *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail (see dsac_join_tail); 0 (default): everything in stream order
+ *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave, 6 / 7 its high-occupancy builds (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
 DSAC_API int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
@@ -302,6 +303,13 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
                         const int32_t* perm, int steps, int max_inl, int min_inl, const double* gt_jp6_or_null, double* poses, int32_t* sets_out,
                         uint8_t* ok, float* err_or_null, double* scores_or_null, double* w, double* entropy, double* avg6, double* ref6,
                         int32_t* steps_done, int32_t* inlier_maps_or_null, double* out4_or_null);
+/* With dsac_set_option("pi_defer_tail", 1) and device-resident arguments, dsac_process_images hands its refinement tail (K6, K7: a latency chain on
+ * one wave per frame) to a stream of its own, where it runs under sampling and scoring of the NEXT dsac_process_images call -- the loop over image
+ * batches of core/test_ransac_softam.cpp:97-230 pipelined by one batch.  The tail's outputs (ref6, steps_done, inlier_maps, out4) are then ordered
+ * on the context's stream only after dsac_join_tail (enqueues the dependency, does not block the host), any other entry point that enqueues work, or
+ * dsac_synchronize; everything else (poses, sets, ok, err, scores, w, entropy, avg6) is in stream order as always.  A following dsac_process_images
+ * must therefore be given other ref6 / steps_done / inlier_maps / out4 buffers if the previous batch's have not been consumed yet. */
+DSAC_API int dsac_join_tail(dsac_ctx* ctx);
 
 /* ---- gradient assembly ------------------------------------------------------------------------------ */
 /* Replaces core/train_ransac_softam.cpp:344-376: with v6 = dLoss/dRef * dRef/dAvg (1 x 6),

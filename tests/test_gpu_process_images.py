@@ -92,3 +92,68 @@ def test_process_images_at_baseline_size_on_device(engine, synth):
         assert torch.allclose(b["refAvgHyp"][f], s["refAvgHyp"][0], rtol=1e-6, atol=1e-6) and torch.allclose(b["out4"][f], s["out4"][0], rtol=1e-6, atol=1e-6)
     del err
     torch.cuda.empty_cache()
+
+
+def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
+    """dsac_set_option("pi_defer_tail", 1): K6 / K7 of a batch run on their own stream under K1 / K2 of the next batch.  Three batches of different
+    frames in a row, every tail output in its own buffer, read after joinTail: bit-equal to the same three calls in stream order; a host
+    destination switches the deferral off for that call; other entry points see a pending tail's results in stream order."""
+    import torch
+    H, W, F, N = 120, 160, 4, 128
+    P = H * W
+    dev = torch.device("cuda", 0)
+    perm = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    cam = None
+    batches = []
+    for k in range(3):
+        frames = [synth.chess_like_frame(H, W, seed=900 + 10 * k + f) for f in range(F)]
+        cam = frames[0]["cam"]
+        batches.append(torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev))
+    gts = torch.zeros(F, 6, dtype=torch.float64, device=dev)
+
+    def bufs():
+        n = F * N
+        return dict(hyps=torch.zeros(n, 6, dtype=torch.float64, device=dev), sampledPoints=torch.zeros(n, 4, dtype=torch.int32, device=dev),
+                    ok=torch.zeros(n, dtype=torch.uint8, device=dev), scores=torch.zeros(n, dtype=torch.float64, device=dev),
+                    sfScores=torch.zeros(n, dtype=torch.float64, device=dev), sfEntropy=torch.zeros(F, dtype=torch.float64, device=dev),
+                    avgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev), refAvgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev),
+                    refSteps=torch.zeros(F, dtype=torch.int32, device=dev), out4=torch.zeros(F, 4, dtype=torch.float64, device=dev),
+                    inlierMaps=torch.zeros(F, P, dtype=torch.int32, device=dev))
+
+    def run(defer):
+        engine.set_option("pi_defer_tail", 1 if defer else 0)
+        shared = bufs()          # everything but the tail's outputs is shared by the three calls, as a loop over batches would do
+        outs = []
+        for k in range(3):
+            o = dict(shared)
+            t = bufs()
+            for key in ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores"):
+                o[key] = t[key]
+            engine.set_frames(batches[k], None, H, W, cam, borrow=True)
+            engine.processImages(N, perm, gt_jp6=gts, seed=31 + k, out=o)
+            outs.append(o)
+        engine.joinTail()
+        engine.synchronize()
+        return [{key: v.cpu().numpy().copy() for key, v in o.items()} for o in outs]
+
+    try:
+        plain = run(False)
+        deferred = run(True)
+        for a, b in zip(plain, deferred):
+            assert (a["refSteps"] == 8).all() and a["ok"].all()
+            for key in a:
+                assert np.array_equal(a[key], b[key]), key
+        # another entry point after a deferred call: ordered behind the tail without an explicit join (K7 on the refined poses of the last batch)
+        engine.set_option("pi_defer_tail", 1)
+        o = bufs()
+        engine.set_frames(batches[0], None, H, W, cam, borrow=True)
+        engine.processImages(N, perm, gt_jp6=gts, seed=31, out=o)
+        from dsac_amd.capi import lib, ptr, check
+        again = np.zeros((F, 4))  # est is read on the device, the result comes back to the host (synchronous)
+        check(engine._ctx, lib.dsac_loss_frames(engine._ctx, F, ptr(o["refAvgHyp"]), ptr(gts), ptr(again), None))
+        assert np.array_equal(again, plain[0]["out4"])
+        # a host destination: no deferral for that call, complete on return
+        h = engine.processImages(N, perm, gt_jp6=gts, seed=31)
+        assert np.array_equal(h["refAvgHyp"], plain[0]["refAvgHyp"]) and np.array_equal(h["out4"], plain[0]["out4"])
+    finally:
+        engine.set_option("pi_defer_tail", 0)
