@@ -42,6 +42,28 @@ __global__ void k_tile(float* out, int N, int P, int R, int CHW, int order, int 
         }
 }
 
+// k_tile in plain order with a row stride of its own (Pp floats between the rows, P pixels written per row)
+__global__ void k_tile_stride(float* out, int N, int P, int Pp, int R, int CHW, int work, float seedv) {
+    const int waves = blockDim.x >> 6;
+    const int tile_px = waves * CHW * 64;
+    const int PT = (P + tile_px - 1) / tile_px;
+    const int b = blockIdx.x;
+    const int pt = b % PT, rt = b / PT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    float acc = seedv + (float)tid;
+    for (int i = 0; i < work; i++) acc = __builtin_fmaf(acc, 1.0000001f, 0.5f);
+    const f4 v = {acc, (float)b, 2.f, 3.f};
+    for (int gi = 0; gi < R / 16; gi++)
+        for (int ch = 0; ch < CHW; ch++) {
+            const int col = pt * tile_px + (wave * CHW + ch) * 64 + 4 * c;
+            if (col >= P) continue;
+            for (int r = 0; r < 4; r++) {
+                const int row = rt * R + gi * 16 + 4 * g + r;
+                if (row < N) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + (size_t)row * Pp + col));
+            }
+        }
+}
+
 // the same tiles with ROW-CONTIGUOUS store instructions: a wave store covers ONE row x 1 KiB (lane l writes pixels 4l .. 4l+3 of a 256-pixel span) instead
 // of 4 rows x 256 B -- what an LDS transpose of K2's tile would give.  tile_px must be a multiple of 256; the R x (tile_px / 256) spans of the tile are
 // dealt round-robin to the waves.
@@ -113,7 +135,7 @@ int main(int argc, char** argv) {
         return best;
     };
     const size_t chunks = (size_t)N * P / 1024;
-    const bool rows_only = argc > 1 && argv[1][0] == 'r';
+    const bool rows_only = argc > 1 && (argv[1][0] == 'r' || argv[1][0] == 'p');
     for (int work : {0, 200, 800}) {
         if (rows_only) break;
         const float ms = timeit([&] { hipLaunchKernelGGL(k_seq, dim3((unsigned)chunks), dim3(256), 0, 0, out, chunks, work, 1.f); });
@@ -126,6 +148,22 @@ int main(int argc, char** argv) {
                 const float ms = timeit([&] { hipLaunchKernelGGL(k_sweep, dim3(grid), dim3(waves * 64), 0, 0, out, N, P, ppw, work, 1.f); });
                 printf("sweep px/wave %3d waves/wg %d (%5d waves) work %3d : %7.1f us  %6.0f GB/s\n", ppw, waves, nw, work, ms * 1e3, (double)N * P * 4 / ms / 1e6);
             }
+    if (argc > 1 && argv[1][0] == 'p') {  // row stride: does the distance between the rows of a tile (P * 4 bytes = 300 x 4 KiB for 640 x 480) matter?
+        struct C2 { int R, CHW, WAVES; };
+        float* big;
+        CK(hipMalloc(&big, (size_t)N * (P + 8192) * 4));
+        for (int work : {0, 300})
+            for (C2 c : {C2{32, 4, 1}, C2{64, 4, 4}, C2{16, 1, 4}})
+                for (int pad : {0, 64, 256, 320, 1024, 1088, 4096, 4160, 8192}) {
+                    const int Pp = P + pad;  // the tiles cover the first P pixels of every row, rows are Pp floats apart
+                    const int tile_px = c.WAVES * c.CHW * 64;
+                    const int PT = (P + tile_px - 1) / tile_px, RT = (N + c.R - 1) / c.R;
+                    const float ms = timeit([&] { hipLaunchKernelGGL(k_tile_stride, dim3((unsigned)(PT * RT)), dim3(c.WAVES * 64), 0, 0, big, N, P, Pp, c.R, c.CHW, work, 1.f); });
+                    printf("R %2d CHW %d WAVES %2d work %3d row stride %7d floats (+%4d) : %7.1f us  %6.0f GB/s\n", c.R, c.CHW, c.WAVES, work, Pp, pad, ms * 1e3,
+                           (double)N * P * 4 / ms / 1e6);
+                }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'r') {  // store-instruction shape A/B on K2's tiles
         struct C2 { int R, CHW, WAVES; };
         for (int work : {0, 300})
