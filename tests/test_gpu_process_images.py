@@ -123,12 +123,15 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
     def run(defer):
         engine.set_option("pi_defer_tail", 1 if defer else 0)
         shared = bufs()          # everything but the tail's outputs is shared by the three calls, as a loop over batches would do
+        own = [bufs() for _ in range(3)]
+        # torch zero-fills the new buffers on ITS stream, the engine writes them from its own (non-blocking) streams: without this a fill can land after
+        # the engine's write when the queues are time-sliced (seen late in a full test session, never in a short one)
+        torch.cuda.synchronize(dev)
         outs = []
         for k in range(3):
             o = dict(shared)
-            t = bufs()
             for key in ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores"):
-                o[key] = t[key]
+                o[key] = own[k][key]
             engine.set_frames(batches[k], None, H, W, cam, borrow=True)
             engine.processImages(N, perm, gt_jp6=gts, seed=31 + k, out=o)
             outs.append(o)
@@ -146,6 +149,7 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
         # another entry point after a deferred call: ordered behind the tail without an explicit join (K7 on the refined poses of the last batch)
         engine.set_option("pi_defer_tail", 1)
         o = bufs()
+        torch.cuda.synchronize(dev)
         engine.set_frames(batches[0], None, H, W, cam, borrow=True)
         engine.processImages(N, perm, gt_jp6=gts, seed=31, out=o)
         from dsac_amd.capi import lib, ptr, check
