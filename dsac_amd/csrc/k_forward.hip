@@ -539,7 +539,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
     // per chunk in front of every use instead of living in 8 registers per chunk
     float Bm[CHW][4];
     f2 ppix[G64 ? 1 : CHW][4];
-    f2 pbase[G64 ? CHW : 1];
+    // G64: row and first column of a chunk are wave-uniform and live in SCALAR registers (late round 3: as a lane-dependent pair per chunk they
+    // were 8 vector registers, exactly what the 128-register build of the <64 hypotheses, 256 pixels> form spilled)
+    int sx0[G64 ? CHW : 1];
+    float sby[G64 ? CHW : 1];
     int p0[CHW];
     bool valid[CHW];
     const int chunk0 = (pt * WAVES + wave) * CHW;
@@ -553,13 +556,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             Bm[ch][m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
         }
     }
+    // A operands: with up to two groups all of them are loaded up front; with four they are fetched one group ahead (two register sets instead of
+    // four: the 128-register build of the <64 hypotheses, 256 pixels> form needs the six registers)
+    constexpr bool A_AHEAD = NG > 2;
     float ax[NG], ay[NG], az[NG];
-#pragma unroll
-    for (int gi = 0; gi < NG; gi++) {
+    auto load_A = [&](int gi) {
         const int hyp = min(16 * gi + c, nh - 1);  // beyond the ragged end: repeat the last valid hypothesis (never stored)
         const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
         ax[gi] = rec[0]; ay[gi] = rec[4]; az[gi] = rec[8];
-    }
+    };
+#pragma unroll
+    for (int gi = 0; gi < (A_AHEAD ? 1 : NG); gi++) load_A(gi);
 #pragma unroll
     for (int ch = 0; ch < CHW; ch++) {
         if (UV) {
@@ -576,7 +583,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             // row and first column are wave-uniform (scalar division)
             const int cpr = W >> 6;
             const int y = (chunk0 + ch) / cpr, xc0 = ((chunk0 + ch) - y * cpr) * 64;
-            pbase[ch] = f2{(float)(xc0 + 4 * c) - cx, (float)y - cy};
+            sx0[ch] = __builtin_amdgcn_readfirstlane(xc0);
+            sby[ch] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, (float)y - cy)));
         } else {
             constexpr int pc = G64 ? 0 : 1;
             int y = p0[ch] / W, x = p0[ch] - y * W;
@@ -591,6 +599,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
 #pragma unroll
     for (int gi = 0; gi < NG; gi++) {
         if (16 * gi >= nh) break;
+        if (A_AHEAD && gi + 1 < NG) {
+            asm volatile("" ::: "memory");  // keeps the compiler from hoisting the fetch to the top of the kernel (that is the up-front form)
+            load_A(gi + 1);
+        }
         const float nax = -ax[gi], nay = -ay[gi];  // x and y rows negated: the MFMA yields (-xc, -yc, zc)
         const int hyp0 = 16 * gi + 4 * g;
         f2 ssum[4] = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             f4 ev[4];
             f2 sloc[4];
             if (G64) {
-                f2 pb = pbase[ch];
+                f2 pb = f2{(float)(sx0[ch] + 4 * c) - cx, sby[ch]};  // the same numbers as a stored pair: (float)(column) - cx, (float)(row) - cy
                 asm volatile("" : "+v"(pb));  // rebuilt per use: keeps the 8 position registers of a chunk from staying live across the whole kernel
 #pragma unroll
                 for (int m = 0; m < 4; m++) ppix[0][m] = f2{pb.x + (float)m, pb.y};
@@ -913,8 +925,10 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         // pixels> per one-wave workgroup (no LDS, no barrier, operands straight from the staged records, per-wave partial sums) in PLAIN
         // pixel-minor block order: 842-870 us against 904-950 for round 2's <64,4> (0.73-0.75 of the HBM spec instead of 0.67-0.70); one frame
         // of 256 hypotheses takes <64 hypotheses, 4 waves x 64 pixels>: 56.7-58.0 against 60.2-60.8 us.
+        // Late round 3: <64 hypotheses, 256 pixels> per one-wave workgroup at >= 4 waves per SIMD (form 58) instead of <32, 256> (form 45): 1 % ahead in
+        // every A/B on six boxes (profiles/r03_k2_ab_58_45.txt: 861-867 against 872-875 us alternating on one box) and half the partial-sum rows
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
-        variant = soft_part ? (big ? 45 : 42) : 0;
+        variant = soft_part ? (big ? 58 : 42) : 0;
         if (soft_part && big) kf |= 32;
     }
     switch (variant) {
