@@ -927,8 +927,11 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         // of 256 hypotheses takes <64 hypotheses, 4 waves x 64 pixels>: 56.7-58.0 against 60.2-60.8 us.
         // Late round 3: <64 hypotheses, 256 pixels> per one-wave workgroup at >= 4 waves per SIMD (form 58) instead of <32, 256> (form 45): 1 % ahead in
         // every A/B on six boxes (profiles/r03_k2_ab_58_45.txt: 861-867 against 872-875 us alternating on one box) and half the partial-sum rows
+        // (with sampled pixel positions, or a map width that is not a multiple of 64, the kernel keeps the positions of every chunk in vector
+        // registers: form 58's 128-register build would spill 108-116 bytes per lane there, form 45 needs no scratch)
         const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
-        variant = soft_part ? (big ? 58 : 42) : 0;
+        const bool grid64 = F.uv == nullptr && (F.W & 63) == 0;
+        variant = soft_part ? (big ? (grid64 ? 58 : 45) : 42) : 0;
         if (soft_part && big) kf |= 32;
     }
     switch (variant) {
