@@ -929,9 +929,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         // every A/B on six boxes (profiles/r03_k2_ab_58_45.txt: 861-867 against 872-875 us alternating on one box) and half the partial-sum rows
         // (with sampled pixel positions, or a map width that is not a multiple of 64, the kernel keeps the positions of every chunk in vector
         // registers: form 58's 128-register build would spill 108-116 bytes per lane there, form 45 needs no scratch)
-        const bool big = (double)N * (double)F.P * 4.0 > 1.5e9;
+        // By size (A/B inside bench.py at 2 ... 16 frames of 256 hypotheses per launch, profiles/r03_k2_ab_mid.txt): up to 1 GB of error images form 42
+        // (2 frames: 111.7 us against 115.1 for form 45 and 121.6 for 58), up to 4.4 GB form 45 (4 frames 220.5 against 224 / 232; 8 frames
+        // 424-427 us = 0.75 of the HBM spec against 443 / 460-465; 12 frames 644 = 638-644), above it form 58 (16 frames: 861-867 against 872-875)
+        const double bytes = (double)N * (double)F.P * 4.0;
+        const bool big = bytes > 1.0e9;
         const bool grid64 = F.uv == nullptr && (F.W & 63) == 0;
-        variant = soft_part ? (big ? (grid64 ? 58 : 45) : 42) : 0;
+        variant = soft_part ? (big ? ((grid64 && bytes > 4.4e9) ? 58 : 45) : 42) : 0;
         if (soft_part && big) kf |= 32;
     }
     switch (variant) {
