@@ -342,7 +342,11 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
                                          "underneath it (use DSAC_FRAME_BORROW frames with the pipelined calls)");
     if (borrow) {
         if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
-        if (flags & DSAC_FRAME_QUANTISE_INT16) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: cannot quantise a borrowed frame");
+        if (flags & DSAC_FRAME_QUANTISE_INT16) {  // the caller's own device buffer, rounded to the int16 grid in place (core/cnn_softam.h:265)
+            const size_t n = P * 3;
+            hipLaunchKernelGGL(k_quantise_int16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, const_cast<float*>(xyz), n);
+            HIP_TRY(c, hipGetLastError());
+        }
         c->F.xyz = xyz;
         c->F.uv = uv;
     } else {
@@ -374,6 +378,58 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
     c->F.xyz_stride = (long long)P1 * 3;
     c->F.uv_stride = (uv && uv_per_frame) ? (long long)P1 * 2 : 0;
     c->have_frame = true;
+    return DSAC_OK;
+}
+
+int dsac_device_alloc(dsac_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return fail(c, DSAC_ERR_INVALID, "dsac_device_alloc: NULL argument");
+    *out = nullptr;
+    if (bytes == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (hipMalloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(c, DSAC_ERR_ALLOC, "dsac_device_alloc: %zu bytes of device memory", bytes); }
+    return DSAC_OK;
+}
+
+int dsac_device_free(dsac_ctx* c, void* p) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_device_free: ctx is NULL");
+    if (!p) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipFree(p));  // waits for the work that still uses the buffer
+    return DSAC_OK;
+}
+
+int dsac_host_alloc(dsac_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return fail(c, DSAC_ERR_INVALID, "dsac_host_alloc: NULL argument");
+    *out = nullptr;
+    if (bytes == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return fail(c, DSAC_ERR_ALLOC, "dsac_host_alloc: %zu bytes of page-locked memory", bytes); }
+    return DSAC_OK;
+}
+
+int dsac_host_free(dsac_ctx* c, void* p) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_host_free: ctx is NULL");
+    if (!p) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipHostFree(p));
+    return DSAC_OK;
+}
+
+int dsac_copy_async(dsac_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(c, DSAC_ERR_INVALID, "dsac_copy_async: NULL argument");
+    if (bytes == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // a source on the device may be something a deferred refinement tail is still writing (ref6 / out4 / steps_done / inlier maps)
+    if (is_device_ptr(src)) join_tail(c);
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    return DSAC_OK;
+}
+
+int dsac_fill_zero_async(dsac_ctx* c, void* dst, size_t bytes) {
+    if (!c || (bytes && !dst)) return fail(c, DSAC_ERR_INVALID, "dsac_fill_zero_async: NULL argument");
+    if (bytes == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(dst, 0, bytes, c->stream));
     return DSAC_OK;
 }
 

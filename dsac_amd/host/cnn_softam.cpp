@@ -1,7 +1,11 @@
 // cnn_softam.cpp -- see cnn_softam.h.  Marshals std::vector containers into the C ABI; no geometry on the CPU.
 #include "cnn_softam.h"
 
+#include <algorithm>
 #include <cmath>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 
@@ -16,26 +20,72 @@ static std::vector<double> flatten(const std::vector<cv_trans_t>& h) {
     return v;
 }
 
-void Frame::check(int rc, const char* what) {
+// ---- Context -------------------------------------------------------------------------------------------------------------------------
+Context::Context(int device) {
+    const int rc = dsac_create(&ctx_, device);
+    if (rc != DSAC_OK) throw Error(rc, std::string("dsac_create: ") + dsac_last_error(nullptr));
+}
+
+Context::~Context() { dsac_destroy(ctx_); }
+
+Context& Context::shared(int device) {
+    static std::map<int, std::unique_ptr<Context>> contexts;  // destroyed at exit, after every Frame of a well-formed program
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    std::unique_ptr<Context>& c = contexts[device];
+    if (!c) c.reset(new Context(device));
+    return *c;
+}
+
+void Context::check(int rc, const char* what) {
     if (rc != DSAC_OK) throw Error(rc, std::string(what) + ": " + dsac_last_error(ctx_));
 }
+void Context::synchronize() { check(dsac_synchronize(ctx_), "dsac_synchronize"); }
+void Context::setOption(const char* key, int value) { check(dsac_set_option(ctx_, key, value), "dsac_set_option"); }
+void* Context::deviceAlloc(size_t bytes) { void* p = nullptr; check(dsac_device_alloc(ctx_, bytes, &p), "dsac_device_alloc"); return p; }
+void Context::deviceFree(void* p) noexcept { (void)dsac_device_free(ctx_, p); }
+void* Context::hostAlloc(size_t bytes) { void* p = nullptr; check(dsac_host_alloc(ctx_, bytes, &p), "dsac_host_alloc"); return p; }
+void Context::hostFree(void* p) noexcept { (void)dsac_host_free(ctx_, p); }
+void Context::copy(void* dst, const void* src, size_t bytes) { check(dsac_copy_async(ctx_, dst, src, bytes), "dsac_copy_async"); }
+void Context::zero(void* dst, size_t bytes) { check(dsac_fill_zero_async(ctx_, dst, bytes), "dsac_fill_zero_async"); }
 
-Frame::Frame(const float* estObj, const float* sampling, int H, int W, const Camera& cam, int device, bool quantiseInt16) : H_(H), W_(W) {
-    int rc = dsac_create(&ctx_, device);
-    if (rc != DSAC_OK) throw Error(rc, std::string("dsac_create: ") + dsac_last_error(nullptr));
-    rc = dsac_set_frame(ctx_, estObj, sampling, H, W, cam.fx, cam.fy, cam.cx, cam.cy, quantiseInt16 ? DSAC_FRAME_QUANTISE_INT16 : 0u);
-    if (rc != DSAC_OK) {
-        const std::string msg = dsac_last_error(ctx_);
-        dsac_destroy(ctx_);
-        ctx_ = nullptr;
-        throw Error(rc, "dsac_set_frame: " + msg);
+// ---- Frame ---------------------------------------------------------------------------------------------------------------------------
+void Frame::check(int rc, const char* what) { C_->check(rc, what); }
+
+Frame::Frame(Context& ctx, const float* estObj, const float* sampling, int H, int W, const Camera& cam, bool quantiseInt16)
+    : C_(&ctx), ctx_(ctx.get()), H_(H), W_(W), cam_(cam), quantise_(quantiseInt16) {
+    if (!estObj || H <= 0 || W <= 0) throw Error(DSAC_ERR_INVALID, "Frame: need estObj and H, W > 0");
+    const size_t P = (size_t)H * W;
+    xyz_.resize(ctx, P * 3);
+    xyz_.upload(estObj, P * 3);
+    if (sampling) {
+        uv_.resize(ctx, P * 2);
+        uv_.upload(sampling, P * 2);
     }
+    C_->synchronize();  // the caller's host arrays may go away after the constructor returns
+    bind();
 }
 
-Frame::~Frame() { dsac_destroy(ctx_); }
+Frame::Frame(const float* estObj, const float* sampling, int H, int W, const Camera& cam, int device, bool quantiseInt16)
+    : Frame(Context::shared(device), estObj, sampling, H, W, cam, quantiseInt16) {}
+
+Frame::~Frame() {
+    if (C_ && C_->boundTo() == this) C_->setBound(nullptr);
+    // xyz_ / uv_ are freed by their destructors (hipFree waits for work that still reads them)
+}
+
+void Frame::bind() {
+    if (C_->boundTo() == this) return;
+    unsigned flags = DSAC_FRAME_BORROW;
+    if (quantise_ && !quantised_) flags |= DSAC_FRAME_QUANTISE_INT16;  // in place, once
+    check(dsac_set_frame(ctx_, xyz_.data(), uv_.data(), H_, W_, cam_.fx, cam_.fy, cam_.cx, cam_.cy, flags), "dsac_set_frame");
+    quantised_ = quantise_;
+    C_->setBound(this);
+}
 
 std::vector<uint8_t> Frame::sampleHypotheses(int objHyps, uint64_t seed, int inlierThreshold2D, std::vector<cv_trans_t>& hyps,
                                              std::vector<std::array<int32_t, 4>>& imgIdx, int maxTries) {
+    bind();
     std::vector<double> poses((size_t)objHyps * 6);
     std::vector<uint8_t> ok(objHyps);
     imgIdx.assign(objHyps, {0, 0, 0, 0});
@@ -46,6 +96,7 @@ std::vector<uint8_t> Frame::sampleHypotheses(int objHyps, uint64_t seed, int inl
 }
 
 std::vector<float> Frame::getDiffMaps(const std::vector<cv_trans_t>& hyps) {
+    bind();
     std::vector<float> err(hyps.size() * (size_t)H_ * W_);
     const std::vector<double> p = flatten(hyps);
     check(dsac_reproject(ctx_, (int)hyps.size(), p.data(), (float)CNN_OBJ_MAXINPUT, err.data(), 0.f, 0.f, nullptr), "dsac_reproject");
@@ -55,6 +106,7 @@ std::vector<float> Frame::getDiffMaps(const std::vector<cv_trans_t>& hyps) {
 std::vector<float> Frame::getDiffMap(const cv_trans_t& hyp) { return getDiffMaps({hyp}); }
 
 std::vector<double> Frame::softInlierScores(const std::vector<cv_trans_t>& hyps, float tau, float beta) {
+    bind();
     std::vector<double> s(hyps.size());
     const std::vector<double> p = flatten(hyps);
     check(dsac_reproject(ctx_, (int)hyps.size(), p.data(), (float)CNN_OBJ_MAXINPUT, nullptr, tau, beta, s.data()), "dsac_reproject");
@@ -63,6 +115,7 @@ std::vector<double> Frame::softInlierScores(const std::vector<cv_trans_t>& hyps,
 
 std::vector<double> Frame::softArgMax(const std::vector<double>& scores, double scale, const std::vector<cv_trans_t>& hyps, double& sfEntropy,
                                       cv_trans_t& avgHyp) {
+    bind();
     std::vector<double> w(scores.size());
     const std::vector<double> p = flatten(hyps);
     double avg[6];
@@ -72,6 +125,7 @@ std::vector<double> Frame::softArgMax(const std::vector<double>& scores, double 
 }
 
 std::vector<double> Frame::dPNP(const std::vector<std::array<int32_t, 4>>& imgIdx, float eps) {
+    bind();
     std::vector<double> J(imgIdx.size() * 72);
     check(dsac_dpnp(ctx_, (int)imgIdx.size(), &imgIdx[0][0], eps, J.data()), "dsac_dpnp");
     return J;
@@ -79,6 +133,7 @@ std::vector<double> Frame::dPNP(const std::vector<std::array<int32_t, 4>>& imgId
 
 void Frame::dScore(const std::vector<cv_trans_t>& hyps, const std::vector<std::array<int32_t, 4>>& imgIdx, const std::vector<float>& dDiffMaps,
                    std::vector<double>& jacobean, bool referenceIndexQuirk) {
+    bind();
     jacobean.resize((size_t)H_ * W_ * 3, 0.0);
     const std::vector<double> p = flatten(hyps);
     check(dsac_score_backward(ctx_, (int)hyps.size(), p.data(), &imgIdx[0][0], dDiffMaps.data(), nullptr,
@@ -88,6 +143,7 @@ void Frame::dScore(const std::vector<cv_trans_t>& hyps, const std::vector<std::a
 
 cv_trans_t Frame::refine(int inlierCount, int refSteps, float inlierThreshold2D, const std::vector<int32_t>& pixelIdxs, const cv_trans_t& initHyp,
                          std::vector<int32_t>* inlierMap, int* stepsDone) {
+    bind();
     const Pose6 in = pack(initHyp);
     double out[6];
     int32_t sd = 0;
@@ -102,6 +158,7 @@ cv_trans_t Frame::refine(int inlierCount, int refSteps, float inlierThreshold2D,
 void Frame::dRefine(int inlierCount, int refSteps, float inlierThreshold2D, float subSampleFactor, const std::vector<int32_t>& pixelIdxs,
                     const cv_trans_t& initHyp, const std::vector<int32_t>& inlierMap, std::array<double, 36>& dRefineHyp,
                     std::vector<int32_t>& objPixels, std::vector<double>& dRefineObj) {
+    bind();
     const Pose6 in = pack(initHyp);
     const int cap = 4096;
     objPixels.assign(cap, 0);
@@ -115,6 +172,7 @@ void Frame::dRefine(int inlierCount, int refSteps, float inlierThreshold2D, floa
 }
 
 double Frame::maxLoss(const Hypothesis& gt, const cv_trans_t& est, double* rotErr, double* tErr, bool* correct) {
+    bind();
     const Pose6 e = pack(est);
     const std::vector<double> g = gt.getRodVecAndTrans();
     double out4[4];
@@ -126,6 +184,7 @@ double Frame::maxLoss(const Hypothesis& gt, const cv_trans_t& est, double* rotEr
 }
 
 std::array<double, 6> Frame::dLossMax(const cv_trans_t& est, const Hypothesis& gt) {
+    bind();
     const Pose6 e = pack(est);
     const std::vector<double> g = gt.getRodVecAndTrans();
     std::array<double, 6> J{};
@@ -134,31 +193,161 @@ std::array<double, 6> Frame::dLossMax(const cv_trans_t& est, const Hypothesis& g
     return J;
 }
 
+void Frame::getDiffMapsDevice(const std::vector<cv_trans_t>& hyps, DeviceArray<float>& out) {
+    bind();
+    const size_t n = hyps.size() * (size_t)H_ * W_;
+    if (out.size() < n) out.resize(*C_, n);
+    const std::vector<double> p = flatten(hyps);
+    check(dsac_reproject(ctx_, (int)hyps.size(), p.data(), (float)CNN_OBJ_MAXINPUT, out.data(), 0.f, 0.f, nullptr), "dsac_reproject");
+}
+
+static cv_trans_t pose_at(const double* v) { return unpack({v[0], v[1], v[2], v[3], v[4], v[5]}); }
+
 ProcessImageResult Frame::processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
                                        const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha,
                                        const std::vector<std::array<int32_t, 4>>* givenSets) {
+    bind();
     ProcessImageResult r;
     if (givenSets && !givenSets->empty()) {
+        // replay of recorded minimal sets: the stages one by one (dsac_process_images draws its own sets)
         objHyps = (int)givenSets->size();
         std::vector<double> poses((size_t)objHyps * 6);
         std::vector<uint8_t> ok(objHyps);
         r.imgIdx.assign(objHyps, {0, 0, 0, 0});
         check(dsac_sample(ctx_, objHyps, seed, &(*givenSets)[0][0], (float)inlierThreshold2D, 1, poses.data(), &r.imgIdx[0][0], ok.data()), "dsac_sample");
         r.hyps.resize(objHyps);
-        for (int h = 0; h < objHyps; h++) r.hyps[h] = unpack({poses[h * 6], poses[h * 6 + 1], poses[h * 6 + 2], poses[h * 6 + 3], poses[h * 6 + 4], poses[h * 6 + 5]});
-    } else {
-        sampleHypotheses(objHyps, seed, inlierThreshold2D, r.hyps, r.imgIdx);
+        for (int h = 0; h < objHyps; h++) r.hyps[h] = pose_at(&poses[(size_t)h * 6]);
+        const std::vector<double> scores = softInlierScores(r.hyps, tau, beta);  // the score-CNN seam of cnn_softam.h:1072
+        r.sfScores = softArgMax(scores, alpha, r.hyps, r.sfEntropy, r.avgHyp);
+        r.refAvgHyp = refine(inlierCount, refSteps, (float)inlierThreshold2D, pixelIdxs, r.avgHyp, &r.inlierMap, &r.refStepsDone);
+        r.loss = maxLoss(poseGT, r.refAvgHyp, &r.rotErr, &r.tErr, &r.correct);
+        return r;
     }
-    const std::vector<double> scores = softInlierScores(r.hyps, tau, beta);  // the score-CNN seam of cnn_softam.h:1072
-    r.sfScores = softArgMax(scores, alpha, r.hyps, r.sfEntropy, r.avgHyp);
-    r.refAvgHyp = refine(inlierCount, refSteps, (float)inlierThreshold2D, pixelIdxs, r.avgHyp, &r.inlierMap, &r.refStepsDone);
-    r.loss = maxLoss(poseGT, r.refAvgHyp, &r.rotErr, &r.tErr, &r.correct);
+    // the whole of core/cnn_softam.h:960-1179 in ONE call: sample + P3P, soft-inlier scores, softmax / entropy / soft-argmax pose, the refinement loop,
+    // maxLoss -- one launch chain on the device, one copy-back of the small results
+    if (refSteps < 0 || (size_t)refSteps * H_ * W_ > pixelIdxs.size()) throw std::invalid_argument("Frame::processImage: pixelIdxs holds fewer than refSteps permutations");
+    const size_t P = (size_t)H_ * W_;
+    std::vector<double> poses((size_t)objHyps * 6), gt = poseGT.getRodVecAndTrans();
+    std::vector<uint8_t> ok(objHyps);
+    r.imgIdx.assign(objHyps, {0, 0, 0, 0});
+    r.sfScores.assign(objHyps, 0.0);
+    r.inlierMap.assign(P, 0);
+    double avg[6], ref[6], out4[4];
+    int32_t sd = 0;
+    check(dsac_process_images(ctx_, objHyps, seed, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, pixelIdxs.data(), refSteps, inlierCount,
+                              50, gt.data(), poses.data(), &r.imgIdx[0][0], ok.data(), nullptr, nullptr, r.sfScores.data(), &r.sfEntropy, avg, ref, &sd,
+                              r.inlierMap.data(), out4),
+          "dsac_process_images");
+    r.hyps.resize(objHyps);
+    for (int h = 0; h < objHyps; h++) r.hyps[h] = pose_at(&poses[(size_t)h * 6]);
+    r.avgHyp = pose_at(avg);
+    r.refAvgHyp = pose_at(ref);
+    r.refStepsDone = sd;
+    r.loss = out4[0]; r.rotErr = out4[1]; r.tErr = out4[2]; r.correct = out4[3] > 0.5;
     return r;
+}
+
+// ---- FrameBatch ----------------------------------------------------------------------------------------------------------------------
+FrameBatch::FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam, int objHyps, int refSteps, const std::vector<int32_t>& pixelIdxs,
+                       int maxFramesPerCall, const FrameBatchOptions& opt)
+    : C_(ctx), F_(frames), H_(H), W_(W), N_(objHyps), refSteps_(refSteps), maxCall_(maxFramesPerCall), cam_(cam), opt_(opt) {
+    if (frames <= 0 || H <= 0 || W <= 0 || objHyps <= 0 || refSteps < 0 || maxFramesPerCall <= 0) throw Error(DSAC_ERR_INVALID, "FrameBatch: bad sizes");
+    if (maxCall_ > F_) maxCall_ = F_;
+    if (maxCall_ > 1 && objHyps % 128 != 0) throw Error(DSAC_ERR_INVALID, "FrameBatch: objHyps must be a multiple of 128 when more than one frame goes into a call");
+    const size_t P = (size_t)H * W, F = (size_t)frames, N = (size_t)objHyps;
+    if ((size_t)refSteps * P > pixelIdxs.size()) throw Error(DSAC_ERR_INVALID, "FrameBatch: pixelIdxs holds fewer than refSteps permutations");
+    xyz_.resize(ctx, F * P * 3);
+    gt_.resize(ctx, F * 6);
+    perm_.resize(ctx, (size_t)refSteps * P);
+    perm_.upload(pixelIdxs.data(), (size_t)refSteps * P);
+    poses_.resize(ctx, F * N * 6);
+    sets_.resize(ctx, F * N * 4);
+    ok_.resize(ctx, F * N);
+    scores_.resize(ctx, F * N);
+    w_.resize(ctx, F * N);
+    entropy_.resize(ctx, F);
+    avg_.resize(ctx, F * 6);
+    ref_.resize(ctx, F * 6);
+    out4_.resize(ctx, F * 4);
+    stepsDone_.resize(ctx, F);
+    if (opt.errorImages) err_.resize(ctx, (size_t)maxCall_ * N * P);  // one buffer: K2 of a call overwrites it in stream order (the tail never reads it)
+    if (opt.inlierMaps) maps_.resize(ctx, F * P);
+    done_.assign(F, 0);
+    C_.synchronize();  // pixelIdxs may be a temporary
+}
+
+void FrameBatch::setFrame(int f, const float* estObj, const Hypothesis& poseGT) {
+    if (f < 0 || f >= F_ || !estObj) throw Error(DSAC_ERR_INVALID, "FrameBatch::setFrame: bad frame index");
+    const size_t P = (size_t)H_ * W_;
+    const std::vector<double> g = poseGT.getRodVecAndTrans();
+    xyz_.upload(estObj, P * 3, (size_t)f * P * 3);
+    gt_.upload(g.data(), 6, (size_t)f * 6);
+    C_.synchronize();  // pageable sources: stable once this returns
+    done_[f] = 0;
+}
+
+void FrameBatch::processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau, float beta, double alpha) {
+    if (first < 0 || count <= 0 || first + count > F_ || count > maxCall_) throw Error(DSAC_ERR_INVALID, "FrameBatch::processImages: bad frame range");
+    const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
+    dsac_ctx* c = C_.get();
+    C_.setOption("pi_defer_tail", opt_.deferTail ? 1 : 0);
+    unsigned flags = DSAC_FRAME_BORROW;
+    if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;  // in place; idempotent
+    C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, nullptr, 0, H_, W_, cam_.fx, cam_.fy, cam_.cx, cam_.cy, flags), "dsac_set_frames");
+    C_.setBound(this);
+    C_.check(dsac_process_images(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, perm_.data(),
+                                 refSteps_, inlierCount, 50, gt_.data() + f0 * 6, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, ok_.data() + f0 * N,
+                                 opt_.errorImages ? err_.data() : nullptr, scores_.data() + f0 * N, w_.data() + f0 * N, entropy_.data() + f0, avg_.data() + f0 * 6,
+                                 ref_.data() + f0 * 6, stepsDone_.data() + f0, opt_.inlierMaps ? maps_.data() + f0 * P : nullptr, out4_.data() + f0 * 4),
+             "dsac_process_images");
+    for (int f = first; f < first + count; f++) done_[f] = 1;
+}
+
+void FrameBatch::processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau, float beta, double alpha) {
+    for (int f = 0; f < F_; f += maxCall_) processImages(f, std::min(maxCall_, F_ - f), seedOfFrame0, inlierThreshold2D, inlierCount, tau, beta, alpha);
+}
+
+void FrameBatch::synchronize() {
+    C_.check(dsac_join_tail(C_.get()), "dsac_join_tail");
+    C_.synchronize();
+}
+
+std::vector<ProcessImageResult> FrameBatch::results(bool perHypothesis) {
+    C_.check(dsac_join_tail(C_.get()), "dsac_join_tail");
+    const size_t F = (size_t)F_, N = (size_t)N_, P = (size_t)H_ * W_;
+    const std::vector<double> ent = entropy_.toHost(F), avg = avg_.toHost(F * 6), ref = ref_.toHost(F * 6), o4 = out4_.toHost(F * 4);
+    const std::vector<int32_t> sd = stepsDone_.toHost(F);
+    std::vector<double> poses, w;
+    std::vector<int32_t> sets, maps;
+    if (perHypothesis) { poses = poses_.toHost(F * N * 6); w = w_.toHost(F * N); sets = sets_.toHost(F * N * 4); }
+    if (opt_.inlierMaps) maps = maps_.toHost(F * P);
+    std::vector<ProcessImageResult> out(F);
+    for (size_t f = 0; f < F; f++) {
+        ProcessImageResult& r = out[f];
+        if (!done_[f]) continue;
+        r.sfEntropy = ent[f];
+        r.avgHyp = pose_at(&avg[f * 6]);
+        r.refAvgHyp = pose_at(&ref[f * 6]);
+        r.refStepsDone = sd[f];
+        r.loss = o4[f * 4]; r.rotErr = o4[f * 4 + 1]; r.tErr = o4[f * 4 + 2]; r.correct = o4[f * 4 + 3] > 0.5;
+        if (perHypothesis) {
+            r.hyps.resize(N);
+            r.imgIdx.resize(N);
+            for (size_t h = 0; h < N; h++) {
+                r.hyps[h] = pose_at(&poses[(f * N + h) * 6]);
+                for (int k = 0; k < 4; k++) r.imgIdx[h][k] = sets[(f * N + h) * 4 + k];
+            }
+            r.sfScores.assign(w.begin() + f * N, w.begin() + (f + 1) * N);
+        }
+        if (opt_.inlierMaps) r.inlierMap.assign(maps.begin() + f * P, maps.begin() + (f + 1) * P);
+    }
+    return out;
 }
 
 std::vector<double> Frame::backward(const ProcessImageResult& fwd, const Hypothesis& poseGT, int inlierThreshold2D, int inlierCount, int refSteps,
                                     float subSampleFactor, const std::vector<int32_t>& pixelIdxs, float tau, float beta, double alpha,
                                     bool referenceIndexQuirk) {
+    bind();
     const size_t P = (size_t)H_ * W_;
     const int N = (int)fwd.hyps.size();
     std::vector<double> grad(P * 3, 0.0);

@@ -12,7 +12,11 @@
 //   refine                cnn_softam.h:663                       Frame::refine
 //   dRefineHyp/dRefineObj cnn_softam.h:738 / :853                Frame::dRefine (one batched launch)
 //   maxLoss / dLossMax    maxloss.h:69 / :87                     Frame::maxLoss / dLossMax
-//   processImage          cnn_softam.h:960                       Frame::processImage
+//   processImage          cnn_softam.h:960                       Frame::processImage (one image, one ABI call)
+//   the loop over images  test_ransac_softam.cpp:97-157          FrameBatch::processImages (16 images per launch chain, HBM-resident)
+//
+// One engine context serves the whole program (Context::shared): dsac_create -- device query, stream, scratch allocation -- is paid once,
+// a Frame only uploads its coordinate map and binds it (DSAC_FRAME_BORROW) before a call.
 //
 // Every call throws dsac::Error (carrying the dsac_status and dsac_last_error text) on failure; nothing is
 // computed on the CPU here -- without a gfx950 device the Frame constructor throws.
@@ -48,10 +52,73 @@ struct ProcessImageResult {  // the output parameters of processImage, cnn_softa
     bool correct = false;
 };
 
+// One engine context for the life of the program (or of whoever owns it): the device query, the stream and the library's scratch buffers
+// are created once; Frames and FrameBatches bind their HBM-resident coordinate maps to it call by call.  Single-threaded, like dsac_ctx.
+class Context {
+public:
+    explicit Context(int device = 0);  // throws dsac::Error without a gfx950 device (no CPU fallback)
+    ~Context();
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    static Context& shared(int device = 0);  // the process-wide context of a device, created on first use, destroyed at exit
+
+    dsac_ctx* get() { return ctx_; }
+    void check(int rc, const char* what);
+    void synchronize();
+    void setOption(const char* key, int value);
+    // HBM / page-locked host buffers and stream-ordered copies (dsac_device_alloc, dsac_host_alloc, dsac_copy_async)
+    void* deviceAlloc(size_t bytes);
+    void deviceFree(void* p) noexcept;
+    void* hostAlloc(size_t bytes);
+    void hostFree(void* p) noexcept;
+    void copy(void* dst, const void* src, size_t bytes);
+    void zero(void* dst, size_t bytes);
+    // which Frame / FrameBatch owns the frame currently set in the context (so that re-binding is skipped when nothing changed)
+    const void* boundTo() const { return bound_; }
+    void setBound(const void* owner) { bound_ = owner; }
+
+private:
+    dsac_ctx* ctx_ = nullptr;
+    const void* bound_ = nullptr;
+};
+
+// A typed buffer in HBM, freed with its owner.  upload / download are ordered on the context's stream; download() waits for the data.
+template <typename T>
+class DeviceArray {
+public:
+    DeviceArray() = default;
+    DeviceArray(Context& c, size_t n) { resize(c, n); }
+    ~DeviceArray() { release(); }
+    DeviceArray(const DeviceArray&) = delete;
+    DeviceArray& operator=(const DeviceArray&) = delete;
+    DeviceArray(DeviceArray&& o) noexcept : c_(o.c_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceArray& operator=(DeviceArray&& o) noexcept { if (this != &o) { release(); c_ = o.c_; p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+    void resize(Context& c, size_t n) {
+        if (n == n_ && c_ == &c) return;
+        release();
+        c_ = &c;
+        p_ = n ? static_cast<T*>(c.deviceAlloc(n * sizeof(T))) : nullptr;
+        n_ = n;
+    }
+    void release() noexcept { if (p_ && c_) c_->deviceFree(p_); p_ = nullptr; n_ = 0; }
+    T* data() const { return p_; }
+    size_t size() const { return n_; }
+    void upload(const T* src, size_t count, size_t at = 0) { c_->copy(p_ + at, src, count * sizeof(T)); }
+    void download(T* dst, size_t count, size_t at = 0) const { c_->copy(dst, p_ + at, count * sizeof(T)); c_->synchronize(); }
+    std::vector<T> toHost(size_t count, size_t at = 0) const { std::vector<T> v(count); if (count) download(v.data(), count, at); return v; }
+
+private:
+    Context* c_ = nullptr;
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
 class Frame {
 public:
-    // estObj: H*W*3 float32 mm; sampling: H*W*2 float32 (u,v) or nullptr for the full-resolution grid.
+    // estObj: H*W*3 float32 mm; sampling: H*W*2 float32 (u,v) or nullptr for the full-resolution grid.  The map is uploaded to HBM once;
+    // the context is the process-wide one of `device` (Context::shared) or the caller's.
     Frame(const float* estObj, const float* sampling, int H, int W, const Camera& cam, int device = 0, bool quantiseInt16 = false);
+    Frame(Context& ctx, const float* estObj, const float* sampling, int H, int W, const Camera& cam, bool quantiseInt16 = false);
     ~Frame();
     Frame(const Frame&) = delete;
     Frame& operator=(const Frame&) = delete;
@@ -91,12 +158,62 @@ public:
                                  float subSampleFactor, const std::vector<int32_t>& pixelIdxs, float tau = 10.f, float beta = 0.5f,
                                  double alpha = 0.1, bool referenceIndexQuirk = false);
 
-    dsac_ctx* context() { return ctx_; }
+    // the N error images in HBM (N*H*W floats, hypothesis-major): what the score CNN consumes in place (lua_calls.h:98-104) -- no PCIe round trip
+    void getDiffMapsDevice(const std::vector<cv_trans_t>& hyps, DeviceArray<float>& out);
 
-private:
+    dsac_ctx* context() { bind(); return ctx_; }
+    Context& engine() { return *C_; }
+
+protected:
     void check(int rc, const char* what);
+    void bind();  // make this frame the context's current one (a borrowed-pointer rebind; nothing is copied)
+    Context* C_ = nullptr;
     dsac_ctx* ctx_ = nullptr;
     int H_, W_;
+    Camera cam_;
+    DeviceArray<float> xyz_, uv_;
+    bool quantise_ = false, quantised_ = false;
+};
+
+// The loop over images of core/test_ransac_softam.cpp:97-157 as launches over image BATCHES: F coordinate maps of one geometry live in HBM,
+// processImages(first, count, ...) enqueues processImage (core/cnn_softam.h:960-1179) for `count` of them as ONE chain of launches
+// (dsac_set_frames + dsac_process_images: K1, K2, K3, K6 with a wave per image, K7), every output stays in HBM, the refinement tail of a
+// call runs under sampling and scoring of the next one (pi_defer_tail), and nothing blocks the host until results().  Image i draws from
+// the random stream of seed + i, so the results equal Frame::processImage(seed + i) image by image, bit for bit.
+struct FrameBatchOptions {
+    bool errorImages = true;   // write the N error images per frame (the score CNN's input; one buffer shared by all calls)
+    bool inlierMaps = false;   // keep the refinement's inlier maps (needed by the training backward only)
+    bool deferTail = true;     // dsac_set_option("pi_defer_tail", 1)
+    bool quantiseInt16 = false;
+};
+
+class FrameBatch {
+public:
+    FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam, int objHyps, int refSteps, const std::vector<int32_t>& pixelIdxs,
+               int maxFramesPerCall = 16, const FrameBatchOptions& opt = FrameBatchOptions());
+    int frames() const { return F_; }
+    // stream-ordered upload of frame f's coordinate map (H*W*3 floats, mm) and ground truth
+    void setFrame(int f, const float* estObj, const Hypothesis& poseGT);
+    // enqueue processImage for frames [first, first + count), count <= maxFramesPerCall; returns immediately
+    void processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f,
+                       double alpha = 0.1);
+    // convenience: all frames in calls of maxFramesPerCall
+    void processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
+    void synchronize();  // joins the deferred tail and waits
+    // waits and copies the results back; perHypothesis = false leaves hyps / imgIdx / sfScores empty (the evaluation program needs none of them)
+    std::vector<ProcessImageResult> results(bool perHypothesis = true);
+    const float* errorImagesDevice() const { return err_.data(); }  // of the most recent call, count*objHyps x H*W
+
+private:
+    Context& C_;
+    int F_, H_, W_, N_, refSteps_, maxCall_;
+    Camera cam_;
+    FrameBatchOptions opt_;
+    DeviceArray<float> xyz_, err_;
+    DeviceArray<int32_t> perm_, sets_, stepsDone_, maps_;
+    DeviceArray<uint8_t> ok_;
+    DeviceArray<double> gt_, poses_, scores_, w_, entropy_, avg_, ref_, out4_;
+    std::vector<uint8_t> done_;
 };
 
 // host-side forms of the two trivial reference functions (cnn_softam.h:535-553, :80-88)

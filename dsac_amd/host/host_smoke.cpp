@@ -5,7 +5,12 @@
 
 #include "cnn.h"
 
-int main() {
+// argv[1] (optional): a file that receives the frame and every result of processImage as raw little-endian arrays, in the order written below --
+// tests/test_gpu_host_shim.py recomputes them with the CPU oracle.
+template <typename T>
+static void put(std::FILE* f, const T* p, size_t n) { std::fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char** argv) {
     using namespace dsac;
     const int H = 48, W = 64;
     const Camera cam;
@@ -37,6 +42,49 @@ int main() {
         ProcessImageResult r = frame.processImage(poseGT, 256, 1305, 10, 100, 8, perms);
         std::printf("processImage: entropy %.3f bits, refine steps %d, loss %.4f (rot %.4f deg, trans %.3f mm), correct %d\n", r.sfEntropy,
                     r.refStepsDone, r.loss, r.rotErr, r.tErr, (int)r.correct);
+        // the batched path on the same context: the frame twice, seeds 1305 and 1306 -- image 0 must equal the single-image call bit for bit
+        FrameBatchOptions bo;
+        bo.inlierMaps = true;
+        // (the explicit sampling grid of this frame is not the implicit full-resolution one a FrameBatch assumes: compare on a grid frame)
+        std::vector<float> gxyz = xyz;
+        Frame gframe(gxyz.data(), nullptr, H, W, cam);
+        const ProcessImageResult g1 = gframe.processImage(poseGT, 256, 1305, 10, 100, 8, perms), g2 = gframe.processImage(poseGT, 256, 1306, 10, 100, 8, perms);
+        FrameBatch fb(gframe.engine(), 2, H, W, cam, 256, 8, perms, 2, bo);
+        fb.setFrame(0, gxyz.data(), poseGT);
+        fb.setFrame(1, gxyz.data(), poseGT);
+        fb.processAll(1305, 10, 100);
+        const std::vector<ProcessImageResult> br = fb.results();
+        auto same = [](const ProcessImageResult& a, const ProcessImageResult& b) {
+            bool ok = a.imgIdx == b.imgIdx && a.sfScores == b.sfScores && a.sfEntropy == b.sfEntropy && a.refStepsDone == b.refStepsDone && a.loss == b.loss &&
+                      a.rotErr == b.rotErr && a.tErr == b.tErr && a.inlierMap == b.inlierMap;
+            for (int k = 0; k < 3; k++) ok = ok && a.refAvgHyp.rvec[k] == b.refAvgHyp.rvec[k] && a.refAvgHyp.tvec[k] == b.refAvgHyp.tvec[k] && a.avgHyp.rvec[k] == b.avgHyp.rvec[k];
+            for (size_t h = 0; h < a.hyps.size() && ok; h++)
+                for (int k = 0; k < 3; k++) ok = ok && a.hyps[h].rvec[k] == b.hyps[h].rvec[k] && a.hyps[h].tvec[k] == b.hyps[h].tvec[k];
+            return ok;
+        };
+        const bool batchEqual = br.size() == 2 && same(br[0], g1) && same(br[1], g2);
+        std::printf("FrameBatch: 2 images in one launch chain %s the per-image calls (losses %.6f / %.6f)\n", batchEqual ? "equal" : "DIFFER FROM", br[0].loss, br[1].loss);
+        if (argc > 1) {
+            std::FILE* f = std::fopen(argv[1], "wb");
+            if (!f) { std::printf("cannot write %s\n", argv[1]); return 3; }
+            const int32_t hdr[4] = {H, W, 256, 8};
+            put(f, hdr, 4);
+            put(f, xyz.data(), xyz.size());
+            put(f, uv.data(), uv.size());
+            put(f, perms.data(), perms.size());
+            const std::vector<double> gtv = poseGT.getRodVecAndTrans();
+            put(f, gtv.data(), 6);
+            for (const auto& s4 : r.imgIdx) put(f, s4.data(), 4);
+            for (const auto& h : r.hyps) { const Pose6 p6 = pack(h); put(f, p6.data(), 6); }
+            put(f, r.sfScores.data(), r.sfScores.size());
+            const Pose6 a6 = pack(r.avgHyp), r6 = pack(r.refAvgHyp);
+            put(f, a6.data(), 6);
+            put(f, r6.data(), 6);
+            const double tail[5] = {r.sfEntropy, r.loss, r.rotErr, r.tErr, (double)r.refStepsDone};
+            put(f, tail, 5);
+            put(f, r.inlierMap.data(), r.inlierMap.size());
+            std::fclose(f);
+        }
         std::vector<float> dDiff((size_t)256 * H * W, 1e-3f);
         std::vector<double> jac;
         frame.dScore(r.hyps, r.imgIdx, dDiff, jac);
@@ -56,7 +104,7 @@ int main() {
         for (double v : Jset) ns += v * v;
         std::printf("DSAC variant: hypIdx %d (p = %.3f), expected loss %.4f, winner rot %.4f deg / trans %.3f mm, |dRefine_set| = %.4g, %zu inlier cells\n",
                     d.hypIdx, d.sfScores[d.hypIdx], d.expectedLoss, d.rotErr, d.tErr, std::sqrt(ns), px.size());
-        return (r.correct && r.refStepsDone == 8 && n > 0 && d.correct && ns > 0 && d.expectedLoss > 0) ? 0 : 2;
+        return (r.correct && r.refStepsDone == 8 && n > 0 && d.correct && ns > 0 && d.expectedLoss > 0 && batchEqual) ? 0 : 2;
     } catch (const Error& e) {
         std::printf("dsac error %d: %s\n", e.code, e.what());
         return 1;

@@ -43,6 +43,9 @@ struct EngineParameters {
     int rounds = 0;                   // -rounds : training rounds (reference: 5000, train_ransac_softam.cpp:49); 0 = that default
     int device = 0;                   // -dev
     bool indexQuirk = false;          // -quirk  : reproduce the transposed pixel index of path II (cnn_softam.h:628,641)
+    int batch = 16;                   // -batch  : images per launch chain of the evaluation program (FrameBatch); 0 = one image per call (Frame::processImage)
+    int passes = 1;                   // -passes : process the data set this many times (the first pass warms the device up; timing is reported per pass)
+    bool errorImages = true;          // -errimg : write the N error images of every image (the score CNN's input) as the reference does
 };
 
 class GlobalProperties {

@@ -78,7 +78,8 @@ typedef enum dsac_status {
 
 /* dsac_set_frame flags */
 #define DSAC_FRAME_QUANTISE_INT16 1u /* xyz <- saturate_cast<short>(round(xyz)), core/cnn_softam.h:265, types.h:43 */
-#define DSAC_FRAME_BORROW 2u         /* xyz/uv are device pointers that outlive the frame: use in place, no copy */
+#define DSAC_FRAME_BORROW 2u         /* xyz/uv are device pointers that outlive the frame: use in place, no copy.  Together with
+                                        DSAC_FRAME_QUANTISE_INT16 the caller's xyz buffer is rounded IN PLACE (in stream order) */
 
 /* backward flags */
 #define DSAC_BWD_PARITY_FP64 2u        /* dsac_score_backward only: the fp64 parity mode -- the reference's own evaluation order in double (one lane per
@@ -116,6 +117,20 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
 DSAC_API int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
+
+/* ---- device buffers for a host program that has no HIP toolchain --------------------------------------------- */
+/* The reference keeps every operand in host memory (cv::Mat: jp::img_coord_t estObj core/types.h:43-51, the hypothesis vectors of
+ * core/cnn_softam.h:971-988).  A C++ host that follows INTEGRATION.md keeps them in HBM instead and needs nothing but this header for it:
+ * dsac_device_alloc / dsac_device_free hand out device memory of the context's GPU, dsac_host_alloc / dsac_host_free page-locked host
+ * memory (copies to and from it are truly asynchronous), dsac_copy_async moves `bytes` between any two of them (or pageable host memory)
+ * in the order of the context's stream and returns without waiting unless the runtime has to stage a pageable buffer.  Pointers from
+ * dsac_device_alloc are "device pointers" wherever this header says so; buffers are not tied to the context beyond their GPU. */
+DSAC_API int dsac_device_alloc(dsac_ctx* ctx, size_t bytes, void** out);
+DSAC_API int dsac_device_free(dsac_ctx* ctx, void* p);
+DSAC_API int dsac_host_alloc(dsac_ctx* ctx, size_t bytes, void** out);
+DSAC_API int dsac_host_free(dsac_ctx* ctx, void* p);
+DSAC_API int dsac_copy_async(dsac_ctx* ctx, void* dst, const void* src, size_t bytes);
+DSAC_API int dsac_fill_zero_async(dsac_ctx* ctx, void* dst, size_t bytes);
 
 /* ---- frame ------------------------------------------------------------------------------------ */
 /* Replaces the (estObj, sampling, camMat) triple every reference function takes

@@ -96,3 +96,22 @@ def test_synthetic_run_and_config_precedence(tmp_path):
     assert err.shape == (3, 10) and (err[:, 3] < 5).all() and (err[:, 2] < 50).all() and tot[0] == 1.0  # solvable frames: all within 5 deg / 5 cm
     out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", "1", "-mw", "640", "-mh", "480"], cwd=tmp, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("mw,mh,k,rI,batch", [(64, 48, 5, 128, 4), (640, 480, 3, 256, 2)])
+def test_batched_evaluation_equals_the_per_image_loop(tmp_path, mw, mh, k, rI, batch):
+    """The fast path of the C++ surface (FrameBatch: the data set resident in HBM, `batch` images per launch chain, refinement tail deferred) writes the
+    same two result files as the per-image loop of core/test_ransac_softam.cpp:97-157 (Frame::processImage, -batch 0), byte for byte."""
+    outs = {}
+    for mode in (batch, 0):
+        d = tmp_path / ("b%d" % mode)
+        d.mkdir()
+        out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", str(k), "-mw", str(mw), "-mh", str(mh), "-rI", str(rI), "-batch", str(mode),
+                              "-passes", "2"], cwd=str(d), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "Timing: %d images" % k in out.stdout
+        outs[mode] = [open(os.path.join(str(d), f)).read() for f in ("ransac_test_errors_obj_model_init.net_rdraw1_softam.txt",
+                                                                      "ransac_test_loss_obj_model_init.net_rdraw1_softam.txt")]
+    assert outs[batch] == outs[0]
+    err = np.loadtxt(str(tmp_path / ("b%d" % batch) / "ransac_test_errors_obj_model_init.net_rdraw1_softam.txt")).reshape(-1, 10)
+    assert err.shape[0] == k and (err[:, 3] < 5).all() and (err[:, 2] < 50).all()
