@@ -104,6 +104,10 @@ def parse_args(argv=None):
     ap.add_argument("--event-stride", type=int, default=-1, help="time every n-th K2 launch with HIP events (0 = none, -1 = every launch up to 64 steps)")
     ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] with --hyps 4096)")
     ap.add_argument("--k2-mode", choices=("both", "err", "soft"), default="both", help="K2 outputs: error images and/or soft-inlier sums")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="config3 on ONE GPU: besides the whole 64-image step, time exactly the share rank --emulate-rank of W ranks would run (8 images at "
+                         "W = 8; its gather replaced by the rank's own part) and report per_rank_ms next to one_gpu_ms / W -> predicted efficiency")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true", help="exercise launch / shard / gather / reporting without touching a GPU (CPU tests, gloo)")
     return ap.parse_args(argv)
 
@@ -239,13 +243,30 @@ def run_dry(args, rank, world, dist):
     if args.workload == "config5":
         return run_config5(args, rank, 0, world, "gloo", dist)
     if args.workload == "config3":
+        # the exchange of the real run (dsac_amd.shard.ShardRunner) with a stand-in for the engine: every step writes its rows into the slot's regions,
+        # the gather of step i is launched at the top of step i + 1 and consumed at the top of step i + 2
         mine = ddist.shard_images(CONFIG3_IMAGES, rank, world)
-        res = torch.tensor([[float(i)] * (10 + N) for i in mine], dtype=torch.float64).reshape(len(mine), 10 + N)
+        ex = ddist.FrameResultExchange(CONFIG3_IMAGES, rank, world, (6, 4, N), torch.device("cpu"))
         t0 = time.perf_counter()
-        for _ in range(K):
-            allres = ddist.gather_frame_results(mine, res, CONFIG3_IMAGES)
+        for i in range(K):
+            k = i & 1
+            if i >= 1:
+                ex.wait(k)
+                ex.launch(1 - k)
+            ref_v, out4_v, w_v = ex.views(k)
+            for j, img in enumerate(mine):
+                ref_v[j] = float(img)
+                out4_v[j] = float(i)
+                w_v[j] = 1.0 / N
+        k = (K - 1) & 1
+        if K >= 2:
+            ex.wait(1 - k)
+        ex.launch(k)
+        ex.wait(k)
+        allres = ex.frames(k)
         elapsed = time.perf_counter() - t0
         assert torch.equal(allres[:, 0], torch.arange(CONFIG3_IMAGES, dtype=torch.float64)), "gather lost or misplaced frames"
+        assert bool((allres[:, 6] == float(K - 1)).all()) and bool(((allres[:, 10:].sum(1) - 1.0).abs() < 1e-12).all()), "gather returned a stale step"
         total = CONFIG3_IMAGES * N * K
         scaling, per_step = "strong", CONFIG3_IMAGES
     else:
@@ -450,10 +471,7 @@ def main(argv=None):
     pipelined = (args.overlap == "pipeline" and not args.kernel_only and args.k2_mode == "both" and not args.separate_calls and not config3)
     fr = synth.chess_like_frame(H, W, seed=1305 + rank)
     if config3:
-        imgs = [synth.chess_like_frame(H, W, seed=1305 + i) for i in mine]  # seeds 1305 + i
-        # the rank's images in batches of B frames (the last batch may be smaller; hypothesis counts stay multiples of 128)
-        batches = [list(range(s, min(s + B, len(mine)))) for s in range(0, len(mine), B)]
-        xyz_batches = [torch.from_numpy(np.ascontiguousarray(np.stack([imgs[j]["xyz"] for j in b]))).to(dev) for b in batches]
+        xyz_batches = [torch.from_numpy(fr["xyz"]).to(dev)]  # the engine's first frame; the runner below owns the images of the workload
     elif batched:
         def make_batch(tag):
             frs = [synth.chess_like_frame(H, W, seed=1305 + world * 1000 * (tag + 1) + rank * B + f) for f in range(B)]
@@ -481,7 +499,7 @@ def main(argv=None):
         eng.profile_enable(stride > 0, stride=max(1, stride))
         engines.append((eng, st))
     NB = N * B  # hypotheses per launch and context
-    for i in range(n_buf):
+    for i in range(0 if config3 else n_buf):
         bufs.append(dict(
             poses=torch.zeros(NB, 6, dtype=torch.float64, device=dev), sets=torch.zeros(NB, 4, dtype=torch.int32, device=dev),
             ok=torch.zeros(NB, dtype=torch.uint8, device=dev), err=torch.empty(NB, P, dtype=torch.float32, device=dev),
@@ -502,19 +520,18 @@ def main(argv=None):
         rp = synth.random_poses(N, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])
         for b in bufs:
             b["poses"].copy_(torch.from_numpy(rp))
+    runner = None
     if config3:
-        # per image: refined pose (6) + loss, rotErr, tErr, correct (4) + softmax weights (N) -- what core/test_ransac_softam.cpp:129-263 logs per image
-        results = torch.zeros(len(mine), 10 + N, dtype=torch.float64, device=dev)
+        # per image: refined pose (6) + loss, rotErr, tErr, correct (4) + softmax weights (N) -- what core/test_ransac_softam.cpp:129-263 logs per image.
+        # dsac_amd.shard.ShardRunner: batches through dsac_process_images, the refinement tail of a batch under the next batch -- across step boundaries
+        # too --, the gather of a step launched on a side stream at the top of the next step and consumed one step later, no host synchronisation.
+        from dsac_amd.shard import ShardRunner
         perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
-        gt3 = torch.zeros(B, 6, dtype=torch.float64, device=dev)
-        # per batch of the step: what the deferred refinement tail writes (and the weights the gather reads) -- the tail of batch b runs under K1 / K2 of
-        # batch b + 1 (dsac_set_option "pi_defer_tail"), so its outputs are collected after the loop, behind joinTail
-        nbat3 = (len(mine) + B - 1) // B
-        ref3 = [torch.zeros(B, 6, dtype=torch.float64, device=dev) for _ in range(nbat3)]
-        sd3 = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbat3)]
-        out43 = [torch.zeros(B, 4, dtype=torch.float64, device=dev) for _ in range(nbat3)]
-        w3 = [torch.zeros(B * N, dtype=torch.float64, device=dev) for _ in range(nbat3)]
-        engines[0][0].set_option("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)
+
+        def frames_of(i):
+            return synth.chess_like_frame(H, W, seed=1305 + i)["xyz"]  # seeds 1305 + i
+        runner = ShardRunner(engines[0][0], engines[0][1], dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, fr["cam"], perm3, batch=B,
+                             defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
     torch.cuda.synchronize(dev)
 
     staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
@@ -550,28 +567,7 @@ def main(argv=None):
         eng.scoreSampled(k, b["poses"], b["soft"], b["w"], ent=b["ent"], avg=b["avg"], err=err_shared, clamp=100.0, tau=10.0, beta=0.5, scale=0.1)
 
     def step_config3(i):
-        # one pass over this rank's share of the 64 images, then the gather of 64 x (6 + N) numbers on rank 0's side
-        eng, st = engines[0]
-        b = bufs[0]
-        with torch.cuda.stream(st):
-            for bi, idx in enumerate(batches):
-                nb_ = len(idx)
-                eng.set_frames(xyz_batches[bi], None, H, W, fr["cam"], borrow=True)
-                n_ = nb_ * N
-                # the reference's whole per-image unit (test_ransac_softam.cpp:97-157 -> processImage): K1, K2, K3, 8 refinement steps, loss
-                eng.processImages(N, perm3, gt_jp6=gt3[:nb_], seed=1305 + 64 * i + mine[idx[0]], thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5,
-                                  scale=0.1, err=b["err"][:n_],
-                                  out=dict(hyps=b["poses"][:n_], sampledPoints=b["sets"][:n_], ok=b["ok"][:n_], scores=b["soft"][:n_], sfScores=w3[bi][:n_],
-                                           sfEntropy=b["ent"][:nb_], avgHyp=b["avg"][:nb_], refAvgHyp=ref3[bi][:nb_], refSteps=sd3[bi][:nb_],
-                                           out4=out43[bi][:nb_]))
-            eng.joinTail()  # the stream now waits for the last batch's refinement; everything below is in stream order
-            for bi, idx in enumerate(batches):
-                nb_ = len(idx)
-                results[idx[0]:idx[0] + nb_, :6] = ref3[bi][:nb_]
-                results[idx[0]:idx[0] + nb_, 6:10] = out43[bi][:nb_]
-                results[idx[0]:idx[0] + nb_, 10:] = w3[bi][:nb_ * N].view(nb_, N)
-        st.synchronize()
-        return ddist.gather_frame_results(mine, results if backend == "nccl" else results.cpu(), CONFIG3_IMAGES)
+        runner.step(i)  # enqueues only; results are collected by runner.drain() (inside the timed region, once)
 
     def step(i):
         if config3:
@@ -620,6 +616,8 @@ def main(argv=None):
     for i in range(Wm):
         step(ctr)
         ctr += 1
+    if config3 and runner.steps_done:
+        runner.drain()
     sync_all()
     for eng, _ in engines:
         eng.profile_read(0, reset=True)
@@ -632,6 +630,8 @@ def main(argv=None):
     for i in range(K):
         last = step(ctr)
         ctr += 1
+    if config3:
+        last = runner.drain()  # the last step's refinement tail and gather: part of the job, inside the timed region
     sync_all()
     if distributed:
         dist.barrier()
@@ -642,8 +642,12 @@ def main(argv=None):
         ms, n = eng.profile_read(0, reset=True)
         k2_ms += ms
         k2_n += n
-    ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
-    wsum = float(bufs[0]["w"][:N].sum().item()) if not args.kernel_only else 1.0
+    if config3:
+        ok_frac = float(runner.scratch["ok"][:N * len(runner.batches[-1])].float().mean().item())
+        wsum = float(last[0, 10:].sum().item()) if last is not None else 0.0
+    else:
+        ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
+        wsum = float(bufs[0]["w"][:N].sum().item()) if not args.kernel_only else 1.0
 
     # The ceiling of K2's own write pattern ON THIS BOX: the same launches with k2_flags bit 1 (the kernel issues its store schedule only, no
     # arithmetic; include/dsac_hip.h).  The pool's boxes differ by several per cent for the same binary; this number moves with them.
@@ -692,10 +696,43 @@ def main(argv=None):
         sync_all()
         for e_, _ in engines:
             e_.profile_read(0, reset=True)
+    emulation = None
     if config3 and rank == 0:
         ws = last[:, 10:].sum(1)
         assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
         assert bool((last[:, 6] > 0).all()) and bool(torch.isfinite(last[:, :10]).all()), "config3: gathered refined poses / losses are not finite"
+    if config3 and args.emulate_world > 1 and world == 1:
+        # One-GPU emulation of rank r of W: exactly that rank's images (64 / W per step), its own buffers and launch sequence, the all-gather replaced
+        # by the copy of its own part.  one_gpu_ms / (W * per_rank_ms) is the strong-scaling efficiency the code path allows when every rank has its own
+        # GPU (the collective moves 17 KB per rank on a side stream and is not on the critical path).
+        Wem, rem = args.emulate_world, args.emulate_rank % args.emulate_world
+        eng0, st0 = engines[0]
+        k2_main = eng0.profile_read(0, reset=True)
+        em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
+                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
+        for i in range(max(5, Wm)):
+            em.step(ctr + i)
+        em.drain()
+        sync_all()
+        eng0.profile_read(0, reset=True)
+        Kem = max(K, 40)
+        te = time.perf_counter()
+        for i in range(Kem):
+            em.step(ctr + 100 + i)
+        lem = em.drain()
+        sync_all()
+        per_rank_s = (time.perf_counter() - te) / Kem
+        ms_e, n_e = eng0.profile_read(0, reset=True)
+        # the emulated rank's rows equal the one-GPU run's rows for the same images and step seeds?  (same seeds: seed0 + 64 * step + image)
+        one_gpu_s = elapsed / K
+        emulation = {"world": Wem, "rank": rem, "images_per_rank_step": len(em.mine), "batches_per_rank_step": len(em.batches), "steps": Kem,
+                     "per_rank_ms": per_rank_s * 1e3, "one_gpu_ms": one_gpu_s * 1e3, "ideal_per_rank_ms": one_gpu_s * 1e3 / Wem,
+                     "predicted_speedup": one_gpu_s / per_rank_s, "predicted_efficiency": one_gpu_s / per_rank_s / Wem,
+                     "k2_us_per_launch": ms_e / max(1, n_e) * 1e3, "rows_finite": bool(torch.isfinite(lem[em.mine]).all()),
+                     "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
+                             "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
+        ctr += 200 + Kem
+        runner.eng.set_option("seed_stride", world)
 
     # literal configs[1]: ONE frame per step on the same context (fused call), its own K2 timing
     single = None
@@ -914,6 +951,8 @@ def main(argv=None):
             out["reference_size"] = refsize
         if procimg is not None:
             out["process_image"] = procimg
+        if emulation is not None:
+            out["emulation"] = emulation
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
         print(json.dumps(out), flush=True)

@@ -40,7 +40,7 @@ EXPORTS = [
     "dsac_soft_score_backward", "dsac_refine", "dsac_refine_fd", "dsac_loss", "dsac_path1_and_softmax_backward", "dsac_set_k2_events", "dsac_profile_enable",
     "dsac_profile_read", "dsac_last_pose_gradients", "dsac_refine_all", "dsac_refine_fd_set", "dsac_refine_fd_sets", "dsac_loss_batch", "dsac_gather_patches", "dsac_set_frames", "dsac_score_hypotheses_frames", "dsac_set_option", "dsac_backward_path1",
     "dsac_loss_frames", "dsac_process_images", "dsac_join_tail", "dsac_select",
-    "dsac_device_alloc", "dsac_device_free", "dsac_host_alloc", "dsac_host_free", "dsac_copy_async", "dsac_fill_zero_async",
+    "dsac_device_alloc", "dsac_device_free", "dsac_host_alloc", "dsac_host_free", "dsac_copy_async", "dsac_fill_zero_async", "dsac_tail_wait",
 ]
 
 
@@ -98,6 +98,7 @@ def _load():
     lib.dsac_loss_frames.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.dsac_select.argtypes = [vp, i32, vp, vp, i32, f64, vp, vp, vp]
     lib.dsac_join_tail.argtypes = [vp]
+    lib.dsac_tail_wait.argtypes = [vp, vp]
     lib.dsac_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.dsac_device_free.argtypes = [vp, vp]
     lib.dsac_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]

@@ -60,6 +60,7 @@ struct dsac_ctx {
     dk::K2Opts k2;  // launch knobs, read once in dsac_create (DSAC_K2_*) or set with dsac_set_option; no process-wide state
     dk::K1Opts k1;
     int k1_cus = 0;       // > 0: the auxiliary stream of the pipelined pair (K1 of the next step) is confined to that many CUs (DSAC_K1_CUS / "k1_cus")
+    int seed_stride = 1;  // frame f of a batch samples from the stream of seed + f * seed_stride ("seed_stride": images sharded round-robin over ranks keep their own seeds)
     int k4_variant = -1;  // K4 main-pass form (dk::backward_plan), DSAC_K4_VARIANT / dsac_set_option("k4_variant")
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
 
@@ -79,6 +80,7 @@ struct dsac_ctx {
     hipStream_t tail = nullptr;
     hipEvent_t tail_go = nullptr, tail_done = nullptr;  // go: K3 of the batch done (main stream); done: its K6 / K7 done (tail stream)
     bool tail_pending = false;                          // a tail is in flight that the main stream has not been ordered behind yet
+    hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
 
     // measurement hooks: event pairs around the dominant kernels
     bool profiling = false;
@@ -289,6 +291,7 @@ void dsac_destroy(dsac_ctx* c) {
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->tail_go) (void)hipEventDestroy(c->tail_go);
     if (c->tail_done) (void)hipEventDestroy(c->tail_done);
+    if (c->xs_event) (void)hipEventDestroy(c->xs_event);
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -375,6 +378,7 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
     c->F.H = H; c->F.W = W; c->F.P = (int)P1;
     c->F.fx = fx; c->F.fy = fy; c->F.cx = cx; c->F.cy = cy;
     c->F.frames = frames;
+    c->F.seed_stride = c->seed_stride;
     c->F.xyz_stride = (long long)P1 * 3;
     c->F.uv_stride = (uv && uv_per_frame) ? (long long)P1 * 2 : 0;
     c->have_frame = true;
@@ -722,6 +726,11 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k4_variant") {
         if (!dk::backward_variant_known(value)) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown K4 kernel form %d", value);
         c->k4_variant = value;
+    }
+    else if (k == "seed_stride") {
+        if (value < 1) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: seed_stride must be >= 1");
+        c->seed_stride = value;
+        c->F.seed_stride = value;
     }
     else if (k == "pi_defer_tail") { join_tail(c); c->pi_defer_tail = value != 0; }
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
@@ -1301,6 +1310,18 @@ int dsac_join_tail(dsac_ctx* c) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_join_tail: ctx is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     join_tail(c);
+    return DSAC_OK;
+}
+
+int dsac_tail_wait(dsac_ctx* c, void* hip_stream) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_tail_wait: ctx is NULL");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (s == c->stream) return fail(c, DSAC_ERR_INVALID, "dsac_tail_wait: that is the context's own stream (use dsac_join_tail)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->xs_event) HIP_TRY(c, hipEventCreateWithFlags(&c->xs_event, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->xs_event, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(s, c->xs_event, 0));
+    if (c->tail_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->tail_done, 0));
     return DSAC_OK;
 }
 

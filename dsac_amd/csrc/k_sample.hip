@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * WPB, MINW) void k_sample(int N, uint64_t seed,
     const int frame = hc / Nf;           // Nf == N for a single frame
     F.xyz += (long long)frame * F.xyz_stride;
     if (F.uv) F.uv += (long long)frame * F.uv_stride;
-    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(hc - frame * Nf));
+    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame * (uint64_t)F.seed_stride, (uint32_t)(hc - frame * Nf));
     const dm::Cam K = make_cam(F);
     for (int base = 0; base < max_tries; base += APR) {
         if (__ballot(!done) == 0ull) return;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * WPH) void k_sample_wide(int N, uint64_t seed, 
     const int frame = h / Nf;
     F.xyz += (long long)frame * F.xyz_stride;
     if (F.uv) F.uv += (long long)frame * F.uv_stride;
-    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+    const uint64_t key = dm::hyp_key(seed + (uint64_t)frame * (uint64_t)F.seed_stride, (uint32_t)(h - frame * Nf));
     const dm::Cam K = make_cam(F);
     const double thr_hi = (double)thr_int + 0.01;
     bool done = false;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed,
         const int frame = h / Nf;
         F.xyz = xyz0 + (long long)frame * F.xyz_stride;
         F.uv = uv0 ? uv0 + (long long)frame * F.uv_stride : nullptr;
-        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame * (uint64_t)F.seed_stride, (uint32_t)(h - frame * Nf));
         const long long att = (long long)bt + 16ll * sl + (lane >> 2);
         const uint32_t attempt = (uint32_t)att;
         int32_t set4[4];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * SW) void k_sample_shared(int N, uint64_t seed,
         const int frame = h / Nf;
         F.xyz = xyz0 + (long long)frame * F.xyz_stride;
         F.uv = uv0 ? uv0 + (long long)frame * F.uv_stride : nullptr;
-        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame, (uint32_t)(h - frame * Nf));
+        const uint64_t key = dm::hyp_key(seed + (uint64_t)frame * (uint64_t)F.seed_stride, (uint32_t)(h - frame * Nf));
         int32_t set4[4];
         draw_set(F, key, (uint32_t)(max_tries - 1), set4);
 #pragma unroll

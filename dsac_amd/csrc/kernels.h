@@ -16,6 +16,7 @@ struct FrameDev {
     // (floats); uv is shared (uv_stride == 0) or per frame.  Only K1 (random sampling), K2 and K3 look at frames > 0.
     int frames = 1;
     long long xyz_stride = 0, uv_stride = 0;
+    int seed_stride = 1;  // frame f of a batch draws from the random stream of seed + f * seed_stride (dsac_set_option "seed_stride")
 };
 
 // Staged pose record used by K2, 12 floats (48 B, three float4 rows) per hypothesis:

@@ -154,6 +154,7 @@ class GradientReducer:
             return
         self.buckets = _buckets(list(reversed(self.params)), bucket_bytes)
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0  # buckets leave strictly in index order, on every rank the same sequence of collectives whatever gradients exist locally
         where = {}
         for bi, b in enumerate(self.buckets):
             for p in b:
@@ -161,25 +162,37 @@ class GradientReducer:
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(where[id(p)])))
 
+    def _launch(self, bi):
+        # a parameter without a gradient this step travels as zeros: the collective sequence must not depend on what a rank happened to differentiate
+        for q in self.buckets[bi]:
+            if q.grad is None:
+                q.grad = torch.zeros_like(q)  # ... and receives the other ranks' average like everyone else
+        g = [q.grad for q in self.buckets[bi]]
+        self.handle.add(_Flight(g, self.average, self.group, self.mode))
+
     def _make_hook(self, bi):
         def hook(param):
             self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self.handle.add(_Flight([q.grad for q in self.buckets[bi]], self.average, self.group, self.mode))
+            if self._pending[bi] < 0:
+                raise RuntimeError("GradientReducer: a second backward pass reached bucket %d before wait() finished the first one "
+                                   "(call wait() once per backward)" % bi)
+            while self._next < len(self.buckets) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def wait(self):
-        """Finish every launched bucket; buckets whose hooks never fired completely (a parameter without gradient this step) are reduced now."""
+        """Finish every bucket: those whose gradients did not all arrive (a parameter unused this step) are sent now, in index order, so that every
+        rank issues buckets 0 .. B-1 exactly once per step in the same order."""
         if not self.enabled:
             return 0
-        for bi, left in enumerate(self._pending):
-            if left > 0:
-                g = [q.grad for q in self.buckets[bi] if q.grad is not None]
-                if g:
-                    self.handle.add(_Flight(g, self.average, self.group, self.mode))
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
         n = self.handle.wait()
         self.handle = GradientReduce()
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0
         return n
 
     def close(self):
@@ -191,7 +204,8 @@ class GradientReducer:
 def gather_frame_results(local_indices, local_results, n_images, group=None):
     """Collect per-frame result rows (e.g. refined pose 6 + loss 4 + weights N) on every rank, ordered by frame index.
     local_results: (len(local_indices), D) tensor on the communication device.  Every rank contributes ceil(n_images / world) rows (padded), one
-    all-gather moves exactly the rows that exist -- not a dense all-reduce of a zero-padded n_images x D table."""
+    all-gather moves exactly the rows that exist -- not a dense all-reduce of a zero-padded n_images x D table.  The frame indices travel as their own
+    int64 tensor (a column of the results' dtype would round them in fp16 / bf16, or in fp32 beyond 2^24 images)."""
     D = int(local_results.shape[1]) if local_results.ndim == 2 else 1
     out = torch.zeros(n_images, D, dtype=local_results.dtype, device=local_results.device)
     world = _world(group)
@@ -200,15 +214,89 @@ def gather_frame_results(local_indices, local_results, n_images, group=None):
             out[torch.as_tensor(local_indices, device=local_results.device)] = local_results.reshape(len(local_indices), D)
         return out
     per = (n_images + world - 1) // world
-    mine = torch.zeros(per, D + 1, dtype=local_results.dtype, device=local_results.device)
-    mine[:, 0] = -1  # frame index column; -1 = padding row
+    mine = torch.zeros(per, D, dtype=local_results.dtype, device=local_results.device)
+    idx = torch.full((per,), -1, dtype=torch.int64, device=local_results.device)  # -1 = padding row
     k = len(local_indices)
     if k:
-        mine[:k, 0] = torch.as_tensor(local_indices, dtype=local_results.dtype, device=local_results.device)
-        mine[:k, 1:] = local_results.reshape(k, D)
+        idx[:k] = torch.as_tensor(local_indices, dtype=torch.int64, device=local_results.device)
+        mine[:k] = local_results.reshape(k, D)
     parts = [torch.empty_like(mine) for _ in range(world)]
+    iparts = [torch.empty_like(idx) for _ in range(world)]
     dist.all_gather(parts, mine, group=group)
-    allrows = torch.cat(parts)
-    valid = allrows[:, 0] >= 0
-    out[allrows[valid, 0].long()] = allrows[valid, 1:]
+    dist.all_gather(iparts, idx, group=group)
+    allrows, allidx = torch.cat(parts), torch.cat(iparts)
+    valid = allidx >= 0
+    out[allidx[valid]] = allrows[valid]
     return out
+
+
+class FrameResultExchange:
+    """Per-frame results of a sharded evaluation (BASELINE configs[3]: image i -> rank i mod world), gathered ASYNCHRONOUSLY and consumed one step late.
+
+    A rank's results of a step live in one flat buffer per slot, laid out region by region -- for widths (6, 4, N): `per` refined poses, then `per` loss
+    rows, then `per` weight rows -- so that the engine writes every output straight into its place (views()) and the exchange is ONE
+    all_gather_into_tensor of that buffer with no packing kernels.  With round-robin sharding the frame of (rank r, local row j) is r + j * world, so no
+    index column travels.  launch(slot) only enqueues (async_op: on RCCL the collective runs on its own stream behind the work already enqueued on the
+    current stream); wait(slot) orders the current stream (gloo: the host) behind it; frames(slot) decodes the gathered buffer into frame order.
+    Two slots alternate, so the gather of step i runs beside the computation of step i + 1.
+
+    world / rank are those of the SHARDING; without a process group of that size (one process: world 1, or a one-GPU emulation of rank r of W) the
+    collective is replaced by the copy of the local buffer into its own part -- the rank's half of the gather."""
+
+    def __init__(self, n_images, rank, world, widths, device, dtype=torch.float64, group=None, slots=2, pin_host=False):
+        self.n, self.rank, self.world, self.group = int(n_images), int(rank), int(world), group
+        self.per = (self.n + self.world - 1) // self.world
+        self.widths = tuple(int(w) for w in widths)
+        self.D = sum(self.widths)
+        self.real = _world(group) > 1
+        if self.real and _world(group) != self.world:
+            raise ValueError("FrameResultExchange: the process group has %d ranks, the sharding %d" % (_world(group), self.world))
+        self.local = [torch.zeros(self.per * self.D, dtype=dtype, device=device) for _ in range(slots)]
+        self.all = [torch.zeros(self.world * self.per * self.D, dtype=dtype, device=device) for _ in range(slots)]
+        self.work = [None] * slots
+        self.launched = [False] * slots
+        self.host = None
+        if pin_host:
+            self.host = [torch.zeros(self.world * self.per * self.D, dtype=dtype).pin_memory() for _ in range(slots)]
+
+    def views(self, slot):
+        """One (per, width) view per region of the slot's local buffer: hand these (or row ranges of them) to the engine as output arrays."""
+        out, off = [], 0
+        for w in self.widths:
+            out.append(self.local[slot][off * self.per:(off + w) * self.per].view(self.per, w))
+            off += w
+        return out
+
+    def launch(self, slot):
+        """Enqueue the gather of the slot's local buffer.  The producers must already be ordered on the current stream."""
+        if self.real:
+            self.work[slot] = dist.all_gather_into_tensor(self.all[slot], self.local[slot], group=self.group, async_op=True)
+        else:
+            self.all[slot].view(self.world, self.per * self.D)[self.rank].copy_(self.local[slot], non_blocking=True)
+            self.work[slot] = None
+        self.launched[slot] = True
+
+    def wait(self, slot):
+        """Order the current stream (gloo / CPU tensors: the host) behind the slot's gather.  False when nothing was launched on the slot."""
+        if not self.launched[slot]:
+            return False
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        return True
+
+    def to_host(self, slot):
+        """Asynchronous copy of the gathered slot into page-locked host memory (pin_host=True), on the current stream."""
+        self.host[slot].copy_(self.all[slot], non_blocking=True)
+        return self.host[slot]
+
+    def frames(self, slot, source=None):
+        """(n_images, D) in frame order, decoded from the gathered buffer of the slot (or from `source`, e.g. its host copy).  In a one-GPU emulation only the
+        rows of the emulated rank's frames are filled."""
+        g = (self.all[slot] if source is None else source).view(self.world, self.per * self.D)
+        cols, off = [], 0
+        for w in self.widths:
+            r = g[:, off * self.per:(off + w) * self.per].reshape(self.world, self.per, w)
+            cols.append(r.permute(1, 0, 2).reshape(self.per * self.world, w)[:self.n])  # frame = j * world + r
+            off += w
+        return torch.cat(cols, dim=1)

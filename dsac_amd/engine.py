@@ -169,6 +169,12 @@ class Engine:
                                                  ptr(scores), ptr(w), ptr(ent), ptr(avg), ptr(ref), ptr(sd), ptr(maps), ptr(out4)))
         return o
 
+    def tailWait(self, stream):
+        """dsac_tail_wait: `stream` (a torch.cuda.Stream or a raw hipStream_t) waits for the deferred refinement tail in flight and for everything
+        enqueued on the engine's stream so far; the engine's own stream is not held up."""
+        h = getattr(stream, "cuda_stream", stream)
+        check(self._ctx, lib.dsac_tail_wait(self._ctx, int(h)))
+
     def joinTail(self):
         """Order the engine's stream behind a deferred refinement tail (set_option("pi_defer_tail", 1)): after this call the refined poses, step
         counts, inlier maps and losses of the last processImages are complete in stream order.  Does not block the host."""

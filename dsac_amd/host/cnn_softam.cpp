@@ -223,20 +223,33 @@ ProcessImageResult Frame::processImage(const Hypothesis& poseGT, int objHyps, ui
         r.loss = maxLoss(poseGT, r.refAvgHyp, &r.rotErr, &r.tErr, &r.correct);
         return r;
     }
-    // the whole of core/cnn_softam.h:960-1179 in ONE call: sample + P3P, soft-inlier scores, softmax / entropy / soft-argmax pose, the refinement loop,
-    // maxLoss -- one launch chain on the device, one copy-back of the small results
     if (refSteps < 0 || (size_t)refSteps * H_ * W_ > pixelIdxs.size()) throw std::invalid_argument("Frame::processImage: pixelIdxs holds fewer than refSteps permutations");
+    return processImageCall(poseGT, objHyps, seed, inlierThreshold2D, inlierCount, refSteps, pixelIdxs.data(), tau, beta, alpha, true);
+}
+
+ProcessImageResult Frame::processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
+                                       const DeviceArray<int32_t>& pixelIdxsDevice, float tau, float beta, double alpha, bool wantInlierMap) {
+    if (refSteps < 0 || (size_t)refSteps * H_ * W_ > pixelIdxsDevice.size()) throw std::invalid_argument("Frame::processImage: pixelIdxs holds fewer than refSteps permutations");
+    return processImageCall(poseGT, objHyps, seed, inlierThreshold2D, inlierCount, refSteps, pixelIdxsDevice.data(), tau, beta, alpha, wantInlierMap);
+}
+
+// the whole of core/cnn_softam.h:960-1179 in ONE call: sample + P3P, soft-inlier scores, softmax / entropy / soft-argmax pose, the refinement loop,
+// maxLoss -- one launch chain on the device, one copy-back of the small results
+ProcessImageResult Frame::processImageCall(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
+                                           const int32_t* pixelIdxs, float tau, float beta, double alpha, bool wantInlierMap) {
+    bind();
+    ProcessImageResult r;
     const size_t P = (size_t)H_ * W_;
     std::vector<double> poses((size_t)objHyps * 6), gt = poseGT.getRodVecAndTrans();
     std::vector<uint8_t> ok(objHyps);
     r.imgIdx.assign(objHyps, {0, 0, 0, 0});
     r.sfScores.assign(objHyps, 0.0);
-    r.inlierMap.assign(P, 0);
+    if (wantInlierMap) r.inlierMap.assign(P, 0);
     double avg[6], ref[6], out4[4];
     int32_t sd = 0;
-    check(dsac_process_images(ctx_, objHyps, seed, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, pixelIdxs.data(), refSteps, inlierCount,
+    check(dsac_process_images(ctx_, objHyps, seed, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, pixelIdxs, refSteps, inlierCount,
                               50, gt.data(), poses.data(), &r.imgIdx[0][0], ok.data(), nullptr, nullptr, r.sfScores.data(), &r.sfEntropy, avg, ref, &sd,
-                              r.inlierMap.data(), out4),
+                              wantInlierMap ? r.inlierMap.data() : nullptr, out4),
           "dsac_process_images");
     r.hyps.resize(objHyps);
     for (int h = 0; h < objHyps; h++) r.hyps[h] = pose_at(&poses[(size_t)h * 6]);

@@ -151,6 +151,9 @@ public:
     ProcessImageResult processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
                                     const std::vector<int32_t>& pixelIdxs, float tau = 10.f, float beta = 0.5f, double alpha = 0.1,
                                     const std::vector<std::array<int32_t, 4>>* givenSets = nullptr);
+    // the same with the refinement permutations already in HBM (refSteps * H*W indices): an evaluation loop uploads them once, not per image
+    ProcessImageResult processImage(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
+                                    const DeviceArray<int32_t>& pixelIdxsDevice, float tau = 10.f, float beta = 0.5f, double alpha = 0.1, bool wantInlierMap = true);
     // The backward section of the trainer, core/train_ransac_softam.cpp:288-394: dLoss/d(scene coordinates), H*W x 3, from the
     // forward pass's results.  Path I: dLossMax . (dRefineObj + dRefineHyp . sum_h w_h dPNP_h); path II: softmax backward -> score
     // gradients -> (soft-inlier) score backward.  referenceIndexQuirk reproduces the transposed pixel index of path II (:628,641).
@@ -165,6 +168,8 @@ public:
     Context& engine() { return *C_; }
 
 protected:
+    ProcessImageResult processImageCall(const Hypothesis& poseGT, int objHyps, uint64_t seed, int inlierThreshold2D, int inlierCount, int refSteps,
+                                        const int32_t* pixelIdxsHostOrDevice, float tau, float beta, double alpha, bool wantInlierMap);
     void check(int rc, const char* what);
     void bind();  // make this frame the context's current one (a borrowed-pointer rebind; nothing is copied)
     Context* C_ = nullptr;

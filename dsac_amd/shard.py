@@ -1,0 +1,114 @@
+"""The per-image evaluation loop of the reference (core/test_ransac_softam.cpp:97-230) for ONE rank of an image-sharded job -- BASELINE.json configs[3]:
+n_images x N hypotheses, image i owned by rank i mod world (dist.shard_images).
+
+A step is one pass over this rank's images.  Nothing in it waits:
+  * the images go through dsac_process_images in batches (K1, K2, K3, then K6 / K7 on the engine's tail stream: "pi_defer_tail"), every output
+    written straight into the rank's exchange buffer (dist.FrameResultExchange.views: refined pose 6 | loss, rotErr, tErr, correct 4 | N weights);
+  * the refinement tail of the LAST batch of step i runs under sampling and scoring of step i + 1 (with 8 ranks a step is a single batch: without
+    this the 90-110 us K6 latency chain would sit exposed in every step);
+  * the gather of step i is launched at the top of step i + 1 on a side stream that waits for that tail (dsac_tail_wait) -- beside K1 / K2 of step
+    i + 1, not in front of them -- and is consumed (ordered, copied to page-locked host memory) at the top of step i + 2;
+  * the host never synchronises inside a step; drain() finishes the last step's tail and gather.
+Every image keeps the seed it has in the unsharded loop (seed0 + image index; "seed_stride" = world), so the results do not depend on the number
+of ranks, and they equal the in-order calls bit for bit (tests/test_gpu_shard.py).
+
+emulate=True runs exactly the share of (rank, world) on one GPU without a process group: the gather is replaced by the copy of the rank's own part
+(what that rank contributes to the all-gather), everything else is the code path the rank would run."""
+import numpy as np
+import torch
+
+from . import dist as ddist
+
+
+class ShardRunner:
+    def __init__(self, engine, stream, device, frames_of, n_images, rank, world, N, H, W, cam, perm, gt_of=None, batch=16, group=None, emulate=False,
+                 seed0=1305, seed_per_step=64, write_err=True, defer=True):
+        """frames_of(i) -> H*W x 3 float32 coordinate map of image i (host array); gt_of(i) -> jp 6-vector or None (zeros).  perm: refSteps x H*W int32
+        (device tensor).  group: the process group of the sharding when world > 1 and not emulate."""
+        self.eng, self.st, self.dev = engine, stream, device
+        self.rank, self.world, self.N, self.H, self.W, self.cam = rank, world, N, H, W, cam
+        self.P = H * W
+        self.n_images, self.seed0, self.seed_per_step = n_images, seed0, seed_per_step
+        self.mine = ddist.shard_images(n_images, rank, world)
+        self.B = max(1, min(batch, max(1, len(self.mine))))
+        if self.B > 1 and N % 128 != 0:
+            raise ValueError("ShardRunner: the hypothesis count must be a multiple of 128 for image batches")
+        self.batches = [list(range(s, min(s + self.B, len(self.mine)))) for s in range(0, len(self.mine), self.B)]
+        self.xyz = [torch.from_numpy(np.ascontiguousarray(np.stack([frames_of(self.mine[j]) for j in b]))).to(device) for b in self.batches]
+        g = np.zeros((max(1, len(self.mine)), 6))
+        if gt_of is not None:
+            for j, i in enumerate(self.mine):
+                g[j] = gt_of(i)
+        self.gt = torch.from_numpy(g).to(device)
+        self.perm = perm
+        self.defer = defer
+        if world > 1 and not emulate and group is None:
+            import torch.distributed as tdist
+            group = tdist.group.WORLD
+        self.ex = ddist.FrameResultExchange(n_images, rank, world, (6, 4, N), device, group=group if (world > 1 and not emulate) else None,
+                                            pin_host=(device.type == "cuda"))
+        NB = N * self.B
+        self.scratch = dict(poses=torch.zeros(NB, 6, dtype=torch.float64, device=device), sets=torch.zeros(NB, 4, dtype=torch.int32, device=device),
+                            ok=torch.zeros(NB, dtype=torch.uint8, device=device), soft=torch.zeros(NB, dtype=torch.float64, device=device),
+                            ent=torch.zeros(self.B, dtype=torch.float64, device=device), avg=torch.zeros(self.B, 6, dtype=torch.float64, device=device),
+                            sd=torch.zeros(self.B, dtype=torch.int32, device=device))
+        self.err = torch.zeros(NB, self.P, dtype=torch.float32, device=device) if write_err else None
+        self.gs = torch.cuda.Stream(device=device)  # gather / host copy beside the engine's stream
+        self.consumed = [None, None]                # event per slot: its gathered buffer has been copied out, the slot may be refilled
+        self.steps_done = 0
+        engine.set_option("pi_defer_tail", 1 if defer else 0)
+        engine.set_option("seed_stride", world)
+        self._last_slot = None
+
+    # -- one step ---------------------------------------------------------------------------------------------------------------------------
+    def _launch_gather(self, slot):
+        """On the side stream: wait for the engine's stream and the tail in flight, then gather `slot` asynchronously."""
+        self.eng.tailWait(self.gs)
+        with torch.cuda.stream(self.gs):
+            self.ex.launch(slot)
+
+    def _consume(self, slot):
+        """On the side stream: order it behind the slot's gather, copy the gathered rows to page-locked host memory, mark the slot reusable."""
+        with torch.cuda.stream(self.gs):
+            if self.ex.wait(slot):
+                self.ex.to_host(slot)
+            ev = torch.cuda.Event()
+            ev.record(self.gs)
+            self.consumed[slot] = ev
+
+    def step(self, i=None):
+        i = self.steps_done if i is None else i
+        k = self.steps_done & 1
+        if self.steps_done >= 1:
+            self._consume(k)              # the gather launched one step ago (data of two steps ago) -- long finished
+            self._launch_gather(1 - k)    # the previous step's results: beside this step's K1 / K2
+        ref_v, out4_v, w_v = self.ex.views(k)
+        s = self.scratch
+        with torch.cuda.stream(self.st):
+            if self.consumed[k] is not None:
+                self.st.wait_event(self.consumed[k])  # this step's K3 / tail write the slot's local buffer: its last gather must have read it
+            for bi, idx in enumerate(self.batches):
+                nb, j0 = len(idx), idx[0]
+                n = nb * self.N
+                self.eng.set_frames(self.xyz[bi], None, self.H, self.W, self.cam, borrow=True)
+                self.eng.processImages(self.N, self.perm, gt_jp6=self.gt[j0:j0 + nb], seed=self.seed0 + self.seed_per_step * i + self.mine[j0], thr=10.0,
+                                       max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=None if self.err is None else self.err[:n],
+                                       out=dict(hyps=s["poses"][:n], sampledPoints=s["sets"][:n], ok=s["ok"][:n], scores=s["soft"][:n],
+                                                sfScores=w_v[j0:j0 + nb].view(-1), sfEntropy=s["ent"][:nb], avgHyp=s["avg"][:nb], refAvgHyp=ref_v[j0:j0 + nb],
+                                                refSteps=s["sd"][:nb], out4=out4_v[j0:j0 + nb]))
+        self._last_slot = k
+        self.steps_done += 1
+
+    def drain(self):
+        """Finish what is in flight: the tail and the gather of the last step.  Returns its results in frame order, (n_images, 10 + N) on the host."""
+        if self._last_slot is None:
+            return None
+        k = self._last_slot
+        if self.steps_done >= 2:
+            self._consume(1 - k)
+        self._launch_gather(k)
+        self._consume(k)
+        self.gs.synchronize()
+        self.eng.joinTail()
+        self.eng.synchronize()
+        return self.ex.frames(k, source=self.ex.host[k] if self.ex.host is not None else None)

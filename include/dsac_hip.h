@@ -112,6 +112,8 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
  *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
+ *   "seed_stride"  frame f of a frame batch draws from the random stream of seed + f * seed_stride (default 1).  Images sharded round-robin over W ranks
+ *                 (rank r owns images r, r + W, ...) keep the seeds they have in the unsharded loop with seed_stride = W: results do not depend on W
  *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail (see dsac_join_tail); 0 (default): everything in stream order
  *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave, 6 / 7 its high-occupancy builds (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
@@ -220,9 +222,10 @@ DSAC_API int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, cons
 /* The backward calls need fx == fy: the reference's Jacobians use the single focal length camMat(0,0) for both axes
  * (core/cnn_softam.h:406,466); a camera with two focal lengths is rejected with DSAC_ERR_INVALID rather than differentiated
  * inconsistently with the forward kernels.  Quirk 7 of the reference (dProjectdHyp writes the re-derived rotation back into the
- * hypothesis through a const reference, :506-508, so the rotation drifts by round-off from pixel to pixel) is NOT reproduced: the
- * product is the "fixed" mode (rotation re-derived once per hypothesis); the parity mode is the oracle's quirk_rot_writeback
- * switch, and tests/test_gpu_backward.py::test_quirk7_rot_writeback bounds the difference between the two.
+ * hypothesis through a const reference, :506-508, so the rotation drifts by round-off from pixel to pixel): the fast fp32 kernels are
+ * the "fixed" mode (rotation re-derived once per hypothesis); dsac_score_backward reproduces the write-back with
+ * DSAC_BWD_PARITY_FP64 | DSAC_BWD_QUIRK_ROT_WRITEBACK (fp64, the reference's evaluation order; 6e-12 against the oracle's
+ * quirk_rot_writeback mode), and tests/test_gpu_backward.py::test_quirk7_rot_writeback bounds the difference between the two modes.
  * Same with the soft-inlier score: d_err[h][p] = g[h] * d soft[h] / d err[h][p], formed in-kernel
  * (no N x P read).  g = dLoss/d soft[h]. */
 DSAC_API int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
@@ -323,8 +326,18 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * batches of core/test_ransac_softam.cpp:97-230 pipelined by one batch.  The tail's outputs (ref6, steps_done, inlier_maps, out4) are then ordered
  * on the context's stream only after dsac_join_tail (enqueues the dependency, does not block the host), any other entry point that enqueues work, or
  * dsac_synchronize; everything else (poses, sets, ok, err, scores, w, entropy, avg6) is in stream order as always.  A following dsac_process_images
- * must therefore be given other ref6 / steps_done / inlier_maps / out4 buffers if the previous batch's have not been consumed yet. */
+ * must therefore be given other ref6 / steps_done / inlier_maps / out4 buffers if the previous batch's have not been consumed yet.
+ * The tail also READS after the call has returned: the frame's xyz / uv (a DSAC_FRAME_BORROW frame is the caller's memory), perm, gt_jp6 and the avg6
+ * it starts from.  None of them may be overwritten -- not even by work enqueued on the context's stream, which is not ordered against the tail --
+ * before dsac_join_tail, another entry point that enqueues work, or dsac_synchronize; a following dsac_process_images may use the same perm / gt and
+ * other frames, and orders its own write of avg6 behind the previous tail.  A pipeline that refills ONE borrowed coordinate buffer batch after batch
+ * must call dsac_join_tail before the refill (tests/test_gpu_process_images.py::test_deferred_tail_and_a_reused_borrowed_frame_buffer). */
 DSAC_API int dsac_join_tail(dsac_ctx* ctx);
+/* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight and for
+ * everything enqueued on the context's stream so far; the context's own stream is not held up and the tail stays pending for it.  This is how a
+ * consumer of the tail's outputs (a copy to the host, the result gather of a multi-GPU evaluation) runs beside sampling / scoring of the next batch
+ * instead of in front of it.  Without a tail in flight it is an ordinary cross-stream dependency on the context's stream. */
+DSAC_API int dsac_tail_wait(dsac_ctx* ctx, void* hip_stream);
 
 /* ---- gradient assembly ------------------------------------------------------------------------------ */
 /* Replaces core/train_ransac_softam.cpp:344-376: with v6 = dLoss/dRef * dRef/dAvg (1 x 6),

@@ -101,3 +101,96 @@ def test_single_process_is_a_no_op():
     assert ddist.shard_images(5, 0, 1) == [0, 1, 2, 3, 4]
     r = ddist.gather_frame_results([0, 1], torch.tensor([[1.0], [2.0]], dtype=torch.float64), 2)
     assert r.tolist() == [[1.0], [2.0]]
+
+
+def _worker_exchange(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from dsac_amd import dist as ddist
+    ddist.init(backend="gloo")
+    n_images, N, steps = 7, 5, 4
+    mine = ddist.shard_images(n_images, rank, world)
+    ex = ddist.FrameResultExchange(n_images, rank, world, (6, 4, N), torch.device("cpu"), group=dist.group.WORLD)
+    seen = []
+    # the schedule of dsac_amd.shard.ShardRunner: the gather of step i is launched at the top of step i + 1 and consumed at the top of step i + 2
+    for i in range(steps):
+        k = i & 1
+        if i >= 1:
+            if ex.wait(k):
+                seen.append(ex.frames(k).clone())   # data of step i - 2
+            ex.launch(1 - k)                         # data of step i - 1
+        ref_v, out4_v, w_v = ex.views(k)
+        for j, img in enumerate(mine):
+            ref_v[j] = float(img) + 0.5
+            out4_v[j] = float(i)
+            w_v[j] = torch.arange(N, dtype=torch.float64) + 100.0 * img
+    k = (steps - 1) & 1
+    ex.wait(1 - k)
+    seen.append(ex.frames(1 - k).clone())
+    ex.launch(k)
+    ex.wait(k)
+    seen.append(ex.frames(k).clone())
+    # rank-variant gradients: rank 1 does not differentiate the second head -- the collective sequence must still match (buckets leave in index order,
+    # missing gradients travel as zeros), and a second backward without wait() is refused
+    torch.manual_seed(0)
+    trunk, head_a, head_b = torch.nn.Linear(4, 8), torch.nn.Linear(8, 2), torch.nn.Linear(8, 3)
+    params = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+    red = ddist.GradientReducer(params, bucket_bytes=64)
+    x = torch.full((5, 4), float(rank + 1))
+    h = torch.relu(trunk(x))
+    loss = head_a(h).sum() + (head_b(h).sum() if rank == 0 else 0.0)
+    loss.backward()
+    nb = red.wait()
+    grads = [p.grad.numpy().copy() for p in params]
+    refused = False
+    torch.relu(trunk(x)).sum().backward()
+    try:
+        torch.relu(trunk(x)).sum().backward()
+    except RuntimeError as e:
+        refused = "wait()" in str(e)
+    q.put((rank, [t.numpy() for t in seen], nb, grads, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_one_step_late_result_exchange_and_rank_variant_gradients_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort(key=lambda o: o[0])
+    n_images, N, steps = 7, 5, 4
+    for o in out:
+        assert len(o[1]) == steps  # every step's results arrived exactly once, in step order, complete and in frame order
+        for i, rows in enumerate(o[1]):
+            assert rows.shape == (n_images, 10 + N)
+            assert np.array_equal(rows[:, 0], np.arange(n_images) + 0.5) and np.array_equal(rows[:, 6], np.full(n_images, float(i)))
+            assert np.array_equal(rows[:, 10:], np.arange(N)[None, :] + 100.0 * np.arange(n_images)[:, None])
+        assert o[4], "a second backward without wait() must be refused"
+    assert out[0][2] == out[1][2] >= 3  # the same number of collectives on both ranks
+    for a_, b_ in zip(out[0][3], out[1][3]):
+        assert np.array_equal(a_, b_)    # both ranks hold the same averages, head_b's included (rank 1 contributed zeros)
+    assert np.abs(out[1][3][-1]).max() > 0
+
+
+def test_frame_result_exchange_single_process_emulation():
+    """world 3 emulated in one process: the gather is the copy of the rank's own part; frames() fills that rank's rows only."""
+    from dsac_amd import dist as ddist
+    ex = ddist.FrameResultExchange(10, 1, 3, (6, 4, 2), torch.device("cpu"))
+    ref_v, out4_v, w_v = ex.views(0)
+    assert ref_v.shape == (4, 6) and out4_v.shape == (4, 4) and w_v.shape == (4, 2)
+    for j, img in enumerate(ddist.shard_images(10, 1, 3)):
+        ref_v[j], out4_v[j], w_v[j] = float(img), 2.0, 0.5
+    assert not ex.wait(0)
+    ex.launch(0)
+    assert ex.wait(0)
+    f = ex.frames(0)
+    assert f.shape == (10, 12) and f[[1, 4, 7]][:, 0].tolist() == [1.0, 4.0, 7.0] and not f[[0, 2, 3, 5, 6, 8, 9]].any()

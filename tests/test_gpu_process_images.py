@@ -161,3 +161,56 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
         assert np.array_equal(h["refAvgHyp"], plain[0]["refAvgHyp"]) and np.array_equal(h["out4"], plain[0]["out4"])
     finally:
         engine.set_option("pi_defer_tail", 0)
+
+
+def test_deferred_tail_and_a_reused_borrowed_frame_buffer(engine, synth):
+    """The deferred tail (K6 / K7) reads the frame after dsac_process_images has returned; with DSAC_FRAME_BORROW that is the caller's memory
+    (include/dsac_hip.h, dsac_join_tail).  A pipeline that refills ONE borrowed coordinate buffer batch after batch must join the tail before the refill:
+    then the results equal the in-order run bit for bit.  (Refilling without the join races with K6 -- the engine's stream is not ordered against
+    the tail -- which is exactly why the header asks for the join.)"""
+    import torch
+    H, W, F, N = 120, 160, 4, 128
+    P = H * W
+    dev = torch.device("cuda", 0)
+    perm = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    srcs = []
+    cam = None
+    for k in range(3):
+        frames = [synth.chess_like_frame(H, W, seed=400 + 10 * k + f) for f in range(F)]
+        cam = frames[0]["cam"]
+        srcs.append(torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev))
+    gts = torch.zeros(F, 6, dtype=torch.float64, device=dev)
+    st = torch.cuda.ExternalStream(engine.stream(), device=dev)
+
+    def bufs():
+        n = F * N
+        return dict(hyps=torch.zeros(n, 6, dtype=torch.float64, device=dev), sampledPoints=torch.zeros(n, 4, dtype=torch.int32, device=dev),
+                    ok=torch.zeros(n, dtype=torch.uint8, device=dev), scores=torch.zeros(n, dtype=torch.float64, device=dev),
+                    sfScores=torch.zeros(n, dtype=torch.float64, device=dev), sfEntropy=torch.zeros(F, dtype=torch.float64, device=dev),
+                    avgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev), refAvgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev),
+                    refSteps=torch.zeros(F, dtype=torch.int32, device=dev), out4=torch.zeros(F, 4, dtype=torch.float64, device=dev))
+
+    def run(defer):
+        engine.set_option("pi_defer_tail", 1 if defer else 0)
+        one = torch.zeros_like(srcs[0])   # the ONE borrowed buffer every batch is copied into
+        outs = [bufs() for _ in range(3)]
+        torch.cuda.synchronize(dev)
+        for k in range(3):
+            if defer:
+                engine.joinTail()         # the previous batch's K6 still reads `one`: order the refill behind it
+            with torch.cuda.stream(st):
+                one.copy_(srcs[k])        # refill on the engine's stream
+            engine.set_frames(one, None, H, W, cam, borrow=True)
+            engine.processImages(N, perm, gt_jp6=gts, seed=77 + k, out=outs[k])
+        engine.joinTail()
+        engine.synchronize()
+        return [{key: v.cpu().numpy().copy() for key, v in o.items()} for o in outs]
+
+    try:
+        plain, deferred = run(False), run(True)
+        for a, b in zip(plain, deferred):
+            assert (a["refSteps"] == 8).all() and a["ok"].all()
+            for key in a:
+                assert np.array_equal(a[key], b[key]), key
+    finally:
+        engine.set_option("pi_defer_tail", 0)

@@ -1,0 +1,59 @@
+"""dsac_amd.shard.ShardRunner -- BASELINE.json configs[3] for one rank: batches through dsac_process_images with the refinement tail deferred across batch
+AND step boundaries, results written straight into the exchange buffer, the gather of a step launched at the top of the next step on a side stream
+(dsac_tail_wait) and consumed one step later, no host synchronisation inside a step.  Parity: every image's row equals the in-order, per-image,
+nothing-deferred call with the same seed bit for bit -- for the unsharded run and for every emulated rank of a 3-rank sharding (whose union is the
+unsharded result: "seed_stride" keeps an image's seed independent of the sharding)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H, W, N, NIMG, STEPS = 48, 64, 128, 12, 3
+
+
+def _reference_rows(synth, perm_np, gts, step):
+    """The per-image loop of core/test_ransac_softam.cpp:97-157, one image per call, in stream order (no deferral), host results."""
+    import dsac_amd
+    rows = np.zeros((NIMG, 10 + N))
+    with dsac_amd.Engine(0) as eng:
+        for i in range(NIMG):
+            fr = synth.chess_like_frame(H, W, seed=700 + i)
+            eng.set_frame(fr["xyz"], None, H, W, fr["cam"])
+            r = eng.processImages(N, perm_np, gt_jp6=gts[i:i + 1], seed=1305 + 64 * step + i, max_tries=1 << 16)
+            rows[i, :6], rows[i, 6:10], rows[i, 10:] = r["refAvgHyp"][0], r["out4"][0], r["sfScores"]
+    return rows
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world):
+    import torch
+    import dsac_amd
+    from dsac_amd.shard import ShardRunner
+    dev = torch.device("cuda", 0)
+    perm_np = synth.fast_permutations(H * W, 8)
+    perm = torch.from_numpy(perm_np).to(dev)
+    frames = [synth.chess_like_frame(H, W, seed=700 + i) for i in range(NIMG)]
+    gts = np.stack([orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for fr in frames])
+    want = _reference_rows(synth, perm_np, gts, STEPS - 1)
+    got = np.zeros_like(want)
+    for rank in range(world):
+        st = torch.cuda.Stream(device=dev)
+        eng = dsac_amd.Engine(0, stream=st)
+        try:
+            run = ShardRunner(eng, st, dev, lambda i: frames[i]["xyz"], NIMG, rank, world, N, H, W, frames[0]["cam"], perm, gt_of=lambda i: gts[i], batch=4,
+                              emulate=world > 1)
+            assert run.mine == list(range(rank, NIMG, world))
+            for s in range(STEPS):
+                run.step(s)      # never waits: the tail of step s runs under step s + 1, the gather of step s is launched in step s + 1
+            rows = run.drain().numpy()
+            got[run.mine] = rows[run.mine]
+            other = [i for i in range(NIMG) if i not in run.mine]
+            assert not rows[other].any()  # an emulated rank fills its own part of the gather only
+            # a second drain-and-continue cycle: slots keep alternating
+            run.step(STEPS - 1)
+            again = run.drain().numpy()
+            assert np.array_equal(again[run.mine], rows[run.mine])
+        finally:
+            eng.close()
+    assert (want[:, 6] > 0).all() and np.abs(want[:, 10:].sum(1) - 1).max() < 1e-12
+    assert np.array_equal(got, want)
