@@ -487,7 +487,7 @@ def main(argv=None):
     engines, bufs = [], []
 
     def set_frames_of(eng, x):
-        if batched:
+        if batched and not config3:
             eng.set_frames(x, None, H, W, fr["cam"], borrow=True)
         else:
             eng.set_frame(x, None, H, W, fr["cam"], borrow=True)  # implicit full-resolution pixel grid
@@ -716,9 +716,12 @@ def main(argv=None):
         sync_all()
         eng0.profile_read(0, reset=True)
         Kem = max(K, 40)
+        for key in em.host_us:
+            em.host_us[key] = 0.0
         te = time.perf_counter()
         for i in range(Kem):
             em.step(ctr + 100 + i)
+        host_s = (time.perf_counter() - te) / Kem  # what the host needs to enqueue a step (it never waits inside one)
         lem = em.drain()
         sync_all()
         per_rank_s = (time.perf_counter() - te) / Kem
@@ -726,13 +729,15 @@ def main(argv=None):
         # the emulated rank's rows equal the one-GPU run's rows for the same images and step seeds?  (same seeds: seed0 + 64 * step + image)
         one_gpu_s = elapsed / K
         emulation = {"world": Wem, "rank": rem, "images_per_rank_step": len(em.mine), "batches_per_rank_step": len(em.batches), "steps": Kem,
-                     "per_rank_ms": per_rank_s * 1e3, "one_gpu_ms": one_gpu_s * 1e3, "ideal_per_rank_ms": one_gpu_s * 1e3 / Wem,
+                     "per_rank_ms": per_rank_s * 1e3, "host_enqueue_ms_per_step": host_s * 1e3, "host_enqueue_us_by_phase": {k_: v_ / Kem * 1e6 for k_, v_ in em.host_us.items()}, "one_gpu_ms": one_gpu_s * 1e3, "ideal_per_rank_ms": one_gpu_s * 1e3 / Wem,
                      "predicted_speedup": one_gpu_s / per_rank_s, "predicted_efficiency": one_gpu_s / per_rank_s / Wem,
                      "k2_us_per_launch": ms_e / max(1, n_e) * 1e3, "rows_finite": bool(torch.isfinite(lem[em.mine]).all()),
                      "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
                              "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
         ctr += 200 + Kem
-        runner.eng.set_option("seed_stride", world)
+        em.close()
+        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)):
+            runner.eng.set_option(key, v)
 
     # literal configs[1]: ONE frame per step on the same context (fused call), its own K2 timing
     single = None

@@ -60,6 +60,7 @@ struct dsac_ctx {
     dk::K2Opts k2;  // launch knobs, read once in dsac_create (DSAC_K2_*) or set with dsac_set_option; no process-wide state
     dk::K1Opts k1;
     int k1_cus = 0;       // > 0: the auxiliary stream of the pipelined pair (K1 of the next step) is confined to that many CUs (DSAC_K1_CUS / "k1_cus")
+    bool device_args = false;  // "device_args": every pointer argument is a device pointer (the caller's promise; skips hipPointerGetAttributes per argument)
     int seed_stride = 1;  // frame f of a batch samples from the stream of seed + f * seed_stride ("seed_stride": images sharded round-robin over ranks keep their own seeds)
     int k4_variant = -1;  // K4 main-pass form (dk::backward_plan), DSAC_K4_VARIANT / dsac_set_option("k4_variant")
     hipEvent_t k2_wait = nullptr, k2_record = nullptr;  // optional gate around the bandwidth-bound kernel (dsac_set_k2_events)
@@ -109,8 +110,10 @@ int fail(dsac_ctx* c, int code, const char* fmt, ...) {
         if (e__ != hipSuccess) return fail((c), DSAC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__));      \
     } while (0)
 
-bool is_device_ptr(const void* p) {
+// c: with dsac_set_option("device_args", 1) the caller has promised that every pointer argument is a device pointer: no runtime query
+bool is_device_ptr(const void* p, const dsac_ctx* c = nullptr) {
     if (!p) return false;
+    if (c && c->device_args) return true;
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -141,7 +144,7 @@ DevBuf& next_slot(dsac_ctx* c) {
 template <typename T>
 int in_arg(dsac_ctx* c, const T* p, size_t count, const T** out) {
     if (!p || count == 0) { *out = nullptr; return DSAC_OK; }
-    if (is_device_ptr(p)) { *out = p; return DSAC_OK; }
+    if (is_device_ptr(p, c)) { *out = p; return DSAC_OK; }
     DevBuf& s = next_slot(c);
     HIP_TRY(c, s.reserve(count * sizeof(T)));
     HIP_TRY(c, hipMemcpyAsync(s.p, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
@@ -154,7 +157,7 @@ int in_arg(dsac_ctx* c, const T* p, size_t count, const T** out) {
 template <typename T>
 int out_arg(dsac_ctx* c, T* p, size_t count, T** out, bool preload = false) {
     if (!p || count == 0) { *out = nullptr; return DSAC_OK; }
-    if (is_device_ptr(p)) { *out = p; return DSAC_OK; }
+    if (is_device_ptr(p, c)) { *out = p; return DSAC_OK; }
     DevBuf& s = next_slot(c);
     HIP_TRY(c, s.reserve(count * sizeof(T)));
     if (preload) HIP_TRY(c, hipMemcpyAsync(s.p, p, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
@@ -344,7 +347,7 @@ static int set_frames_common(dsac_ctx* c, int frames, const float* xyz, const fl
         return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: a pipelined slot is sampled but not yet scored; the library's own frame copy cannot be replaced "
                                          "underneath it (use DSAC_FRAME_BORROW frames with the pipelined calls)");
     if (borrow) {
-        if (!is_device_ptr(xyz) || (uv && !is_device_ptr(uv))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
+        if (!is_device_ptr(xyz, c) || (uv && !is_device_ptr(uv, c))) return fail(c, DSAC_ERR_INVALID, "dsac_set_frame: DSAC_FRAME_BORROW needs device pointers");
         if (flags & DSAC_FRAME_QUANTISE_INT16) {  // the caller's own device buffer, rounded to the int16 grid in place (core/cnn_softam.h:265)
             const size_t n = P * 3;
             hipLaunchKernelGGL(k_quantise_int16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, const_cast<float*>(xyz), n);
@@ -488,10 +491,16 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     HIP_TRY(c, dk::pose_prep(c->stream, N, d_poses, c->F, c->staged.as<float>()));
     float* d_part = nullptr;
     const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
-    if (d_soft) {
+    // Error images only on a big launch: the streaming form WITH the sigmoid arithmetic is the faster kernel -- the arithmetic spaces a wave's stores
+    // (N = 4096: 860 us against 890-900 for any form without it; idling the wave instead, k2_flags bits 16-23, does not reproduce the effect:
+    // profiles/r04_k2_err_ab.txt).  So the auto policy runs that kernel and drops its partial sums (1200 x N floats of scratch, 0.4 % of the
+    // stores; no reduction launch).  k2_flags bit 24 switches the policy off (A/B).
+    const bool fused_for_err = !d_soft && d_err && c->k2.variant < 0 && !(c->k2.flags & (1 << 24)) && (double)N * (double)P * 4.0 > 1.0e9;
+    if (d_soft || fused_for_err) {
         HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
         d_part = c->soft_part.as<float>();
     }
+    if (fused_for_err && !(beta > 0.f)) { tau = 10.f; beta = 0.5f; }  // any finite sigmoid; the sums are not used
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
@@ -727,6 +736,7 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
         if (!dk::backward_variant_known(value)) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown K4 kernel form %d", value);
         c->k4_variant = value;
     }
+    else if (k == "device_args") c->device_args = value != 0;
     else if (k == "seed_stride") {
         if (value < 1) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: seed_stride must be >= 1");
         c->seed_stride = value;
@@ -1281,7 +1291,7 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     // NEXT dsac_process_images call.  Its outputs (ref6, steps_done, inlier maps, out4) are complete in the order of the context's stream only after
     // the next call of any other entry point, dsac_join_tail or dsac_synchronize.  Only with device-resident arguments: a host destination is copied
     // back at the end of this call, and a host `perm` / `gt` lives in a staging slot that the next call reuses.
-    const bool defer = c->pi_defer_tail && c->pending.empty() && is_device_ptr(perm) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null));
+    const bool defer = c->pi_defer_tail && c->pending.empty() && is_device_ptr(perm, c) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null, c));
     join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
     HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
     hipStream_t ts = c->stream;
@@ -1318,10 +1328,15 @@ int dsac_tail_wait(dsac_ctx* c, void* hip_stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     if (s == c->stream) return fail(c, DSAC_ERR_INVALID, "dsac_tail_wait: that is the context's own stream (use dsac_join_tail)");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->tail_pending) {
+        // the tail started behind K3 of its dsac_process_images call, which was behind everything the context's stream held then: its completion event
+        // alone covers that call and all earlier work -- no marker has to be put into the context's stream (a record between two steps costs a bubble)
+        HIP_TRY(c, hipStreamWaitEvent(s, c->tail_done, 0));
+        return DSAC_OK;
+    }
     if (!c->xs_event) HIP_TRY(c, hipEventCreateWithFlags(&c->xs_event, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->xs_event, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(s, c->xs_event, 0));
-    if (c->tail_pending) HIP_TRY(c, hipStreamWaitEvent(s, c->tail_done, 0));
     return DSAC_OK;
 }
 

@@ -640,6 +640,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
                         if (hyp0 + r < nh) __builtin_nontemporal_store(ev[r], dst + r * rs);
                 }
             }
+            if (ERR && !SOFT) {
+                // error images only: the sigmoid arithmetic of the fused form is what spaces a wave's stores; without it the
+                // wave idles for as long instead (k2_flags bits 16-19: units of 64 clocks per chunk, bits 20-23: units of 16) -- no VALU issue slots taken
+                const int ps = (kflags >> 16) & 15, pn = (kflags >> 20) & 15;
+                for (int i = 0; i < ps; i++) __builtin_amdgcn_s_sleep(1);
+                for (int i = 0; i < pn; i++) asm volatile("s_nop 15");
+            }
         }
         if (SOFT) {
             const float s0 = row16_sum(ssum[0].x + ssum[0].y), s1 = row16_sum(ssum[1].x + ssum[1].y);

@@ -14,10 +14,14 @@ of ranks, and they equal the in-order calls bit for bit (tests/test_gpu_shard.py
 
 emulate=True runs exactly the share of (rank, world) on one GPU without a process group: the gather is replaced by the copy of the rank's own part
 (what that rank contributes to the all-gather), everything else is the code path the rank would run."""
+import time
+
 import numpy as np
 import torch
 
+from . import capi
 from . import dist as ddist
+from .capi import check, lib, ptr
 
 
 class ShardRunner:
@@ -54,16 +58,36 @@ class ShardRunner:
                             sd=torch.zeros(self.B, dtype=torch.int32, device=device))
         self.err = torch.zeros(NB, self.P, dtype=torch.float32, device=device) if write_err else None
         self.gs = torch.cuda.Stream(device=device)  # gather / host copy beside the engine's stream
-        self.consumed = [None, None]                # event per slot: its gathered buffer has been copied out, the slot may be refilled
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]  # per slot: its gathered buffer has been copied out, the slot may be refilled
+        self.consumed_valid = [False, False]
         self.steps_done = 0
+        self.host_us = dict(consume=0.0, gather=0.0, slot_wait=0.0, process_images=0.0)  # host seconds spent enqueueing, by phase (diagnostics)
         engine.set_option("pi_defer_tail", 1 if defer else 0)
         engine.set_option("seed_stride", world)
         self._last_slot = None
+        # The host side of a step is a handful of C-ABI calls with constant arguments (only the seed changes): they are bound once here -- with 8 ranks
+        # a step is ~0.5 ms of GPU work, and marshalling two dozen tensors through Python per call would cost a third of that.
+        ctx = engine._ctx
+        fx, fy, cx, cy = [float(c) for c in cam]
+        s = self.scratch
+        self._set_frames_args, self._process_args = [], [[], []]
+        for bi, idx in enumerate(self.batches):
+            nb, j0 = len(idx), idx[0]
+            n = nb * N
+            self._set_frames_args.append((ctx, nb, ptr(self.xyz[bi]), None, 0, H, W, fx, fy, cx, cy, capi.DSAC_FRAME_BORROW))
+            for k in (0, 1):
+                ref_v, out4_v, w_v = self.ex.views(k)
+                self._process_args[k].append([ctx, N, 0, 10.0, 1 << 16, 100.0, 10.0, 0.5, 0.1, ptr(self.perm), int(self.perm.shape[0]), 100, 50, ptr(self.gt[j0:j0 + nb]),
+                                              ptr(s["poses"][:n]), ptr(s["sets"][:n]), ptr(s["ok"][:n]), None if self.err is None else ptr(self.err[:n]),
+                                              ptr(s["soft"][:n]), ptr(w_v[j0:j0 + nb]), ptr(s["ent"][:nb]), ptr(s["avg"][:nb]), ptr(ref_v[j0:j0 + nb]),
+                                              ptr(s["sd"][:nb]), None, ptr(out4_v[j0:j0 + nb])])
+        self._seed_base = [self.mine[idx[0]] for idx in self.batches]
+        engine.set_option("device_args", 1)  # every argument above lives in HBM
 
     # -- one step ---------------------------------------------------------------------------------------------------------------------------
     def _launch_gather(self, slot):
         """On the side stream: wait for the engine's stream and the tail in flight, then gather `slot` asynchronously."""
-        self.eng.tailWait(self.gs)
+        check(self.eng._ctx, lib.dsac_tail_wait(self.eng._ctx, self.gs.cuda_stream))
         with torch.cuda.stream(self.gs):
             self.ex.launch(slot)
 
@@ -72,30 +96,34 @@ class ShardRunner:
         with torch.cuda.stream(self.gs):
             if self.ex.wait(slot):
                 self.ex.to_host(slot)
-            ev = torch.cuda.Event()
-            ev.record(self.gs)
-            self.consumed[slot] = ev
+            self.consumed[slot].record(self.gs)
+            self.consumed_valid[slot] = True
 
     def step(self, i=None):
         i = self.steps_done if i is None else i
         k = self.steps_done & 1
+        T = self.host_us
+        t0 = time.perf_counter()
         if self.steps_done >= 1:
             self._consume(k)              # the gather launched one step ago (data of two steps ago) -- long finished
+            t1 = time.perf_counter(); T["consume"] += t1 - t0; t0 = t1
             self._launch_gather(1 - k)    # the previous step's results: beside this step's K1 / K2
-        ref_v, out4_v, w_v = self.ex.views(k)
-        s = self.scratch
-        with torch.cuda.stream(self.st):
-            if self.consumed[k] is not None:
-                self.st.wait_event(self.consumed[k])  # this step's K3 / tail write the slot's local buffer: its last gather must have read it
-            for bi, idx in enumerate(self.batches):
-                nb, j0 = len(idx), idx[0]
-                n = nb * self.N
-                self.eng.set_frames(self.xyz[bi], None, self.H, self.W, self.cam, borrow=True)
-                self.eng.processImages(self.N, self.perm, gt_jp6=self.gt[j0:j0 + nb], seed=self.seed0 + self.seed_per_step * i + self.mine[j0], thr=10.0,
-                                       max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=None if self.err is None else self.err[:n],
-                                       out=dict(hyps=s["poses"][:n], sampledPoints=s["sets"][:n], ok=s["ok"][:n], scores=s["soft"][:n],
-                                                sfScores=w_v[j0:j0 + nb].view(-1), sfEntropy=s["ent"][:nb], avgHyp=s["avg"][:nb], refAvgHyp=ref_v[j0:j0 + nb],
-                                                refSteps=s["sd"][:nb], out4=out4_v[j0:j0 + nb]))
+            t1 = time.perf_counter(); T["gather"] += t1 - t0; t0 = t1
+        if self.consumed_valid[k] and not self.consumed[k].query():
+            # this step's K3 / tail write the slot's local buffer: its last gather must have read it.  That gather was launched a whole step ago, so
+            # the event has normally completed by now and nothing needs to be put into the engine's stream
+            self.st.wait_event(self.consumed[k])
+        ctx = self.eng._ctx
+        seed0 = self.seed0 + self.seed_per_step * i
+        t1 = time.perf_counter(); T["slot_wait"] += t1 - t0; t0 = t1
+        for bi in range(len(self.batches)):
+            check(ctx, lib.dsac_set_frames(*self._set_frames_args[bi]))
+            a = self._process_args[k][bi]
+            a[2] = (seed0 + self._seed_base[bi]) & 0xFFFFFFFFFFFFFFFF
+            # the reference's whole per-image unit (test_ransac_softam.cpp:97-157 -> processImage): K1, K2, K3, 8 refinement steps, loss
+            check(ctx, lib.dsac_process_images(*a))
+        T["process_images"] += time.perf_counter() - t0
+        self.eng.frames = len(self.batches[-1])
         self._last_slot = k
         self.steps_done += 1
 
@@ -112,3 +140,11 @@ class ShardRunner:
         self.eng.joinTail()
         self.eng.synchronize()
         return self.ex.frames(k, source=self.ex.host[k] if self.ex.host is not None else None)
+
+    def close(self):
+        """Give the engine back as it was found: argument detection on, unit seed stride, no deferred tail."""
+        self.eng.joinTail()
+        self.eng.synchronize()
+        self.gs.synchronize()
+        for key, v in (("device_args", 0), ("seed_stride", 1), ("pi_defer_tail", 0)):
+            self.eng.set_option(key, v)

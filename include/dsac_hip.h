@@ -102,7 +102,7 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  * None of them changes a result beyond rounding; -1 / the default is the measured policy.  Unknown keys are DSAC_ERR_INVALID.
  *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
  *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
- *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments)
+ *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments); bits 16-19 / 20-23: error-images-only streaming forms idle for that many units of 64 / 16 clocks after a chunk's stores (pacing experiment); bit 24: error images only on a big launch do NOT take the fused kernel
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_rl"       lanes per sampling attempt: 1 (default) = one lane per attempt, the quartic's roots in sequence, 64 attempts per round and
  *                 hypothesis; 4 = one lane per root, 16 attempts per round (the form the wpb / hpw / minw / share knobs below act on)
@@ -112,6 +112,9 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
  *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
+ *   "device_args"  1: the caller promises that EVERY pointer argument from now on is a device pointer (dsac_device_alloc, torch, hipMalloc): the library skips
+ *                 its per-argument hipPointerGetAttributes query (about a microsecond each, 20-odd per dsac_process_images).  A host pointer passed under
+ *                 this promise is a caller bug with undefined behaviour; 0 (default): detect
  *   "seed_stride"  frame f of a frame batch draws from the random stream of seed + f * seed_stride (default 1).  Images sharded round-robin over W ranks
  *                 (rank r owns images r, r + W, ...) keep the seeds they have in the unsharded loop with seed_stride = W: results do not depend on W
  *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail (see dsac_join_tail); 0 (default): everything in stream order
@@ -333,10 +336,11 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * other frames, and orders its own write of avg6 behind the previous tail.  A pipeline that refills ONE borrowed coordinate buffer batch after batch
  * must call dsac_join_tail before the refill (tests/test_gpu_process_images.py::test_deferred_tail_and_a_reused_borrowed_frame_buffer). */
 DSAC_API int dsac_join_tail(dsac_ctx* ctx);
-/* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight and for
- * everything enqueued on the context's stream so far; the context's own stream is not held up and the tail stays pending for it.  This is how a
- * consumer of the tail's outputs (a copy to the host, the result gather of a multi-GPU evaluation) runs beside sampling / scoring of the next batch
- * instead of in front of it.  Without a tail in flight it is an ordinary cross-stream dependency on the context's stream. */
+/* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight -- and
+ * thereby for the dsac_process_images call it belongs to and everything the context's stream held before that call (the tail starts behind that call's
+ * K3); the context's own stream is not held up, nothing is inserted into it, and the tail stays pending for it.  This is how a consumer of the tail's
+ * outputs (a copy to the host, the result gather of a multi-GPU evaluation) runs beside sampling / scoring of the next batch instead of in front of
+ * it.  Without a tail in flight it is an ordinary cross-stream dependency on the context's stream as it is now (one event record). */
 DSAC_API int dsac_tail_wait(dsac_ctx* ctx, void* hip_stream);
 
 /* ---- gradient assembly ------------------------------------------------------------------------------ */

@@ -53,3 +53,41 @@ def engine():
 def excl_clamp_edge(a, b, clamp=100.0, tol=1e-3):
     """mask of entries not within tol of the clamp value in either array"""
     return (np.abs(a - clamp) > tol) & (np.abs(b - clamp) > tol)
+
+
+# ---- parity margins -------------------------------------------------------------------------------------------------------------------
+# Every parity test records its measured worst case next to the tolerance it asserts and the tolerance the documents state (SURVEY.md 8(c),
+# BASELINE.md 3).  At the end of a session the records go to $DSAC_MARGINS_FILE (default gpurun_out/parity_margins.txt): the closing script of a
+# round copies that file to profiles/rNN_parity_margins.txt, so that "tolerance = k x measured" can be audited from the repository.
+_MARGINS = []
+
+
+def margin(row, what, measured, asserted, stated=None, at_least=False):
+    """Record (and assert) one parity figure.  row: the SURVEY.md 8 row ("a3", "(b)", ...); measured <= asserted (at_least: >=); stated: the documented
+    tolerance when it differs from the asserted one (None: the same)."""
+    measured = float(measured)
+    _MARGINS.append((row, what, measured, float(asserted), None if stated is None else float(stated), at_least))
+    print("margin %-6s %-92s measured %.3e  asserted %s %.1e%s" % (row, what, measured, ">=" if at_least else "<=", asserted,
+                                                                 "" if stated is None else "  stated %.1e" % stated))
+    ok = measured >= asserted if at_least else measured <= asserted
+    assert ok, "%s %s: measured %.3e, tolerance %s %.1e" % (row, what, measured, ">=" if at_least else "<=", asserted)
+    return measured
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MARGINS:
+        return
+    path = os.environ.get("DSAC_MARGINS_FILE") or os.path.join(ROOT, "gpurun_out", "parity_margins.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        worst = {}
+        for row, what, m, a, st, al in _MARGINS:  # a parametrised test records the same line several times: keep the worst
+            k = (row, what, a, st, al)
+            worst[k] = (min if al else max)(worst.get(k, m), m)
+        with open(path, "w") as f:
+            f.write("# SURVEY.md 8 row | what | measured worst case | asserted tolerance | stated tolerance (SURVEY 8(c) / BASELINE.md 3) | asserted / measured\n")
+            for (row, what, a, st, al), m in sorted(worst.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+                ratio = (m / a if al else a / m) if (m > 0 and a > 0) else float("inf")
+                f.write("%-6s | %-100s | %.3e | %s %.1e | %s | %.1fx\n" % (row, what, m, ">=" if al else "<=", a, "same" if st is None else "%.1e" % st, ratio))
+    except OSError:
+        pass

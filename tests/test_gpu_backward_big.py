@@ -14,6 +14,8 @@ hypotheses (40 core-seconds per 64), and the other hypotheses' pose sums must co
 import numpy as np
 import pytest
 
+from conftest import margin
+
 pytestmark = pytest.mark.gpu
 
 H, W = 480, 640
@@ -67,7 +69,23 @@ def big_case(request, orc, synth, engine):
         d[np.arange(d.shape[0])[:, None], sets[idx]] = 0
         return d
     ref_s, G6_s = _oracle(orc, fr, uv, sets, active, soft_ddiff)
-    return dict(N=N, fr=fr, uv=uv, poses=poses, sets=sets, dpnp=dpnp, d_err=d_err, g=g, active=active, ref_d=ref_d, G6_d=G6_d, ref_s=ref_s, G6_s=G6_s)
+    # The own-cell effect, removed on the ORACLE's side: at a hypothesis' own four cells the residual is zero up to round-off (1e-10 px in fp64, a few
+    # 1e-5 px in fp32), so d|r|/dr is a unit vector u of round-off on every implementation, while sigmoid' is NOT zero there.  The oracle's sums above
+    # leave those cells out; whatever direction u takes, the cells can move component k of the pose sum of hypothesis h by at most
+    #   bound[h, k] = sum over its 4 cells of |g_h| * beta * s0 (1 - s0) * |(dP/dH)_k|,    s0 = sigmoid(beta * tau),
+    # with (dP/dH)_k the 2-vector of pixel derivatives (taken from dProjectdHyp with a unit residual along x, then along y).  The engine's sums are
+    # compared with the oracle's up to exactly that bound.
+    s0 = 1.0 / (1.0 + np.exp(-BETA * TAU))
+    own_bound = np.zeros((N, 6))
+    for h in active:
+        R, t = orc.cv2our(poses[h])
+        for p in sets[h]:
+            X = fr["xyz"][p]
+            px = uv[p].astype(np.float64)  # the projection of an own cell is the cell itself (|r| ~ 1e-10 px)
+            Jx = orc.dProjectdHyp((px + np.array([1.0, 0.0])).astype(np.float32), X, R, t, fr["cam"])
+            Jy = orc.dProjectdHyp((px + np.array([0.0, 1.0])).astype(np.float32), X, R, t, fr["cam"])
+            own_bound[h] += abs(g[h]) * BETA * s0 * (1 - s0) * np.sqrt(Jx ** 2 + Jy ** 2)
+    return dict(own_bound=own_bound, N=N, fr=fr, uv=uv, poses=poses, sets=sets, dpnp=dpnp, d_err=d_err, g=g, active=active, ref_d=ref_d, G6_d=G6_d, ref_s=ref_s, G6_s=G6_s)
 
 
 @pytest.mark.parametrize("variant", K4_FORMS)
@@ -89,11 +107,13 @@ def test_k4_at_the_benchmarked_shapes(engine, big_case, variant):
         idle = np.setdiff1d(np.arange(N), act)
         assert not G6[idle].any(), "hypotheses without input have non-zero pose sums"
         relp = np.abs(G6[act] - c["G6_d"][act]).max(1) / np.abs(c["G6_d"][act]).max(1)
-        print("K4 N=%d k4_variant %d d_err: max-rel %.2e l2-rel %.2e | pose sums median %.2e max %.2e" % (N, variant, emax, el2, np.median(relp), relp.max()))
-        assert emax <= 1e-3 and el2 <= 5e-4  # measured 3e-5 / 1.3e-5 (N = 256), 9e-7 / 1.4e-6 (N = 1024, sparse input)
+        form = "VALU fallback form" if variant == 0 else "matrix-core forms"
+        margin("a9", "K4 d_err N=%d x 640x480, %s: gradient max |g - oracle| / max |oracle| (SURVEY 8(c) fp32-fast 1e-3)" % (N, form), emax, 1e-3)
+        margin("a9", "K4 d_err N=%d x 640x480, %s: gradient relative l2 error" % (N, form), el2, 5e-4)
         # pose sums: measured median 3e-6, max 5e-5 on the matrix-core forms; the VALU fallback form (k4_variant 0) sums c (x) X against the
         # raw coordinates (thousands of mm) in fp32 per wave and reaches 2.6e-3 on one hypothesis in 128
-        assert np.median(relp) <= 1e-4 and relp.max() <= (5e-3 if variant == 0 else 1e-3)
+        margin("a10", "K4 d_err N=%d, %s: pose sums, median over hypotheses of max-rel error" % (N, form), np.median(relp), 1e-4)
+        margin("a10", "K4 d_err N=%d, %s: pose sums, max over hypotheses of max-rel error" % (N, form), relp.max(), 5e-3 if variant == 0 else 1e-3, stated=1e-3)
         del d_err
         # fused soft-inlier form: the same sums with d_err formed in the kernel.  The hypotheses' own cells have |r| = 0 exactly on the oracle's
         # side and a few 1e-5 px on the fp32 side, where sigmoid' is not zero: their weight is what the own-cell exclusion removes in the oracle,
@@ -109,10 +129,18 @@ def test_k4_at_the_benchmarked_shapes(engine, big_case, variant):
         emax, el2 = _rel(got[mask], c["ref_s"][mask])
         G6 = engine.lastPoseGradients(N)
         assert not G6[idle].any()
-        relp = np.abs(G6[act] - c["G6_s"][act]).max(1) / np.abs(c["G6_s"][act]).max(1)
-        print("K4 N=%d k4_variant %d fused soft: max-rel %.2e l2-rel %.2e | pose sums median %.2e max %.2e" % (N, variant, emax, el2, np.median(relp), relp.max()))
-        assert emax <= 1e-3 and el2 <= 5e-4
-        assert np.median(relp) <= 1e-3 and np.quantile(relp, 0.95) <= 1e-2
+        scale = np.abs(c["G6_s"][act]).max(1)
+        diff = np.abs(G6[act] - c["G6_s"][act])
+        relp = diff.max(1) / scale
+        # beyond what the four own cells can contribute (see big_case): the stated 1e-3 holds for EVERY hypothesis, no quantile
+        excess = np.maximum(diff - 1.01 * c["own_bound"][act], 0.0).max(1) / scale
+        margin("a9", "K4 fused soft N=%d x 640x480, %s: gradient max-rel (own cells excluded)" % (N, form), emax, 1e-3)
+        margin("a9", "K4 fused soft N=%d x 640x480, %s: gradient relative l2 error" % (N, form), el2, 5e-4)
+        margin("a10", "K4 fused soft N=%d, %s: pose sums, max over hypotheses of the error BEYOND the own-cell round-off bound" % (N, form), excess.max(),
+               5e-3 if variant == 0 else 1e-3, stated=1e-3)
+        margin("a10", "K4 fused soft N=%d, %s: pose sums, median raw max-rel error (own-cell term included)" % (N, form), np.median(relp), 1e-3)
+        print("K4 N=%d k4_variant %d fused soft: raw pose-sum error median %.2e p95 %.2e max %.2e; own-cell bound / scale: median %.2e max %.2e" %
+              (N, variant, np.median(relp), np.quantile(relp, 0.95), relp.max(), np.median(c["own_bound"][act].max(1) / scale), (c["own_bound"][act].max(1) / scale).max()))
     finally:
         engine.set_option("k4_variant", -1)
         torch.cuda.empty_cache()

@@ -4,6 +4,8 @@ dSMScore and the trainer's backward section -- HIP engine through the C ABI agai
 import numpy as np
 import pytest
 
+from conftest import margin
+
 pytestmark = pytest.mark.gpu
 H = W = 40
 
@@ -86,7 +88,8 @@ def test_training_backward_of_the_dsac_variant(engine, orc, fwd_state):
     emax = np.abs(bwd["grad"] - grad).max() / np.abs(grad).max()
     el2 = np.linalg.norm(bwd["grad"] - grad) / np.linalg.norm(grad)
     print("DSAC-variant end-to-end gradient: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 1e-5 and el2 <= 1e-5  # measured 4e-8 vs the reference (tests/test_gpu_reference_golden_dsac.py)
+    margin("(f)1", "DSAC variant end-to-end gradient vs the oracle's chain: max-rel", emax, 1e-5)
+    assert el2 <= 1e-5  # measured 4e-8 vs the reference (tests/test_gpu_reference_golden_dsac.py)
 
 
 def test_batched_drefine_equals_per_hypothesis_calls(engine, fwd_state):

@@ -79,7 +79,7 @@ def test_seam_against_the_oracle(setup, orc, quirk):
     (clamped at 0.1, train_score_softam.lua:97) -> dScore (cnn_softam.h:564-645).  quirk = the reference's index conventions: gradient images
     read back transposed (lua_calls.h:329-335) and dScore's column index x*cols*3 + y*3 (cnn_softam.h:628,641)."""
     import torch
-    from conftest import excl_clamp_edge
+    from conftest import excl_clamp_edge, margin
     ts, fr, patches, uv, perm, gt = setup
     N, P = 64, S * S
     out = ts.forward_backward(patches, uv, gt, perm, seed=1305, quirk_transpose=quirk)
@@ -92,7 +92,7 @@ def test_seam_against_the_oracle(setup, orc, quirk):
     err_o = orc.get_diff_maps(poses, xyz, uvh, S, S, cam)
     err_g = ts.err.cpu().numpy().reshape(N, P)
     m = excl_clamp_edge(err_g, err_o, 100.0)
-    assert np.abs(err_g - err_o)[m].max() <= 1e-3
+    margin("(f)2", "score-CNN seam: K2's tensor vs getDiffMap of every hypothesis (n, y, x order), max px", np.abs(err_g - err_o)[m].max(), 1e-3)
     # the score CNN is the caller's: its scores (float32) feed the oracle's softmax / soft-argmax / refinement
     scores = ts.scores.double().cpu().numpy()
     w_o = orc.softMax(scores)
@@ -100,7 +100,7 @@ def test_seam_against_the_oracle(setup, orc, quirk):
     avg_o = orc.avg_pose(w_o, poses)
     assert np.abs(avg_o - out["avgHyp"]).max() <= 1e-9 * max(1.0, np.abs(avg_o).max())
     ref_o, imap_o, steps_o = orc.refine(avg_o, perm, xyz, uvh, S, S, cam, want_inlier_map=True)
-    assert np.abs(ref_o[0] - out["refAvgHyp"]).max() <= 1e-6 * max(1.0, np.abs(ref_o).max())
+    margin("(f)2", "score-CNN seam: refined pose vs the oracle's chain from the CNN's scores, max-rel", np.abs(ref_o[0] - out["refAvgHyp"]).max() / max(1.0, np.abs(ref_o).max()), 1e-6)
     assert np.array_equal(imap_o, ts.imap.cpu().numpy())
     # backward: the oracle's chain
     dL = orc.dLossMax(orc.cv_to_jp6(ref_o[0]), gt)
@@ -121,10 +121,10 @@ def test_seam_against_the_oracle(setup, orc, quirk):
     same = np.abs(p3p_o - poses).max(1) <= 1e-6 * np.maximum(1.0, np.abs(poses).max(1))
     assert same.mean() >= 0.9
     if same.all():
-        assert np.abs(got - grad_o).max() <= 1e-5 * scale, "seam gradient differs from the oracle by %.3e of its largest entry" % (np.abs(got - grad_o).max() / scale)
+        margin("(f)2", "score-CNN seam: scene-coordinate gradient through the CNN's own autograd vs the oracle's chain, max / max|g|", np.abs(got - grad_o).max() / scale, 1e-5)
     else:
         rel = np.abs(got - grad_o).max(1) / scale
-        assert np.quantile(rel, 0.9) <= 1e-5
+        margin("(f)2", "score-CNN seam: gradient, 0.9 quantile over cells (an ill-conditioned P3P set differs between K1 and the oracle)", np.quantile(rel, 0.9), 1e-5)
 
 
 def test_step_with_the_reference_architectures(synth, frame40, orc):

@@ -16,7 +16,7 @@ oracle, through the C ABI.  Tolerances:
 import numpy as np
 import pytest
 
-from conftest import excl_clamp_edge
+from conftest import excl_clamp_edge, margin
 
 pytestmark = pytest.mark.gpu
 
@@ -33,9 +33,9 @@ def assert_poses_close(pg, pr):
         ang[i] = np.degrees(np.arccos(np.clip((np.trace(D) - 1) / 2, -1, 1)))
         trel[i] = np.linalg.norm(a[3:] - b[3:]) / max(np.linalg.norm(b[3:]), 1e-9)
     tight = (ang <= 1e-5) & (trel <= 1e-6)
-    assert tight.mean() >= 0.95, "fraction of tightly matching hypotheses: %.3f" % tight.mean()
+    margin("a2", "K1 P3P poses vs oracle: fraction within 1e-5 deg / 1e-6 rel translation", tight.mean(), 0.95, at_least=True)
     loose = (ang <= 0.1) & (trel <= 5e-3)
-    assert loose.mean() >= 0.99, "fraction within 0.1 deg / 0.5 %%: %.3f (worst %.3g deg)" % (loose.mean(), ang.max())
+    margin("a2", "K1 P3P poses vs oracle: fraction within 0.1 deg / 0.5 %% translation (rest: ill-conditioned sets, see the per-pose bound)", loose.mean(), 0.99, at_least=True)
 
 
 def _set(engine, fr, implicit_uv=False, **kw):
@@ -50,7 +50,7 @@ def test_reproject_parity_reference_size(engine, orc, frame40):
     got = engine.getDiffMap(poses).reshape(256, -1)
     m = excl_clamp_edge(got, ref)
     assert m.mean() > 0.2
-    assert np.abs(got - ref)[m].max() <= 1e-3
+    margin("a3", "K2 residuals 40x40 int16 map, 256 hyps: max |err - oracle| px (clamp-edge cells excluded)", np.abs(got - ref)[m].max(), 1e-3)
     assert np.abs(got - ref).max() <= 2e-3  # clamp-edge entries can only differ by the tolerance as well
 
 
@@ -61,7 +61,7 @@ def test_reproject_parity_full_resolution(engine, orc, frame_full):
     ref = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
     got = engine.getDiffMap(poses).reshape(64, -1)
     m = excl_clamp_edge(got, ref)
-    assert np.abs(got - ref)[m].max() <= 1e-3
+    margin("a3", "K2 residuals 640x480, 64 hyps: max |err - oracle| px (clamp-edge cells excluded)", np.abs(got - ref)[m].max(), 1e-3)
     # explicit uv must give the same bits as the implicit grid
     _set(engine, fr, implicit_uv=False)
     got2 = engine.getDiffMap(poses).reshape(64, -1)
@@ -104,7 +104,8 @@ def test_soft_inlier_scores(engine, orc, frame40, frame_full):
         ref_err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
         ref = orc.soft_inlier(ref_err, 10.0, 0.5)
         got = engine.softInlierScores(poses, tau=10.0, beta=0.5)
-        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        margin("north*", "soft-inlier scores %dx%d: max |soft - oracle| relative to the largest score" % (fr["W"], fr["H"]),
+               np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), 1e-4)
         # err + soft in one launch agrees with the separate launches (the launcher may pick a different kernel form --
         # matrix-core vs VALU fmaf chains round in a different order -- so not bit-for-bit)
         err = np.zeros((N, fr["H"] * fr["W"]), np.float32)
@@ -123,9 +124,9 @@ def test_softmax_entropy_avg(engine, orc):
         poses = rng.normal(size=(N, 6))
         w, ent, avg = engine.softMax(scores, 1.0, poses)
         wr = orc.softMax(scores)
-        assert np.abs(w - wr).max() <= 1e-12
-        assert abs(ent[0] - orc.entropy(wr)) <= 1e-10
-        assert np.abs(avg - orc.avg_pose(wr, poses)).max() <= 1e-10
+        margin("a4", "K3 softmax given equal scores: max |w - oracle|", np.abs(w - wr).max(), 1e-12)
+        margin("a4", "K3 entropy given equal scores: |H - oracle| bits", abs(ent[0] - orc.entropy(wr)), 1e-10)
+        margin("a5", "K3 soft-argmax pose given equal scores and poses: max abs difference", np.abs(avg - orc.avg_pose(wr, poses)).max(), 1e-10)
     # scale argument
     w, _, _ = engine.softMax(scores, 0.1)
     assert np.abs(w - orc.softMax(0.1 * scores)).max() <= 1e-12
@@ -187,7 +188,9 @@ def test_dpnp_parity(engine, orc, frame40):
                 sens[h] = max(sens[h], np.abs(orc.dPNP(fr["uv"][sets[h]], X1.reshape(4, 3), fr["cam"], eps=0.1) - Jr).max() / sc)
         print("dPNP seed %d rel err: median %.2e  p90 %.2e  max %.2e;  max rel / one-ulp sensitivity %.2f" %
               (seed, np.median(rel), np.quantile(rel, 0.9), rel.max(), (rel / np.maximum(sens, 1e-7)).max()))
-        assert np.median(rel) <= 1e-6
+        margin("a11", "K5 dPNP vs oracle: median relative error", np.median(rel), 1e-6)
+        margin("a11", "K5 dPNP vs oracle: max relative error (SURVEY 8(c): 1e-3 allowed)", rel.max(), 1e-3)
+        margin("a11", "K5 dPNP vs oracle: worst error in units of the oracle's own one-float-ulp sensitivity", (rel / np.maximum(sens, 1e-6 / 4.0)).max(), 4.0)
         assert (rel <= 1e-4).mean() >= 0.9
         assert np.all(rel <= np.maximum(1e-6, 4.0 * sens)), (seed, np.argmax(rel / np.maximum(sens, 1e-7)), rel.max())
 
@@ -224,7 +227,7 @@ def test_device_pointers_through_torch(engine, orc, frame40):
     m = excl_clamp_edge(got, ref)
     assert np.abs(got - ref)[m].max() <= 1e-3
     wr = orc.softMax(0.1 * orc.soft_inlier(ref, 10.0, 0.5))
-    assert np.abs(w.cpu().numpy() - wr).max() <= 1e-4  # softmax weights given the same poses
+    margin("a4", "softmax weights 40x40 (scale 0.1) from the oracle's scores of the same poses: max |w - oracle| (BASELINE.md 3: 1e-4)", np.abs(w.cpu().numpy() - wr).max(), 1e-4)
     assert abs(w.sum().item() - 1.0) < 1e-12
     # end to end (oracle's own P3P poses): ill-conditioned minimal sets may move a little weight around
     w_e2e = orc.softMax(0.1 * orc.soft_inlier(orc.get_diff_maps(pr, fr["xyz"], fr["uv"], 40, 40, fr["cam"]), 10.0, 0.5))

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import margin
+
 pytestmark = pytest.mark.gpu
 GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FRAMES = ["refd_frame_v1.npz", "refd_frame_v2.npz"]  # v2: another scene, more noise and outliers, another draw seed (make_golden_ref.py 2)
@@ -66,4 +68,5 @@ def test_drefine_and_training_backward(engine, g):
     emax = np.abs(bwd["grad"] - want).max() / np.abs(want).max()
     el2 = np.linalg.norm(bwd["grad"] - want) / np.linalg.norm(want)
     print("DSAC-variant end-to-end gradient vs the reference: max-rel %.3e l2-rel %.3e" % (emax, el2))
-    assert emax <= 1e-3 and el2 <= 1e-3
+    margin("(f)1", "DSAC variant, golden frames (REAL cnn.h): end-to-end gradient, max-rel", emax, 1e-3)
+    assert el2 <= 1e-3

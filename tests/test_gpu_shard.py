@@ -53,6 +53,7 @@ def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world):
             run.step(STEPS - 1)
             again = run.drain().numpy()
             assert np.array_equal(again[run.mine], rows[run.mine])
+            run.close()
         finally:
             eng.close()
     assert (want[:, 6] > 0).all() and np.abs(want[:, 10:].sum(1) - 1).max() < 1e-12

@@ -15,7 +15,7 @@ oracle's scores are checked to 5e-3 absolute -- at this map size a score is a su
 import numpy as np
 import pytest
 
-from conftest import excl_clamp_edge
+from conftest import excl_clamp_edge, margin
 
 pytestmark = pytest.mark.gpu
 
@@ -31,8 +31,7 @@ def _check_rows(orc, err_dev, rows, poses, xyz, uv, cam, what):
     ref = orc.get_diff_maps(poses[rows], xyz, uv, H, W, cam)
     m = excl_clamp_edge(got, ref, CLAMP)
     assert m.mean() > 0.01, what
-    worst = np.abs(got - ref)[m].max()
-    assert worst <= 1e-3, "%s: max |err - oracle| = %.3e px" % (what, worst)
+    worst = margin("a3", "K2 residuals at the TIMED shapes (16 x 256 x 640x480 batch, configs[2] N = 4096, every kernel form): max |err - oracle| px", np.abs(got - ref)[m].max(), 1e-3)
     assert np.abs(got - ref).max() <= 2e-3, what
     return worst
 
@@ -41,17 +40,16 @@ def _check_scores(orc, soft_gpu, w_gpu, poses, xyz, uv, cam, what, engine=None):
     """all soft-inlier scores and softmax weights of one frame"""
     ref_err = orc.get_diff_maps(poses, xyz, uv, H, W, cam)
     soft_ref = orc.soft_inlier(ref_err, TAU, BETA)
-    rel = np.abs(soft_gpu - soft_ref).max() / max(1.0, np.abs(soft_ref).max())
-    assert rel <= 1e-4, "%s: soft scores differ by %.3e (relative to the largest)" % (what, rel)
+    rel = margin("north*", "soft-inlier scores at 640x480 (sum of 307 200 sigmoids): max |soft - oracle| relative to the largest score", np.abs(soft_gpu - soft_ref).max() / max(1.0, np.abs(soft_ref).max()), 1e-4)
     # K3 proper: the GPU's softmax of the GPU's own scores
-    assert np.abs(w_gpu - orc.softMax(SCALE * soft_gpu)).max() <= 1e-12, what
-    dw = np.abs(w_gpu - orc.softMax(SCALE * soft_ref)).max()
-    assert dw <= 5e-3, "%s: softmax weights differ by %.3e" % (what, dw)
+    margin("a4", "K3 at 640x480: softmax of the GPU's own scores vs the oracle's softmax of the same numbers", np.abs(w_gpu - orc.softMax(SCALE * soft_gpu)).max(), 1e-12)
+    # ... and end to end through the scores: 0.1 x (sum of 307 200 fp32-rounded sigmoids).  BASELINE.md 3 states 1e-4 for the reference-sized map (met:
+    # 2e-6); at 640x480 the fp32 residual rounding (1e-4 px) moves a score by ~7e-3, i.e. a weight by ~7e-4 of itself: asserted 1e-3 (see BASELINE.md 3)
+    dw = margin("a4", "softmax weights at 640x480, scale 0.1, from the ORACLE's scores of the same poses: max |w - oracle|", np.abs(w_gpu - orc.softMax(SCALE * soft_ref)).max(), 1e-3, stated=1e-4)
     if engine is not None:
         # with the bench's scale (0.1) a 640x480 softmax is one-hot (scores ~1e5); a scale that spreads the weights makes the comparison bite
         w2, _, _ = engine.softMax(soft_gpu, 1e-3)
-        dw2 = np.abs(w2 - orc.softMax(1e-3 * soft_ref)).max()
-        assert dw2 <= 1e-3, "%s: softmax weights (scale 1e-3) differ by %.3e" % (what, dw2)
+        dw2 = margin("a4", "softmax weights at 640x480, scale 1e-3 (spread distribution), from the oracle's scores: max |w - oracle|", np.abs(w2 - orc.softMax(1e-3 * soft_ref)).max(), 1e-4)
         dw = max(dw, dw2)
     return rel, dw
 
@@ -126,7 +124,7 @@ def test_config2_4096_hypotheses_against_the_oracle(engine, orc, synth, mode):
         assert rel <= 1e-4, "configs[2] soft scores differ by %.3e" % rel
         w, entr, _ = engine.softMax(sg, SCALE)
         assert np.abs(w - orc.softMax(SCALE * sg)).max() <= 1e-12
-        assert np.abs(w - orc.softMax(SCALE * sr)).max() <= 5e-3
+        margin("a4", "configs[2] (N = 4096): softmax weights, scale 0.1, from the oracle's scores: max |w - oracle|", np.abs(w - orc.softMax(SCALE * sr)).max(), 1e-3, stated=1e-4)
     print("configs[2] %s: worst residual difference %.2e px" % (mode, worst))
     del err
     torch.cuda.empty_cache()
