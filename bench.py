@@ -45,21 +45,44 @@ def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
     return 12 * P + (8 * P if explicit_uv else 0) + 48 * N + (4 * N * P if write_err else 0) + 4 * N
 
 
+# issue rates of the VALU classes on this chip, wall cycles per wave64 instruction and SIMD at a nominal 2.4 GHz (profiles/r03_valu_rate.txt,
+# r03_valu_rate_trans.txt, r03_valu_rate_mfma.txt: measured with scripts/micro/valu_rate.hip; MFMAs do not overlap the VALU stream)
+ISSUE_CYCLES = {"packed_fp32": 5.3, "transcendental": 8.8, "plain_valu": 2.9, "mfma": 38.0}
+
+
+def soft_only_isa_mix(n_hyps, P):
+    """Instruction counts per 16 hypotheses x 64 pixels of the kernel the auto policy runs for a soft-inlier-only launch of this size, as
+    dsac_amd/csrc/Makefile read them from the built ISA (scripts/isa_mix.py).  None when the launch takes a form that is not priced."""
+    nbytes = float(n_hyps) * float(P) * 4.0
+    form = 58 if nbytes > 4.4e9 else 45 if nbytes > 1.0e9 else None  # k_forward.hip reproject(): the auto policy by size
+    if form is None:
+        return None
+    path = os.path.join(ROOT, "dsac_amd", "csrc", "build", "k2_soft_isa_%d.json" % form)
+    try:
+        j = json.load(open(path))
+        return dict(j["per_1024_pairs"], kernel=j["kernel"], form=form, source=j["source"])
+    except Exception:  # noqa: BLE001 -- not built here: no price rather than a stale constant
+        return None
+
+
 def soft_only_roofline(n_hyps, P, k2_s, launches):
     """SURVEY.md 8(d) secondary measurement: the fused soft-inlier mode (scores without the error-image output) moves 12 P + 48 N + 4 N bytes
     for N P x 36 flop -- it is priced against the fp32 VECTOR roof, never as an HBM fraction."""
     flop = float(n_hyps) * float(P) * FLOP_PER_PAIR
     ach = flop / k2_s / 1e12 if k2_s > 0 else 0.0
-    # issue_model: the kernel's own instruction mix per 16 hypotheses x 64 pixels (61 packed fp32, 64 quarter-rate transcendentals, 57 plain, 12 exact-fp32
-    # MFMAs; ISA of k_reproject_st<2,4,1,...,soft only>) priced with the issue rates measured on this chip (profiles/r03_valu_rate*.txt: 5.3 / 8.8 / 2.9 / 38
-    # cycles at a nominal 2.4 GHz, MFMAs do not overlap the VALU stream): a constant, like `traffic` -- the time the arithmetic cannot go below
-    cyc_per_1024_pairs = 61 * 5.3 + 64 * 8.8 + 57 * 2.9 + 12 * 38.0
-    priced_s = float(n_hyps) * float(P) / 1024.0 * cyc_per_1024_pairs / (1024 * 2.4e9)
-    return {"kernel": "k_reproject (K2), soft-inlier sums only (no error-image output)", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "flop_per_launch": flop, "flop_per_pair": FLOP_PER_PAIR, "avg_launch_us": k2_s * 1e6,
-            "launches_timed": launches, "hyp_per_s": n_hyps / k2_s if k2_s > 0 else None,
-            "issue_model": {"cycles_per_1024_pairs": cyc_per_1024_pairs, "priced_us": priced_s * 1e6, "frac": priced_s / k2_s if k2_s > 0 else None,
-                            "source": "constant: instruction mix of the kernel's ISA x issue rates of profiles/r03_valu_rate.txt, r03_valu_rate_mfma.txt"}}
+    out = {"kernel": "k_reproject (K2), soft-inlier sums only (no error-image output)", "bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS,
+           "unit": "TFLOP/s", "frac": ach / VALU_PEAK_TFLOPS, "flop_per_launch": flop, "flop_per_pair": FLOP_PER_PAIR, "avg_launch_us": k2_s * 1e6,
+           "launches_timed": launches, "hyp_per_s": n_hyps / k2_s if k2_s > 0 else None}
+    # issue_model: the kernel's OWN instruction mix per 16 hypotheses x 64 pixels -- counted in the built ISA by the Makefile, so it follows the kernel
+    # when the kernel changes -- priced with the issue rates measured on this chip: the time the arithmetic cannot go below
+    mix = soft_only_isa_mix(n_hyps, P)
+    if mix is not None:
+        cyc = sum(mix[k] * ISSUE_CYCLES[k] for k in ISSUE_CYCLES)
+        priced_s = float(n_hyps) * float(P) / 1024.0 * cyc / (1024 * 2.4e9)
+        out["issue_model"] = {"instructions_per_1024_pairs": {k: mix[k] for k in ISSUE_CYCLES}, "cycles_per_instruction": ISSUE_CYCLES,
+                              "cycles_per_1024_pairs": cyc, "priced_us": priced_s * 1e6, "frac": priced_s / k2_s if k2_s > 0 else None,
+                              "kernel_form": mix["form"], "source": mix["source"] + "; issue rates: profiles/r03_valu_rate*.txt"}
+    return out
 
 
 def event_stride_for(steps, requested):
@@ -97,6 +120,7 @@ def parse_args(argv=None):
                     help="independent 640x480 frames (each with --hyps hypotheses) batched into one step: dsac_set_frames / dsac_score_hypotheses_frames carry "
                          "them through K1, K2, K3 in three launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-driver", action="store_true", help="skip the timing of the C++ evaluation program (dsac_amd/host/test_ransac_softam)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra single-frame (literal configs[1]) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed clock / TLB settling before the warm-up steps (not counted as steps)")
@@ -232,6 +256,34 @@ def cpu_baseline(args, fr, N, H, W):
     s40, _ = orc.time_forward(N, 1305, f40["xyz"], f40["uv"], 40, 40, f40["cam"], reps=r40)
     out["reference_size"] = {"value": N * r40 / s40, "unit": "hyp/s", "cores": cores, "sample": "%d frames x %d hypotheses x 40x40 int16 map, %.2f s" % (r40, N, s40)}
     return out
+
+
+def host_driver_leg(N, H, W, device=0, images=64, batch=16, passes=6):
+    """The reference-shaped C++ program on the engine (dsac_amd/host/test_ransac_softam: GlobalProperties, FrameBatch over the C ABI, the reference's
+    output files) on `images` synthetic frames: one engine context for the run, the data set resident in HBM, `batch` images per launch chain, the
+    refinement tail of a batch under the next batch.  Returns what its "Timing:" line says -- the C++ host path's own clock around a pass."""
+    import re
+    import tempfile
+    exe = os.path.join(ROOT, "dsac_amd", "host", "test_ransac_softam")
+    if not os.path.exists(exe):
+        return {"error": "dsac_amd/host/test_ransac_softam is not built"}
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [exe, "-synth", str(images), "-mw", str(W), "-mh", str(H), "-rI", str(N), "-batch", str(batch), "-passes", str(passes), "-dev", str(device)]
+        try:
+            out = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=600)
+        except Exception as e:  # noqa: BLE001
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+        m = re.search(r"Timing: .*?: ([0-9.eE+-]+) us per image \(([0-9.eE+-]+) ms per pass over (\d+) timed pass\(es\); first pass ([0-9.eE+-]+) ms; upload \+ set-up ([0-9.eE+-]+) ms\)",
+                      out.stdout)
+        acc = re.search(r"accuracy: ([0-9.eE+-]+)%", out.stdout)
+        if out.returncode != 0 or not m:
+            return {"error": "rc %d: %s" % (out.returncode, (out.stdout + out.stderr)[-300:])}
+        return {"program": "dsac_amd/host/test_ransac_softam " + " ".join(cmd[1:]),
+                "what": "C++ host over the C ABI (dsac::Context + FrameBatch::processImages = dsac_set_frames + dsac_process_images): the whole processImage of "
+                        "every image (sample + P3P, error images, soft-argmax, 8 refinement steps, loss), %d images per launch chain, refinement tail deferred "
+                        "under the next batch, data set resident in HBM, results copied back once per pass" % batch,
+                "us_per_image": float(m.group(1)), "ms_per_pass": float(m.group(2)), "timed_passes": int(m.group(3)), "first_pass_ms": float(m.group(4)),
+                "upload_and_setup_ms": float(m.group(5)), "images": images, "hypotheses": N, "accuracy_percent": float(acc.group(1)) if acc else None}
 
 
 def run_dry(args, rank, world, dist):
@@ -403,8 +455,8 @@ def run_config5(args, rank, local_rank, world, backend, dist):
         dev_name = torch.cuda.get_device_name(di)
         ts.engine.close()
     if rank == 0:
-        out = {"metric": "hypotheses scored/sec over 640x480 coord map", "value": value, "unit": "hyp/s", "n_gpus": world, "steps": K, "warmup": Wm,
-               "ms_per_step": line["step_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        out = {"metric": "hypotheses scored/sec (end-to-end training step: 40x40 sub-sampled coord map per frame, BASELINE configs[4])", "value": value, "unit": "hyp/s",
+               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": line["step_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[4]: end-to-end training step, ONE frame per GPU and step (40x40 sub-sampled map, %d hypotheses), "
                                       "scene-coordinate CNN + score CNN (reference architectures, random weights), geometry forward + backward, gradient "
                                       "exchange over %s" % (N, "RCCL" if backend == "nccl" else backend),
@@ -960,6 +1012,13 @@ def main(argv=None):
             out["emulation"] = emulation
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
+        if (not args.no_host_driver and world == 1 and not config3 and not args.kernel_only and args.k2_mode == "both" and not args.no_single_frame
+                and N % 128 == 0):
+            hd = host_driver_leg(N, H, W, device=local_rank)
+            ref = (procimg or {}).get("%dx%d_batch_of_%d_refinement_under_the_next_batch" % (W, H, B)) if batched else None
+            if ref and "us_per_image" in hd:
+                hd["vs_process_image_python_ctypes"] = hd["us_per_image"] / ref["us_per_image"]  # the same unit of work driven from Python (process_image above)
+            out["host_driver"] = hd
         print(json.dumps(out), flush=True)
 
     for eng, _ in engines:

@@ -831,19 +831,25 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         return end_call(c);
     }
     const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
-    HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
-    HIP_TRY(c, c->dRdH.reserve((size_t)N * dk::BWD_DRDH * sizeof(double)));
-    HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * plan.glayers * P * 3 * sizeof(float)));
+    // Round 4, the fused stage (plan.fused): two launches instead of four -- the main pass derives its hypothesis records from the poses in its prologue
+    // and (one hypothesis tile: plan.direct) adds the gradient straight into grad_xyz, the finish kernel derives dR/drod itself.  The round-3 staging
+    // (k_backward_prep -> main -> k_grad_reduce -> k_support_scatter) remains for the VALU form and behind k4_variant + 1000.
+    if (!plan.fused) {
+        HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
+        HIP_TRY(c, c->dRdH.reserve((size_t)N * dk::BWD_DRDH * sizeof(double)));
+    }
+    if (!plan.direct) HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * plan.glayers * P * 3 * sizeof(float)));
     HIP_TRY(c, c->g12_part.reserve((size_t)plan.rows * N * 12 * sizeof(float)));
     HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
-    HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
+    if (!plan.fused) HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
     {
         ProfScope ps(c, 1);
         HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
-                                      c->g12_part.as<float>(), plan));
+                                      c->g12_part.as<float>(), plan, d_poses, d_grad, flags));
     }
-    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.NT * plan.glayers, c->g12_part.as<float>(), plan.rows, c->dRdH.as<double>(),
-                                         d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(), plan.variant > 0 ? c->bwd_staged.as<float>() : nullptr));
+    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.direct ? 0 : plan.NT * plan.glayers, c->g12_part.as<float>(), plan.rows,
+                                         c->dRdH.as<double>(), d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(),
+                                         (plan.variant > 0 && !plan.fused) ? c->bwd_staged.as<float>() : nullptr, plan.fused ? d_poses : nullptr));
     c->g6_n = N;
     return end_call(c);
 }

@@ -350,7 +350,12 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                                                                     const float* __restrict__ uv, const float* __restrict__ d_err,
                                                                     const double* __restrict__ g, float* __restrict__ grad_part,
                                                                     float* __restrict__ G12_part, int N, int P, int W, int PT, int NT, int G,
-                                                                    float f, float cx, float cy, float clampv, float kA, float kB, float beta, int HT) {
+                                                                    float f, float cx, float cy, float clampv, float kA, float kB, float beta, int HT,
+                                                                    const double* __restrict__ poses, double* __restrict__ grad_direct, unsigned gflags) {
+    // Round 4 (the fused stage): poses != nullptr -> the workgroup derives its hypothesis records from the cv poses itself (no k_backward_prep launch,
+    // no record image in HBM) and writes G12_part hypothesis-major ([hyp][row][12]: the finish kernel reads a hypothesis' rows as one contiguous run);
+    // grad_direct != nullptr (one hypothesis tile, N <= 256) -> the workgroups add their gradient straight into the caller's fp64 grad_xyz with atomics
+    // (no grad_part volume, no k_grad_reduce launch; gflags bit 0 = the transposed cell index of cnn_softam.h:628).
     const int ht = blockIdx.x % NT;   // hypothesis tile of this workgroup
     const int pw = blockIdx.x / NT;   // its index among the G workgroups that share the pixel tiles
     const int h0 = ht * HT;
@@ -366,9 +371,33 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     float* s_img = s_dyn;                                // [HT/16][384]: B operands [3][64] + coefficients [16][12] (k_backward_prep's image)
     float* s_G = s_img + HT16 * 384;                     // [HT/16][4 waves][16][12]
     {
-        const f4* src = reinterpret_cast<const f4*>(rec + (size_t)N * BWD_REC + (size_t)(h0 >> 4) * 384);
-        f4* dst = reinterpret_cast<f4*>(s_img);
-        for (int i = tid; i < ngi * 96; i += K4_THREADS) dst[i] = src[i];
+        if (poses) {
+            // one hypothesis per lane: cv -> jp pose in fp64 (dm::cv2our: Rodrigues, sign flips, det check), rounded to float and laid out as the MFMA
+            // B operands [x row | negated y row | z row][k][column] and the 16 x 12 gradient coefficients -- exactly k_backward_prep's image
+            for (int i = tid; i < ngi * 16; i += K4_THREADS) {
+                const int hh = h0 + min(i, nh - 1);  // columns beyond the ragged end repeat the last hypothesis (masked in the loop)
+                double cv6[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) cv6[k] = poses[(size_t)hh * 6 + k];
+                double R[9], t[3];
+                dm::cv2our(cv6, R, t);
+                float* gb = s_img + (i >> 4) * 384;
+                const int cc = i & 15;
+                const float r00 = (float)R[0], r01 = (float)R[1], r02 = (float)R[2], r10 = (float)R[3], r11 = (float)R[4], r12 = (float)R[5];
+                const float r20 = (float)R[6], r21 = (float)R[7], r22 = (float)R[8], t0 = (float)t[0], t1 = (float)t[1], t2 = (float)t[2];
+                gb[cc] = f * r00; gb[16 + cc] = f * r01; gb[32 + cc] = f * r02; gb[48 + cc] = f * t0;
+                gb[64 + cc] = f * -r10; gb[80 + cc] = f * -r11; gb[96 + cc] = f * -r12; gb[112 + cc] = f * -t1;
+                gb[128 + cc] = r20; gb[144 + cc] = r21; gb[160 + cc] = r22; gb[176 + cc] = t2;
+                float* gc = gb + 192 + cc * 12;
+                gc[0] = f * r00; gc[1] = f * r01; gc[2] = f * r02; gc[3] = f * -r10; gc[4] = f * -r11; gc[5] = f * -r12;
+                gc[6] = -r20; gc[7] = -r21; gc[8] = -r22;
+                gc[9] = gc[10] = gc[11] = 0.f;
+            }
+        } else {
+            const f4* src = reinterpret_cast<const f4*>(rec + (size_t)N * BWD_REC + (size_t)(h0 >> 4) * 384);
+            f4* dst = reinterpret_cast<f4*>(s_img);
+            for (int i = tid; i < ngi * 96; i += K4_THREADS) dst[i] = src[i];
+        }
         f4* gz4 = reinterpret_cast<f4*>(s_G);
         for (int i = tid; i < ngi * 192; i += K4_THREADS) gz4[i] = f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -386,6 +415,10 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     //  -- but it costs nothing either and keeps the launch time independent of how the tile count divides.  A tile whose
     // groups are split between two workgroups gets its gradient from both: the part that starts at group 0 writes layer 0 of grad_part, the part
     // that starts later writes layer 1 (a workgroup that covers a whole tile zeroes layer 1 for it), k_grad_reduce sums the layers.
+    // grad_direct (round 4): the same balanced ranges; the gradient of a range's tile part is ADDED to grad_xyz with fire-and-forget fp64 atomics
+    // (global_atomic_add_f64, no return value: nothing waits for them; a split tile simply has two adders).  A first version gave every workgroup
+    // whole tiles and a plain read-modify-write: 1200 tiles on 512 workgroups leave 176 of them a third tile (107.7 us against 101.0), and the
+    // read of the read-modify-write sits exposed at the end of every tile (profiles/r04_k4_stage.txt).
     const long long items = (long long)PT * ngi;
     long long it = items * pw / G;
     const long long it_end = items * (pw + 1) / G;
@@ -484,8 +517,11 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                     // the map or the ragged hypothesis end -> 0;  err == 0 -> 0 (the reference divides by err + 1e-8: -0 / 1e-8)
                     // Round 3: the guards as ARITHMETIC, no compare -> scalar mask -> select chain (same instruction count, no scalar round trips;
                     // it also lets lanes beyond the map / the ragged end be switched off through the scale factor, so that their loads are unconditional):
-                    //   keep = clamp((clamp^2 E.z^2 - S) * 1e30, 0, 1) is exactly 1 where err <= clamp (the difference of two numbers ~1e10 is either <= 0 or
-                    //   >= one ulp ~ 1e3), exactly 0 where err > clamp -- and where |E.z| < 1e-8 (then clamp^2 E.z^2 <= 1e-12 << S = f^2 (E.x^2 + E.y^2));
+                    //   keep = clamp((clamp^2 E.z^2 - S) * 1e30, 0, 1) is exactly 1 where err < clamp (the difference of two numbers ~1e10 is either <= 0 or
+                    //   >= one ulp ~ 1e3), exactly 0 where err >= clamp -- the reference drops err > clamp only (cnn_softam.h:425,485): a cell whose fp32
+                    //   residual equals CNN_OBJ_MAXINPUT to the last bit is the one measure-zero difference -- and where |E.z| < 1e-8, because then
+                    //   clamp^2 E.z^2 <= 1e-12 << S = f^2 (E.x^2 + E.y^2) unless the point sits within 2e-9 mm of the camera centre in x and y as well
+                    //   (no fp32 coordinate map can place one there: one ulp at 1 mm is 1e-7 mm; the reference returns 0 for it, this kernel a finite number);
                     //   m = rsq(T + 1e-30) stays finite at err == 0 (A = B = 0 there: every C is an exact 0, as the reference's 0 / 1e-8);
                     //   lanes beyond the map or the ragged hypothesis end: keep = 0 through okscale (their d_err is a clamped re-read of valid cells).
                     const f2 tk = __builtin_elementwise_fma(zz, f2{clampv * clampv, clampv * clampv}, -Sq);
@@ -583,7 +619,22 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                 o[6 * pp + 0] = row16_sum_f(gx[ch][pp].x); o[6 * pp + 1] = row16_sum_f(gy[ch][pp].x); o[6 * pp + 2] = row16_sum_f(gz[ch][pp].x);
                 o[6 * pp + 3] = row16_sum_f(gx[ch][pp].y); o[6 * pp + 4] = row16_sum_f(gy[ch][pp].y); o[6 * pp + 5] = row16_sum_f(gz[ch][pp].y);
             }
-            if (c == 0 && valid[ch]) {
+            if (grad_direct) {
+                // lane c < 12 of a row adds element c of the row's 4 pixels x 3 channels (96 contiguous bytes of fp64 per row)
+                float v = o[0];
+#pragma unroll
+                for (int k = 1; k < 12; k++) v = (c == k) ? o[k] : v;
+                if (c < 12 && valid[ch]) {
+                    const int dp = (c * 11) >> 5, comp = c - 3 * dp;  // c / 3, c % 3
+                    const int pix = p0[ch] + dp;
+                    size_t dst = (size_t)pix * 3 + comp;
+                    if (gflags & 1u) {
+                        const int y = pix / W, x = pix - y * W;
+                        dst = ((size_t)x * W + y) * 3 + comp;  // core/cnn_softam.h:628  x*cols*3 + y*3   (H == W checked by the caller)
+                    }
+                    unsafeAtomicAdd(&grad_direct[dst], (double)v);  // global_atomic_add_f64 without return
+                }
+            } else if (c == 0 && valid[ch]) {
                 const int layer = g_begin > 0 ? 1 : 0;
                 f4* dstg = reinterpret_cast<f4*>(grad_part + ((size_t)ht * 2 + layer) * P * 3 + (size_t)p0[ch] * 3);
                 dstg[0] = f4{o[0], o[1], o[2], o[3]};
@@ -603,9 +654,14 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     {
         const f4* sg4 = reinterpret_cast<const f4*>(s_G);
         f4* out4 = reinterpret_cast<f4*>(G12_part + ((size_t)pw * N + h0) * 12);
+        f4* out4h = reinterpret_cast<f4*>(G12_part);  // hypothesis-major: [hyp][G rows][12]
         for (int i = tid; i < nh * 3; i += K4_THREADS) {
             const int j = i + 144 * (i / 48);
-            out4[i] = (sg4[j] + sg4[j + 48]) + (sg4[j + 96] + sg4[j + 144]);
+            const f4 v = (sg4[j] + sg4[j + 48]) + (sg4[j + 96] + sg4[j + 144]);
+            if (poses) {
+                const int hyp = (i * 683) >> 11, part = i - 3 * hyp;  // i / 3 for i < 768
+                out4h[((size_t)(h0 + hyp) * G + pw) * 3 + part] = v;
+            } else out4[i] = v;
         }
     }
 }
@@ -633,8 +689,9 @@ static size_t k4m_lds_bytes(int HT) {
 // (workgroups do not run in lock-step rounds, and long tiles have the longer tail).  Matrix-core form: all hypotheses of the frame in one
 // tile up to 256 (the d_err stream is read once either way; a single tile writes grad_part once).
 bool backward_variant_known(int v) {
-    if (v == -1) return true;
+    if (v == -1 || v == 1999) return true;
     if (v < 0) return false;
+    if (v >= 1000) v -= 1000;  // + 1000: the round-3 staging (k_backward_prep + grad_part + k_grad_reduce) for A/B runs
     const int form = v % 10, tile = (v / 10) % 10, wgs = v / 100;
     return form <= 7 && tile <= 3 && wgs <= 8;
 }
@@ -646,6 +703,8 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
     // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
     int ht_code = 0, wg_per_cu = 0;
+    bool legacy = false;
+    if (variant >= 1000) { legacy = true; variant -= 1000; if (variant == 999) variant = -1; }  // 1999 = auto form, legacy staging
     if (variant >= 10) { wg_per_cu = variant / 100; ht_code = (variant / 10) % 10; variant = variant % 10; }
     // Chunks per wave (measured, 640 x 480, profiles/r02_k4_chunks.txt): with the d_err stream 4 (N = 256: 131 us; 5: 134, 3: 140, 6 spills),
     // without it 5 (N = 256: 144 vs 147 us, N = 1024: 485 vs 498).  A round-counting model (1200 tiles on 512 persistent workgroups =
@@ -692,6 +751,10 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // every workgroup takes the same number of (tile, 16-hypothesis group) items: at least one group each
         pl.rows = (int)max(1ll, min((long long)pl.rows, (long long)PT * ((pl.HT + 15) / 16)));
         pl.glayers = 2;
+        // round 4: the workgroups derive their records from the poses (no prep launch), G12_part is hypothesis-major, and with a single hypothesis
+        // tile the gradient goes straight into grad_xyz (whole pixel tiles per workgroup: no more workgroups than tiles)
+        pl.fused = !legacy;
+        pl.direct = pl.fused && pl.NT == 1;
         return pl;
     }
     pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
@@ -699,7 +762,8 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
 }
 
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g, float clampv,
-                          float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan) {
+                          float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan, const double* poses, double* grad_xyz,
+                          unsigned flags) {
     if (N <= 0) return hipSuccess;
     const int HT = plan.HT, NT = plan.NT;
     const bool soft = d_err == nullptr;
@@ -708,6 +772,10 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
     const bool UV = F.uv != nullptr;
     if (plan.variant > 0) {
         if (HT < 16 || HT > K4M_HT_MAX || (reinterpret_cast<uintptr_t>(grad_part) & 15)) return hipErrorInvalidValue;
+        if (plan.fused && !poses) return hipErrorInvalidValue;
+        if (plan.direct && !grad_xyz) return hipErrorInvalidValue;
+        const double* k_poses = plan.fused ? poses : nullptr;
+        double* k_direct = plan.direct ? grad_xyz : nullptr;
         const int CH = k4m_chunks(plan.variant);
         const int PT = (F.P + 64 * CH - 1) / (64 * CH);
         const int G = plan.rows;
@@ -719,7 +787,7 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
         if (e_ != hipSuccess) return e_;                                                                                                    \
         hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_, W_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,   \
-                           grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT);                            \
+                           grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT, k_poses, k_direct, flags);  \
     } while (0)
 #define DSAC_K4M_CH(C_, W_)                                                                              \
     do {                                                                                                 \
@@ -783,7 +851,11 @@ __global__ __launch_bounds__(256) void k_grad_reduce(int P, int W, int H, int hy
 __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel_tiles, const float* __restrict__ G12_part,
                                                          const double* __restrict__ dRdH, const double* __restrict__ dpnp,
                                                          const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
-                                                         double* __restrict__ G6_out, const float* __restrict__ rec_e, float f_e) {
+                                                         double* __restrict__ G6_out, const float* __restrict__ rec_e, float f_e,
+                                                         const double* __restrict__ poses) {
+    // poses != nullptr (round 4, the fused stage): G12_part is hypothesis-major ([hyp][row][12]: a wave reads 48 contiguous bytes per lane, the
+    // whole hypothesis one contiguous run), the E-based sums apply, and dR/drod, Omega and t' are derived here from the cv pose -- every lane of the
+    // hypothesis' wave redundantly, under the partial-row loads -- instead of being read from k_backward_prep's output
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
@@ -791,7 +863,7 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 #pragma unroll
     for (int i = 0; i < 12; i++) G[i] = 0;
     for (int t = lane; t < pixel_tiles; t += 64) {
-        const f4* src = reinterpret_cast<const f4*>(G12_part + ((size_t)t * N + h) * 12);
+        const f4* src = reinterpret_cast<const f4*>(G12_part + (poses ? ((size_t)h * pixel_tiles + t) : ((size_t)t * N + h)) * 12);
         const f4 a = src[0], b = src[1], c = src[2];
         G[0] += (double)a.x; G[1] += (double)a.y; G[2] += (double)a.z; G[3] += (double)a.w;
         G[4] += (double)b.x; G[5] += (double)b.y; G[6] += (double)b.z; G[7] += (double)b.w;
@@ -802,13 +874,39 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) G[i] += __shfl_xor(G[i], o, 64);
     }
-    if (rec_e) {
+    double Dloc[27];
+    float tpf[3] = {0.f, 0.f, 0.f};
+    if (poses) {
+        double cv6[6], R[9], t[3], rod[3], Rre[9], J[27];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cv6[k] = poses[(size_t)h * 6 + k];
+        dm::cv2our(cv6, R, t);
+        tpf[0] = (float)t[0]; tpf[1] = (float)t[1]; tpf[2] = (float)t[2];  // t' as the fp32 numbers the main pass computed E from
+        dm::rodrigues_m2v(R, rod);
+        dm::rodrigues_v2m<true>(rod, Rre, J);  // rod = Rodrigues(R'), J = d Rodrigues(rod) / d rod   (core/cnn_softam.h:505-509)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int m = 0; m < 3; m++) {  // Omega_i = (dR / d rod_i) R^T (see k_backward_prep)
+                    double v = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) v += J[i * 9 + 3 * j + k] * Rre[3 * m + k];
+                    Dloc[i * 9 + 3 * j + m] = v;
+                }
+    }
+    if (rec_e || poses) {
         // matrix-core main pass: the sums were taken against E = R'X + t' (signed as the kernel held them):
         //   a[3j + m] = sum C~_j E~_m, a[9 + j] = sum C~_j  with C~ = (C0, -C1, -C2), E~ = (E.x, -E.y, E.z)
         // sum_p C_j (E - t')_m = sum C_j E_m - t'_m sum C_j  (t' as the fp32 record the kernel computed E from); X = R^T (E - t) is applied through
         // Omega below
-        const float* o = rec_e + (size_t)h * BWD_REC;
-        const double tp[3] = {o[6], -(double)o[7], o[11]};
+        double tp[3];
+        if (poses) { tp[0] = tpf[0]; tp[1] = tpf[1]; tp[2] = tpf[2]; }
+        else {
+            const float* o = rec_e + (size_t)h * BWD_REC;
+            tp[0] = o[6]; tp[1] = -(double)o[7]; tp[2] = o[11];
+        }
         // the kernel summed (C0 / f, -C1 / f, -C2) against (f E.x, -f E.y, E.z), off-diagonal pairs only
         const double sj[3] = {(double)f_e, -(double)f_e, -1}, sm[3] = {1.0 / (double)f_e, -1.0 / (double)f_e, 1};
         double A[3][3], B[3];
@@ -826,13 +924,13 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
         }
     }
     // rotation part: sum C_j X_k against dR/drod (VALU form), or sum C_j (E - t)_m against Omega = dR/drod R^T (matrix-core form)
-    const double* D = dRdH + (size_t)h * BWD_DRDH + (rec_e ? 27 : 0);
+    const double* D = poses ? nullptr : dRdH + (size_t)h * BWD_DRDH + (rec_e ? 27 : 0);
     double G6[6];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) s += G[k] * D[i * 9 + k];
+        for (int k = 0; k < 9; k++) s += G[k] * (poses ? Dloc[i * 9 + k] : D[i * 9 + k]);
         G6[i] = s;
         G6[3 + i] = G[9 + i];
     }
@@ -860,12 +958,13 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags, double* grad_xyz,
-                                 double* G6_scratch, const float* rec_if_e_based) {
+                                 double* G6_scratch, const float* rec_if_e_based, const double* poses_if_fused) {
     if (N <= 0) return hipSuccess;
     const size_t n3 = (size_t)F.P * 3;
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
+    // hyp_tiles == 0: the main pass has added its gradient into grad_xyz itself (K4Plan.direct)
+    if (hyp_tiles > 0) hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
     hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
-                       G6_scratch, rec_if_e_based, F.fx);
+                       G6_scratch, rec_if_e_based, F.fx, poses_if_fused);
     return hipGetLastError();
 }
 

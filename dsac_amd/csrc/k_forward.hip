@@ -872,7 +872,9 @@ bool reproject_variant_known(int v) {
     return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77);
 }
 
-int reproject_num_pixel_tiles(int P) { return (P + 63) / 64; }  // the largest count over all forms: one partial row per 64-pixel wave chunk
+// the largest count of partial-sum rows over all forms: one row per 64-pixel wave chunk, and the per-wave-sum forms with several waves per workgroup write
+// PT * WAVES rows (their idle waves of the last workgroup write zero rows): up to WAVES - 1 <= 15 rows beyond ceil(P / 64)
+int reproject_num_pixel_tiles(int P) { return (P + 63) / 64 + 15; }
 
 template <int PX, int HT, bool SPOSE>
 static hipError_t launch_reproject(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,

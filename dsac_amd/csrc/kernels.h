@@ -80,6 +80,8 @@ struct K4Plan {
     int HT, NT;   // hypotheses per workgroup, number of hypothesis tiles (rows of grad_part)
     int rows;     // rows of G12_part the launch writes
     int glayers;  // layers of grad_part per hypothesis tile (matrix-core form: 2 -- a pixel tile's hypothesis groups may be split between two workgroups)
+    bool fused = false;   // round 4: no backward_prep launch -- the main pass derives its records from the poses, the finish kernel dR/drod; G12_part [hyp][row][12]
+    bool direct = false;  // ... and (one hypothesis tile) the main pass adds its gradient straight into grad_xyz: no grad_part, no gradient reduction launch
 };
 K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant);
 bool backward_variant_known(int variant);  // -1 (auto), 0 .. 5, or a form + 10 * tile code + 100 * workgroups per CU (see backward_plan)
@@ -87,13 +89,16 @@ constexpr int BWD_DRDH = 54;  // per hypothesis: dR/drod (27) and Omega_i = (dR/
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x BWD_DRDH*/);
 // K4 main pass.  d_err (N x P) or nullptr with g (N doubles) for the soft-inlier score.
 //   grad_part : [hyp_tiles][P*3] floats       G12_part : [partial rows][N][12] floats
+// poses (cv, N x 6) / grad_xyz (P x 3 fp64, accumulated into) / flags: used when plan.fused / plan.direct (staged_bwd and grad_part may then be nullptr)
 hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const FrameDev& F, const float* d_err, const double* g,
-                          float clampv, float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan);
+                          float clampv, float tau, float beta, float* grad_part, float* G12_part, const K4Plan& plan, const double* poses = nullptr,
+                          double* grad_xyz = nullptr, unsigned flags = 0);
 // Epilogue: grad_xyz (P x 3 double) += sum over hyp tiles; then per hypothesis G6 = [G9 * dRdH, G3],
 // S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
-                                 double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr);
+                                 double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr, const double* poses_if_fused = nullptr);
+// hyp_tiles == 0: no gradient reduction (plan.direct); poses_if_fused: the cv poses when plan.fused (dRdH and rec_if_e_based are then unused)
 // rec_if_e_based: the BWD records when G12_part holds the matrix-core form's E-based sums (K4Plan.variant > 0), else nullptr
 // K4 parity mode (fp64, the reference's evaluation order; flags bit 0 = transposed columns, bit 2 = rotation write-back); jac_scratch: N x P*3 doubles
 hipError_t score_backward_parity(hipStream_t st, int N, const double* poses, const FrameDev& F, const float* d_err, const double* dpnp, const int32_t* sets,

@@ -7,7 +7,7 @@ A step is one pass over this rank's images.  Nothing in it waits:
   * the refinement tail of the LAST batch of step i runs under sampling and scoring of step i + 1 (with 8 ranks a step is a single batch: without
     this the 90-110 us K6 latency chain would sit exposed in every step);
   * the gather of step i is launched at the top of step i + 1 on a side stream that waits for that tail (dsac_tail_wait) -- beside K1 / K2 of step
-    i + 1, not in front of them -- and is consumed (ordered, copied to page-locked host memory) at the top of step i + 2;
+    i + 1, not in front of them -- and is consumed (ordered on that stream; its slot released for refilling) at the top of step i + 2;
   * the host never synchronises inside a step; drain() finishes the last step's tail and gather.
 Every image keeps the seed it has in the unsharded loop (seed0 + image index; "seed_stride" = world), so the results do not depend on the number
 of ranks, and they equal the in-order calls bit for bit (tests/test_gpu_shard.py).
@@ -26,7 +26,7 @@ from .capi import check, lib, ptr
 
 class ShardRunner:
     def __init__(self, engine, stream, device, frames_of, n_images, rank, world, N, H, W, cam, perm, gt_of=None, batch=16, group=None, emulate=False,
-                 seed0=1305, seed_per_step=64, write_err=True, defer=True):
+                 seed0=1305, seed_per_step=64, write_err=True, defer=True, host_copy=False):
         """frames_of(i) -> H*W x 3 float32 coordinate map of image i (host array); gt_of(i) -> jp 6-vector or None (zeros).  perm: refSteps x H*W int32
         (device tensor).  group: the process group of the sharding when world > 1 and not emulate."""
         self.eng, self.st, self.dev = engine, stream, device
@@ -46,6 +46,7 @@ class ShardRunner:
         self.gt = torch.from_numpy(g).to(device)
         self.perm = perm
         self.defer = defer
+        self.host_copy = host_copy
         if world > 1 and not emulate and group is None:
             import torch.distributed as tdist
             group = tdist.group.WORLD
@@ -92,9 +93,11 @@ class ShardRunner:
             self.ex.launch(slot)
 
     def _consume(self, slot):
-        """On the side stream: order it behind the slot's gather, copy the gathered rows to page-locked host memory, mark the slot reusable."""
+        """On the side stream: order it behind the slot's gather and mark the slot reusable; with host_copy also copy the gathered rows to page-locked
+        host memory (off by default: the gathered rows stay in HBM, drain() brings the last step's to the host -- on this stack torch's "non-blocking"
+        device-to-host copy held the calling thread for most of a step, profiles/r04_config3_emulated.json: 451 of 525 us of host time per step)."""
         with torch.cuda.stream(self.gs):
-            if self.ex.wait(slot):
+            if self.ex.wait(slot) and self.host_copy:
                 self.ex.to_host(slot)
             self.consumed[slot].record(self.gs)
             self.consumed_valid[slot] = True
@@ -136,6 +139,9 @@ class ShardRunner:
             self._consume(1 - k)
         self._launch_gather(k)
         self._consume(k)
+        with torch.cuda.stream(self.gs):
+            if self.ex.host is not None:
+                self.ex.to_host(k)
         self.gs.synchronize()
         self.eng.joinTail()
         self.eng.synchronize()

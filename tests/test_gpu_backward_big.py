@@ -66,20 +66,26 @@ def big_case(request, orc, synth, engine):
         e = orc.get_diff_maps(poses[idx], fr["xyz"], uv, H, W, fr["cam"]).astype(np.float64)
         s = 1.0 / (1.0 + np.exp(-BETA * (TAU - e)))
         d = g[idx, None] * (-BETA) * s * (1 - s)
-        d[np.arange(d.shape[0])[:, None], sets[idx]] = 0
+        # only the three points P3P was solved from have a zero residual (round-off direction, see own_bound below); the set's FOURTH point is an
+        # ordinary cell with a residual of several pixels and a large weight (rounds 1-3 dropped it on the oracle's side too: that, not round-off,
+        # was the 1e-2 "own-cell effect" of the pose sums -- profiles/r04_diag_k4_soft.txt)
+        rows = np.arange(d.shape[0])[:, None]
+        zero_res = e[rows, sets[idx]] < 1e-3
+        d[rows, sets[idx]] = np.where(zero_res, 0.0, d[rows, sets[idx]])
         return d
     ref_s, G6_s = _oracle(orc, fr, uv, sets, active, soft_ddiff)
-    # The own-cell effect, removed on the ORACLE's side: at a hypothesis' own four cells the residual is zero up to round-off (1e-10 px in fp64, a few
-    # 1e-5 px in fp32), so d|r|/dr is a unit vector u of round-off on every implementation, while sigmoid' is NOT zero there.  The oracle's sums above
-    # leave those cells out; whatever direction u takes, the cells can move component k of the pose sum of hypothesis h by at most
-    #   bound[h, k] = sum over its 4 cells of |g_h| * beta * s0 (1 - s0) * |(dP/dH)_k|,    s0 = sigmoid(beta * tau),
+    # The own-cell effect, removed on the ORACLE's side: at the three cells a hypothesis was solved from the residual is zero up to round-off (1e-10 px
+    # in fp64, a few 1e-5 px in fp32), so d|r|/dr is a unit vector u of round-off on every implementation, while sigmoid' is NOT zero there.  The oracle's
+    # sums above leave those cells out; whatever direction u takes, the cells can move component k of the pose sum of hypothesis h by at most
+    #   bound[h, k] = sum over those cells of |g_h| * beta * s0 (1 - s0) * |(dP/dH)_k|,    s0 = sigmoid(beta * tau),
     # with (dP/dH)_k the 2-vector of pixel derivatives (taken from dProjectdHyp with a unit residual along x, then along y).  The engine's sums are
     # compared with the oracle's up to exactly that bound.
     s0 = 1.0 / (1.0 + np.exp(-BETA * TAU))
     own_bound = np.zeros((N, 6))
     for h in active:
         R, t = orc.cv2our(poses[h])
-        for p in sets[h]:
+        e_own = orc.get_diff_maps(poses[h:h + 1], fr["xyz"][sets[h]], uv[sets[h]], 1, 4, fr["cam"])[0]
+        for p in sets[h][e_own < 1e-3]:
             X = fr["xyz"][p]
             px = uv[p].astype(np.float64)  # the projection of an own cell is the cell itself (|r| ~ 1e-10 px)
             Jx = orc.dProjectdHyp((px + np.array([1.0, 0.0])).astype(np.float32), X, R, t, fr["cam"])

@@ -89,6 +89,29 @@ def test_many_hypotheses_and_big_frame(engine, orc, synth):
     assert np.abs(e[:, cells] - ref)[m].max() <= 2e-3  # larger focal length and coordinates: fp32 projection error grows with f
 
 
+@pytest.mark.parametrize("variant", [53, 55, 57, 65, 69, 72])
+def test_per_wave_sum_forms_on_a_map_whose_chunk_count_is_not_a_multiple_of_the_waves(engine, orc, synth, variant):
+    """The per-wave partial-sum forms with several waves per workgroup write PT * WAVES rows of partial sums; on the reference's 40 x 40 map
+    (25 chunks of 64 cells) that exceeds ceil(P / 64) -- the scratch must hold them (it held 25 rows for 28) and the idle waves' zero rows
+    must not disturb the sums."""
+    fr = synth.chess_like_frame(40, 40, seed=5, quantise_int16=True)
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    poses, sets, ok, _ = orc.sample(128, 3, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    ref_err = orc.get_diff_maps(poses, fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    ref = orc.soft_inlier(ref_err, 10.0, 0.5)
+    engine.set_option("k2_variant", variant)
+    try:
+        for rep in range(3):  # an overflow would corrupt a neighbouring allocation: repeat and compare everything
+            err = np.zeros((128, 1600), np.float32)
+            soft = np.zeros(128)
+            engine.reproject(poses, err=err, soft=soft)
+            assert np.abs(soft - ref).max() <= 1e-4 * max(1.0, ref.max())
+            m = excl_clamp_edge(err, ref_err)
+            assert np.abs(err - ref_err)[m].max() <= 1e-3
+    finally:
+        engine.set_option("k2_variant", -1)
+
+
 def test_frames_can_be_replaced_and_contexts_are_independent(orc, synth):
     a = synth.chess_like_frame(40, 40, seed=1)
     b = synth.chess_like_frame(24, 56, seed=2)

@@ -43,9 +43,9 @@ def _check_scores(orc, soft_gpu, w_gpu, poses, xyz, uv, cam, what, engine=None):
     rel = margin("north*", "soft-inlier scores at 640x480 (sum of 307 200 sigmoids): max |soft - oracle| relative to the largest score", np.abs(soft_gpu - soft_ref).max() / max(1.0, np.abs(soft_ref).max()), 1e-4)
     # K3 proper: the GPU's softmax of the GPU's own scores
     margin("a4", "K3 at 640x480: softmax of the GPU's own scores vs the oracle's softmax of the same numbers", np.abs(w_gpu - orc.softMax(SCALE * soft_gpu)).max(), 1e-12)
-    # ... and end to end through the scores: 0.1 x (sum of 307 200 fp32-rounded sigmoids).  BASELINE.md 3 states 1e-4 for the reference-sized map (met:
-    # 2e-6); at 640x480 the fp32 residual rounding (1e-4 px) moves a score by ~7e-3, i.e. a weight by ~7e-4 of itself: asserted 1e-3
-    dw = margin("a4", "softmax weights at 640x480, scale 0.1, from the ORACLE's scores of the same poses: max |w - oracle|", np.abs(w_gpu - orc.softMax(SCALE * soft_ref)).max(), 1e-3, stated=1e-4)
+    # ... and end to end through the scores, 0.1 x (sum of 307 200 fp32-rounded sigmoids): the stated 1e-4 holds on these frames with six orders
+    # of margin because the distribution is nearly one-hot; the worst case -- two hypotheses in a tie -- is test_softmax_weights_in_a_tie_at_640x480
+    dw = margin("a4", "softmax weights at 640x480, scale 0.1, from the ORACLE's scores of the same poses: max |w - oracle|", np.abs(w_gpu - orc.softMax(SCALE * soft_ref)).max(), 1e-4)
     if engine is not None:
         # with the bench's scale (0.1) a 640x480 softmax is one-hot (scores ~1e5); a scale that spreads the weights makes the comparison bite
         w2, _, _ = engine.softMax(soft_gpu, 1e-3)
@@ -96,6 +96,30 @@ def test_bench_shape_frame_batch_against_the_oracle(engine, orc, synth):
     print("bench shape: K2 %.1f us, worst residual difference %.2e px, last frame soft rel %.2e, dw %.2e" % (ms * 1e3, worst, rel, dw))
 
 
+def test_softmax_weights_in_a_tie_at_640x480(engine, orc, synth):
+    """The worst case for the softmax weights at this map size: two hypotheses whose scores tie.  A weight then moves by w (1 - w) * scale * (score error)
+    = 0.25 * 0.1 * delta: with scores ~2e4 summed from 307 200 fp32-rounded sigmoids (measured relative error 1e-6, i.e. delta ~ 0.02) that is ~5e-4 --
+    above BASELINE.md 3's 1e-4, which therefore holds at 640x480 for distributions without ties only (the one-hot frames of the other tests: 1e-10) and
+    is stated as 1e-3 for ties.  The best hypothesis of a frame is duplicated with a pose moved by 1e-9 rad / 1e-6 mm."""
+    fr = synth.chess_like_frame(H, W, seed=1305 + 1000)
+    uv = synth.pixel_grid(H, W)
+    cam = fr["cam"]
+    engine.set_frame(fr["xyz"], None, H, W, cam)
+    poses, sets, ok = engine.sample(256, seed=4711, thr=10.0, max_tries=1 << 16)
+    soft0 = engine.softInlierScores(poses, tau=TAU, beta=BETA)
+    best = int(np.argmax(soft0))
+    tie = poses.copy()
+    tie[(best + 1) % 256] = poses[best] + np.array([1e-9, -1e-9, 1e-9, 1e-6, 1e-6, -1e-6])
+    soft = engine.softInlierScores(tie, tau=TAU, beta=BETA)
+    w, _, _ = engine.softMax(soft, SCALE)
+    soft_ref = orc.soft_inlier(orc.get_diff_maps(tie, fr["xyz"], uv, H, W, cam), TAU, BETA)
+    w_ref = orc.softMax(SCALE * soft_ref)
+    top2 = np.sort(w_ref)[-2:]
+    assert top2[0] > 0.2, "the constructed pair is not a tie: %s" % top2  # both carry weight
+    margin("a4", "softmax weights at 640x480 in a TIE of the two best hypotheses (worst case), scale 0.1: max |w - oracle|", np.abs(w - w_ref).max(), 1e-3, stated=1e-4)
+    margin("a4", "... the score difference behind it: |soft - oracle| of the tied pair (absolute, scores ~2e4)", np.abs(soft - soft_ref)[[best, (best + 1) % 256]].max(), 0.05)
+
+
 @pytest.mark.parametrize("mode", ["err", "both"])
 def test_config2_4096_hypotheses_against_the_oracle(engine, orc, synth, mode):
     """BASELINE.json configs[2]: random coordinate map (seed 7), 4096 random poses, K2 alone."""
@@ -124,7 +148,7 @@ def test_config2_4096_hypotheses_against_the_oracle(engine, orc, synth, mode):
         assert rel <= 1e-4, "configs[2] soft scores differ by %.3e" % rel
         w, entr, _ = engine.softMax(sg, SCALE)
         assert np.abs(w - orc.softMax(SCALE * sg)).max() <= 1e-12
-        margin("a4", "configs[2] (N = 4096): softmax weights, scale 0.1, from the oracle's scores: max |w - oracle|", np.abs(w - orc.softMax(SCALE * sr)).max(), 1e-3, stated=1e-4)
+        margin("a4", "configs[2] (N = 4096): softmax weights, scale 0.1, from the oracle's scores: max |w - oracle|", np.abs(w - orc.softMax(SCALE * sr)).max(), 1e-4)
     print("configs[2] %s: worst residual difference %.2e px" % (mode, worst))
     del err
     torch.cuda.empty_cache()
