@@ -702,7 +702,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
 int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_dpnp: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_dpnp: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    if (c->F.frames > 1 && N % c->F.frames != 0) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: with a frame batch N must be frames x (sets per frame), got %d for %d frames", N, c->F.frames);
     if (N < 0 || !sets || !J || !(eps > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_dpnp: need sets, J and eps > 0");
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -711,7 +711,7 @@ int dsac_dpnp(dsac_ctx* c, int N, const int32_t* sets, float eps, double* J) {
     double* d_J;
     ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
     ARG_TRY(out_arg(c, J, (size_t)N * 72, &d_J));
-    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, eps, d_J));
+    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, eps, d_J, c->F.frames > 1 ? N / c->F.frames : 0));
     return end_call(c);
 }
 
@@ -788,7 +788,11 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
                                  double* grad_xyz) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "%s: ctx is NULL", who);
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "%s: no frame set", who);
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "%s: a frame batch is set; only dsac_score_hypotheses_frames works on batches", who);
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    const int Nf = frames > 1 ? N / frames : 0;
+    if (frames > 1 && (N % frames != 0 || Nf % 16 != 0 || Nf > 256))
+        return fail(c, DSAC_ERR_INVALID, "%s: with a frame batch N must be frames x (hypotheses per frame: a multiple of 16, at most 256), got %d for %d frames", who, N, frames);
+    if (frames > 1 && (flags & DSAC_BWD_PARITY_FP64)) return fail(c, DSAC_ERR_INVALID, "%s: the fp64 parity mode works on one frame", who);
     // the reference's jp-convention Jacobians use one focal length, f = camMat(0,0), for both axes (core/cnn_softam.h:406,466);
     // a camera with fx != fy would make this backward inconsistent with the forward kernels, which honour both
     if (c->F.fx != c->F.fy) return fail(c, DSAC_ERR_INVALID, "%s: needs fx == fy (got %g, %g): dProjectdObj / dProjectdHyp use a single focal length", who,
@@ -814,11 +818,11 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     ARG_TRY(in_arg(c, d_err, (size_t)N * P, &d_derr));
     ARG_TRY(in_arg(c, g, (size_t)N, &d_g));
     ARG_TRY(in_arg(c, dpnp_or_null, (size_t)N * 72, &d_dpnp));
-    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    ARG_TRY(out_arg(c, grad_xyz, (size_t)frames * P * 3, &d_grad, /*preload=*/true));
     if (!d_dpnp) {  // dPNP with the reference's default eps (core/cnn_softam.h:104)
         DevBuf& s = next_slot(c);
         HIP_TRY(c, s.reserve((size_t)N * 72 * sizeof(double)));
-        HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>()));
+        HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>(), Nf));
         d_dpnp = s.as<double>();
     }
     if (parity) {
@@ -830,7 +834,10 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         c->g6_n = N;
         return end_call(c);
     }
-    const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant);
+    const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant, Nf);
+    if (plan.Nf < 0)
+        return fail(c, DSAC_ERR_INVALID, "%s: this map / kernel form (k4_variant %d) has no frame-batch mode (needs the matrix-core form: 16-byte aligned buffers, "
+                                         "H*W and W multiples of 4)", who, c->k4_variant);
     // Round 4, the fused stage (plan.fused): two launches instead of four -- the main pass derives its hypothesis records from the poses in its prologue
     // and (one hypothesis tile: plan.direct) adds the gradient straight into grad_xyz, the finish kernel derives dR/drod itself.  The round-3 staging
     // (k_backward_prep -> main -> k_grad_reduce -> k_support_scatter) remains for the VALU form and behind k4_variant + 1000.
@@ -849,7 +856,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     }
     HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.direct ? 0 : plan.NT * plan.glayers, c->g12_part.as<float>(), plan.rows,
                                          c->dRdH.as<double>(), d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(),
-                                         (plan.variant > 0 && !plan.fused) ? c->bwd_staged.as<float>() : nullptr, plan.fused ? d_poses : nullptr));
+                                         (plan.variant > 0 && !plan.fused) ? c->bwd_staged.as<float>() : nullptr, plan.fused ? d_poses : nullptr, Nf));
     c->g6_n = N;
     return end_call(c);
 }
@@ -857,7 +864,6 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
 int dsac_last_pose_gradients(dsac_ctx* c, int N, double* G6) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_last_pose_gradients: ctx is NULL");
     if (N < 0 || !G6) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: NULL argument or negative count");
-    if (c->have_frame && c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: a frame batch is set");
     if (N > c->g6_n) return fail(c, DSAC_ERR_INVALID, "dsac_last_pose_gradients: %d requested, the last score-backward call had %d", N, c->g6_n);
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -917,7 +923,7 @@ int dsac_refine_fd(dsac_ctx* c, const double* init_pose, const int32_t* perm, in
                    int cap, int32_t* n_obj) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;  // frame batch: every per-image argument holds one slice per frame, one launch per stage
     if (!init_pose || !perm || !inlier_map || !J_hyp || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
         return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd: need 1 <= max_inl <= 256");
@@ -931,30 +937,32 @@ int dsac_refine_fd(dsac_ctx* c, const double* init_pose, const int32_t* perm, in
     const int32_t *d_perm, *d_map;
     double *d_Jh, *d_Jo;
     int32_t *d_px, *d_n;
-    ARG_TRY(in_arg(c, init_pose, 6, &d_init));
+    const size_t Fz = (size_t)frames;
+    ARG_TRY(in_arg(c, init_pose, Fz * 6, &d_init));
     ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
-    ARG_TRY(in_arg(c, inlier_map, P, &d_map));
-    ARG_TRY(out_arg(c, J_hyp, 36, &d_Jh));
-    ARG_TRY(out_arg(c, obj_pixels, (size_t)cap, &d_px));
-    ARG_TRY(out_arg(c, J_obj, (size_t)cap * 18, &d_Jo));
-    ARG_TRY(out_arg(c, n_obj, 1, &d_n));
-    const size_t B = 12 + 6 * (size_t)cap;
+    ARG_TRY(in_arg(c, inlier_map, Fz * P, &d_map));
+    ARG_TRY(out_arg(c, J_hyp, Fz * 36, &d_Jh));
+    ARG_TRY(out_arg(c, obj_pixels, Fz * (size_t)cap, &d_px));
+    ARG_TRY(out_arg(c, J_obj, Fz * (size_t)cap * 18, &d_Jo));
+    ARG_TRY(out_arg(c, n_obj, Fz, &d_n));
+    const size_t B = (12 + 6 * (size_t)cap) * Fz;
     DevBuf& rp = next_slot(c); HIP_TRY(c, rp.reserve(B * 6 * sizeof(double)));
     DevBuf& rx = next_slot(c); HIP_TRY(c, rx.reserve(B * 2 * sizeof(int32_t)));
     DevBuf& rv = next_slot(c); HIP_TRY(c, rv.reserve(B * sizeof(float)));
     DevBuf& ro = next_slot(c); HIP_TRY(c, ro.reserve(B * 6 * sizeof(double)));
-    DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap + 1) * sizeof(int32_t)));
+    DevBuf& px = next_slot(c); HIP_TRY(c, px.reserve(((size_t)cap * Fz + 1) * sizeof(int32_t)));
     int32_t* d_pxbuf = d_px ? d_px : px.as<int32_t>();
     int32_t* plan_scratch = nullptr;
     if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
         DevBuf& ps = next_slot(c);
-        HIP_TRY(c, ps.reserve(ni * sizeof(int32_t)));
+        HIP_TRY(c, ps.reserve(ni * Fz * sizeof(int32_t)));
         plan_scratch = ps.as<int32_t>();
     }
     HIP_TRY(c, dk::refine_fd_plan(c->stream, d_init, d_map, c->F, skip, eps_hyp, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_pxbuf, d_n,
-                                  plan_scratch));
-    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>()));
-    HIP_TRY(c, dk::refine_fd_finish(c->stream, ro.as<double>(), d_n, cap, skip, eps_hyp, eps_obj, d_Jh, d_Jo));
+                                  plan_scratch, frames, cap));
+    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F, ro.as<double>(),
+                                 frames));
+    HIP_TRY(c, dk::refine_fd_finish(c->stream, ro.as<double>(), d_n, cap, skip, eps_hyp, eps_obj, d_Jh, d_Jo, frames));
     return end_call(c);
 }
 
@@ -1133,8 +1141,11 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
                         double* v6_out_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_backward_path1: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_backward_path1: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
-    if (N <= 0 || !poses || !sets || !w || !avg_cv6 || !ref_cv6 || !gt_jp6 || !perm || !inlier_map || !grad_xyz || !g || steps < 0)
+    // frame batch: N = frames x hypotheses per frame; every per-hypothesis array is frame-major, every per-image argument (avg, ref, gt, inlier map, grad_xyz,
+    // dL, v6) holds one slice per frame; each stage of the chain is ONE launch over all frames (core/train_ransac_softam.cpp:288-376 is per image)
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (N <= 0 || N % frames != 0) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: N must be positive and frames x (hypotheses per frame)");
+    if (!poses || !sets || !w || !avg_cv6 || !ref_cv6 || !gt_jp6 || !perm || !inlier_map || !grad_xyz || !g || steps < 0)
         return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: NULL argument or bad count");
     if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: need 1 <= max_inl <= 256");
     if (!(sub_sample > 0.f) || !(eps_hyp > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: sub_sample, eps_hyp, eps_obj must be > 0");
@@ -1142,59 +1153,60 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
     if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_backward_path1: sub_sample > 1");
     HIP_TRY(c, hipSetDevice(c->device));
     begin_call(c);
-    const size_t P = (size_t)c->F.P;
+    const size_t P = (size_t)c->F.P, Fz = (size_t)frames;
+    const int Nf = N / frames;
     const double *d_poses, *d_w, *d_avg, *d_ref, *d_gt;
     const int32_t *d_sets, *d_perm, *d_map;
     double *d_dpnp, *d_grad, *d_g, *d_dL, *d_v6;
     ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
     ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
     ARG_TRY(in_arg(c, w, (size_t)N, &d_w));
-    ARG_TRY(in_arg(c, avg_cv6, 6, &d_avg));
-    ARG_TRY(in_arg(c, ref_cv6, 6, &d_ref));
-    ARG_TRY(in_arg(c, gt_jp6, 6, &d_gt));
+    ARG_TRY(in_arg(c, avg_cv6, Fz * 6, &d_avg));
+    ARG_TRY(in_arg(c, ref_cv6, Fz * 6, &d_ref));
+    ARG_TRY(in_arg(c, gt_jp6, Fz * 6, &d_gt));
     ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
-    ARG_TRY(in_arg(c, inlier_map, P, &d_map));
+    ARG_TRY(in_arg(c, inlier_map, Fz * P, &d_map));
     ARG_TRY(out_arg(c, dpnp_out_or_null, (size_t)N * 72, &d_dpnp));
-    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    ARG_TRY(out_arg(c, grad_xyz, Fz * P * 3, &d_grad, /*preload=*/true));
     ARG_TRY(out_arg(c, g, (size_t)N, &d_g));
-    ARG_TRY(out_arg(c, dL_out_or_null, 6, &d_dL));
-    ARG_TRY(out_arg(c, v6_out_or_null, 6, &d_v6));
+    ARG_TRY(out_arg(c, dL_out_or_null, Fz * 6, &d_dL));
+    ARG_TRY(out_arg(c, v6_out_or_null, Fz * 6, &d_v6));
     // the inlier map holds at most steps * max_inl hits, every skip-th of them is differentiated
     const int cap = (int)std::min<size_t>(4096, (size_t)steps * (size_t)max_inl / (size_t)skip + 1);
-    const size_t B = 12 + 6 * (size_t)cap;
-    DevBuf& sc = next_slot(c);  // dL 6 | out4 4 | v6 6 | J_hyp 36 | J_obj cap*18 | rep poses B*6 | rep out B*6   (doubles)
-    const size_t nd = 6 + 4 + 6 + 36 + (size_t)cap * 18 + B * 6 + B * 6;
+    const size_t R = 12 + 6 * (size_t)cap, B = R * Fz;
+    DevBuf& sc = next_slot(c);  // per frame: dL 6 | out4 4 | v6 6 | J_hyp 36 | J_obj cap*18 ; then rep poses B*6 | rep out B*6   (doubles)
+    const size_t nd = Fz * (6 + 4 + 6 + 36 + (size_t)cap * 18) + B * 6 + B * 6;
     HIP_TRY(c, sc.reserve(nd * sizeof(double)));
     double* base = sc.as<double>();
-    double *s_dL = d_dL ? d_dL : base, *s_out4 = base + 6, *s_v6 = d_v6 ? d_v6 : base + 10, *s_Jh = base + 16, *s_Jo = base + 52;
-    double *s_rp = s_Jo + (size_t)cap * 18, *s_ro = s_rp + B * 6;
-    DevBuf& si = next_slot(c);  // rep px/c B*2 | obj pixels cap + 1 | n 1  (int32) ; rep value B (float)
-    HIP_TRY(c, si.reserve((B * 2 + (size_t)cap + 2) * sizeof(int32_t) + B * sizeof(float)));
+    double *s_dL = d_dL ? d_dL : base, *s_out4 = base + Fz * 6, *s_v6 = d_v6 ? d_v6 : base + Fz * 10, *s_Jh = base + Fz * 16, *s_Jo = base + Fz * 52;
+    double *s_rp = s_Jo + Fz * (size_t)cap * 18, *s_ro = s_rp + B * 6;
+    DevBuf& si = next_slot(c);  // rep px/c B*2 | obj pixels frames*cap + 1 | n frames  (int32) ; rep value B (float)
+    HIP_TRY(c, si.reserve((B * 2 + Fz * (size_t)cap + 1 + Fz) * sizeof(int32_t) + B * sizeof(float)));
     int32_t* s_rx = si.as<int32_t>();
     int32_t* s_px = s_rx + B * 2;
-    int32_t* s_n = s_px + cap + 1;
-    float* s_rv = reinterpret_cast<float*>(s_n + 1);
+    int32_t* s_n = s_px + Fz * (size_t)cap + 1;
+    float* s_rv = reinterpret_cast<float*>(s_n + Fz);
     if (!d_dpnp) {
         DevBuf& sd = next_slot(c);
         HIP_TRY(c, sd.reserve((size_t)N * 72 * sizeof(double)));
         d_dpnp = sd.as<double>();
     }
-    // dLossMax at the refined pose (train_ransac_softam.cpp:301-304)
-    HIP_TRY(c, dk::pose_loss(c->stream, 1, d_ref, d_gt, s_out4, s_dL));
+    // dLossMax at the refined pose (train_ransac_softam.cpp:301-304), one ground truth per frame
+    HIP_TRY(c, dk::pose_loss(c->stream, frames, d_ref, d_gt, s_out4, s_dL, 6));
     // dRefineObj / dRefineHyp as one batch of finite-difference replicas (:307-341)
     int32_t* plan_scratch = nullptr;
     if (const size_t ni = dk::refine_fd_plan_scratch_ints(c->F)) {
         DevBuf& ps = next_slot(c);
-        HIP_TRY(c, ps.reserve(ni * sizeof(int32_t)));
+        HIP_TRY(c, ps.reserve(ni * Fz * sizeof(int32_t)));
         plan_scratch = ps.as<int32_t>();
     }
-    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n, plan_scratch));
-    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, s_n, s_rp, d_perm, steps, max_inl, min_inl, thr, s_rx, s_rv, c->F, s_ro));
-    HIP_TRY(c, dk::refine_fd_finish(c->stream, s_ro, s_n, cap, skip, eps_hyp, eps_obj, s_Jh, s_Jo));
-    HIP_TRY(c, dk::path1_assemble(c->stream, s_dL, s_Jh, s_px, s_Jo, s_n, cap, (int)P, d_grad, s_v6));
+    HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n, plan_scratch, frames, cap));
+    HIP_TRY(c, dk::refine_fd_run(c->stream, cap, s_n, s_rp, d_perm, steps, max_inl, min_inl, thr, s_rx, s_rv, c->F, s_ro, frames));
+    HIP_TRY(c, dk::refine_fd_finish(c->stream, s_ro, s_n, cap, skip, eps_hyp, eps_obj, s_Jh, s_Jo, frames));
+    HIP_TRY(c, dk::path1_assemble(c->stream, s_dL, s_Jh, s_px, s_Jo, s_n, cap, (int)P, d_grad, s_v6, frames, cap));
     // sum_h w_h dPNP_h to the support points and the softmax backward (:344-376)
-    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp));
-    HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale));
+    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp, Nf));
+    HIP_TRY(c, dk::path1_softmax_backward(c->stream, Nf, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale, frames));
     return end_call(c);
 }
 
@@ -1350,8 +1362,8 @@ int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const 
                                     const double* dpnp, double* grad_xyz, double* g) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_path1_and_softmax_backward: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
-    if (N <= 0 || !v6 || !w || !poses || !g) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: NULL argument");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;  // frame batch: N = frames x hypotheses per frame, v6 frames x 6, grad_xyz frames x H*W x 3
+    if (N <= 0 || N % frames != 0 || !v6 || !w || !poses || !g) return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: NULL argument or N not frames x hypotheses per frame");
     if ((grad_xyz != nullptr) != (dpnp != nullptr) || (grad_xyz && !sets))
         return fail(c, DSAC_ERR_INVALID, "dsac_path1_and_softmax_backward: grad_xyz, dpnp and sets go together");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1360,14 +1372,14 @@ int dsac_path1_and_softmax_backward(dsac_ctx* c, int N, const double* v6, const 
     const double *d_v6, *d_w, *d_poses, *d_dpnp;
     const int32_t* d_sets;
     double *d_grad, *d_g;
-    ARG_TRY(in_arg(c, v6, 6, &d_v6));
+    ARG_TRY(in_arg(c, v6, (size_t)frames * 6, &d_v6));
     ARG_TRY(in_arg(c, w, (size_t)N, &d_w));
     ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
     ARG_TRY(in_arg(c, sets, (size_t)N * 4, &d_sets));
     ARG_TRY(in_arg(c, dpnp, (size_t)N * 72, &d_dpnp));
-    ARG_TRY(out_arg(c, grad_xyz, P * 3, &d_grad, /*preload=*/true));
+    ARG_TRY(out_arg(c, grad_xyz, (size_t)frames * P * 3, &d_grad, /*preload=*/true));
     ARG_TRY(out_arg(c, g, (size_t)N, &d_g));
-    HIP_TRY(c, dk::path1_softmax_backward(c->stream, N, c->F.P, d_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g));
+    HIP_TRY(c, dk::path1_softmax_backward(c->stream, N / frames, c->F.P, d_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, 1.0, frames));
     return end_call(c);
 }
 

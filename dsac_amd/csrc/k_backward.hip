@@ -351,7 +351,8 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
                                                                     const double* __restrict__ g, float* __restrict__ grad_part,
                                                                     float* __restrict__ G12_part, int N, int P, int W, int PT, int NT, int G,
                                                                     float f, float cx, float cy, float clampv, float kA, float kB, float beta, int HT,
-                                                                    const double* __restrict__ poses, double* __restrict__ grad_direct, unsigned gflags) {
+                                                                    const double* __restrict__ poses, double* __restrict__ grad_direct, unsigned gflags,
+                                                                    int frame_Nf, long long xyz_stride, long long uv_stride) {
     // Round 4 (the fused stage): poses != nullptr -> the workgroup derives its hypothesis records from the cv poses itself (no k_backward_prep launch,
     // no record image in HBM) and writes G12_part hypothesis-major ([hyp][row][12]: the finish kernel reads a hypothesis' rows as one contiguous run);
     // grad_direct != nullptr (one hypothesis tile, N <= 256) -> the workgroups add their gradient straight into the caller's fp64 grad_xyz with atomics
@@ -363,6 +364,12 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     const int ngi = (nh + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, gq = lane >> 4;
+    if (frame_Nf > 0) {  // frame batch: one hypothesis tile per frame -- its coordinate map, pixel positions and gradient
+        const int fr = h0 / frame_Nf;
+        xyz += (long long)fr * xyz_stride;
+        if (UV) uv += (long long)fr * uv_stride;
+        if (grad_direct) grad_direct += (size_t)fr * P * 3;
+    }
 
     // LDS: MFMA B operands in lane order (x row, negated y row, z row of 16 hypotheses), the per-hypothesis coefficients of the
     // gradient accumulation, and the 12 sums of every (hypothesis, wave) accumulated over the workgroup's pixel tiles
@@ -696,9 +703,11 @@ bool backward_variant_known(int v) {
     return form <= 7 && tile <= 3 && wgs <= 8;
 }
 
-K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) {
+K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant, int Nf) {
     K4Plan pl{};
     pl.glayers = 1;
+    const bool batch = Nf > 0 && F.frames > 1;
+    if (batch && (Nf % 16 != 0 || Nf > K4M_HT_MAX || N % Nf != 0 || (variant >= 0 && variant % 10 == 0) || variant >= 1000)) { pl.variant = 0; pl.Nf = -1; return pl; }
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
     // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
@@ -717,6 +726,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
     // the matrix-core form reads 4 consecutive pixels per lane as one row of the implicit grid
     if (!vec || variant > 7 || (!F.uv && F.W % 4 != 0)) variant = 0;
     pl.variant = variant;
+    if (batch && variant == 0) { pl.Nf = -1; return pl; }  // the VALU fallback form has no batch mode
     if (variant == 0) {
         pl.HT = 32;
         const int tile = vec ? K4_THREADS * 4 * K4_PXG : K4_THREADS;
@@ -726,7 +736,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // 16 hypothesis groups -- 37 us of pure latency for 0.4 M pairs.  When the tiles would not even give every CU a workgroup, take 2
         // chunks per wave and the largest hypothesis tile that does (down to one 16-hypothesis group per workgroup).
         int ht_small = 0;
-        if (auto_form && ht_code == 0) {
+        if (auto_form && ht_code == 0 && !batch) {
             const int CHb = k4m_chunks(variant), PTb = (F.P + 64 * CHb - 1) / (64 * CHb);
             const int HTb = min(K4M_HT_MAX, ((max(N, 1) + 15) / 16) * 16), NTb = (max(N, 1) + HTb - 1) / HTb;
             if (PTb * NTb < 256) {
@@ -746,6 +756,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         const bool hi_occ = variant >= 6;
         const int ht_max = ht_code == 1 ? 64 : (ht_code == 2 || (hi_occ && ht_code == 0)) ? 128 : K4M_HT_MAX;
         pl.HT = min(ht_small > 0 ? ht_small : ht_max, ((max(N, 1) + 15) / 16) * 16);
+        if (batch) pl.HT = Nf;  // one hypothesis tile per frame
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
         pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : hi_occ ? k4m_min_waves(variant) : 2) * 256 + pl.NT - 1) / pl.NT));
         // every workgroup takes the same number of (tile, 16-hypothesis group) items: at least one group each
@@ -754,7 +765,8 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant) 
         // round 4: the workgroups derive their records from the poses (no prep launch), G12_part is hypothesis-major, and with a single hypothesis
         // tile the gradient goes straight into grad_xyz (whole pixel tiles per workgroup: no more workgroups than tiles)
         pl.fused = !legacy;
-        pl.direct = pl.fused && pl.NT == 1;
+        pl.direct = pl.fused && (pl.NT == 1 || batch);
+        pl.Nf = batch ? Nf : 0;
         return pl;
     }
     pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
@@ -787,7 +799,8 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                            \
         if (e_ != hipSuccess) return e_;                                                                                                    \
         hipLaunchKernelGGL((k_score_backward_mfma<C_, S_, U_, W_>), dim3(grid), dim3(K4_THREADS), lds, st, staged_bwd, F.xyz, F.uv, d_err, g,   \
-                           grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT, k_poses, k_direct, flags);  \
+                           grad_part, G12_part, N, F.P, F.W, PT, NT, G, F.fx, F.cx, F.cy, clampv, kA, kB, beta, HT, k_poses, k_direct, flags,   \
+                           plan.Nf, F.xyz_stride, F.uv_stride);                                                                                  \
     } while (0)
 #define DSAC_K4M_CH(C_, W_)                                                                              \
     do {                                                                                                 \
@@ -852,13 +865,14 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
                                                          const double* __restrict__ dRdH, const double* __restrict__ dpnp,
                                                          const int32_t* __restrict__ sets, int P, unsigned flags, double* __restrict__ grad_xyz,
                                                          double* __restrict__ G6_out, const float* __restrict__ rec_e, float f_e,
-                                                         const double* __restrict__ poses) {
+                                                         const double* __restrict__ poses, int Nf) {
     // poses != nullptr (round 4, the fused stage): G12_part is hypothesis-major ([hyp][row][12]: a wave reads 48 contiguous bytes per lane, the
     // whole hypothesis one contiguous run), the E-based sums apply, and dR/drod, Omega and t' are derived here from the cv pose -- every lane of the
     // hypothesis' wave redundantly, under the partial-row loads -- instead of being read from k_backward_prep's output
     const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
+    if (Nf > 0) grad_xyz += (size_t)(h / Nf) * P * 3;  // frame batch: the support cells of hypothesis h lie in frame h / Nf
     double G[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) G[i] = 0;
@@ -958,13 +972,13 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
 
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags, double* grad_xyz,
-                                 double* G6_scratch, const float* rec_if_e_based, const double* poses_if_fused) {
+                                 double* G6_scratch, const float* rec_if_e_based, const double* poses_if_fused, int Nf) {
     if (N <= 0) return hipSuccess;
     const size_t n3 = (size_t)F.P * 3;
     // hyp_tiles == 0: the main pass has added its gradient into grad_xyz itself (K4Plan.direct)
     if (hyp_tiles > 0) hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, F.P, F.W, F.H, hyp_tiles, grad_part, flags, grad_xyz);
     hipLaunchKernelGGL(k_support_scatter, dim3((N + 3) / 4), dim3(256), 0, st, N, F.W, pixel_tiles, G12_part, dRdH, dpnp, sets, F.P, flags, grad_xyz,
-                       G6_scratch, rec_if_e_based, F.fx, poses_if_fused);
+                       G6_scratch, rec_if_e_based, F.fx, poses_if_fused, F.frames > 1 ? Nf : 0);
     return hipGetLastError();
 }
 
@@ -1101,6 +1115,13 @@ __global__ __launch_bounds__(256) void k_path1_softmax_bwd(int N, int P, const d
                                                            const double* __restrict__ poses, const int32_t* __restrict__ sets,
                                                            const double* __restrict__ dpnp, double* __restrict__ grad_xyz,
                                                            double* __restrict__ g, double g_scale) {
+    {   // frame f of a batch (blockIdx.x): N hypotheses per frame
+        const size_t f = blockIdx.x;
+        v6 += 6 * f; w += f * N; poses += f * N * 6; g += f * N;
+        if (sets) sets += f * N * 4;
+        if (dpnp) dpnp += f * N * 72;
+        if (grad_xyz) grad_xyz += f * (size_t)P * 3;
+    }
     __shared__ double s_buf[256];
     const int tid = threadIdx.x;
     double v[6];
@@ -1141,9 +1162,9 @@ __global__ __launch_bounds__(256) void k_path1_softmax_bwd(int N, int P, const d
 }
 
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
-                                  const double* dpnp, double* grad_xyz, double* g, double g_scale) {
+                                  const double* dpnp, double* grad_xyz, double* g, double g_scale, int frames) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_path1_softmax_bwd, dim3(1), dim3(256), 0, st, N, P, v6, w, poses, sets, dpnp, grad_xyz, g, g_scale);
+    hipLaunchKernelGGL(k_path1_softmax_bwd, dim3(frames < 1 ? 1 : frames), dim3(256), 0, st, N, P, v6, w, poses, sets, dpnp, grad_xyz, g, g_scale);
     return hipGetLastError();
 }
 
@@ -1153,7 +1174,11 @@ hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_path1_assemble(const double* __restrict__ dL, const double* __restrict__ J_hyp, const int32_t* __restrict__ obj_pixels,
                                                         const double* __restrict__ J_obj, const int32_t* __restrict__ n_obj, int cap, int P,
-                                                        double* __restrict__ grad_xyz, double* __restrict__ v6) {
+                                                        double* __restrict__ grad_xyz, double* __restrict__ v6, int px_stride) {
+    {   // frame f of a batch (blockIdx.y)
+        const size_t f = blockIdx.y;
+        dL += 6 * f; J_hyp += 36 * f; obj_pixels += f * (size_t)px_stride; J_obj += f * (size_t)cap * 18; n_obj += f; grad_xyz += f * (size_t)P * 3; v6 += 6 * f;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(n_obj[0], cap);
     if (i < n * 3) {
@@ -1173,8 +1198,9 @@ __global__ __launch_bounds__(256) void k_path1_assemble(const double* __restrict
 }
 
 hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp, const int32_t* obj_pixels, const double* J_obj, const int32_t* n_obj,
-                          int cap, int P, double* grad_xyz, double* v6) {
-    hipLaunchKernelGGL(k_path1_assemble, dim3((cap * 3 + 255) / 256 + 1), dim3(256), 0, st, dL, J_hyp, obj_pixels, J_obj, n_obj, cap, P, grad_xyz, v6);
+                          int cap, int P, double* grad_xyz, double* v6, int frames, int px_stride) {
+    hipLaunchKernelGGL(k_path1_assemble, dim3((cap * 3 + 255) / 256 + 1, frames < 1 ? 1 : frames), dim3(256), 0, st, dL, J_hyp, obj_pixels, J_obj, n_obj, cap, P,
+                       grad_xyz, v6, px_stride > 0 ? px_stride : cap);
     return hipGetLastError();
 }
 

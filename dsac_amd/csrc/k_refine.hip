@@ -511,9 +511,14 @@ DM_INLINE int plan_segment_prefix(const int32_t* __restrict__ inlier_map, const 
 __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan(const double* __restrict__ init_pose, const int32_t* __restrict__ inlier_map, FrameDev F,
                                                                  int skip, float eps_hyp, float eps_obj, int cap, double* __restrict__ rep_poses,
                                                                  int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value,
-                                                                 int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj) {
+                                                                 int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj, int px_stride) {
     __shared__ int s_cnt[PLAN_THREADS];
     const int lane = threadIdx.x;
+    {   // frame f of a batch (blockIdx.x): its start pose, inlier map, coordinate map and slice of the replica arrays (12 + 6*cap replicas per frame)
+        const size_t f = blockIdx.x, R = 12 + 6 * (size_t)cap;
+        init_pose += 6 * f; inlier_map += f * F.P; F.xyz += (long long)f * F.xyz_stride;
+        rep_poses += f * R * 6; rep_px_c += f * R * 2; rep_value += f * R; obj_pixels += f * px_stride; n_obj += f;
+    }
     double init[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) init[i] = init_pose[i];
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* _
                                                                  int skip, float eps_hyp, float eps_obj, int cap, const int32_t* __restrict__ scratch,
                                                                  double* __restrict__ rep_poses, int32_t* __restrict__ rep_px_c,
                                                                  float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels,
-                                                                 int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4) {
+                                                                 int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4, int px_stride) {
     const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
     const int x0 = blockIdx.x * 64, x = x0 + lane;
     double init[6] = {0, 0, 0, 0, 0, 0};
@@ -631,6 +636,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* _
             rep_value[tid] = (tid & 1) ? vf - 2 * eps_obj : vf;
         }
     } else {
+        // frame f of a batch (blockIdx.y): its start pose, inlier map, coordinate map, counts and slice of the replica arrays
+        const size_t f = blockIdx.y, R = 12 + 6 * (size_t)cap;
+        init_pose += 6 * f; inlier_map += f * F.P; F.xyz += (long long)f * F.xyz_stride; scratch += f * F.W * (PLAN_SEGS + 1);
+        rep_poses += f * R * 6; rep_px_c += f * R * 2; rep_value += f * R; obj_pixels += f * (size_t)px_stride; n_obj += f;
 #pragma unroll
         for (int i = 0; i < 6; i++) init[i] = init_pose[i];
     }
@@ -682,25 +691,32 @@ size_t refine_fd_plan_scratch_ints(const FrameDev& F) { return F.P > PLAN_TILED_
 
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj,
-                          int32_t* scratch) {
+                          int32_t* scratch, int frames, int px_stride) {
+    if (frames < 1) frames = 1;
+    if (px_stride <= 0) px_stride = cap;
     if (scratch && F.P > PLAN_TILED_MIN_CELLS) {
         const int tiles = (F.W + 63) / 64;
-        hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
-        hipLaunchKernelGGL(k_refine_fd_emit<false>, dim3(tiles), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch, rep_poses,
-                           rep_px_c, rep_value, obj_pixels, n_obj, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles, frames), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
+        hipLaunchKernelGGL(k_refine_fd_emit<false>, dim3(tiles, frames), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch,
+                           rep_poses, rep_px_c, rep_value, obj_pixels, n_obj, (const int32_t*)nullptr, px_stride);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_refine_fd_plan, dim3(1), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c, rep_value,
-                       obj_pixels, n_obj);
+    hipLaunchKernelGGL(k_refine_fd_plan, dim3(frames), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c,
+                       rep_value, obj_pixels, n_obj, px_stride);
     return hipGetLastError();
 }
 
 // launches the replicas: grid = 12 + 6*cap waves, those beyond 12 + 6*n_obj exit immediately
 hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out) {
+                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int frames) {
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
-    const int B = 12 + 6 * cap;
-    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
+    const int R = 12 + 6 * cap;
+    if (frames > 1) {  // one replica list per frame: list m = b / R refines against frame m, replicas beyond 12 + 6 * n_obj[m] exit at once
+        hipLaunchKernelGGL(k_refine, dim3(R * frames), dim3(64), 0, st, R * frames, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
+                           rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_refine, dim3(R), dim3(64), 0, st, R, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
                        (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0);
     return hipGetLastError();
 }
@@ -807,7 +823,7 @@ hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t
         const int tiles = (F.W + 63) / 64;
         hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
         hipLaunchKernelGGL(k_refine_fd_emit<true>, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, (const double*)nullptr, inlier_map, F, skip, 0.f, eps_obj, cap, scratch,
-                           (double*)nullptr, rep_px_c, rep_value, obj_pixels, n_obj, set4);
+                           (double*)nullptr, rep_px_c, rep_value, obj_pixels, n_obj, set4, cap);
     } else
     hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(PLAN_THREADS), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
     const int R = 18 + 6 * cap;
@@ -862,6 +878,10 @@ hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int
 // central differences of the jp 6-vectors (getRodVecAndTrans(Hypothesis(cv2our(.))), core/cnn_softam.h:721-722)
 __global__ __launch_bounds__(64) void k_refine_fd_finish(const double* __restrict__ rep_out, const int32_t* __restrict__ n_obj, int cap, int skip,
                                                          float eps_hyp, float eps_obj, double* __restrict__ J_hyp, double* __restrict__ J_obj) {
+    {   // frame f of a batch (blockIdx.y): its replica results and Jacobians
+        const size_t f = blockIdx.y;
+        rep_out += f * (12 + 6 * (size_t)cap) * 6; n_obj += f; J_hyp += f * 36; J_obj += f * (size_t)cap * 18;
+    }
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;  // replica pair index: 0..5 hyp, 6.. obj (3 per cell)
     const int npairs = 6 + 3 * min(n_obj[0], cap);
     if (pair >= npairs) return;
@@ -884,9 +904,9 @@ __global__ __launch_bounds__(64) void k_refine_fd_finish(const double* __restric
 }
 
 hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_hyp, float eps_obj,
-                            double* J_hyp, double* J_obj) {
+                            double* J_hyp, double* J_obj, int frames) {
     const int pairs = 6 + 3 * cap;
-    hipLaunchKernelGGL(k_refine_fd_finish, dim3((pairs + 63) / 64), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_hyp, eps_obj, J_hyp, J_obj);
+    hipLaunchKernelGGL(k_refine_fd_finish, dim3((pairs + 63) / 64, frames < 1 ? 1 : frames), dim3(64), 0, st, rep_out, n_obj, cap, skip, eps_hyp, eps_obj, J_hyp, J_obj);
     return hipGetLastError();
 }
 

@@ -536,8 +536,13 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
 // roots' Horn/Jacobi alignments, the long pole of a solve, run side by side as in K1's four-lane form (round 1 ran them in sequence on
 // ONE lane per solve with two hypotheses per wave: 62 us for 256 hypotheses on 128 of the chip's 1024 SIMDs).
 // Thread t: solve s = t >> 2 (forward s = 2c, backward s = 2c + 1: neighbouring quads), root t & 3.
-__global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__ sets, FrameDev F, float eps, double* __restrict__ J) {
+__global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__ sets, FrameDev F, float eps, double* __restrict__ J, int Nf) {
     const int h = blockIdx.x;
+    if (Nf > 0) {  // frame batch: hypothesis h belongs to frame h / Nf
+        const int f = h / Nf;
+        F.xyz += (long long)f * F.xyz_stride;
+        if (F.uv) F.uv += (long long)f * F.uv_stride;
+    }
     const int t = threadIdx.x, lane = t & 63;
     const int s = t >> 2, root = t & 3;
     const bool active = s < 24;
@@ -609,9 +614,9 @@ __global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__
     }
 }
 
-hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J) {
+hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J, int Nf) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dpnp, dim3(N), dim3(128), 0, st, N, sets, F, eps, J);
+    hipLaunchKernelGGL(k_dpnp, dim3(N), dim3(128), 0, st, N, sets, F, eps, J, F.frames > 1 ? Nf : 0);
     return hipGetLastError();
 }
 

@@ -67,7 +67,8 @@ struct K1Opts {
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
                   double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr, int Nf = 0,
                   const K1Opts& opts = K1Opts());  // staged: K2 records (N x 12)
-hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J);
+// Nf (frame batch): hypotheses per frame, hypothesis h reads frame h / Nf
+hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J, int Nf = 0);
 
 // ---- k_backward.hip --------------------------------------------------------------------------------
 // jp-convention staged records for the backward pass, BWD_STRIDE floats per hypothesis (see k_backward.hip).
@@ -82,8 +83,11 @@ struct K4Plan {
     int glayers;  // layers of grad_part per hypothesis tile (matrix-core form: 2 -- a pixel tile's hypothesis groups may be split between two workgroups)
     bool fused = false;   // round 4: no backward_prep launch -- the main pass derives its records from the poses, the finish kernel dR/drod; G12_part [hyp][row][12]
     bool direct = false;  // ... and (one hypothesis tile) the main pass adds its gradient straight into grad_xyz: no grad_part, no gradient reduction launch
+    int Nf = 0;           // frame batch: hypotheses per frame (= HT), 0 = one frame
 };
-K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant);
+// Nf > 0 (frame batch): N = frames x Nf hypotheses, one hypothesis tile per frame (Nf a multiple of 16, <= 256), gradient per frame (grad_xyz frames x P x 3);
+// plan.variant == 0 then means: not available for a batch
+K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant, int Nf = 0);
 bool backward_variant_known(int variant);  // -1 (auto), 0 .. 5, or a form + 10 * tile code + 100 * workgroups per CU (see backward_plan)
 constexpr int BWD_DRDH = 54;  // per hypothesis: dR/drod (27) and Omega_i = (dR/drod_i) R^T (27)
 hipError_t backward_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_bwd, double* dRdH /*N x BWD_DRDH*/);
@@ -97,17 +101,19 @@ hipError_t score_backward(hipStream_t st, int N, const float* staged_bwd, const 
 // S = G6 * dPNP_h, scatter-add S to the 4 support pixels.
 hipError_t score_backward_finish(hipStream_t st, int N, const FrameDev& F, const float* grad_part, int hyp_tiles, const float* G12_part,
                                  int pixel_tiles, const double* dRdH, const double* dpnp, const int32_t* sets, unsigned flags,
-                                 double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr, const double* poses_if_fused = nullptr);
+                                 double* grad_xyz, double* G6_scratch, const float* rec_if_e_based = nullptr, const double* poses_if_fused = nullptr, int Nf = 0);
 // hyp_tiles == 0: no gradient reduction (plan.direct); poses_if_fused: the cv poses when plan.fused (dRdH and rec_if_e_based are then unused)
 // rec_if_e_based: the BWD records when G12_part holds the matrix-core form's E-based sums (K4Plan.variant > 0), else nullptr
 // K4 parity mode (fp64, the reference's evaluation order; flags bit 0 = transposed columns, bit 2 = rotation write-back); jac_scratch: N x P*3 doubles
 hipError_t score_backward_parity(hipStream_t st, int N, const double* poses, const FrameDev& F, const float* d_err, const double* dpnp, const int32_t* sets,
                                  unsigned flags, double* jac_scratch, double* grad_xyz, double* G6_out);
+// frames > 1: N hypotheses PER FRAME, v6 frames x 6, grad_xyz frames x P x 3, one workgroup per frame
 hipError_t path1_softmax_backward(hipStream_t st, int N, int P, const double* v6, const double* w, const double* poses, const int32_t* sets,
-                                  const double* dpnp, double* grad_xyz, double* g, double g_scale = 1.0);
+                                  const double* dpnp, double* grad_xyz, double* g, double g_scale = 1.0, int frames = 1);
 // grad[obj_pixels[i]] += dL . J_obj[i] for i < min(*n_obj, cap), v6 = dL . J_hyp
+// frames > 1: every array holds one slice per frame (dL 6, J_hyp 36, obj_pixels px_stride, J_obj cap*18, n_obj 1, grad_xyz P*3, v6 6)
 hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp, const int32_t* obj_pixels, const double* J_obj, const int32_t* n_obj,
-                          int cap, int P, double* grad_xyz, double* v6);
+                          int cap, int P, double* grad_xyz, double* v6, int frames = 1, int px_stride = 0);
 
 // ---- k_refine.hip ----------------------------------------------------------------------------------
 // inlier_map: map_stride == 0 -> H*W counters of problem 0 only; map_stride == H*W -> one map per problem
@@ -131,14 +137,16 @@ hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int
 // builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
 // scratch: refine_fd_plan_scratch_ints(F) int32 of device memory (0: not needed, small map) -- large maps are planned by two tiled launches
 size_t refine_fd_plan_scratch_ints(const FrameDev& F);
+// frames > 1 (frame batch): one replica list of 12 + 6*cap entries per frame (init_pose frames x 6, inlier_map frames x H*W, obj_pixels frames x px_stride,
+// n_obj frames, scratch frames x refine_fd_plan_scratch_ints); perturbed values are read from the frame's own map
 hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_hyp,
                           float eps_obj, int cap, double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels,
-                          int32_t* n_obj, int32_t* scratch = nullptr);
+                          int32_t* n_obj, int32_t* scratch = nullptr, int frames = 1, int px_stride = 0);
 // launches 12 + 6*cap replica waves; those beyond 12 + 6*n_obj[0] exit immediately
 hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out);
+                         int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int frames = 1);
 hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_hyp, float eps_obj,
-                            double* J_hyp, double* J_obj);
+                            double* J_hyp, double* J_obj, int frames = 1);
 
 // ---- k_loss.hip ------------------------------------------------------------------------------------
 // gt_stride: 0 = one ground truth (6 doubles) for all estimates, 6 = one per estimate

@@ -279,7 +279,7 @@ class Engine:
         d_err = _np(d_err, np.float32)
         N = int(sets.shape[0])
         if grad is None:
-            grad = np.zeros((self.P, 3))
+            grad = np.zeros((getattr(self, "frames", 1) * self.P, 3))  # frame batch: one P x 3 gradient per frame
         flags = (capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0) | (capi.DSAC_BWD_PARITY_FP64 if (parity_fp64 or quirk_rot_writeback) else 0) | \
                 (capi.DSAC_BWD_QUIRK_ROT_WRITEBACK if quirk_rot_writeback else 0)
         check(self._ctx, lib.dsac_score_backward(self._ctx, N, ptr(poses), ptr(sets), ptr(d_err), ptr(_np(dpnp, np.float64) if dpnp is not None else None),
@@ -292,7 +292,7 @@ class Engine:
         g = _np(g, np.float64)
         N = int(sets.shape[0])
         if grad is None:
-            grad = np.zeros((self.P, 3))
+            grad = np.zeros((getattr(self, "frames", 1) * self.P, 3))
         flags = capi.DSAC_BWD_QUIRK_TRANSPOSE if quirk_transpose else 0
         check(self._ctx, lib.dsac_soft_score_backward(self._ctx, N, ptr(poses), ptr(sets), ptr(g), float(clamp), float(tau), float(beta),
                                                       ptr(_np(dpnp, np.float64) if dpnp is not None else None), flags, ptr(grad)))
@@ -320,6 +320,19 @@ class Engine:
         check(self._ctx, lib.dsac_refine(self._ctx, B, ptr(init_poses), ptr(perm), steps, int(max_inl), int(min_inl), float(thr), ptr(px), ptr(pv),
                                          ptr(out), ptr(imap), ptr(sd)))
         return (out, sd, imap) if want_inlier_map else (out, sd)
+
+    def dRefineFrames(self, init_poses, perm, inlier_maps, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01, eps_hyp=0.001, eps_obj=2.0, cap=256):
+        """dsac_refine_fd on a frame batch: dRefineHyp / dRefineObj of every frame in one launch per stage.
+        Returns (J_hyp F x 6 x 6, obj_pixels F x cap, J_obj F x cap x 6 x 3, n_obj F)."""
+        F = getattr(self, "frames", 1)
+        init_poses = np.ascontiguousarray(np.asarray(init_poses, dtype=np.float64).reshape(F, 6))
+        perm = _np(perm, np.int32)
+        inlier_maps = _np(inlier_maps, np.int32)
+        J_hyp, px, J_obj, n = np.zeros((F, 6, 6)), np.zeros((F, cap), np.int32), np.zeros((F, cap, 6, 3)), np.zeros(F, np.int32)
+        check(self._ctx, lib.dsac_refine_fd(self._ctx, ptr(init_poses), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl), float(thr),
+                                            ptr(inlier_maps), float(sub_sample), float(eps_hyp), float(eps_obj), ptr(J_hyp), ptr(px), ptr(J_obj),
+                                            int(cap), ptr(n)))
+        return J_hyp, px, J_obj, n
 
     def dRefine(self, init_pose, perm, inlier_map, max_inl=100, min_inl=50, thr=10.0, sub_sample=0.01, eps_hyp=0.001, eps_obj=2.0, cap=4096):
         """dRefineHyp (cnn_softam.h:738-836) and dRefineObj (:853-923) as one batch.
@@ -357,7 +370,7 @@ class Engine:
         """train_ransac_softam.cpp:344-376.  Returns (grad, g); out_g = preallocated N float64 (host or device)."""
         N = int(np.asarray(w).shape[0]) if isinstance(w, np.ndarray) else int(w.shape[0])
         if grad is None:
-            grad = np.zeros((self.P, 3))
+            grad = np.zeros((getattr(self, "frames", 1) * self.P, 3))
         g = out_g if out_g is not None else np.zeros(N)
         check(self._ctx, lib.dsac_path1_and_softmax_backward(self._ctx, N, ptr(_np(v6, np.float64)), ptr(_np(w, np.float64)), ptr(_np(poses, np.float64)),
                                                              ptr(_np(sets, np.int32)), ptr(_np(dpnp, np.float64)), ptr(grad), ptr(g)))
@@ -368,11 +381,12 @@ class Engine:
         """train_ransac_softam.cpp:294-376 as one device-side chain (dsac_backward_path1).  Returns dict(grad, g, dpnp[, dL, v6])."""
         N = int(sets.shape[0])
         perm = _np(perm, np.int32)
+        F = getattr(self, "frames", 1)  # frame batch: N = F x hypotheses per frame, per-image arguments F x ...
         if grad is None:
-            grad = np.zeros((self.P, 3))
+            grad = np.zeros((F * self.P, 3))
         g = out_g if out_g is not None else np.zeros(N)
-        dL = np.zeros(6) if want_small else None
-        v6 = np.zeros(6) if want_small else None
+        dL = np.zeros((F, 6) if F > 1 else 6) if want_small else None
+        v6 = np.zeros((F, 6) if F > 1 else 6) if want_small else None
         check(self._ctx, lib.dsac_backward_path1(self._ctx, N, ptr(_np(poses, np.float64)), ptr(_np(sets, np.int32)), ptr(_np(w, np.float64)),
                                                  ptr(_np(avg_cv6, np.float64)), ptr(_np(ref_cv6, np.float64)), ptr(_np(gt_jp6, np.float64)), ptr(perm),
                                                  int(perm.shape[0]), int(max_inl), int(min_inl), float(thr), ptr(_np(inlier_map, np.int32)),

@@ -146,8 +146,14 @@ DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_
 /* Frame batch: `frames` coordinate maps of the same H x W and camera, stored back to back (frame f at xyz + f*H*W*3); uv is one
  * shared H*W x 2 table (uv_per_frame = 0), one table per frame (uv_per_frame = 1) or NULL (implicit grid).  Independent frames
  * are the unit the path shards over (core/test_ransac_softam.cpp:97-230); batching them lets one launch carry several frames.
- * Only dsac_score_hypotheses_frames and the pipelined pair dsac_sample_ahead / dsac_score_sampled (N = frames x hypotheses per frame,
- * outputs frame-major) accept a batch; every other call reports DSAC_ERR_INVALID while one is set. */
+ * A batch is accepted by: dsac_score_hypotheses_frames, the pipelined pair dsac_sample_ahead / dsac_score_sampled, dsac_process_images, dsac_refine,
+ * dsac_loss_frames, and -- since round 4 -- the backward calls dsac_dpnp, dsac_score_backward, dsac_soft_score_backward, dsac_last_pose_gradients,
+ * dsac_refine_fd, dsac_backward_path1 and dsac_path1_and_softmax_backward: there N = frames x hypotheses per frame (per-hypothesis arrays frame-major),
+ * every per-image argument (start / refined pose, ground truth, inlier map, J_hyp, obj_pixels, J_obj, n_obj, dL, v6) holds one slice per frame, grad_xyz
+ * is frames x H*W x 3, and every stage is ONE launch over all frames; the results equal `frames` single-frame calls bit for bit
+ * (core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what the data-parallel step of SURVEY.md 5 puts on one GPU).  The score
+ * backward needs 16 | hypotheses per frame <= 256 for a batch.  Every other call (dsac_sample, dsac_reproject, dsac_score_hypotheses, the DSAC-variant
+ * calls) reports DSAC_ERR_INVALID while a batch is set. */
 DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
                     float cx, float cy, unsigned flags);
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).

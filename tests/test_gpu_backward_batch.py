@@ -1,0 +1,124 @@
+"""The training backward on FRAME BATCHES (round 4): dsac_dpnp, dsac_backward_path1 (dLossMax -> dRefineObj / dRefineHyp -> contraction -> dPNP -> support
+scatter + softmax backward), dsac_refine_fd, dsac_soft_score_backward and dsac_score_backward with a batch set by dsac_set_frames -- one launch per stage
+for all frames, one P x 3 gradient per frame.  core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what a data-parallel step puts on
+one GPU.
+
+Parity: (1) the batch equals F single-frame calls -- bit for bit for the fp64 chain (dLossMax, K5, the finite-difference replicas and their Jacobians,
+v6, the score gradients), to 1e-12 where fp64 atomics sum several hypotheses' terms into a shared support cell, and to fp32 rounding (1e-5 of the
+largest entry) for the score backward K4, whose fp32 partial sums are grouped by the launch's workgroup count (32 workgroups per frame in a batch
+of 16, 512 for a single frame); (2) the batch result of every frame against the ORACLE's chain."""
+import numpy as np
+import pytest
+
+from conftest import margin
+from test_gpu_pipeline import dpnp_substitution, oracle_backward
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid_frame(synth, H, W, seed, cam):
+    """A 'chess-like' frame whose pixel positions ARE the map's grid (u = x, v = y) under a camera scaled to the map -- what the engine's implicit grid
+    assumes (synth.chess_like_frame places a small map's cells on a stride-4 sub-sample of a 640 x 480 image)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = cam
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    rvec = axis * np.deg2rad(rng.uniform(0, 30))
+    tvec = (rng.uniform(-1, 1, size=3) + np.array([0, 0, 2.5])) * 1000.0
+    R = synth.rodrigues(rvec)
+    uv = np.stack(np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)), -1).reshape(-1, 2)
+    P = H * W
+    depth = rng.uniform(800.0, 3500.0, size=P)
+    Xc = np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth, depth], -1)
+    Xgt = (Xc - tvec) @ R
+    xyz = Xgt + rng.normal(scale=20.0, size=(P, 3))
+    out = rng.uniform(size=P) < 0.3
+    xyz[out] = Xgt.mean(0) + rng.uniform(-2000.0, 2000.0, size=(int(out.sum()), 3))
+    return dict(xyz=xyz.astype(np.float32), uv=uv, gt_pose=np.concatenate([rvec, tvec]), H=H, W=W, cam=tuple(float(c) for c in cam))
+
+
+@pytest.mark.parametrize("H,W,F,N,implicit", [(40, 40, 3, 128, False), (120, 160, 2, 256, True)])
+def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
+    P = H * W
+    frames = ([_grid_frame(synth, H, W, 300 + f, (525.0 * W / 640, 525.0 * W / 640, W / 2.0, H / 2.0)) for f in range(F)] if implicit else
+              [synth.chess_like_frame(H, W, seed=300 + f, quantise_int16=(H == 40)) for f in range(F)])
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv = None if implicit else frames[0]["uv"]
+    # the oracle's view of the pixel positions: the engine's implicit grid is u = x, v = y of the MAP (synth.pixel_grid is the stride-4 sampling of a 640 x 480 image)
+    uvh = np.stack(np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)), -1).reshape(-1, 2) if implicit else frames[0]["uv"]
+    cam = frames[0]["cam"]
+    perm = synth.fast_permutations(P, 8)
+    gts = np.stack([orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for fr in frames])
+    alpha, tau, beta, sub = 0.1, 10.0, 0.5, 0.2
+    # forward of the batch (dsac_process_images): what the backward starts from
+    engine.set_frames(xyz, uv, H, W, cam)
+    fwd = engine.processImages(N, perm, gt_jp6=gts, seed=41, want_inlier_maps=True)
+    assert fwd["ok"].all() and (fwd["refSteps"] == 8).all()
+    rng = np.random.default_rng(5)
+    d_err = (rng.standard_normal((F * N, P)) * 1e-3).astype(np.float32)
+
+    def backward(nf, sl, fsl):
+        """path I + softmax backward, then the soft-score backward, then an explicit d_err volume on top; nf frames are set in the engine"""
+        J = np.zeros((nf * N, 6, 12))
+        r = engine.backwardPath1(fwd["hyps"][sl], fwd["sampledPoints"][sl], fwd["sfScores"][sl], fwd["avgHyp"][fsl], fwd["refAvgHyp"][fsl], gts[fsl], perm,
+                                 fwd["inlierMaps"][fsl], sub_sample=sub, out_dpnp=J)
+        g_path1 = r["grad"].copy()
+        g_soft = engine.dSoftScore(fwd["hyps"][sl], fwd["sampledPoints"][sl], r["g"] * alpha, tau=tau, beta=beta, dpnp=J)
+        G6_soft = engine.lastPoseGradients(nf * N)
+        g_derr = engine.dScore(fwd["hyps"][sl], fwd["sampledPoints"][sl], d_err[sl], dpnp=J)
+        Jh, px, Jo, n = engine.dRefineFrames(fwd["avgHyp"][fsl], perm, fwd["inlierMaps"][fsl], sub_sample=sub, cap=64)
+        return dict(path1=g_path1, g=r["g"].copy(), dL=np.asarray(r["dL"]).reshape(nf, 6), v6=np.asarray(r["v6"]).reshape(nf, 6), dpnp=J, soft=g_soft, G6=G6_soft,
+                    derr=g_derr, Jh=Jh, px=px, Jo=Jo, n=n, dpnp_call=engine.dPNP(fwd["sampledPoints"][sl]))
+
+    b = backward(F, slice(0, F * N), slice(0, F))
+    assert b["path1"].shape == (F * P, 3) and (b["n"] > 0).all()
+    for f in range(F):
+        engine.set_frame(xyz[f], uv, H, W, cam)
+        s = backward(1, slice(f * N, (f + 1) * N), slice(f, f + 1))
+        hs, ps = slice(f * N, (f + 1) * N), slice(f * P, (f + 1) * P)
+        # the fp64 chain: bit for bit
+        for key, sl_ in (("g", hs), ("dL", slice(f, f + 1)), ("v6", slice(f, f + 1)), ("dpnp", hs), ("dpnp_call", hs), ("Jh", slice(f, f + 1)),
+                         ("px", slice(f, f + 1)), ("Jo", slice(f, f + 1)), ("n", slice(f, f + 1))):
+            assert np.array_equal(b[key][sl_], s[key]), (key, f)
+        # ... except where fp64 ATOMICS add several hypotheses' support terms into one cell (train_ransac_softam.cpp:344-358: minimal sets share cells):
+        # the order of three or more additions is the hardware's, in either form -- two runs of the same call differ by as much
+        margin("a15", "frame batch vs single-frame call, path-I gradient (fp64 atomics on shared support cells): max |d| / max |g|",
+               np.abs(b["path1"][ps] - s["path1"]).max() / max(np.abs(s["path1"]).max(), 1e-300), 1e-12)
+        # K4 (fp32 partial sums grouped by the launch's workgroup count): to fp32 rounding
+        for key in ("soft", "derr"):
+            margin("a15", "frame batch vs single-frame call, K4 gradient (%s): max |d| / max |g|" % key, np.abs(b[key][ps] - s[key]).max() / max(np.abs(s[key]).max(), 1e-300), 1e-5)
+        margin("a10", "frame batch vs single-frame call, K4 pose sums: max-rel", (np.abs(b["G6"][hs] - s["G6"]).max(1) / np.maximum(np.abs(s["G6"]).max(1), 1e-9 * np.abs(s["G6"]).max() + 1e-300)).max(), 1e-4)
+        # ... and the batch's frame f against the oracle's chain (core/train_ransac_softam.cpp:288-394 for that image)
+        fr = dict(frames[f], uv=uvh)
+        fw = dict(hyps=fwd["hyps"][hs], sampledPoints=fwd["sampledPoints"][hs], sfScores=fwd["sfScores"][hs], avgHyp=fwd["avgHyp"][f], refAvgHyp=fwd["refAvgHyp"][f],
+                  pixelIdxs=perm, inlierMap=fwd["inlierMaps"][f], score_scale=alpha)
+        ref_grad, dL, v6, g, coef6 = oracle_backward(orc, fr, fw, gts[f], tau=tau, beta=beta, sub_sample=sub)
+        ref_grad = ref_grad + dpnp_substitution_frame(engine, orc, fr, xyz[f], uv, H, W, cam, fw["sampledPoints"], coef6)
+        got = b["soft"][ps]  # path I + softmax backward + soft-score backward of frame f (dSoftScore accumulated onto a fresh gradient: add path I)
+        got = got + b["path1"][ps]
+        scale = np.abs(ref_grad).max()
+        assert scale >= 1e-6 * np.abs(dL).max()
+        # the oracle re-solves P3P from the sets; on an ill-conditioned set its pose differs from K1's (tests/test_gpu_forward.py bounds that by the
+        # conditioning of the set) and its dPNP is of the order 1e6: then compare on the cells no such hypothesis dominates, as tests/test_gpu_e2e.py does
+        p3p_o = np.stack([orc.solve_p3p(fr["xyz"][s_], uvh[s_], cam)[1] for s_ in fw["sampledPoints"]])
+        same = np.abs(p3p_o - fw["hyps"]).max(1) <= 1e-6 * np.maximum(1.0, np.abs(fw["hyps"]).max(1))
+        assert same.mean() >= 0.9
+        if same.all():
+            margin("a15", "frame batch: end-to-end gradient of every frame vs the oracle's chain, max-rel", np.abs(got - ref_grad).max() / scale, 1e-5)
+        else:
+            clean = np.ones(P, bool)
+            clean[np.unique(fw["sampledPoints"][~same])] = False  # the support cells of the hypotheses whose P3P pose the two sides disagree on
+            margin("a15", "frame batch: end-to-end gradient of every frame vs the oracle's chain, max-rel (support cells of ill-conditioned sets excluded)",
+                   np.abs(got - ref_grad)[clean].max() / np.abs(ref_grad[clean]).max(), 1e-3)
+        margin("a8", "frame batch: dLossMax of every frame vs oracle", np.abs(b["dL"][f] - dL).max() / max(1.0, np.abs(dL).max()), 1e-8)
+    engine.set_frames(xyz, uv, H, W, cam)
+    with pytest.raises(Exception):
+        engine.dSoftScore(fwd["hyps"][:F * N - 8], fwd["sampledPoints"][:F * N - 8], np.zeros(F * N - 8))  # not frames x (a multiple of 16)
+
+
+def dpnp_substitution_frame(engine, orc, fr, xyz_f, uv, H, W, cam, sets, coef6):
+    """tests/test_gpu_pipeline.dpnp_substitution with the engine's K5 evaluated on THIS frame (the engine holds the batch otherwise)"""
+    import dsac_amd
+    with dsac_amd.Engine(0) as e2:
+        e2.set_frame(xyz_f, uv, H, W, cam)
+        return dpnp_substitution(e2, orc, fr, sets, coef6)
