@@ -761,7 +761,7 @@ def main(argv=None):
         eng0, st0 = engines[0]
         k2_main = eng0.profile_read(0, reset=True)
         em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
-                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
+                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"), err_buffer=runner.err if os.environ.get("DSAC_BENCH_EM_SHARE_ERR") else None)
         for i in range(max(5, Wm)):
             em.step(ctr + i)
         em.drain()

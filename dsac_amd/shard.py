@@ -26,7 +26,7 @@ from .capi import check, lib, ptr
 
 class ShardRunner:
     def __init__(self, engine, stream, device, frames_of, n_images, rank, world, N, H, W, cam, perm, gt_of=None, batch=16, group=None, emulate=False,
-                 seed0=1305, seed_per_step=64, write_err=True, defer=True, host_copy=False):
+                 seed0=1305, seed_per_step=64, write_err=True, defer=True, host_copy=False, err_buffer=None):
         """frames_of(i) -> H*W x 3 float32 coordinate map of image i (host array); gt_of(i) -> jp 6-vector or None (zeros).  perm: refSteps x H*W int32
         (device tensor).  group: the process group of the sharding when world > 1 and not emulate."""
         self.eng, self.st, self.dev = engine, stream, device
@@ -57,7 +57,8 @@ class ShardRunner:
                             ok=torch.zeros(NB, dtype=torch.uint8, device=device), soft=torch.zeros(NB, dtype=torch.float64, device=device),
                             ent=torch.zeros(self.B, dtype=torch.float64, device=device), avg=torch.zeros(self.B, 6, dtype=torch.float64, device=device),
                             sd=torch.zeros(self.B, dtype=torch.int32, device=device))
-        self.err = torch.zeros(NB, self.P, dtype=torch.float32, device=device) if write_err else None
+        # err_buffer: an N*B x P float32 tensor to write the error images into (e.g. one that another, idle runner of this process already owns)
+        self.err = (err_buffer[:NB] if err_buffer is not None else torch.zeros(NB, self.P, dtype=torch.float32, device=device)) if write_err else None
         self.gs = torch.cuda.Stream(device=device)  # gather / host copy beside the engine's stream
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]  # per slot: its gathered buffer has been copied out, the slot may be refilled
         self.consumed_valid = [False, False]
