@@ -652,6 +652,48 @@ def main(argv=None):
             eng.synchronize()
         torch.cuda.synchronize(dev)
 
+    def run_emulation():
+        """One-GPU emulation of rank r of W (--emulate-world): exactly that rank's images (64 / W per step), its own buffers and launch sequence, the
+        all-gather replaced by the copy of its own part.  one_gpu_ms / (W * per_rank_ms) is the strong-scaling efficiency the code path allows when every
+        rank has its own GPU (the collective moves 17 KB per rank on a side stream and is not on the critical path)."""
+        Wem, rem = args.emulate_world, args.emulate_rank % args.emulate_world
+        EM_BASE = int(os.environ.get("DSAC_BENCH_EM_BASE", "100000"))  # first step index of the emulated rank (its seeds: 1305 + 64 * step + image)
+        eng0, st0 = engines[0]
+        eng0.profile_read(0, reset=True)
+        em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
+                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"), err_buffer=runner.err if os.environ.get("DSAC_BENCH_EM_SHARE_ERR") else None)
+        for i in range(max(5, Wm)):
+            em.step(EM_BASE + i)
+        em.drain()
+        sync_all()
+        eng0.profile_read(0, reset=True)
+        Kem = max(K, 40)
+        for key in em.host_us:
+            em.host_us[key] = 0.0
+        te = time.perf_counter()
+        for i in range(Kem):
+            em.step(EM_BASE + 100 + i)
+        host_s = (time.perf_counter() - te) / Kem  # what the host needs to enqueue a step (it never waits inside one)
+        lem = em.drain()
+        sync_all()
+        per_rank_s = (time.perf_counter() - te) / Kem
+        ms_e, n_e = eng0.profile_read(0, reset=True)
+        res = {"world": Wem, "rank": rem, "images_per_rank_step": len(em.mine), "batches_per_rank_step": len(em.batches), "steps": Kem,
+               "per_rank_ms": per_rank_s * 1e3, "host_enqueue_ms_per_step": host_s * 1e3,
+               "host_enqueue_us_by_phase": {k_: v_ / Kem * 1e6 for k_, v_ in em.host_us.items()},
+               "k2_us_per_launch": ms_e / max(1, n_e) * 1e3, "rows_finite": bool(torch.isfinite(lem[em.mine]).all()),
+               "measured": "before the 64-image run" if os.environ.get("DSAC_BENCH_EM_FIRST") else "after the 64-image run, same process and engine",
+               "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
+                       "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
+        em.close()
+        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)):
+            runner.eng.set_option(key, v)
+        return res
+
+    em_early = None
+    if config3 and args.emulate_world > 1 and world == 1 and os.environ.get("DSAC_BENCH_EM_FIRST"):
+        em_early = run_emulation()
+
     if pipelined:
         err_shared = bufs[0]["err"]  # the scoring stage is serial: one error-image buffer
         engines[0][0].sampleAhead(0, NB, seed_of(0), bufs[0]["poses"], bufs[0]["sets"], bufs[0]["ok"], thr=10.0, max_tries=1 << 16)
@@ -754,42 +796,12 @@ def main(argv=None):
         assert bool(((ws - 1.0).abs() < 1e-9).all()), "config3: gathered softmax weights do not sum to 1 for every image"
         assert bool((last[:, 6] > 0).all()) and bool(torch.isfinite(last[:, :10]).all()), "config3: gathered refined poses / losses are not finite"
     if config3 and args.emulate_world > 1 and world == 1:
-        # One-GPU emulation of rank r of W: exactly that rank's images (64 / W per step), its own buffers and launch sequence, the all-gather replaced
-        # by the copy of its own part.  one_gpu_ms / (W * per_rank_ms) is the strong-scaling efficiency the code path allows when every rank has its own
-        # GPU (the collective moves 17 KB per rank on a side stream and is not on the critical path).
-        Wem, rem = args.emulate_world, args.emulate_rank % args.emulate_world
-        eng0, st0 = engines[0]
-        k2_main = eng0.profile_read(0, reset=True)
-        em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
-                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"), err_buffer=runner.err if os.environ.get("DSAC_BENCH_EM_SHARE_ERR") else None)
-        for i in range(max(5, Wm)):
-            em.step(ctr + i)
-        em.drain()
-        sync_all()
-        eng0.profile_read(0, reset=True)
-        Kem = max(K, 40)
-        for key in em.host_us:
-            em.host_us[key] = 0.0
-        te = time.perf_counter()
-        for i in range(Kem):
-            em.step(ctr + 100 + i)
-        host_s = (time.perf_counter() - te) / Kem  # what the host needs to enqueue a step (it never waits inside one)
-        lem = em.drain()
-        sync_all()
-        per_rank_s = (time.perf_counter() - te) / Kem
-        ms_e, n_e = eng0.profile_read(0, reset=True)
-        # the emulated rank's rows equal the one-GPU run's rows for the same images and step seeds?  (same seeds: seed0 + 64 * step + image)
+        em_raw = em_early if em_early is not None else run_emulation()
         one_gpu_s = elapsed / K
-        emulation = {"world": Wem, "rank": rem, "images_per_rank_step": len(em.mine), "batches_per_rank_step": len(em.batches), "steps": Kem,
-                     "per_rank_ms": per_rank_s * 1e3, "host_enqueue_ms_per_step": host_s * 1e3, "host_enqueue_us_by_phase": {k_: v_ / Kem * 1e6 for k_, v_ in em.host_us.items()}, "one_gpu_ms": one_gpu_s * 1e3, "ideal_per_rank_ms": one_gpu_s * 1e3 / Wem,
-                     "predicted_speedup": one_gpu_s / per_rank_s, "predicted_efficiency": one_gpu_s / per_rank_s / Wem,
-                     "k2_us_per_launch": ms_e / max(1, n_e) * 1e3, "rows_finite": bool(torch.isfinite(lem[em.mine]).all()),
-                     "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
-                             "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
-        ctr += 200 + Kem
-        em.close()
-        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)):
-            runner.eng.set_option(key, v)
+        Wem = em_raw.pop("world")
+        emulation = dict(world=Wem, **em_raw)
+        emulation.update({"one_gpu_ms": one_gpu_s * 1e3, "ideal_per_rank_ms": one_gpu_s * 1e3 / Wem,
+                          "predicted_speedup": one_gpu_s / (em_raw["per_rank_ms"] * 1e-3), "predicted_efficiency": one_gpu_s / (em_raw["per_rank_ms"] * 1e-3) / Wem})
 
     # literal configs[1]: ONE frame per step on the same context (fused call), its own K2 timing
     single = None

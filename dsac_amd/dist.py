@@ -269,7 +269,15 @@ class FrameResultExchange:
 
     def launch(self, slot):
         """Enqueue the gather of the slot's local buffer.  The producers must already be ordered on the current stream."""
-        if self.real:
+        if self.real and self.local[slot].is_cuda and dist.get_backend(self.group) != "nccl":
+            # device buffers over a host backend (gloo: several ranks exercising ONE GPU in a test): through host memory, synchronously -- a check of the
+            # multi-rank path, not a fast one
+            mine = self.local[slot].cpu()
+            gathered = torch.empty(self.world * mine.numel(), dtype=mine.dtype)
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            self.all[slot].copy_(gathered)
+            self.work[slot] = None
+        elif self.real:
             self.work[slot] = dist.all_gather_into_tensor(self.all[slot], self.local[slot], group=self.group, async_op=True)
         else:
             self.all[slot].view(self.world, self.per * self.D)[self.rank].copy_(self.local[slot], non_blocking=True)

@@ -58,3 +58,22 @@ def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world):
             eng.close()
     assert (want[:, 6] > 0).all() and np.abs(want[:, 10:].sum(1) - 1).max() < 1e-12
     assert np.array_equal(got, want)
+
+
+def test_two_real_ranks_share_the_gpu_over_gloo():
+    """The NON-emulated multi-rank path of BASELINE configs[3] on real kernels: two ranks (one process each, launched by bench.py itself) shard the 64
+    images, both drive the one GPU of the box, the one-step-late exchange is a real collective (gloo through host memory -- RCCL needs one GPU per
+    rank).  Rank 0 checks the gathered rows of the last step (every image present, weights sum to 1, finite poses and losses) before it prints its line.
+    A launcher / exchange check, not a scaling number."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSAC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "config3", "--steps", "4", "--warmup", "2", "--hyps", "128",
+                          "--height", "96", "--width", "128", "--no-cpu-baseline", "--prewarm-ms", "20"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert "sharded round-robin over 2 rank" in line["config"]["workload"]
