@@ -582,8 +582,11 @@ def main(argv=None):
 
         def frames_of(i):
             return synth.chess_like_frame(H, W, seed=1305 + i)["xyz"]  # seeds 1305 + i
-        runner = ShardRunner(engines[0][0], engines[0][1], dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, fr["cam"], perm3, batch=B,
-                             defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
+        def make_runner():
+            return ShardRunner(engines[0][0], engines[0][1], dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, fr["cam"], perm3, batch=B,
+                               defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
+        if not os.environ.get("DSAC_BENCH_EM_FIRST"):
+            runner = make_runner()
     torch.cuda.synchronize(dev)
 
     staged = (n_ctx == 2 and args.overlap == "stages" and not args.kernel_only)
@@ -661,9 +664,16 @@ def main(argv=None):
         eng0, st0 = engines[0]
         eng0.profile_read(0, reset=True)
         em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
-                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"), err_buffer=runner.err if os.environ.get("DSAC_BENCH_EM_SHARE_ERR") else None)
-        for i in range(max(5, Wm)):
-            em.step(EM_BASE + i)
+                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"),
+                         err_buffer=runner.err if (runner is not None and os.environ.get("DSAC_BENCH_EM_SHARE_ERR")) else None)
+        # settle like the main run does (--prewarm-ms): the runner's set-up above left the GPU idle for about a second (synthetic frames are made on the
+        # host), and 45 steps of 0.5 ms straight out of an idle GPU are timed at a ramping clock (measured: K2 480 us instead of 440)
+        t_pre, n_pre_em = time.perf_counter(), 0
+        while n_pre_em < max(5, Wm) or (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            em.step(EM_BASE + (n_pre_em % 90))
+            n_pre_em += 1
+            if n_pre_em % 16 == 0:
+                sync_all()
         em.drain()
         sync_all()
         eng0.profile_read(0, reset=True)
@@ -687,12 +697,15 @@ def main(argv=None):
                        "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
         em.close()
         for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)):
-            runner.eng.set_option(key, v)
+            eng0.set_option(key, v)
         return res
 
     em_early = None
-    if config3 and args.emulate_world > 1 and world == 1 and os.environ.get("DSAC_BENCH_EM_FIRST"):
-        em_early = run_emulation()
+    if config3 and os.environ.get("DSAC_BENCH_EM_FIRST"):
+        # experiment: the emulated rank BEFORE anything of the 64-image run exists (its runner, its 5 GB of error images)
+        if args.emulate_world > 1 and world == 1:
+            em_early = run_emulation()
+        runner = make_runner()
 
     if pipelined:
         err_shared = bufs[0]["err"]  # the scoring stage is serial: one error-image buffer
