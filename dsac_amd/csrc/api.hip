@@ -742,7 +742,11 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
         c->seed_stride = value;
         c->F.seed_stride = value;
     }
-    else if (k == "pi_defer_tail") { join_tail(c); c->pi_defer_tail = value != 0; }
+    else if (k == "pi_defer_tail") {
+        // a CHANGE of mode orders the stream behind a tail in flight; setting the mode it already has is a no-op (a host that sets it before every
+        // batch must not serialise the batches: the C++ FrameBatch did, and its tails sat exposed -- 70 us per image instead of 65)
+        if ((value != 0) != (c->pi_defer_tail != 0)) { join_tail(c); c->pi_defer_tail = value != 0; }
+    }
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
     return DSAC_OK;
