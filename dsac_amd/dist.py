@@ -69,9 +69,10 @@ def _buckets(tensors, bucket_bytes):
 
 
 class _Flight:
-    """One bucket in flight: launched with launch(), finished (averaged, copied back into its tensors) with wait()."""
+    """One bucket in flight: launched at construction, finished (averaged, copied back into its tensors) with wait().  flat: the bucket already IS one
+    contiguous tensor that the gradients live in (GradientReducer's flat buckets) -- then nothing is concatenated and nothing is copied back."""
 
-    def __init__(self, tensors, average, group, mode):
+    def __init__(self, tensors, average, group, mode, flat=None):
         self.tensors, self.average, self.group = tensors, average, group
         self.world = _world(group)
         n = sum(t.numel() for t in tensors)
@@ -79,7 +80,11 @@ class _Flight:
         self.mode = mode if (mode == "reduce_scatter" and backend == "nccl" and self.world > 1) else "all_reduce"  # gloo has no reduce-scatter
         pad = (-n) % self.world if self.mode == "reduce_scatter" else 0
         self.n = n
-        self.flat = torch.cat([t.reshape(-1) for t in tensors] + ([tensors[0].new_zeros(pad)] if pad else []))
+        self.in_place = flat is not None and flat.numel() >= n + pad
+        if self.in_place:
+            self.flat = flat[:n + pad]
+        else:
+            self.flat = torch.cat([t.reshape(-1) for t in tensors] + ([tensors[0].new_zeros(pad)] if pad else []))
         if self.mode == "reduce_scatter":
             self.shard = torch.empty(self.flat.numel() // self.world, dtype=self.flat.dtype, device=self.flat.device)
             self.work = dist.reduce_scatter_tensor(self.shard, self.flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -94,6 +99,8 @@ class _Flight:
             dist.all_gather_into_tensor(self.flat, self.shard, group=self.group)
         elif self.average:
             self.flat /= self.world
+        if self.in_place:
+            return  # the gradients ARE the bucket
         off = 0
         for t in self.tensors:
             k = t.numel()
@@ -149,10 +156,27 @@ class GradientReducer:
         self.average, self.group, self.mode = average, group, mode
         self.handle = GradientReduce()
         self.enabled = _world(group) > 1
+        self.in_place_flights = 0  # buckets that travelled as they lay (no concatenation, no copy back)
         self._hooks = []
         if not self.enabled:
             return
         self.buckets = _buckets(list(reversed(self.params)), bucket_bytes)
+        # Flat buckets: the gradients of a bucket LIVE in one contiguous tensor (p.grad is a view into it), so a collective runs on the bucket as it is --
+        # no torch.cat before it and no copy back after it (round 3 moved 2 x 157 MB per step that way).  Holds as long as the gradients are zeroed in
+        # place (optimizer.zero_grad(set_to_none=False), as e2e.TrainStep does); a gradient that has been replaced falls back to the copying path.
+        world = _world(group)
+        self._flat = []
+        for b in self.buckets:
+            n = sum(q.numel() for q in b)
+            flat = torch.zeros(n + (-n) % world, dtype=b[0].dtype, device=b[0].device)
+            off = 0
+            for q in b:
+                view = flat[off:off + q.numel()].view_as(q)
+                if q.grad is not None:
+                    view.copy_(q.grad)
+                q.grad = view
+                off += q.numel()
+            self._flat.append(flat)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0  # buckets leave strictly in index order, on every rank the same sequence of collectives whatever gradients exist locally
         where = {}
@@ -168,7 +192,12 @@ class GradientReducer:
             if q.grad is None:
                 q.grad = torch.zeros_like(q)  # ... and receives the other ranks' average like everyone else
         g = [q.grad for q in self.buckets[bi]]
-        self.handle.add(_Flight(g, self.average, self.group, self.mode))
+        flat, off, in_place = self._flat[bi], 0, True
+        for q in self.buckets[bi]:  # still the views handed out in __init__?
+            in_place = in_place and q.grad.data_ptr() == flat.data_ptr() + off * flat.element_size() and q.grad.is_contiguous()
+            off += q.numel()
+        self.in_place_flights += 1 if in_place else 0
+        self.handle.add(_Flight(g, self.average, self.group, self.mode, flat=flat if in_place else None))
 
     def _make_hook(self, bi):
         def hook(param):

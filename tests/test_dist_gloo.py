@@ -44,6 +44,9 @@ def _worker(rank, world, port, q):
     net(x).sum().backward()
     launched_before_wait = red.handle.collectives
     nb3 = red.wait()
+    assert red.in_place_flights == nb3, "the buckets of a network whose gradients are zeroed in place travel without a copy"
+    assert all(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * f.element_size()
+               for b, f in zip(red.buckets, red._flat) for p in b)
     grads = [p.grad.numpy().copy() for p in net.parameters()]
     # second step: hooks re-armed
     for p in net.parameters():
