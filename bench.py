@@ -578,13 +578,15 @@ def main(argv=None):
         # dsac_amd.shard.ShardRunner: batches through dsac_process_images, the refinement tail of a batch under the next batch -- across step boundaries
         # too --, the gather of a step launched on a side stream at the top of the next step and consumed one step later, no host synchronisation.
         from dsac_amd.shard import ShardRunner
+        # 2: refinement AND score tail of a batch under the next batch (dsac_hip.h "pi_defer_tail"); DSAC_BENCH_DEFER_MODE=1 / DSAC_BENCH_NO_DEFER for the A/B
+        DEFER_MODE = 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else int(os.environ.get("DSAC_BENCH_DEFER_MODE", "2"))
         perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
 
         def frames_of(i):
             return synth.chess_like_frame(H, W, seed=1305 + i)["xyz"]  # seeds 1305 + i
         def make_runner():
             return ShardRunner(engines[0][0], engines[0][1], dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, fr["cam"], perm3, batch=B,
-                               defer=not os.environ.get("DSAC_BENCH_NO_DEFER"))
+                               defer=DEFER_MODE)
         if not os.environ.get("DSAC_BENCH_EM_FIRST"):
             runner = make_runner()
     torch.cuda.synchronize(dev)
@@ -664,7 +666,7 @@ def main(argv=None):
         eng0, st0 = engines[0]
         eng0.profile_read(0, reset=True)
         em = ShardRunner(eng0, st0, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, fr["cam"], perm3, batch=B, emulate=True,
-                         defer=not os.environ.get("DSAC_BENCH_NO_DEFER"),
+                         defer=DEFER_MODE,
                          err_buffer=runner.err if (runner is not None and os.environ.get("DSAC_BENCH_EM_SHARE_ERR")) else None)
         # settle like the main run does (--prewarm-ms): the runner's set-up above left the GPU idle for about a second (synthetic frames are made on the
         # host), and 45 steps of 0.5 ms straight out of an idle GPU are timed at a ramping clock (measured: K2 480 us instead of 440)
@@ -696,7 +698,7 @@ def main(argv=None):
                "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
                        "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
         em.close()
-        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", 0 if os.environ.get("DSAC_BENCH_NO_DEFER") else 1)):
+        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", DEFER_MODE)):
             eng0.set_option(key, v)
         return res
 
@@ -750,7 +752,7 @@ def main(argv=None):
         k2_ms += ms
         k2_n += n
     if config3:
-        ok_frac = float(runner.scratch["ok"][:N * len(runner.batches[-1])].float().mean().item())
+        ok_frac = float(runner.scratch[0]["ok"][:N * len(runner.batches[-1])].float().mean().item())
         wsum = float(last[0, 10:].sum().item()) if last is not None else 0.0
     else:
         ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0
@@ -933,6 +935,28 @@ def main(argv=None):
                 proc(10 + i)
             eng.synchronize()
             procimg["%dx%d" % (ww, hh)] = {"us_per_image": (time.perf_counter() - tp) / npi * 1e6, "images": npi, "refine_steps_done": int(sd_d.item())}
+            # the same unit as a STREAM of images (the loop over images of test_ransac_softam.cpp:97): one dsac_process_images chain per image, the
+            # refinement tail of image i under sampling / scoring of image i + 1 (dsac_hip.h "pi_defer_tail" = 1; = 2 the score tail as well).  The
+            # latency of ONE image stays the in-order figure above; this is what a loop over images pays per image
+            f64_ = dict(dtype=torch.float64, device=dev)
+            two = [dict(hyps=torch.zeros(N, 6, **f64_), sampledPoints=torch.zeros(N, 4, dtype=torch.int32, device=dev), ok=torch.zeros(N, dtype=torch.uint8, device=dev),
+                        scores=torch.zeros(N, **f64_), sfScores=torch.zeros(N, **f64_), sfEntropy=torch.zeros(1, **f64_), avgHyp=torch.zeros(1, 6, **f64_),
+                        refAvgHyp=torch.zeros(1, 6, **f64_), refSteps=torch.zeros(1, dtype=torch.int32, device=dev), out4=torch.zeros(1, 4, **f64_)) for _ in (0, 1)]
+            gt1 = torch.zeros(1, 6, **f64_)
+            torch.cuda.synchronize()
+            for mode_ in (1, 2):
+                eng.set_option("pi_defer_tail", mode_)
+                for i in range(10):
+                    eng.processImages(N, perm_d, gt_jp6=gt1, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=errp, out=two[i & 1])
+                eng.synchronize()
+                tp = time.perf_counter()
+                for i in range(npi):
+                    eng.processImages(N, perm_d, gt_jp6=gt1, seed=seed_of(10 + i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=errp,
+                                      out=two[i & 1])
+                eng.synchronize()
+                procimg["%dx%d_stream_of_images_%s_under_the_next_image" % (ww, hh, "refinement" if mode_ == 1 else "score_and_refinement")] = {
+                    "us_per_image": (time.perf_counter() - tp) / npi * 1e6, "images": npi, "refine_steps_done": int(two[(npi - 1) & 1]["refSteps"].item())}
+            eng.set_option("pi_defer_tail", 0)
         if batched:
             # the same unit for the %d frames of a step in ONE call (dsac_process_images: one launch per stage, K6 one wave per frame)
             Bf = B
@@ -945,9 +969,17 @@ def main(argv=None):
 
             def procB(i):
                 eng.processImages(N, permB, gt_jp6=gtB, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"], out=outB)
-            for key, defer in (("%dx%d_batch_of_%d" % (W, H, Bf), 0), ("%dx%d_batch_of_%d_refinement_under_the_next_batch" % (W, H, Bf), 1)):
-                # defer = 1: dsac_set_option("pi_defer_tail"): K6 / K7 of a batch run on their own stream under K1 / K2 of the next one
+            outB2 = {k_: torch.zeros_like(v_) for k_, v_ in outB.items()}  # defer = 2: consecutive calls write different arrays (dsac_hip.h)
+
+            def procB2(i):
+                eng.processImages(N, permB, gt_jp6=gtB, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"],
+                                  out=outB2 if (i & 1) else outB)
+            for key, defer in (("%dx%d_batch_of_%d" % (W, H, Bf), 0), ("%dx%d_batch_of_%d_refinement_under_the_next_batch" % (W, H, Bf), 1),
+                               ("%dx%d_batch_of_%d_score_and_refinement_under_the_next_batch" % (W, H, Bf), 2)):
+                # defer = 1: dsac_set_option("pi_defer_tail"): K6 / K7 of a batch run on their own stream under K1 / K2 of the next one; 2: the score
+                # reduction and K3 too (K1 of the next batch follows K2 directly)
                 eng.set_option("pi_defer_tail", defer)
+                procB = procB2 if defer == 2 else procB
                 for i in range(5):
                     procB(i)
                 eng.synchronize()

@@ -81,6 +81,12 @@ struct dsac_ctx {
     hipStream_t tail = nullptr;
     hipEvent_t tail_go = nullptr, tail_done = nullptr;  // go: K3 of the batch done (main stream); done: its K6 / K7 done (tail stream)
     bool tail_pending = false;                          // a tail is in flight that the main stream has not been ordered behind yet
+    // mode 2 (score tail deferred as well: reduction + K3 of batch i also run on `tail`): the partial sums alternate between two buffers, and call
+    // i + 2 starts only after K3 of call i (pi_scored: recorded on `tail`), which read that call's poses and partial sums
+    DevBuf pi_soft[2], pi_scores[2];
+    hipEvent_t pi_k2done = nullptr, pi_scored[2] = {nullptr, nullptr};
+    bool pi_scored_rec[2] = {false, false};
+    unsigned pi_calls = 0;
     hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
 
     // measurement hooks: event pairs around the dominant kernels
@@ -294,6 +300,9 @@ void dsac_destroy(dsac_ctx* c) {
     if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
     if (c->tail_go) (void)hipEventDestroy(c->tail_go);
     if (c->tail_done) (void)hipEventDestroy(c->tail_done);
+    if (c->pi_k2done) (void)hipEventDestroy(c->pi_k2done);
+    for (int k = 0; k < 2; k++)
+        if (c->pi_scored[k]) (void)hipEventDestroy(c->pi_scored[k]);
     if (c->xs_event) (void)hipEventDestroy(c->xs_event);
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -745,7 +754,8 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "pi_defer_tail") {
         // a CHANGE of mode orders the stream behind a tail in flight; setting the mode it already has is a no-op (a host that sets it before every
         // batch must not serialise the batches: the C++ FrameBatch did, and its tails sat exposed -- 70 us per image instead of 65)
-        if ((value != 0) != (c->pi_defer_tail != 0)) { join_tail(c); c->pi_defer_tail = value != 0; }
+        if (value < 0 || value > 2) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: pi_defer_tail is 0 (in order), 1 (refinement tail deferred) or 2 (score tail too)");
+        if (value != c->pi_defer_tail) { join_tail(c); c->pi_defer_tail = value; }
     }
     else if (k == "k1_cus") { if (c->aux) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k1_cus must be set before the first dsac_sample_ahead"); c->k1_cus = value; }
     else return fail(c, DSAC_ERR_INVALID, "dsac_set_option: unknown key '%s'", key);
@@ -1288,14 +1298,41 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     ARG_TRY(out_arg(c, steps_done, (size_t)frames, &d_sd));
     ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)frames * P, &d_maps));
     ARG_TRY(out_arg(c, out4_or_null, (size_t)frames * 4, &d_out4));
+    // "pi_defer_tail" = 1: the refinement tail (K6, a 90 us latency chain on one wave per frame, and K7) goes to its own stream and runs under K1 / K2 of
+    // the NEXT dsac_process_images call.  Its outputs (ref6, steps_done, inlier maps, out4) are complete in the order of the context's stream only after
+    // the next call of any other entry point, dsac_join_tail or dsac_synchronize.  = 2: the score tail (reduction of the per-tile sums, K3) goes there
+    // too -- K1 of the next call follows K2 of this one directly, and EVERY output of this call except the error images is complete only then.
+    // Only with device-resident arguments: a host destination is copied back at the end of this call, and a host `perm` / `gt` lives in a staging
+    // slot that the next call reuses.
+    const int mode = (c->pending.empty() && is_device_ptr(perm, c) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null, c))) ? c->pi_defer_tail : 0;
+    const bool defer = mode != 0;
+    const int b = (int)(c->pi_calls++ & 1u);
     if (!d_scores) {
-        DevBuf& s = next_slot(c);
-        HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
-        d_scores = s.as<double>();
+        if (mode == 2) {
+            HIP_TRY(c, c->pi_scores[b].reserve((size_t)N * sizeof(double)));
+            d_scores = c->pi_scores[b].as<double>();
+        } else {
+            DevBuf& s = next_slot(c);
+            HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
+            d_scores = s.as<double>();
+        }
     }
     const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    DevBuf& part = mode == 2 ? c->pi_soft[b] : c->soft_part;
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
-    HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+    HIP_TRY(c, part.reserve((size_t)tiles * N * sizeof(float)));
+    if (defer && !c->tail) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming));
+    }
+    if (mode == 2 && !c->pi_k2done) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->pi_k2done, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->pi_scored[k], hipEventDisableTiming));
+    }
+    // the call before the previous one used this half of the alternating buffers (and, by the caller's contract, possibly these output arrays): its K3
+    // on the tail stream must have read them.  Two K2 launches have run since -- the event has long completed
+    if (mode == 2 && c->pi_scored_rec[b]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pi_scored[b], 0));
     // processImage (core/cnn_softam.h:960-1179) for every frame of the batch, one launch per stage:
     //   K1 sample + P3P (:1010-1060)  ->  K2 error images + soft-inlier sums (:1067-1072)  ->  scores  ->  K3 softmax / entropy / soft-argmax
     //   (:1078-1094)  ->  K6 the refinement loop, one wave per frame (:1099-1154)  ->  K7 maxLoss against each frame's ground truth (:1160-1179)
@@ -1304,28 +1341,28 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(), &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, part.as<float>(), ps.k2(), &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
-    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
-    // "pi_defer_tail": the refinement tail (K6, a 90 us latency chain on one wave per frame, and K7) goes to its own stream and runs under K1 / K2 of the
-    // NEXT dsac_process_images call.  Its outputs (ref6, steps_done, inlier maps, out4) are complete in the order of the context's stream only after
-    // the next call of any other entry point, dsac_join_tail or dsac_synchronize.  Only with device-resident arguments: a host destination is copied
-    // back at the end of this call, and a host `perm` / `gt` lives in a staging slot that the next call reuses.
-    const bool defer = c->pi_defer_tail && c->pending.empty() && is_device_ptr(perm, c) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null, c));
-    join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
-    HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
     hipStream_t ts = c->stream;
-    if (defer) {
-        if (!c->tail) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming));
+    if (mode == 2) {
+        ts = c->tail;  // in order behind the previous call's tail: its K6 has read the soft-argmax poses before this K3 can overwrite them
+        HIP_TRY(c, hipEventRecord(c->pi_k2done, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ts, c->pi_k2done, 0));
+        HIP_TRY(c, dk::reduce_soft(ts, N, used, part.as<float>(), d_scores));
+        HIP_TRY(c, dk::softmax(ts, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
+        c->pi_scored_rec[b] = true;
+    } else {
+        HIP_TRY(c, dk::reduce_soft(c->stream, N, used, part.as<float>(), d_scores));
+        join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
+        HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        if (defer) {
+            HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
+            ts = c->tail;
         }
-        HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
-        ts = c->tail;
     }
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
     HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,

@@ -303,7 +303,10 @@ void FrameBatch::processImages(int first, int count, uint64_t seedOfFrame0, int 
     if (first < 0 || count <= 0 || first + count > F_ || count > maxCall_) throw Error(DSAC_ERR_INVALID, "FrameBatch::processImages: bad frame range");
     const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
     dsac_ctx* c = C_.get();
-    C_.setOption("pi_defer_tail", opt_.deferTail ? 1 : 0);
+    C_.setOption("pi_defer_tail", opt_.deferTail ? (opt_.deferScoreTail ? 2 : 1) : 0);
+    // with the score tail deferred every result row of the previous call is still being written: the same frames again (one call per pass) go in order
+    if (opt_.deferTail && opt_.deferScoreTail && first < lastFirst_ + lastCount_ && lastFirst_ < first + count) C_.check(dsac_join_tail(c), "dsac_join_tail");
+    lastFirst_ = first; lastCount_ = count;
     unsigned flags = DSAC_FRAME_BORROW;
     if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;  // in place; idempotent
     C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, nullptr, 0, H_, W_, cam_.fx, cam_.fy, cam_.cx, cam_.cy, flags), "dsac_set_frames");

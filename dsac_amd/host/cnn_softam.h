@@ -188,7 +188,9 @@ protected:
 struct FrameBatchOptions {
     bool errorImages = true;   // write the N error images per frame (the score CNN's input; one buffer shared by all calls)
     bool inlierMaps = false;   // keep the refinement's inlier maps (needed by the training backward only)
-    bool deferTail = true;     // dsac_set_option("pi_defer_tail", 1)
+    bool deferTail = true;     // dsac_set_option("pi_defer_tail", ...): the refinement tail of a call runs under K1 / K2 of the next one
+    bool deferScoreTail = true;  // ... = 2: the score reduction and K3 as well (consecutive calls write different frames' result rows); 64 images in
+                                 // batches of 16: 65.6 (in order) / 62.8 / 62.6 us per image, in batches of 4: 87.9 / - / 65.7 (profiles/r04_host_driver_defer_ab.txt)
     bool quantiseInt16 = false;
 };
 
@@ -212,6 +214,7 @@ public:
 private:
     Context& C_;
     int F_, H_, W_, N_, refSteps_, maxCall_;
+    int lastFirst_ = 0, lastCount_ = 0;  // the frame range of the previous call (its result rows are still being written with a deferred score tail)
     Camera cam_;
     FrameBatchOptions opt_;
     DeviceArray<float> xyz_, err_;

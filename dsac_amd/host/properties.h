@@ -46,6 +46,7 @@ struct EngineParameters {
     int batch = 16;                   // -batch  : images per launch chain of the evaluation program (FrameBatch); 0 = one image per call (Frame::processImage)
     int passes = 1;                   // -passes : process the data set this many times (the first pass warms the device up; timing is reported per pass)
     bool errorImages = true;          // -errimg : write the N error images of every image (the score CNN's input) as the reference does
+    int defer = 2;                    // -defer  : 0 batches in stream order, 1 refinement tail of a batch under the next batch, 2 score tail too (dsac_hip.h "pi_defer_tail")
 };
 
 class GlobalProperties {

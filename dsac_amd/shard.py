@@ -2,8 +2,9 @@
 n_images x N hypotheses, image i owned by rank i mod world (dist.shard_images).
 
 A step is one pass over this rank's images.  Nothing in it waits:
-  * the images go through dsac_process_images in batches (K1, K2, K3, then K6 / K7 on the engine's tail stream: "pi_defer_tail"), every output
-    written straight into the rank's exchange buffer (dist.FrameResultExchange.views: refined pose 6 | loss, rotErr, tErr, correct 4 | N weights);
+  * the images go through dsac_process_images in batches (K1 and K2 on the engine's stream; the score reduction, K3, K6 and K7 on its tail stream:
+    "pi_defer_tail" = 2), every output written straight into the rank's exchange buffer (dist.FrameResultExchange.views: refined pose 6 | loss,
+    rotErr, tErr, correct 4 | N weights); K1 of the next batch follows K2 of this one without a gap;
   * the refinement tail of the LAST batch of step i runs under sampling and scoring of step i + 1 (with 8 ranks a step is a single batch: without
     this the 90-110 us K6 latency chain would sit exposed in every step);
   * the gather of step i is launched at the top of step i + 1 on a side stream that waits for that tail (dsac_tail_wait) -- beside K1 / K2 of step
@@ -45,7 +46,7 @@ class ShardRunner:
                 g[j] = gt_of(i)
         self.gt = torch.from_numpy(g).to(device)
         self.perm = perm
-        self.defer = defer
+        self.defer = int(defer) if not isinstance(defer, bool) else (2 if defer else 0)  # 0 in order, 1 refinement tail deferred, 2 score tail too
         self.host_copy = host_copy
         if world > 1 and not emulate and group is None:
             import torch.distributed as tdist
@@ -53,10 +54,12 @@ class ShardRunner:
         self.ex = ddist.FrameResultExchange(n_images, rank, world, (6, 4, N), device, group=group if (world > 1 and not emulate) else None,
                                             pin_host=(device.type == "cuda"))
         NB = N * self.B
-        self.scratch = dict(poses=torch.zeros(NB, 6, dtype=torch.float64, device=device), sets=torch.zeros(NB, 4, dtype=torch.int32, device=device),
-                            ok=torch.zeros(NB, dtype=torch.uint8, device=device), soft=torch.zeros(NB, dtype=torch.float64, device=device),
-                            ent=torch.zeros(self.B, dtype=torch.float64, device=device), avg=torch.zeros(self.B, 6, dtype=torch.float64, device=device),
-                            sd=torch.zeros(self.B, dtype=torch.int32, device=device))
+        # per-hypothesis outputs nobody gathers.  Two sets: with the score tail deferred K3 of a call still reads its poses / scores while K1 of the
+        # next call runs, so consecutive calls alternate (dsac_hip.h, "pi_defer_tail" 2)
+        self.scratch = [dict(poses=torch.zeros(NB, 6, dtype=torch.float64, device=device), sets=torch.zeros(NB, 4, dtype=torch.int32, device=device),
+                             ok=torch.zeros(NB, dtype=torch.uint8, device=device), soft=torch.zeros(NB, dtype=torch.float64, device=device),
+                             ent=torch.zeros(self.B, dtype=torch.float64, device=device), avg=torch.zeros(self.B, 6, dtype=torch.float64, device=device),
+                             sd=torch.zeros(self.B, dtype=torch.int32, device=device)) for _ in range(2 if self.defer == 2 else 1)]
         # err_buffer: an N*B x P float32 tensor to write the error images into (e.g. one that another, idle runner of this process already owns)
         self.err = (err_buffer[:NB] if err_buffer is not None else torch.zeros(NB, self.P, dtype=torch.float32, device=device)) if write_err else None
         self.gs = torch.cuda.Stream(device=device)  # gather / host copy beside the engine's stream
@@ -64,20 +67,22 @@ class ShardRunner:
         self.consumed_valid = [False, False]
         self.steps_done = 0
         self.host_us = dict(consume=0.0, gather=0.0, slot_wait=0.0, process_images=0.0)  # host seconds spent enqueueing, by phase (diagnostics)
-        engine.set_option("pi_defer_tail", 1 if defer else 0)
+        engine.set_option("pi_defer_tail", self.defer)
         engine.set_option("seed_stride", world)
         self._last_slot = None
         # The host side of a step is a handful of C-ABI calls with constant arguments (only the seed changes): they are bound once here -- with 8 ranks
         # a step is ~0.5 ms of GPU work, and marshalling two dozen tensors through Python per call would cost a third of that.
         ctx = engine._ctx
         fx, fy, cx, cy = [float(c) for c in cam]
-        s = self.scratch
         self._set_frames_args, self._process_args = [], [[], []]
+        odd = len(self.batches) & 1
         for bi, idx in enumerate(self.batches):
             nb, j0 = len(idx), idx[0]
             n = nb * N
             self._set_frames_args.append((ctx, nb, ptr(self.xyz[bi]), None, 0, H, W, fx, fy, cx, cy, capi.DSAC_FRAME_BORROW))
             for k in (0, 1):
+                # consecutive calls -- within a step and across the step boundary (step parity k) -- use different scratch sets
+                s = self.scratch[(bi + (k if odd else 0)) & 1] if len(self.scratch) == 2 else self.scratch[0]
                 ref_v, out4_v, w_v = self.ex.views(k)
                 self._process_args[k].append([ctx, N, 0, 10.0, 1 << 16, 100.0, 10.0, 0.5, 0.1, ptr(self.perm), int(self.perm.shape[0]), 100, 50, ptr(self.gt[j0:j0 + nb]),
                                               ptr(s["poses"][:n]), ptr(s["sets"][:n]), ptr(s["ok"][:n]), None if self.err is None else ptr(self.err[:n]),

@@ -117,7 +117,8 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 this promise is a caller bug with undefined behaviour; 0 (default): detect
  *   "seed_stride"  frame f of a frame batch draws from the random stream of seed + f * seed_stride (default 1).  Images sharded round-robin over W ranks
  *                 (rank r owns images r, r + W, ...) keep the seeds they have in the unsharded loop with seed_stride = W: results do not depend on W
- *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail (see dsac_join_tail); 0 (default): everything in stream order
+ *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail, 2: its score tail (reduction, K3) as well (see dsac_join_tail);
+ *                   0 (default): everything in stream order
  *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave, 6 / 7 its high-occupancy builds (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
  * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
@@ -340,7 +341,13 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * it starts from.  None of them may be overwritten -- not even by work enqueued on the context's stream, which is not ordered against the tail --
  * before dsac_join_tail, another entry point that enqueues work, or dsac_synchronize; a following dsac_process_images may use the same perm / gt and
  * other frames, and orders its own write of avg6 behind the previous tail.  A pipeline that refills ONE borrowed coordinate buffer batch after batch
- * must call dsac_join_tail before the refill (tests/test_gpu_process_images.py::test_deferred_tail_and_a_reused_borrowed_frame_buffer). */
+ * must call dsac_join_tail before the refill (tests/test_gpu_process_images.py::test_deferred_tail_and_a_reused_borrowed_frame_buffer).
+ * dsac_set_option("pi_defer_tail", 2) moves the score tail to that stream as well: the reduction of the per-tile soft-inlier sums and K3 of batch i run
+ * beside K1 of batch i + 1, which then follows K2 of batch i without a gap (the reduction and K3 are two small launches that leave the chip idle
+ * while they run in order).  Then EVERY output of the call except the error images -- poses, sets_out, ok, scores, w, entropy, avg6 and the tail's
+ * four -- is ordered on the context's stream only after dsac_join_tail / another entry point / dsac_synchronize, and consecutive calls must be given
+ * different arrays for all of them; the call after the next may reuse them (the library orders its K1 behind K3 of the call two back).  Results
+ * are the same bit for bit in all three modes (tests/test_gpu_process_images.py). */
 DSAC_API int dsac_join_tail(dsac_ctx* ctx);
 /* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight -- and
  * thereby for the dsac_process_images call it belongs to and everything the context's stream held before that call (the tail starts behind that call's

@@ -76,7 +76,7 @@ def drive(mode, reps):
                 st.wait_event(runner.consumed[k])
             ref_v, out4_v, w_v = runner.ex.views(k)
             eng.set_frames(runner.xyz[0], None, H, W, cam, borrow=True)
-            s = runner.scratch
+            s = runner.scratch[0]
             eng.processImages(N, perm, gt_jp6=runner.gt[:F], seed=1305 + 64 * i, thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
                               err=runner.err, out=dict(hyps=s["poses"], sampledPoints=s["sets"], ok=s["ok"], scores=s["soft"], sfScores=w_v[:F].view(-1),
                                                        sfEntropy=s["ent"], avgHyp=s["avg"], refAvgHyp=ref_v[:F], refSteps=s["sd"], out4=out4_v[:F]))

@@ -98,7 +98,8 @@ def test_process_images_at_baseline_size_on_device(engine, synth):
 
 
 def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
-    """dsac_set_option("pi_defer_tail", 1): K6 / K7 of a batch run on their own stream under K1 / K2 of the next batch.  Three batches of different
+    """dsac_set_option("pi_defer_tail", 1): K6 / K7 of a batch run on their own stream under K1 / K2 of the next batch (2: the score reduction and
+    K3 as well).  Three batches of different
     frames in a row, every tail output in its own buffer, read after joinTail: bit-equal to the same three calls in stream order; a host
     destination switches the deferral off for that call; other entry points see a pending tail's results in stream order."""
     import torch
@@ -124,7 +125,7 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
                     inlierMaps=torch.zeros(F, P, dtype=torch.int32, device=dev))
 
     def run(defer):
-        engine.set_option("pi_defer_tail", 1 if defer else 0)
+        engine.set_option("pi_defer_tail", int(defer))
         shared = bufs()          # everything but the tail's outputs is shared by the three calls, as a loop over batches would do
         own = [bufs() for _ in range(3)]
         # torch zero-fills the new buffers on ITS stream, the engine writes them from its own (non-blocking) streams: without this a fill can land after
@@ -133,7 +134,8 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
         outs = []
         for k in range(3):
             o = dict(shared)
-            for key in ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores"):
+            # mode 2 (score tail deferred too): K3 of a call reads its poses / scores beside K1 of the next -- every output in its own buffer
+            for key in (own[k] if int(defer) == 2 else ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores")):
                 o[key] = own[k][key]
             engine.set_frames(batches[k], None, H, W, cam, borrow=True)
             engine.processImages(N, perm, gt_jp6=gts, seed=31 + k, out=o)
@@ -145,10 +147,30 @@ def test_deferred_refinement_tail_gives_the_same_results(engine, synth):
     try:
         plain = run(False)
         deferred = run(True)
-        for a, b in zip(plain, deferred):
+        both_tails = run(2)
+        for a, b, c2 in zip(plain, deferred, both_tails):
             assert (a["refSteps"] == 8).all() and a["ok"].all()
             for key in a:
                 assert np.array_equal(a[key], b[key]), key
+            # shared buffers of the in-order run hold the LAST call's values: compare what every call owns in both
+            for key in ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores"):
+                assert np.array_equal(a[key], c2[key]), key
+        for key in plain[2]:
+            assert np.array_equal(plain[2][key], both_tails[2][key]), key
+        # mode 2, the call after the next reuses a call's arrays (the library orders its K1 behind K3 of the call two back): five calls over two
+        # sets of arrays, the last two equal the in-order calls
+        engine.set_option("pi_defer_tail", 2)
+        two = [bufs(), bufs()]
+        torch.cuda.synchronize(dev)
+        for k in range(5):
+            engine.set_frames(batches[k % 3], None, H, W, cam, borrow=True)
+            engine.processImages(N, perm, gt_jp6=gts, seed=31 + (k % 3), out=two[k & 1])
+        engine.joinTail()
+        engine.synchronize()
+        for k in (3, 4):
+            ref_call = plain[k % 3]
+            for key in ("refAvgHyp", "refSteps", "out4", "inlierMaps", "avgHyp", "sfScores"):
+                assert np.array_equal(ref_call[key], two[k & 1][key].cpu().numpy()), (k, key)
         # another entry point after a deferred call: ordered behind the tail without an explicit join (K7 on the refined poses of the last batch)
         engine.set_option("pi_defer_tail", 1)
         o = bufs()

@@ -24,8 +24,8 @@ def _reference_rows(synth, perm_np, gts, step):
     return rows
 
 
-@pytest.mark.parametrize("world", [1, 3])
-def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world):
+@pytest.mark.parametrize("world,defer", [(1, 2), (3, 2), (3, 1), (1, 0)])
+def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world, defer):
     import torch
     import dsac_amd
     from dsac_amd.shard import ShardRunner
@@ -41,7 +41,7 @@ def test_shard_runner_equals_the_in_order_per_image_loop(synth, orc, world):
         eng = dsac_amd.Engine(0, stream=st)
         try:
             run = ShardRunner(eng, st, dev, lambda i: frames[i]["xyz"], NIMG, rank, world, N, H, W, frames[0]["cam"], perm, gt_of=lambda i: gts[i], batch=4,
-                              emulate=world > 1)
+                              emulate=world > 1, defer=defer)  # 2: score + refinement tail of a batch under the next one, 1: refinement only, 0: in order
             assert run.mine == list(range(rank, NIMG, world))
             for s in range(STEPS):
                 run.step(s)      # never waits: the tail of step s runs under step s + 1, the gather of step s is launched in step s + 1
