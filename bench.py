@@ -268,7 +268,8 @@ def host_driver_leg(N, H, W, device=0, images=64, batch=16, passes=6):
     if not os.path.exists(exe):
         return {"error": "dsac_amd/host/test_ransac_softam is not built"}
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = [exe, "-synth", str(images), "-mw", str(W), "-mh", str(H), "-rI", str(N), "-batch", str(batch), "-passes", str(passes), "-dev", str(device)]
+        # -warmup 300: untimed passes until the clock has settled (the program makes its synthetic data set on the host first: the GPU idles for a second)
+        cmd = [exe, "-synth", str(images), "-mw", str(W), "-mh", str(H), "-rI", str(N), "-batch", str(batch), "-passes", str(passes), "-warmup", "300", "-dev", str(device)]
         try:
             out = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True, timeout=600)
         except Exception as e:  # noqa: BLE001
@@ -278,12 +279,28 @@ def host_driver_leg(N, H, W, device=0, images=64, batch=16, passes=6):
         acc = re.search(r"accuracy: ([0-9.eE+-]+)%", out.stdout)
         if out.returncode != 0 or not m:
             return {"error": "rc %d: %s" % (out.returncode, (out.stdout + out.stderr)[-300:])}
-        return {"program": "dsac_amd/host/test_ransac_softam " + " ".join(cmd[1:]),
-                "what": "C++ host over the C ABI (dsac::Context + FrameBatch::processImages = dsac_set_frames + dsac_process_images): the whole processImage of "
-                        "every image (sample + P3P, error images, soft-argmax, 8 refinement steps, loss), %d images per launch chain, refinement tail deferred "
-                        "under the next batch, data set resident in HBM, results copied back once per pass" % batch,
-                "us_per_image": float(m.group(1)), "ms_per_pass": float(m.group(2)), "timed_passes": int(m.group(3)), "first_pass_ms": float(m.group(4)),
-                "upload_and_setup_ms": float(m.group(5)), "images": images, "hypotheses": N, "accuracy_percent": float(acc.group(1)) if acc else None}
+        res = {"program": "dsac_amd/host/test_ransac_softam " + " ".join(cmd[1:]),
+               "what": "C++ host over the C ABI (dsac::Context + FrameBatch::processImages = dsac_set_frames + dsac_process_images): the whole processImage of "
+                       "every image (sample + P3P, error images, soft-argmax, 8 refinement steps, loss), %d images per launch chain, score and refinement "
+                       "tail of a chain under the next one, data set resident in HBM, timed passes enqueued back to back, results copied back once" % batch,
+               "us_per_image": float(m.group(1)), "ms_per_pass": float(m.group(2)), "timed_passes": int(m.group(3)), "first_pass_ms": float(m.group(4)),
+               "upload_and_setup_ms": float(m.group(5)), "images": images, "hypotheses": N, "accuracy_percent": float(acc.group(1)) if acc else None}
+        # the training program in its device-resident form: the training set in HBM, `batch` random frames per round gathered device-to-device, forward
+        # (processImage with the error images) and backward (train_ransac_softam.cpp:288-394) as one launch chain each, gradients left in HBM
+        exe_t = os.path.join(ROOT, "dsac_amd", "host", "train_ransac_softam")
+        if os.path.exists(exe_t):
+            cmd_t = [exe_t, "-synth", "32", "-mw", str(W), "-mh", str(H), "-rI", str(N), "-rounds", "60", "-batch", str(batch), "-gradstats", "0", "-warmup", "300",
+                     "-dev", str(device)]
+            try:
+                out_t = subprocess.run(cmd_t, cwd=tmp, capture_output=True, text=True, timeout=600)
+                mt = re.search(r"Timing: (\d+) rounds x (\d+) frames .*?: ([0-9.eE+-]+) us per round = ([0-9.eE+-]+) us per frame", out_t.stdout)
+                res["training"] = ({"program": "dsac_amd/host/train_ransac_softam " + " ".join(cmd_t[1:]), "rounds": int(mt.group(1)), "frames_per_round": int(mt.group(2)),
+                                    "us_per_round": float(mt.group(3)), "us_per_frame": float(mt.group(4)),
+                                    "what": "forward + backward of every frame, device-resident (FrameBatch::gatherFramesFrom / processImages / backward)"}
+                                   if (out_t.returncode == 0 and mt) else {"error": "rc %d: %s" % (out_t.returncode, (out_t.stdout + out_t.stderr)[-300:])})
+            except Exception as e:  # noqa: BLE001
+                res["training"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        return res
 
 
 def run_dry(args, rank, world, dist):

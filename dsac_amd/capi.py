@@ -41,6 +41,7 @@ EXPORTS = [
     "dsac_profile_read", "dsac_last_pose_gradients", "dsac_refine_all", "dsac_refine_fd_set", "dsac_refine_fd_sets", "dsac_loss_batch", "dsac_gather_patches", "dsac_set_frames", "dsac_score_hypotheses_frames", "dsac_set_option", "dsac_backward_path1",
     "dsac_loss_frames", "dsac_process_images", "dsac_join_tail", "dsac_select",
     "dsac_device_alloc", "dsac_device_free", "dsac_host_alloc", "dsac_host_free", "dsac_copy_async", "dsac_fill_zero_async", "dsac_tail_wait",
+    "dsac_gather_rows",
 ]
 
 
@@ -105,6 +106,7 @@ def _load():
     lib.dsac_host_free.argtypes = [vp, vp]
     lib.dsac_copy_async.argtypes = [vp, vp, vp, C.c_size_t]
     lib.dsac_fill_zero_async.argtypes = [vp, vp, C.c_size_t]
+    lib.dsac_gather_rows.argtypes = [vp, vp, vp, C.c_size_t, i32, vp]
     lib.dsac_process_images.argtypes = [vp, i32, u64, f32, i32, f32, f32, f32, f64, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dsac_backward_path1.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, f32, f32, f32, f64, vp, vp, vp, vp, vp]
     return lib

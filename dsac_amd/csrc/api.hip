@@ -218,6 +218,16 @@ struct ProfScope {
         if (rc__ != DSAC_OK) return rc__; \
     } while (0)
 
+// dsac_gather_rows: row i of dst = row idx.r[i] of src, rows of `words` 32-bit words; blockIdx.y = destination row.  The indices travel as a kernel
+// argument (no device buffer, no upload): up to 256 rows per launch.
+struct GatherIdx { int32_t r[256]; };
+template <typename V>
+__global__ __launch_bounds__(256) void k_gather_rows(V* __restrict__ dst, const V* __restrict__ src, size_t vecs, GatherIdx idx) {
+    const V* s = src + (size_t)idx.r[blockIdx.y] * vecs;
+    V* d = dst + (size_t)blockIdx.y * vecs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 __global__ void k_quantise_int16(float* xyz, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -438,6 +448,37 @@ int dsac_copy_async(dsac_ctx* c, void* dst, const void* src, size_t bytes) {
     // a source on the device may be something a deferred refinement tail is still writing (ref6 / out4 / steps_done / inlier maps)
     if (is_device_ptr(src)) join_tail(c);
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    return DSAC_OK;
+}
+
+int dsac_gather_rows(dsac_ctx* c, void* dst, const void* src, size_t row_bytes, int n_rows, const int32_t* rows) {
+    if (!c || (n_rows > 0 && (!dst || !src || !rows))) return fail(c, DSAC_ERR_INVALID, "dsac_gather_rows: NULL argument");
+    if (n_rows <= 0 || row_bytes == 0) return DSAC_OK;
+    if (row_bytes % 4 != 0) return fail(c, DSAC_ERR_INVALID, "dsac_gather_rows: row_bytes must be a multiple of 4");
+    if (!is_device_ptr(dst, c) || !is_device_ptr(src, c)) return fail(c, DSAC_ERR_INVALID, "dsac_gather_rows: dst and src are device pointers");
+    HIP_TRY(c, hipSetDevice(c->device));
+    join_tail(c);  // a deferred refinement tail may still read what dst holds (the previous step's frames) or write what src holds
+    const bool v16 = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0;
+    for (int r0 = 0; r0 < n_rows; r0 += 256) {
+        const int n = n_rows - r0 < 256 ? n_rows - r0 : 256;
+        GatherIdx idx;
+        for (int i = 0; i < n; i++) {
+            if (rows[r0 + i] < 0) return fail(c, DSAC_ERR_INVALID, "dsac_gather_rows: negative row index");
+            idx.r[i] = rows[r0 + i];
+        }
+        char* d = static_cast<char*>(dst) + (size_t)r0 * row_bytes;
+        if (v16) {
+            const size_t vecs = row_bytes / 16;
+            const unsigned gx = (unsigned)std::min<size_t>((vecs + 255) / 256, (size_t)std::max(1, 2048 / n));
+            hipLaunchKernelGGL((k_gather_rows<uint4>), dim3(gx, (unsigned)n), dim3(256), 0, c->stream, reinterpret_cast<uint4*>(d), static_cast<const uint4*>(src), vecs, idx);
+        } else {
+            const size_t vecs = row_bytes / 4;
+            const unsigned gx = (unsigned)std::min<size_t>((vecs + 255) / 256, (size_t)std::max(1, 2048 / n));
+            hipLaunchKernelGGL((k_gather_rows<uint32_t>), dim3(gx, (unsigned)n), dim3(256), 0, c->stream, reinterpret_cast<uint32_t*>(d), static_cast<const uint32_t*>(src), vecs,
+                               idx);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
     return DSAC_OK;
 }
 

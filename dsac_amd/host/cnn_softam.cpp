@@ -261,6 +261,18 @@ ProcessImageResult Frame::processImageCall(const Hypothesis& poseGT, int objHyps
 }
 
 // ---- FrameBatch ----------------------------------------------------------------------------------------------------------------------
+namespace {
+// dsac_set_option("device_args", 1) for the calls of a scope whose pointer arguments all live in HBM; back to argument detection on leaving it -- the
+// context is shared with Frame, whose calls take host arrays
+struct DeviceArgsScope {
+    dsac_ctx* c;
+    explicit DeviceArgsScope(dsac_ctx* ctx) : c(ctx) { (void)dsac_set_option(c, "device_args", 1); }
+    ~DeviceArgsScope() { (void)dsac_set_option(c, "device_args", 0); }
+    DeviceArgsScope(const DeviceArgsScope&) = delete;
+    DeviceArgsScope& operator=(const DeviceArgsScope&) = delete;
+};
+}  // namespace
+
 FrameBatch::FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam, int objHyps, int refSteps, const std::vector<int32_t>& pixelIdxs,
                        int maxFramesPerCall, const FrameBatchOptions& opt)
     : C_(ctx), F_(frames), H_(H), W_(W), N_(objHyps), refSteps_(refSteps), maxCall_(maxFramesPerCall), cam_(cam), opt_(opt) {
@@ -270,6 +282,7 @@ FrameBatch::FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam
     const size_t P = (size_t)H * W, F = (size_t)frames, N = (size_t)objHyps;
     if ((size_t)refSteps * P > pixelIdxs.size()) throw Error(DSAC_ERR_INVALID, "FrameBatch: pixelIdxs holds fewer than refSteps permutations");
     xyz_.resize(ctx, F * P * 3);
+    if (opt.sampling) uv_.resize(ctx, F * P * 2);
     gt_.resize(ctx, F * 6);
     perm_.resize(ctx, (size_t)refSteps * P);
     perm_.upload(pixelIdxs.data(), (size_t)refSteps * P);
@@ -289,11 +302,13 @@ FrameBatch::FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam
     C_.synchronize();  // pixelIdxs may be a temporary
 }
 
-void FrameBatch::setFrame(int f, const float* estObj, const Hypothesis& poseGT) {
+void FrameBatch::setFrame(int f, const float* estObj, const Hypothesis& poseGT, const float* sampling) {
     if (f < 0 || f >= F_ || !estObj) throw Error(DSAC_ERR_INVALID, "FrameBatch::setFrame: bad frame index");
+    if (opt_.sampling != (sampling != nullptr)) throw Error(DSAC_ERR_INVALID, "FrameBatch::setFrame: a sampling table goes with FrameBatchOptions::sampling, and only with it");
     const size_t P = (size_t)H_ * W_;
     const std::vector<double> g = poseGT.getRodVecAndTrans();
     xyz_.upload(estObj, P * 3, (size_t)f * P * 3);
+    if (sampling) uv_.upload(sampling, P * 2, (size_t)f * P * 2);
     gt_.upload(g.data(), 6, (size_t)f * 6);
     C_.synchronize();  // pageable sources: stable once this returns
     done_[f] = 0;
@@ -309,14 +324,81 @@ void FrameBatch::processImages(int first, int count, uint64_t seedOfFrame0, int 
     lastFirst_ = first; lastCount_ = count;
     unsigned flags = DSAC_FRAME_BORROW;
     if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;  // in place; idempotent
-    C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, nullptr, 0, H_, W_, cam_.fx, cam_.fy, cam_.cx, cam_.cy, flags), "dsac_set_frames");
+    C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, opt_.sampling ? uv_.data() + f0 * P * 2 : nullptr, opt_.sampling ? 1 : 0, H_, W_, cam_.fx, cam_.fy, cam_.cx,
+                             cam_.cy, flags), "dsac_set_frames");
     C_.setBound(this);
-    C_.check(dsac_process_images(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, perm_.data(),
+    const DeviceArgsScope devArgs(c);  // every argument below lives in HBM: no pointer query per argument
+    const int rcP = dsac_process_images(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, perm_.data(),
                                  refSteps_, inlierCount, 50, gt_.data() + f0 * 6, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, ok_.data() + f0 * N,
                                  opt_.errorImages ? err_.data() : nullptr, scores_.data() + f0 * N, w_.data() + f0 * N, entropy_.data() + f0, avg_.data() + f0 * 6,
-                                 ref_.data() + f0 * 6, stepsDone_.data() + f0, opt_.inlierMaps ? maps_.data() + f0 * P : nullptr, out4_.data() + f0 * 4),
-             "dsac_process_images");
+                                 ref_.data() + f0 * 6, stepsDone_.data() + f0, opt_.inlierMaps ? maps_.data() + f0 * P : nullptr, out4_.data() + f0 * 4);
+    C_.check(rcP, "dsac_process_images");
     for (int f = first; f < first + count; f++) done_[f] = 1;
+}
+
+void FrameBatch::backward(int first, int count, int inlierThreshold2D, int inlierCount, float subSampleFactor, float tau, float beta, double alpha) {
+    if (first < 0 || count <= 0 || first + count > F_ || count > maxCall_) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: bad frame range");
+    if (!opt_.inlierMaps) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: the batch was made without FrameBatchOptions::inlierMaps");
+    for (int f = first; f < first + count; f++)
+        if (!done_[f]) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: processImages has not run on a frame of the range");
+    const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
+    dsac_ctx* c = C_.get();
+    if (grad_.size() == 0) {
+        grad_.resize(C_, (size_t)F_ * P * 3);
+        dpnp_.resize(C_, (size_t)maxCall_ * N * 72);
+        g_.resize(C_, (size_t)maxCall_ * N);
+    }
+    unsigned flags = DSAC_FRAME_BORROW;
+    if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;
+    // any entry point but dsac_process_images orders the stream behind a deferred tail: the refined poses and inlier maps are complete for what follows
+    C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, opt_.sampling ? uv_.data() + f0 * P * 2 : nullptr, opt_.sampling ? 1 : 0, H_, W_, cam_.fx, cam_.fy, cam_.cx,
+                             cam_.cy, flags), "dsac_set_frames");
+    C_.setBound(this);
+    double* grad = grad_.data() + f0 * P * 3;
+    const DeviceArgsScope devArgs(c);
+    C_.check(dsac_fill_zero_async(c, grad, (size_t)count * P * 3 * sizeof(double)), "dsac_fill_zero_async");
+    const int n = count * N_;
+    // path I and the softmax backward (train_ransac_softam.cpp:294-376); g comes back scaled by alpha: the score is alpha x the soft-inlier count
+    C_.check(dsac_backward_path1(c, n, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, w_.data() + f0 * N, avg_.data() + f0 * 6, ref_.data() + f0 * 6,
+                                 gt_.data() + f0 * 6, perm_.data(), refSteps_, inlierCount, 50, (float)inlierThreshold2D, maps_.data() + f0 * P, subSampleFactor, 0.001f,
+                                 2.f, alpha, dpnp_.data(), grad, g_.data(), nullptr, nullptr),
+             "dsac_backward_path1");
+    // path II: score gradients -> error images -> scene coordinates (dScore, :379-383), the error-image gradient formed in-kernel
+    C_.check(dsac_soft_score_backward(c, n, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, g_.data(), (float)CNN_OBJ_MAXINPUT, tau, beta, dpnp_.data(), 0u, grad),
+             "dsac_soft_score_backward");
+    lastFirst_ = 0; lastCount_ = 0;  // the stream is ordered behind every tail now
+}
+
+std::vector<double> FrameBatch::gradients(int f) {
+    if (f < 0 || f >= F_ || grad_.size() == 0) throw Error(DSAC_ERR_INVALID, "FrameBatch::gradients: no backward pass has run");
+    const size_t n = (size_t)H_ * W_ * 3;
+    return grad_.toHost(n, (size_t)f * n);
+}
+
+void FrameBatch::copyFrameFrom(const FrameBatch& src, int srcFrame, int dstFrame) {
+    if (src.H_ != H_ || src.W_ != W_ || src.opt_.sampling != opt_.sampling || srcFrame < 0 || srcFrame >= src.F_ || dstFrame < 0 || dstFrame >= F_)
+        throw Error(DSAC_ERR_INVALID, "FrameBatch::copyFrameFrom: geometry or frame index does not match");
+    const size_t n = (size_t)H_ * W_ * 3;
+    // dsac_copy_async orders the stream behind a deferred tail first (the previous step's refinement may still read the destination)
+    C_.copy(xyz_.data() + (size_t)dstFrame * n, src.xyz_.data() + (size_t)srcFrame * n, n * sizeof(float));
+    C_.copy(gt_.data() + (size_t)dstFrame * 6, src.gt_.data() + (size_t)srcFrame * 6, 6 * sizeof(double));
+    if (opt_.sampling) C_.copy(uv_.data() + (size_t)dstFrame * n / 3 * 2, src.uv_.data() + (size_t)srcFrame * n / 3 * 2, n / 3 * 2 * sizeof(float));
+    done_[dstFrame] = 0;
+}
+
+void FrameBatch::gatherFramesFrom(const FrameBatch& src, const std::vector<int32_t>& srcFrames, int dstFirst) {
+    const int n = (int)srcFrames.size();
+    if (src.H_ != H_ || src.W_ != W_ || src.opt_.sampling != opt_.sampling || dstFirst < 0 || dstFirst + n > F_)
+        throw Error(DSAC_ERR_INVALID, "FrameBatch::gatherFramesFrom: geometry or frame range does not match");
+    for (int32_t f : srcFrames)
+        if (f < 0 || f >= src.F_) throw Error(DSAC_ERR_INVALID, "FrameBatch::gatherFramesFrom: bad source frame");
+    if (n == 0) return;
+    const size_t P = (size_t)H_ * W_, d0 = (size_t)dstFirst;
+    dsac_ctx* c = C_.get();
+    C_.check(dsac_gather_rows(c, xyz_.data() + d0 * P * 3, src.xyz_.data(), P * 3 * sizeof(float), n, srcFrames.data()), "dsac_gather_rows");
+    C_.check(dsac_gather_rows(c, gt_.data() + d0 * 6, src.gt_.data(), 6 * sizeof(double), n, srcFrames.data()), "dsac_gather_rows");
+    if (opt_.sampling) C_.check(dsac_gather_rows(c, uv_.data() + d0 * P * 2, src.uv_.data(), P * 2 * sizeof(float), n, srcFrames.data()), "dsac_gather_rows");
+    for (int k = 0; k < n; k++) done_[dstFirst + k] = 0;
 }
 
 void FrameBatch::processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau, float beta, double alpha) {

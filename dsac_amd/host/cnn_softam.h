@@ -192,6 +192,8 @@ struct FrameBatchOptions {
     bool deferScoreTail = true;  // ... = 2: the score reduction and K3 as well (consecutive calls write different frames' result rows); 64 images in
                                  // batches of 16: 65.6 (in order) / 62.8 / 62.6 us per image, in batches of 4: 87.9 / - / 65.7 (profiles/r04_host_driver_defer_ab.txt)
     bool quantiseInt16 = false;
+    bool sampling = false;     // every frame brings its own H*W x 2 table of image positions (the reference's sub-sampled 40x40 maps: stochasticSubSample,
+                               // core/cnn_softam.h:283-309, draws them per image); false: the full-resolution grid, cell (x, y) at pixel (x, y)
 };
 
 class FrameBatch {
@@ -200,7 +202,7 @@ public:
                int maxFramesPerCall = 16, const FrameBatchOptions& opt = FrameBatchOptions());
     int frames() const { return F_; }
     // stream-ordered upload of frame f's coordinate map (H*W*3 floats, mm) and ground truth
-    void setFrame(int f, const float* estObj, const Hypothesis& poseGT);
+    void setFrame(int f, const float* estObj, const Hypothesis& poseGT, const float* sampling = nullptr);  // sampling: FrameBatchOptions::sampling
     // enqueue processImage for frames [first, first + count), count <= maxFramesPerCall; returns immediately
     void processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f,
                        double alpha = 0.1);
@@ -211,16 +213,32 @@ public:
     std::vector<ProcessImageResult> results(bool perHypothesis = true);
     const float* errorImagesDevice() const { return err_.data(); }  // of the most recent call, count*objHyps x H*W
 
+    // ---- training (core/train_ransac_softam.cpp:288-394 for every frame of the range, one launch chain; needs FrameBatchOptions::inlierMaps) ----
+    // Enqueue the backward pass of frames [first, first + count) behind their processImages: dLossMax at each refined pose, dRefineObj / dRefineHyp
+    // (12 + 6n finite-difference replicas per frame), dPNP of the count * objHyps minimal sets, the path-I assembly, the softmax backward and the
+    // soft-inlier score backward (K4) -- dsac_backward_path1 + dsac_soft_score_backward on the frame batch.  The gradient of the loss with respect to
+    // frame f's scene coordinates (H*W x 3 doubles, what the reference hands to the scene-coordinate CNN's backward, :412) stays in HBM
+    // (gradientsDevice); returns immediately.  count * objHyps hypotheses: objHyps a multiple of 16 and at most 256 when count > 1.
+    void backward(int first, int count, int inlierThreshold2D, int inlierCount, float subSampleFactor, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
+    const double* gradientsDevice(int f) const { return grad_.data() + (size_t)f * H_ * W_ * 3; }
+    std::vector<double> gradients(int f);  // waits, copies frame f's gradient back
+    // device-to-device: frame `srcFrame` of another batch of the same geometry becomes frame `dstFrame` of this one (coordinate map + ground truth),
+    // in stream order -- how a training step draws its frames from a data set that stays resident in HBM
+    void copyFrameFrom(const FrameBatch& src, int srcFrame, int dstFrame);
+    // the same for frames dstFirst, dstFirst + 1, ... at once: dsac_gather_rows, one launch per array instead of one copy per frame and array
+    void gatherFramesFrom(const FrameBatch& src, const std::vector<int32_t>& srcFrames, int dstFirst = 0);
+
 private:
     Context& C_;
     int F_, H_, W_, N_, refSteps_, maxCall_;
     int lastFirst_ = 0, lastCount_ = 0;  // the frame range of the previous call (its result rows are still being written with a deferred score tail)
     Camera cam_;
     FrameBatchOptions opt_;
-    DeviceArray<float> xyz_, err_;
+    DeviceArray<float> xyz_, uv_, err_;
     DeviceArray<int32_t> perm_, sets_, stepsDone_, maps_;
     DeviceArray<uint8_t> ok_;
     DeviceArray<double> gt_, poses_, scores_, w_, entropy_, avg_, ref_, out4_;
+    DeviceArray<double> grad_, dpnp_, g_;  // training: F x H*W x 3 gradient, maxCall x objHyps x 72 dPNP, maxCall x objHyps score gradients
     std::vector<uint8_t> done_;
 };
 

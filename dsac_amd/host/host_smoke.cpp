@@ -64,6 +64,36 @@ int main(int argc, char** argv) {
         };
         const bool batchEqual = br.size() == 2 && same(br[0], g1) && same(br[1], g2);
         std::printf("FrameBatch: 2 images in one launch chain %s the per-image calls (losses %.6f / %.6f)\n", batchEqual ? "equal" : "DIFFER FROM", br[0].loss, br[1].loss);
+        // sub-sampled frames bring their own table of image positions (FrameBatchOptions::sampling): the batch on (xyz, uv) equals frame.processImage,
+        // its backward pass equals Frame::backward, and a step batch filled device-to-device (gatherFramesFrom / copyFrameFrom) gives the same again
+        bool samplingEqual = false;
+        {
+            FrameBatchOptions so = bo;
+            so.sampling = true;
+            FrameBatch sb(frame.engine(), 2, H, W, cam, 256, 8, perms, 2, so);
+            sb.setFrame(0, xyz.data(), poseGT, uv.data());
+            sb.setFrame(1, xyz.data(), poseGT, uv.data());
+            sb.processAll(1305, 10, 100);
+            const std::vector<ProcessImageResult> sr = sb.results();
+            sb.backward(0, 2, 10, 100, 0.05f);
+            const std::vector<double> gb = sb.gradients(0);
+            const std::vector<double> gl = frame.backward(r, poseGT, 10, 100, 8, 0.05f, perms);
+            double dmax = 0, gmax = 0;
+            for (size_t i = 0; i < gl.size(); i++) { dmax = std::max(dmax, std::fabs(gl[i] - gb[i])); gmax = std::max(gmax, std::fabs(gl[i])); }
+            FrameBatch step(frame.engine(), 2, H, W, cam, 256, 8, perms, 2, so);
+            step.gatherFramesFrom(sb, std::vector<int32_t>{1, 0});
+            step.processAll(1305, 10, 100);
+            const std::vector<ProcessImageResult> s1 = step.results();
+            step.copyFrameFrom(sb, 0, 1);
+            step.copyFrameFrom(sb, 1, 0);
+            step.processAll(1305, 10, 100);
+            const std::vector<ProcessImageResult> s2 = step.results();
+            samplingEqual = sr.size() == 2 && same(sr[0], r) && same(s1[0], sr[0]) && same(s1[1], sr[1]) && same(s2[0], sr[0]) && same(s2[1], sr[1]) && gmax > 0 &&
+                            dmax <= 1e-4 * gmax;  // K4's fp32 partial sums are grouped by the launch's workgroup count (two frames per launch here, one in Frame::backward)
+            std::printf("FrameBatch with sampling tables: forward %s Frame::processImage, backward |d| / |g| = %.3g, gathered step batch %s\n",
+                        (sr.size() == 2 && same(sr[0], r)) ? "equals" : "DIFFERS FROM", gmax > 0 ? dmax / gmax : -1.0,
+                        (same(s1[0], sr[0]) && same(s2[1], sr[1])) ? "equal" : "DIFFERS");
+        }
         if (argc > 1) {
             std::FILE* f = std::fopen(argv[1], "wb");
             if (!f) { std::printf("cannot write %s\n", argv[1]); return 3; }
@@ -104,7 +134,7 @@ int main(int argc, char** argv) {
         for (double v : Jset) ns += v * v;
         std::printf("DSAC variant: hypIdx %d (p = %.3f), expected loss %.4f, winner rot %.4f deg / trans %.3f mm, |dRefine_set| = %.4g, %zu inlier cells\n",
                     d.hypIdx, d.sfScores[d.hypIdx], d.expectedLoss, d.rotErr, d.tErr, std::sqrt(ns), px.size());
-        return (r.correct && r.refStepsDone == 8 && n > 0 && d.correct && ns > 0 && d.expectedLoss > 0 && batchEqual) ? 0 : 2;
+        return (r.correct && r.refStepsDone == 8 && n > 0 && d.correct && ns > 0 && d.expectedLoss > 0 && batchEqual && samplingEqual) ? 0 : 2;
     } catch (const Error& e) {
         std::printf("dsac error %d: %s\n", e.code, e.what());
         return 1;

@@ -64,8 +64,10 @@ bool GlobalProperties::readArguments(std::vector<std::string> argv) {
         if (s == "-rounds") { eP.rounds = std::atoi(next().c_str()); std::cout << "training rounds: " << eP.rounds << "\n"; continue; }
         if (s == "-dev") { eP.device = std::atoi(next().c_str()); std::cout << "device: " << eP.device << "\n"; continue; }
         if (s == "-quirk") { eP.indexQuirk = std::atoi(next().c_str()) != 0; std::cout << "path II index quirk: " << eP.indexQuirk << "\n"; continue; }
-        if (s == "-batch") { eP.batch = std::atoi(next().c_str()); std::cout << "images per launch chain: " << eP.batch << "\n"; continue; }
+        if (s == "-batch") { eP.batchGiven = true; eP.batch = std::atoi(next().c_str()); std::cout << "images per launch chain: " << eP.batch << "\n"; continue; }
         if (s == "-passes") { eP.passes = std::atoi(next().c_str()); std::cout << "passes over the data set: " << eP.passes << "\n"; continue; }
+        if (s == "-warmup") { eP.warmupMs = std::atoi(next().c_str()); std::cout << "warm-up: " << eP.warmupMs << " ms\n"; continue; }
+        if (s == "-gradstats") { eP.gradStats = std::atoi(next().c_str()); std::cout << "gradient statistics every: " << eP.gradStats << "\n"; continue; }
         if (s == "-defer") { eP.defer = std::atoi(next().c_str()); std::cout << "deferred tails: " << eP.defer << "\n"; continue; }
         if (s == "-errimg") { eP.errorImages = std::atoi(next().c_str()) != 0; std::cout << "error images: " << eP.errorImages << "\n"; continue; }
         std::cout << "unkown argument: " << argv[i] << "\n";  // (sic) core/properties.cpp:264

@@ -43,9 +43,14 @@ struct EngineParameters {
     int rounds = 0;                   // -rounds : training rounds (reference: 5000, train_ransac_softam.cpp:49); 0 = that default
     int device = 0;                   // -dev
     bool indexQuirk = false;          // -quirk  : reproduce the transposed pixel index of path II (cnn_softam.h:628,641)
-    int batch = 16;                   // -batch  : images per launch chain of the evaluation program (FrameBatch); 0 = one image per call (Frame::processImage)
+    int batch = 16;                   // -batch  : images per launch chain of the evaluation program (FrameBatch); 0 = one image per call (Frame::processImage).
+                                      //           Training program: frames per round, device-resident (default there: 0 = the reference's per-image loop)
+    bool batchGiven = false;          //           (set when -batch is on the command line)
     int passes = 1;                   // -passes : process the data set this many times (the first pass warms the device up; timing is reported per pass)
     bool errorImages = true;          // -errimg : write the N error images of every image (the score CNN's input) as the reference does
+    int warmupMs = 0;                 // -warmup : run untimed (and unlogged) passes / rounds for this many milliseconds first -- a GPU that idled while the host made
+                                      //           or loaded the data set needs ~0.3 s of work before its clock has settled (batch paths only)
+    int gradStats = 1;                // -gradstats : the training program prints / logs the gradient statistics every this many rounds (0: never; -batch only)
     int defer = 2;                    // -defer  : 0 batches in stream order, 1 refinement tail of a batch under the next batch, 2 score tail too (dsac_hip.h "pi_defer_tail")
 };
 

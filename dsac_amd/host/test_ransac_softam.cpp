@@ -74,18 +74,19 @@ int main(int argc, const char* argv[]) {
         // hypothesis counts take the per-image path.  Both give the same numbers image by image (tests/test_gpu_drivers.py).
         bool batchable = gp->eP.batch > 0 && nImg > 0 && (gp->eP.batch == 1 || objHyps % 128 == 0);
         for (const DriverFrame& fr : testDataset)
-            batchable = batchable && fr.H == testDataset[0].H && fr.W == testDataset[0].W && fr.sets.empty() && fr.sampling.empty() &&
+            batchable = batchable && fr.H == testDataset[0].H && fr.W == testDataset[0].W && fr.sets.empty() && fr.sampling.empty() == testDataset[0].sampling.empty() &&
                         (fr.pixelIdxs.empty() || fr.permSteps < refSteps);
         const int passes = std::max(1, gp->eP.passes);
         if (batchable) {
             const int H = testDataset[0].H, W = testDataset[0].W;
             FrameBatchOptions opt;
             opt.errorImages = gp->eP.errorImages;
+            opt.sampling = !testDataset[0].sampling.empty();  // sub-sampled maps: every image has its own table of image positions
             opt.deferTail = gp->eP.defer >= 1;
             opt.deferScoreTail = gp->eP.defer >= 2;
             const clk::time_point tUp = clk::now();
             FrameBatch batch(engine, (int)nImg, H, W, camMat, objHyps, refSteps, refinePermutations(H * W, refSteps), gp->eP.batch, opt);
-            for (size_t i = 0; i < nImg; i++) batch.setFrame((int)i, testDataset[i].estObj.data(), testDataset[i].poseGT);
+            for (size_t i = 0; i < nImg; i++) batch.setFrame((int)i, testDataset[i].estObj.data(), testDataset[i].poseGT, opt.sampling ? testDataset[i].sampling.data() : nullptr);
             engine.synchronize();
             const double upMs = ms_since(tUp);
             double firstMs = 0, restMs = 0;
@@ -97,6 +98,10 @@ int main(int argc, const char* argv[]) {
                 batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
                 batch.synchronize();
                 firstMs = ms_since(t0);
+            }
+            for (const clk::time_point tw = clk::now(); ms_since(tw) < gp->eP.warmupMs;) {  // -warmup: let the clock settle before the timed passes
+                batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                batch.synchronize();
             }
             if (passes > 1) {
                 const clk::time_point t0 = clk::now();

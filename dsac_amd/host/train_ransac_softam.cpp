@@ -7,6 +7,7 @@
 // the gradient the CNN would receive: its statistics go to the console as in the reference and, additionally, to
 // ransac_training_grad_<objScript>.txt (round, max, avg, median of the row norms, number of zero rows).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <iostream>
@@ -45,6 +46,100 @@ int main(int argc, const char* argv[]) {
         trainFile.precision(10);
         gradFile.precision(10);
         std::mt19937 frameRng(1305);  // irand(0, size) of the reference's ThreadRand, thread_rand.h:100 (seed 1305 + thread id 0)
+
+        // -batch F (F >= 1): the device-resident form of the loop below.  The training set stays in HBM, a round draws F random frames (the reference
+        // draws one, :227-235; F frames per round is what a data-parallel step puts on one GPU), copies them device-to-device into the step's batch and
+        // runs forward and backward of all F as ONE launch chain each (FrameBatch::processImages / backward); the gradients stay in HBM for a CNN that
+        // runs there.  Frame k of a round samples from seed + 7919 round + k, so -batch 1 equals the per-image loop round by round.
+        const int framesPerRound = gp->eP.batchGiven ? gp->eP.batch : 0;
+        bool batchable = framesPerRound >= 1 && !trainingDataset.empty();
+        for (const DriverFrame& fr : trainingDataset)
+            batchable = batchable && fr.H == trainingDataset[0].H && fr.W == trainingDataset[0].W && fr.sets.empty() && fr.sampling.empty() == trainingDataset[0].sampling.empty() &&
+                        (fr.pixelIdxs.empty() || fr.permSteps < refSteps);
+        if (framesPerRound >= 1 && !batchable) std::cout << "-batch: the training set is not uniform (sizes, given sets or sampling tables); one image per round." << std::endl;
+        if (batchable) {
+            typedef std::chrono::steady_clock clk;
+            const int H = trainingDataset[0].H, W = trainingDataset[0].W, F = framesPerRound;
+            const size_t P = (size_t)H * W;
+            Context& engine = Context::shared(gp->eP.device);
+            const std::vector<int32_t> perms = refinePermutations(H * W, refSteps);
+            FrameBatchOptions dataOpt;
+            dataOpt.errorImages = false;
+            dataOpt.sampling = !trainingDataset[0].sampling.empty();
+            FrameBatch data(engine, (int)trainingDataset.size(), H, W, camMat, objHyps, refSteps, perms, 1, dataOpt);  // storage only: the resident training set
+            for (size_t i = 0; i < trainingDataset.size(); i++) data.setFrame((int)i, trainingDataset[i].estObj.data(), trainingDataset[i].poseGT, dataOpt.sampling ? trainingDataset[i].sampling.data() : nullptr);
+            FrameBatchOptions stepOpt;
+            stepOpt.errorImages = gp->eP.errorImages;
+            stepOpt.inlierMaps = true;
+            stepOpt.sampling = dataOpt.sampling;
+            stepOpt.deferTail = false;  // the backward pass follows the forward pass of the same frames: nothing to run the tail under
+            FrameBatch step(engine, F, H, W, camMat, objHyps, refSteps, perms, F, stepOpt);
+            engine.synchronize();
+            const int statsEvery = gp->eP.gradStats;
+            {   // -warmup: untimed, unlogged rounds on frames drawn from a generator of their own (the training sequence below is not disturbed)
+                std::mt19937 warmRng(7);
+                for (const clk::time_point tw = clk::now(); std::chrono::duration<double, std::milli>(clk::now() - tw).count() < gp->eP.warmupMs;) {
+                    std::vector<int32_t> ids(F);
+                    for (int k = 0; k < F; k++) ids[k] = (int32_t)(std::uniform_int_distribution<int>(0, (int)trainingDataset.size() - 1)(warmRng));
+                    step.gatherFramesFrom(data, ids);
+                    step.processImages(0, F, gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                    step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                    engine.synchronize();
+                }
+            }
+            clk::time_point t0 = clk::now();
+            int timedRounds = 0;
+            for (int round = 0; round <= trainingRounds; round++) {
+                if (round == 1) { engine.synchronize(); t0 = clk::now(); }  // round 0 warms the device up
+                std::vector<int32_t> ids(F);
+                for (int k = 0; k < F; k++) ids[k] = (int32_t)(std::uniform_int_distribution<int>(0, (int)trainingDataset.size() - 1)(frameRng));
+                step.gatherFramesFrom(data, ids);  // device-to-device, one launch per array
+                step.processImages(0, F, gp->eP.seed + 7919ull * round, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                if (round >= 1) timedRounds++;
+                const bool stats = statsEvery > 0 && round % statsEvery == 0;
+                if (!stats && round != trainingRounds) continue;  // nothing of this round is needed on the host: the next one is enqueued behind it
+                const std::vector<ProcessImageResult> res = step.results(/*perHypothesis=*/false);
+                double loss = 0, ent = 0;
+                for (const ProcessImageResult& r : res) { loss += r.loss; ent += r.sfEntropy; }
+                std::cout << "Round " << round << " of " << trainingRounds << "." << std::endl;
+                if (stats) {
+                    double maxN = 0, avgN = 0;
+                    int zeroGrads = 0;
+                    std::vector<double> norms;
+                    norms.reserve(P * (size_t)F);
+                    for (int k = 0; k < F; k++) {
+                        const std::vector<double> d = step.gradients(k);
+                        for (size_t p = 0; p < P; p++) {
+                            const double n = std::sqrt(d[p * 3] * d[p * 3] + d[p * 3 + 1] * d[p * 3 + 1] + d[p * 3 + 2] * d[p * 3 + 2]);
+                            norms.push_back(n);
+                            if (n < 1e-8) zeroGrads++;
+                            avgN += n;
+                            maxN = std::max(maxN, n);
+                        }
+                    }
+                    avgN /= (double)norms.size();
+                    const double medN = medianOf(norms);
+                    std::cout << "Combined statistics:" << std::endl;
+                    std::cout << "Max gradient: " << maxN << std::endl;
+                    std::cout << "Avg gradient: " << avgN << std::endl;
+                    std::cout << "Med gradient: " << medN << std::endl;
+                    std::cout << "Zero gradients: " << zeroGrads << std::endl;
+                    gradFile << round << " " << maxN << " " << avgN << " " << medN << " " << zeroGrads << std::endl;
+                }
+                trainFile << round << " " << loss / F << " " << ent / F << std::endl;  // mean over the round's frames (F = 1: the reference's line)
+                std::cout << std::endl;
+            }
+            engine.synchronize();
+            const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            if (timedRounds > 0)
+                std::cout << "Timing: " << timedRounds << " rounds x " << F << " frames x " << objHyps << " hypotheses, " << W << "x" << H
+                          << " coordinate maps, forward + backward device-resident: " << ms * 1e3 / timedRounds << " us per round = "
+                          << ms * 1e3 / timedRounds / F << " us per frame (gradient statistics every " << statsEvery << " rounds)" << std::endl;
+            trainFile.close();
+            gradFile.close();
+            return 0;
+        }
 
         for (int round = 0; round <= trainingRounds; round++) {
             std::cout << "Round " << round << " of " << trainingRounds << "." << std::endl;

@@ -137,6 +137,11 @@ DSAC_API int dsac_host_alloc(dsac_ctx* ctx, size_t bytes, void** out);
 DSAC_API int dsac_host_free(dsac_ctx* ctx, void* p);
 DSAC_API int dsac_copy_async(dsac_ctx* ctx, void* dst, const void* src, size_t bytes);
 DSAC_API int dsac_fill_zero_async(dsac_ctx* ctx, void* dst, size_t bytes);
+/* Row i of dst = row rows[i] of src (device pointers, rows of row_bytes bytes, a multiple of 4), in the order of the context's stream, ONE launch for
+ * up to 256 rows; `rows` is a HOST array that is read before the call returns.  This is how a training round draws its frames from a training set that
+ * stays in HBM (core/train_ransac_softam.cpp:227-235 picks a random frame per round): n_rows coordinate maps -- and their sampling tables and ground
+ * truths -- into the round's batch with three launches instead of 3 n_rows copies. */
+DSAC_API int dsac_gather_rows(dsac_ctx* ctx, void* dst, const void* src, size_t row_bytes, int n_rows, const int32_t* rows);
 
 /* ---- frame ------------------------------------------------------------------------------------ */
 /* Replaces the (estObj, sampling, camMat) triple every reference function takes

@@ -37,13 +37,18 @@ def _grid_frame(synth, H, W, seed, cam):
     return dict(xyz=xyz.astype(np.float32), uv=uv, gt_pose=np.concatenate([rvec, tvec]), H=H, W=W, cam=tuple(float(c) for c in cam))
 
 
-@pytest.mark.parametrize("H,W,F,N,implicit", [(40, 40, 3, 128, False), (120, 160, 2, 256, True)])
+@pytest.mark.parametrize("H,W,F,N,implicit", [(40, 40, 3, 128, False), (120, 160, 2, 256, True), (40, 40, 3, 128, "own")])
 def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
+    """implicit = False: one table of image positions shared by the frames; True: the implicit grid; "own": one table PER FRAME (uv_per_frame -- the
+    reference's sub-sampled maps, whose positions stochasticSubSample draws per image, core/cnn_softam.h:283-309)."""
+    own = implicit == "own"
+    implicit = implicit is True
     P = H * W
     frames = ([_grid_frame(synth, H, W, 300 + f, (525.0 * W / 640, 525.0 * W / 640, W / 2.0, H / 2.0)) for f in range(F)] if implicit else
               [synth.chess_like_frame(H, W, seed=300 + f, quantise_int16=(H == 40)) for f in range(F)])
     xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
-    uv = None if implicit else frames[0]["uv"]
+    uv = None if implicit else (np.ascontiguousarray(np.stack([fr["uv"] for fr in frames])) if own else frames[0]["uv"])
+    uv_of = (lambda f: uv[f]) if own else (lambda f: uv)
     # the oracle's view of the pixel positions: the engine's implicit grid is u = x, v = y of the MAP (synth.pixel_grid is the stride-4 sampling of a 640 x 480 image)
     uvh = np.stack(np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32)), -1).reshape(-1, 2) if implicit else frames[0]["uv"]
     cam = frames[0]["cam"]
@@ -51,7 +56,7 @@ def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
     gts = np.stack([orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for fr in frames])
     alpha, tau, beta, sub = 0.1, 10.0, 0.5, 0.2
     # forward of the batch (dsac_process_images): what the backward starts from
-    engine.set_frames(xyz, uv, H, W, cam)
+    engine.set_frames(xyz, uv, H, W, cam, uv_per_frame=own)
     fwd = engine.processImages(N, perm, gt_jp6=gts, seed=41, want_inlier_maps=True)
     assert fwd["ok"].all() and (fwd["refSteps"] == 8).all()
     rng = np.random.default_rng(5)
@@ -73,7 +78,12 @@ def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
     b = backward(F, slice(0, F * N), slice(0, F))
     assert b["path1"].shape == (F * P, 3) and (b["n"] > 0).all()
     for f in range(F):
-        engine.set_frame(xyz[f], uv, H, W, cam)
+        engine.set_frame(xyz[f], uv_of(f), H, W, cam)
+        if own:  # the forward of the batch as well: frame f with ITS table, bit for bit
+            s1 = engine.processImages(N, perm, gt_jp6=gts[f:f + 1], seed=41 + f, want_inlier_maps=True)
+            for key in ("hyps", "sampledPoints", "sfScores"):
+                assert np.array_equal(fwd[key][f * N:(f + 1) * N], s1[key]), key
+            assert np.array_equal(fwd["refAvgHyp"][f], s1["refAvgHyp"][0]) and np.array_equal(fwd["inlierMaps"][f], s1["inlierMaps"][0])
         s = backward(1, slice(f * N, (f + 1) * N), slice(f, f + 1))
         hs, ps = slice(f * N, (f + 1) * N), slice(f * P, (f + 1) * P)
         # the fp64 chain: bit for bit
@@ -89,11 +99,13 @@ def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
             margin("a15", "frame batch vs single-frame call, K4 gradient (%s): max |d| / max |g|" % key, np.abs(b[key][ps] - s[key]).max() / max(np.abs(s[key]).max(), 1e-300), 1e-5)
         margin("a10", "frame batch vs single-frame call, K4 pose sums: max-rel", (np.abs(b["G6"][hs] - s["G6"]).max(1) / np.maximum(np.abs(s["G6"]).max(1), 1e-9 * np.abs(s["G6"]).max() + 1e-300)).max(), 1e-4)
         # ... and the batch's frame f against the oracle's chain (core/train_ransac_softam.cpp:288-394 for that image)
+        if own:
+            uvh = uv[f]
         fr = dict(frames[f], uv=uvh)
         fw = dict(hyps=fwd["hyps"][hs], sampledPoints=fwd["sampledPoints"][hs], sfScores=fwd["sfScores"][hs], avgHyp=fwd["avgHyp"][f], refAvgHyp=fwd["refAvgHyp"][f],
                   pixelIdxs=perm, inlierMap=fwd["inlierMaps"][f], score_scale=alpha)
         ref_grad, dL, v6, g, coef6 = oracle_backward(orc, fr, fw, gts[f], tau=tau, beta=beta, sub_sample=sub)
-        ref_grad = ref_grad + dpnp_substitution_frame(engine, orc, fr, xyz[f], uv, H, W, cam, fw["sampledPoints"], coef6)
+        ref_grad = ref_grad + dpnp_substitution_frame(engine, orc, fr, xyz[f], uv_of(f), H, W, cam, fw["sampledPoints"], coef6)
         got = b["soft"][ps]  # path I + softmax backward + soft-score backward of frame f (dSoftScore accumulated onto a fresh gradient: add path I)
         got = got + b["path1"][ps]
         scale = np.abs(ref_grad).max()
@@ -111,7 +123,7 @@ def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
             margin("a15", "frame batch: end-to-end gradient of every frame vs the oracle's chain, max-rel (support cells of ill-conditioned sets excluded)",
                    np.abs(got - ref_grad)[clean].max() / np.abs(ref_grad[clean]).max(), 1e-3)
         margin("a8", "frame batch: dLossMax of every frame vs oracle", np.abs(b["dL"][f] - dL).max() / max(1.0, np.abs(dL).max()), 1e-8)
-    engine.set_frames(xyz, uv, H, W, cam)
+    engine.set_frames(xyz, uv, H, W, cam, uv_per_frame=own)
     with pytest.raises(Exception):
         engine.dSoftScore(fwd["hyps"][:F * N - 8], fwd["sampledPoints"][:F * N - 8], np.zeros(F * N - 8))  # not frames x (a multiple of 16)
 

@@ -152,3 +152,24 @@ def test_bad_arguments_are_rejected(engine, frame40):
     engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
     p, s, ok = engine.sample(2, sets=np.array([[0, 1, 2, 10 ** 6], [-5, 3, 4, 5]], np.int32))
     assert p.shape == (2, 6)
+
+
+def test_gather_rows(engine):
+    """dsac_gather_rows: row i of dst = row rows[i] of src, one launch per 256 rows, 16-byte and 4-byte vector paths, repeated and out-of-order indices."""
+    import torch
+    from dsac_amd.capi import lib, ptr, check
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for row_words, n_src, n_rows in ((4 * 1000, 7, 5), (3 * 333, 300, 700), (6, 40, 16)):
+        src = torch.from_numpy(rng.integers(0, 1 << 30, size=(n_src, row_words), dtype=np.int32)).to(dev)
+        rows = rng.integers(0, n_src, size=n_rows).astype(np.int32)
+        dst = torch.zeros(n_rows, row_words, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        check(engine._ctx, lib.dsac_gather_rows(engine._ctx, ptr(dst), ptr(src), row_words * 4, n_rows, ptr(rows)))
+        engine.synchronize()
+        assert torch.equal(dst.cpu(), src.cpu()[torch.from_numpy(rows.astype(np.int64))])
+    bad = np.array([0, -1], np.int32)
+    with pytest.raises(Exception):
+        check(engine._ctx, lib.dsac_gather_rows(engine._ctx, ptr(dst), ptr(src), 24, 2, ptr(bad)))
+    with pytest.raises(Exception):
+        check(engine._ctx, lib.dsac_gather_rows(engine._ctx, ptr(dst), ptr(src), 6, 1, ptr(rows)))  # not a multiple of 4
