@@ -301,6 +301,8 @@ void dsac_destroy(dsac_ctx* c) {
     for (int k = 0; k < 2; k++) {
         c->slot_staged[k].release();
         c->slot_soft_part[k].release();
+        c->pi_soft[k].release();
+        c->pi_scores[k].release();
         if (c->slot_reduced[k]) (void)hipEventDestroy(c->slot_reduced[k]);
         if (c->slot_ready[k]) (void)hipEventDestroy(c->slot_ready[k]);
         if (c->slot_free[k]) (void)hipEventDestroy(c->slot_free[k]);
