@@ -15,7 +15,7 @@ for w in 4 2; do timeout 600 python bench.py --workload config3 --steps 20 --war
 DSAC_BENCH_NO_DEFER=1 timeout 600 python bench.py --workload config3 --steps 20 --warmup 5 --emulate-world 8 --no-cpu-baseline 2>>$O/bench.err | tail -1 > $O/config3_emulated_w8_tail_in_order.json
 echo "== config5"; timeout 600 python bench.py --workload config5 --steps 10 --warmup 3 2>>$O/bench.err | tail -1 | tee $O/bench_config5.json | cut -c1-200
 echo "== K2 only: configs[2] N=4096, both / err / soft"; for m in both err soft; do timeout 600 python bench.py --steps 30 --warmup 5 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --k2-mode $m 2>>$O/bench.err | tail -1 | tee $O/bench_k2only_4096_$m.json | cut -c1-160; done
-echo "== C++ host driver"; ( cd $O && for b in 16 0; do $REPO/dsac_amd/host/test_ransac_softam -synth 64 -mw 640 -mh 480 -batch $b -passes 6 2>&1 | grep -E "Timing|Avg|Median" ; done ) | tee $O/host_driver.txt
+echo "== C++ host driver"; ( cd $O && for b in 16 0; do $REPO/dsac_amd/host/test_ransac_softam -synth 64 -mw 640 -mh 480 -batch $b -passes 12 -warmup 300 2>&1 | grep -E "Timing|Avg|Median" ; done ) | tee $O/host_driver.txt
 echo "== K4 stage, fused (default) and the round-3 staging, alternating"; for i in 1 2; do timeout 600 python scripts/k4_bench.py 2>&1 | grep "K4 N" | sed "s/^/fused   /"; DSAC_K4_VARIANT=1999 timeout 600 python scripts/k4_bench.py 2>&1 | grep "K4 N" | sed "s/^/staging /"; done | tee $O/k4_stage.txt
 echo "== training geometry on frame batches"; timeout 900 python scripts/train_geometry_bench.py 2>&1 | grep "device-resident" | tee $O/train_geometry.txt
 echo "== rank step lab"; timeout 600 python scripts/r04_rank_step_lab.py 8 60 4 2>&1 | grep -v amdgpu | tee $O/rank_step_lab_8.txt
