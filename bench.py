@@ -938,11 +938,14 @@ def main(argv=None):
             errp = b["err"][:N] if pp == P else torch.empty(N, pp, dtype=torch.float32, device=dev)
             torch.cuda.synchronize()
 
+            one_out = dict(hyps=b["poses"][:N], sampledPoints=b["sets"][:N], ok=b["ok"][:N], scores=b["soft"][:N], sfScores=b["w"][:N], sfEntropy=b["ent"][:1],
+                           avgHyp=b["avg"][:1], refAvgHyp=ref_d.view(1, 6), refSteps=sd_d, out4=out4_d.view(1, 4))
+            gt_row = gt_d.view(1, 6)
+
             def proc(i):
-                eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=errp,
-                                    out=(b["poses"][:N], b["sets"][:N], b["ok"][:N], b["soft"][:N], b["w"][:N], b["ent"][:1], b["avg"][0]))
-                _check(eng._ctx, _lib.dsac_refine(eng._ctx, 1, _ptr(b["avg"][0]), _ptr(perm_d), 8, 100, 50, 10.0, None, None, _ptr(ref_d), None, _ptr(sd_d)))
-                _check(eng._ctx, _lib.dsac_loss(eng._ctx, _ptr(ref_d), _ptr(gt_d), _ptr(out4_d), None))
+                # ONE call, in stream order (dsac_process_images on a single frame: K1, K2, the score tail in one launch, K6 with the loss at its end) --
+                # what Frame::processImage of the C++ surface issues; until round 4 this leg timed the same stages as three calls (K7 its own launch)
+                eng.processImages(N, perm_d, gt_jp6=gt_row, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=errp, out=one_out)
             for i in range(10):
                 proc(i)
             eng.synchronize()

@@ -141,6 +141,15 @@ void begin_call(dsac_ctx* c, bool keep_tail = false) {
     if (!keep_tail) join_tail(c);
 }
 
+// The score tail of a scoring call on stream `st`: per-tile sums -> scores -> softmax / entropy / soft-argmax pose (two launches; a one-launch form with
+// a ticket per frame was measured 4-5 us SLOWER per call -- its release / acquire fences write back and invalidate an L2 full of error images --)
+hipError_t score_tail(hipStream_t st, int Nf, int frames, int tiles, const float* part, double* scores, double scale, double* w, double* ent,
+                      const double* poses, double* avg) {
+    hipError_t e = dk::reduce_soft(st, Nf * frames, tiles, part, scores);
+    if (e != hipSuccess) return e;
+    return dk::softmax(st, Nf, scores, scale, w, ent, poses, avg, frames);
+}
+
 DevBuf& next_slot(dsac_ctx* c) {
     if (c->slot_next >= c->slots.size()) c->slots.emplace_back();
     return c->slots[c->slot_next++];
@@ -627,8 +636,8 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
-    HIP_TRY(c, dk::reduce_soft(c->stream, N, used, c->soft_part.as<float>(), d_scores));
-    HIP_TRY(c, dk::softmax(c->stream, Nf > 0 ? Nf : N, d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg, frames));
+    HIP_TRY(c, score_tail(c->stream, Nf > 0 ? Nf : N, frames, used, c->soft_part.as<float>(), d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr,
+                          d_avg));
     return end_call(c);
 }
 
@@ -1393,14 +1402,12 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
         ts = c->tail;  // in order behind the previous call's tail: its K6 has read the soft-argmax poses before this K3 can overwrite them
         HIP_TRY(c, hipEventRecord(c->pi_k2done, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(ts, c->pi_k2done, 0));
-        HIP_TRY(c, dk::reduce_soft(ts, N, used, part.as<float>(), d_scores));
-        HIP_TRY(c, dk::softmax(ts, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        HIP_TRY(c, score_tail(ts, hyps_per_frame, frames, used, part.as<float>(), d_scores, scale, d_w, d_ent, d_poses, d_avg));
         HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
         c->pi_scored_rec[b] = true;
     } else {
-        HIP_TRY(c, dk::reduce_soft(c->stream, N, used, part.as<float>(), d_scores));
         join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
-        HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        HIP_TRY(c, score_tail(c->stream, hyps_per_frame, frames, used, part.as<float>(), d_scores, scale, d_w, d_ent, d_poses, d_avg));
         if (defer) {
             HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
@@ -1408,9 +1415,9 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
         }
     }
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
+    // K7 rides at the end of K6's wave: the loss of a refined pose is computed by the lane that holds it (one launch less behind the refinement chain)
     HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
-                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0));
-    if (d_out4) HIP_TRY(c, dk::pose_loss(ts, frames, d_ref, d_gt, d_out4, nullptr, 6));
+                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4));
     if (defer) {
         HIP_TRY(c, hipEventRecord(c->tail_done, c->tail));
         c->tail_pending = true;

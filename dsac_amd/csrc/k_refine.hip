@@ -21,6 +21,7 @@
 // a replica is (start pose, optionally one replaced coordinate), so the whole Jacobian is one launch.
 #include "kernels.h"
 #include "dmath.h"
+#include "loss_math.h"
 
 namespace dk {
 
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
-                                               int32_t* __restrict__ steps_done, int map_stride, int group, int per_frame) {
+                                               int32_t* __restrict__ steps_done, int map_stride, int group, int per_frame,
+                                               const double* __restrict__ loss_gt, double* __restrict__ loss_out4) {
     const int b = blockIdx.x;
     if (b >= B) return;
     if (per_frame > 0) {  // frame batch: one wave per (frame, problem) -- the per-image refinement of test_ransac_softam.cpp:97-157 for F images at once
@@ -454,16 +456,22 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 6; i++) out_poses[(size_t)b * 6 + i] = pose[i];
         if (steps_done) steps_done[b] = done;
+        // processImage's last stage (core/cnn_softam.h:1160-1179): maxLoss of the refined pose against this problem's ground truth, by the lane that
+        // holds it -- K7's arithmetic (loss_math.h) without K7's launch behind a 90 us chain
+        if (loss_out4) {
+            double R1[9], t1[3], gt[6];
+            max_loss_forward(pose, loss_gt + (size_t)b * 6, R1, t1, gt, loss_out4 + (size_t)b * 4);
+        }
     }
 }
 
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride, int per_frame) {
+                  int32_t* steps_done, int map_stride, int per_frame, const double* loss_gt_jp6, double* loss_out4) {
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame);
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4);
     return hipGetLastError();
 }
 
@@ -713,11 +721,11 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     const int R = 12 + 6 * cap;
     if (frames > 1) {  // one replica list per frame: list m = b / R refines against frame m, replicas beyond 12 + 6 * n_obj[m] exit at once
         hipLaunchKernelGGL(k_refine, dim3(R * frames), dim3(64), 0, st, R * frames, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
-                           rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R);
+                           rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R, (const double*)nullptr, (double*)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_refine, dim3(R), dim3(64), 0, st, R, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0, (const double*)nullptr, (double*)nullptr);
     return hipGetLastError();
 }
 
@@ -839,7 +847,7 @@ hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, cons
     const long long B = (long long)R * M;
     if (B > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
-                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0);
+                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0, (const double*)nullptr, (double*)nullptr);
     return hipGetLastError();
 }
 

@@ -45,7 +45,6 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
                      float* soft_part, const K2Opts& opts, int* tiles_used, int Nf = 0);
 // soft[h] = sum over pixel tiles of soft_part[tile][h]   (double, deterministic)
 hipError_t reduce_soft(hipStream_t st, int N, int tiles, const float* soft_part, double* soft);
-
 // K3.
 // frames > 1: one independent softmax per consecutive group of N scores (outputs entropy[frames], avg6[frames][6])
 hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, double* w, double* entropy, const double* poses, double* avg6,
@@ -120,7 +119,8 @@ hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp,
 // per_frame > 0 (frame batch): problem b refines against frame b / per_frame (F.xyz_stride / F.uv_stride)
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride = 0, int per_frame = 0);
+                  int32_t* steps_done, int map_stride = 0, int per_frame = 0, const double* loss_gt_jp6 = nullptr, double* loss_out4 = nullptr);
+// loss_gt_jp6 (B x 6) / loss_out4 (B x 4): maxLoss of every refined pose against its ground truth in the same launch (K7's arithmetic, loss_math.h)
 // inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)
 hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps);
 // DSAC-variant replica plan (core/cnn.h:854-990 dRefine): 18 replicas perturb the first three points of the minimal set,

@@ -173,3 +173,23 @@ def test_gather_rows(engine):
         check(engine._ctx, lib.dsac_gather_rows(engine._ctx, ptr(dst), ptr(src), 24, 2, ptr(bad)))
     with pytest.raises(Exception):
         check(engine._ctx, lib.dsac_gather_rows(engine._ctx, ptr(dst), ptr(src), 6, 1, ptr(rows)))  # not a multiple of 4
+
+
+def test_loss_at_the_end_of_the_refinement_wave_equals_k7(engine, synth):
+    """dsac_process_images computes maxLoss of a refined pose on the lane that holds it, at the end of K6's wave (csrc/loss_math.h; core/cnn_softam.h:1160-1179)
+    instead of launching K7 behind the refinement: the four numbers equal K7 (dsac_loss_frames) on the refined poses bit for bit -- single frames with
+    N a multiple of 64 and not, frame batches."""
+    H, W = 120, 160
+    perm = synth.fast_permutations(H * W, 8)
+    for F, N in ((1, 256), (1, 100), (3, 128), (5, 256)):
+        frames = [synth.chess_like_frame(H, W, seed=820 + f) for f in range(F)]
+        xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+        uv, cam = frames[0]["uv"], frames[0]["cam"]
+        gts = np.stack([fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]) for fr in frames])
+        if F > 1:
+            engine.set_frames(xyz, uv, H, W, cam)
+        else:
+            engine.set_frame(xyz[0], uv, H, W, cam)
+        b = engine.processImages(N, perm, gt_jp6=gts, seed=9)
+        assert (b["refSteps"] == 8).all() and np.isfinite(b["out4"]).all() and (b["out4"][:, 0] > 0).all()
+        assert np.array_equal(engine.maxLossFrames(b["refAvgHyp"], gts)["out4"], b["out4"]), (F, N)
