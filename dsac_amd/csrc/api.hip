@@ -1406,8 +1406,11 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
         HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
         c->pi_scored_rec[b] = true;
     } else {
-        join_tail(c);  // the previous batch's tail reads the soft-argmax poses that K3 is about to overwrite (it finished long ago: K1 and K2 ran since)
-        HIP_TRY(c, score_tail(c->stream, hyps_per_frame, frames, used, part.as<float>(), d_scores, scale, d_w, d_ent, d_poses, d_avg));
+        HIP_TRY(c, dk::reduce_soft(c->stream, N, used, part.as<float>(), d_scores));
+        // the previous call's tail reads the soft-argmax poses that K3 is about to overwrite.  After a batch it finished long ago (K1 and K2 ran since);
+        // in a loop of single images it is the longer chain, and the reduction above runs while the stream would otherwise wait for it
+        join_tail(c);
+        HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
         if (defer) {
             HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
