@@ -78,15 +78,18 @@ struct dsac_ctx {
 
     // deferred refinement tail of dsac_process_images ("pi_defer_tail"): K6 / K7 of batch i on `tail` under K1 / K2 of batch i + 1
     int pi_defer_tail = 0;
-    hipStream_t tail = nullptr;
-    hipEvent_t tail_go = nullptr, tail_done = nullptr;  // go: K3 of the batch done (main stream); done: its K6 / K7 done (tail stream)
-    bool tail_pending = false;                          // a tail is in flight that the main stream has not been ordered behind yet
+    // two tail streams: mode 1 uses the first; mode 2 alternates (call i on stream i & 1) -- consecutive calls write different arrays there, so their
+    // tails are independent, and in a loop of SINGLE images (where the one-wave refinement chain is longer than K1 + K2) two tails run side by side
+    hipStream_t tail[2] = {nullptr, nullptr};
+    hipEvent_t tail_go = nullptr, tail_done[2] = {nullptr, nullptr};  // go: K3 of the batch done (main stream); done: the tail's last launch done
+    bool tail_pending[2] = {false, false};              // a tail is in flight on that stream that the main stream has not been ordered behind yet
     // mode 2 (score tail deferred as well: reduction + K3 of batch i also run on `tail`): the partial sums alternate between two buffers, and call
     // i + 2 starts only after K3 of call i (pi_scored: recorded on `tail`), which read that call's poses and partial sums
     DevBuf pi_soft[2], pi_scores[2];
     hipEvent_t pi_k2done = nullptr, pi_scored[2] = {nullptr, nullptr};
     bool pi_scored_rec[2] = {false, false};
     unsigned pi_calls = 0;
+    int pi_tail_of[2] = {-1, -1};  // the tail stream the previous call of each parity used (mode 2)
     hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
 
     // measurement hooks: event pairs around the dominant kernels
@@ -128,9 +131,11 @@ bool is_device_ptr(const void* p, const dsac_ctx* c = nullptr) {
 
 // Order the main stream behind a deferred refinement tail that is still in flight (no-op otherwise).
 void join_tail(dsac_ctx* c) {
-    if (!c->tail_pending) return;
-    c->tail_pending = false;
-    if (hipStreamWaitEvent(c->stream, c->tail_done, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->tail); }
+    for (int k = 0; k < 2; k++) {
+        if (!c->tail_pending[k]) continue;
+        c->tail_pending[k] = false;
+        if (hipStreamWaitEvent(c->stream, c->tail_done[k], 0) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->tail[k]); }
+    }
 }
 
 // Begin a call: reset the staging slots.  Every call that enqueues work sees the results of a deferred tail in stream order; dsac_process_images
@@ -318,9 +323,11 @@ void dsac_destroy(dsac_ctx* c) {
         if (c->slot_done[k]) (void)hipEventDestroy(c->slot_done[k]);
     }
     if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
-    if (c->tail) { (void)hipStreamSynchronize(c->tail); (void)hipStreamDestroy(c->tail); }
+    for (int k = 0; k < 2; k++) {
+        if (c->tail[k]) { (void)hipStreamSynchronize(c->tail[k]); (void)hipStreamDestroy(c->tail[k]); }
+        if (c->tail_done[k]) (void)hipEventDestroy(c->tail_done[k]);
+    }
     if (c->tail_go) (void)hipEventDestroy(c->tail_go);
-    if (c->tail_done) (void)hipEventDestroy(c->tail_done);
     if (c->pi_k2done) (void)hipEventDestroy(c->pi_k2done);
     for (int k = 0; k < 2; k++)
         if (c->pi_scored[k]) (void)hipEventDestroy(c->pi_scored[k]);
@@ -335,7 +342,8 @@ int dsac_set_stream(dsac_ctx* c, void* hip_stream) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_set_stream: ctx is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->tail) { HIP_TRY(c, hipStreamSynchronize(c->tail)); c->tail_pending = false; }
+    for (int k = 0; k < 2; k++)
+        if (c->tail[k]) { HIP_TRY(c, hipStreamSynchronize(c->tail[k])); c->tail_pending[k] = false; }
     if (c->own_stream && c->stream) HIP_TRY(c, hipStreamDestroy(c->stream));
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->own_stream = false;
@@ -349,7 +357,8 @@ int dsac_synchronize(dsac_ctx* c) {
     if (c->aux) HIP_TRY(c, hipStreamSynchronize(c->aux));
     if (c->aux2) HIP_TRY(c, hipStreamSynchronize(c->aux2));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->tail) { HIP_TRY(c, hipStreamSynchronize(c->tail)); c->tail_pending = false; }
+    for (int k = 0; k < 2; k++)
+        if (c->tail[k]) { HIP_TRY(c, hipStreamSynchronize(c->tail[k])); c->tail_pending[k] = false; }
     return DSAC_OK;
 }
 
@@ -1373,10 +1382,15 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     DevBuf& part = mode == 2 ? c->pi_soft[b] : c->soft_part;
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
     HIP_TRY(c, part.reserve((size_t)tiles * N * sizeof(float)));
-    if (defer && !c->tail) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done, hipEventDisableTiming));
+    // mode 2, which tail stream: consecutive calls write different arrays there, so their tails are independent -- SMALL calls (up to two full-size
+    // images' worth of hypothesis x cell pairs: K1 + K2 shorter than the one-wave refinement chain) alternate between two streams and two tails run
+    // side by side; larger calls hide their tail under the next call anyway and stay on the first stream (a process has few hardware queues: a
+    // stream more in use cost configs[3]'s rank step 0.51 -> 0.64 ms in the bench process, whose tails then queued behind K2)
+    const int tk = (mode == 2 && (long long)N * (long long)P <= 2ll * 256 * 307200) ? b : 0;
+    if (defer && !c->tail_go) HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
+    if (defer && !c->tail[tk]) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail[tk], hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done[tk], hipEventDisableTiming));
     }
     if (mode == 2 && !c->pi_k2done) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->pi_k2done, hipEventDisableTiming));
@@ -1399,7 +1413,11 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
     hipStream_t ts = c->stream;
     if (mode == 2) {
-        ts = c->tail;  // in order behind the previous call's tail: its K6 has read the soft-argmax poses before this K3 can overwrite them
+        // this tail does not depend on the previous call's (different arrays: the mode's contract); it follows the tail of the call two back, whose
+        // arrays it may have been given again -- in stream order, or through that stream's completion event when the two used different streams
+        ts = c->tail[tk];
+        if (c->pi_tail_of[b] >= 0 && c->pi_tail_of[b] != tk) HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_done[c->pi_tail_of[b]], 0));
+        c->pi_tail_of[b] = tk;
         HIP_TRY(c, hipEventRecord(c->pi_k2done, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(ts, c->pi_k2done, 0));
         HIP_TRY(c, score_tail(ts, hyps_per_frame, frames, used, part.as<float>(), d_scores, scale, d_w, d_ent, d_poses, d_avg));
@@ -1413,8 +1431,8 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
         HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
         if (defer) {
             HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->tail, c->tail_go, 0));
-            ts = c->tail;
+            HIP_TRY(c, hipStreamWaitEvent(c->tail[0], c->tail_go, 0));
+            ts = c->tail[0];
         }
     }
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
@@ -1422,8 +1440,8 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
                           d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4));
     if (defer) {
-        HIP_TRY(c, hipEventRecord(c->tail_done, c->tail));
-        c->tail_pending = true;
+        HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));
+        c->tail_pending[tk] = true;
     }
     return end_call(c);
 }
@@ -1440,10 +1458,12 @@ int dsac_tail_wait(dsac_ctx* c, void* hip_stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     if (s == c->stream) return fail(c, DSAC_ERR_INVALID, "dsac_tail_wait: that is the context's own stream (use dsac_join_tail)");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->tail_pending) {
-        // the tail started behind K3 of its dsac_process_images call, which was behind everything the context's stream held then: its completion event
-        // alone covers that call and all earlier work -- no marker has to be put into the context's stream (a record between two steps costs a bubble)
-        HIP_TRY(c, hipStreamWaitEvent(s, c->tail_done, 0));
+    if (c->tail_pending[0] || c->tail_pending[1]) {
+        // a tail started behind K2 / K3 of its dsac_process_images call, which was behind everything the context's stream held then: the completion
+        // events of the tails in flight cover their calls and all earlier work -- no marker has to be put into the context's stream (a record between
+        // two steps costs a bubble)
+        for (int k = 0; k < 2; k++)
+            if (c->tail_pending[k]) HIP_TRY(c, hipStreamWaitEvent(s, c->tail_done[k], 0));
         return DSAC_OK;
     }
     if (!c->xs_event) HIP_TRY(c, hipEventCreateWithFlags(&c->xs_event, hipEventDisableTiming));

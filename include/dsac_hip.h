@@ -351,8 +351,11 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * beside K1 of batch i + 1, which then follows K2 of batch i without a gap (the reduction and K3 are two small launches that leave the chip idle
  * while they run in order).  Then EVERY output of the call except the error images -- poses, sets_out, ok, scores, w, entropy, avg6 and the tail's
  * four -- is ordered on the context's stream only after dsac_join_tail / another entry point / dsac_synchronize, and consecutive calls must be given
- * different arrays for all of them; the call after the next may reuse them (the library orders its K1 behind K3 of the call two back).  Results
- * are the same bit for bit in all three modes (tests/test_gpu_process_images.py). */
+ * different arrays for all of them; the call after the next may reuse them (the library orders its K1 behind K3 of the call two back, and its tail
+ * behind that call's tail).  Because consecutive tails are independent then, SMALL calls (up to two 640 x 480 images x 256 hypotheses' worth of
+ * pairs) alternate between two tail streams: in a loop of single images -- the loop of core/test_ransac_softam.cpp:97 as it stands -- the one-wave
+ * refinement chains of images i and i + 1 run side by side and the loop is bound by K1 + K2: 173 us per image in order, 122 with mode 1, 81 with
+ * mode 2 (profiles/r04_two_tails_ab.txt).  Results are the same bit for bit in all three modes (tests/test_gpu_process_images.py). */
 DSAC_API int dsac_join_tail(dsac_ctx* ctx);
 /* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight -- and
  * thereby for the dsac_process_images call it belongs to and everything the context's stream held before that call (the tail starts behind that call's
