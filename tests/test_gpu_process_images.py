@@ -240,3 +240,57 @@ def test_deferred_tail_and_a_reused_borrowed_frame_buffer(engine, synth):
                 assert np.array_equal(a[key], b[key]), key
     finally:
         engine.set_option("pi_defer_tail", 0)
+
+
+def test_score_tail_mode_with_small_and_large_calls_mixed(engine, synth):
+    """"pi_defer_tail" = 2 puts the tail of a SMALL call (up to two full-size images' worth of pairs) on one of two alternating streams and the tail of a
+    larger call on the first; a call may be given the arrays of the call two back, whichever stream that one used.  A sequence that mixes one-image and
+    three-image calls at 640 x 480, arrays reused at distance two wherever the shapes agree, equals the same calls in stream order bit for bit."""
+    import torch
+    H, W, N = 480, 640, 256
+    P = H * W
+    dev = torch.device("cuda", 0)
+    perm = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    frames = [synth.chess_like_frame(H, W, seed=610 + f) for f in range(3)]
+    cam = frames[0]["cam"]
+    x3 = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    x1 = [x3[f:f + 1].clone() for f in range(3)]
+    seq = [1, 3, 1, 1, 3, 3, 1, 3, 1, 3]   # frames per call
+
+    def bufs(F):
+        n = F * N
+        f64 = dict(dtype=torch.float64, device=dev)
+        return dict(hyps=torch.zeros(n, 6, **f64), sampledPoints=torch.zeros(n, 4, dtype=torch.int32, device=dev), ok=torch.zeros(n, dtype=torch.uint8, device=dev),
+                    scores=torch.zeros(n, **f64), sfScores=torch.zeros(n, **f64), sfEntropy=torch.zeros(F, **f64), avgHyp=torch.zeros(F, 6, **f64),
+                    refAvgHyp=torch.zeros(F, 6, **f64), refSteps=torch.zeros(F, dtype=torch.int32, device=dev), out4=torch.zeros(F, 4, **f64))
+
+    def run(mode):
+        engine.set_option("pi_defer_tail", mode)
+        outs = []
+        pre = [bufs(F) for F in seq]
+        gts = {1: torch.zeros(1, 6, dtype=torch.float64, device=dev), 3: torch.zeros(3, 6, dtype=torch.float64, device=dev)}
+        torch.cuda.synchronize(dev)  # torch zero-fills on ITS stream: done before the engine's streams write the arrays; nothing below waits
+        for i, F in enumerate(seq):
+            # calls 8 and 9: the arrays of the call two back (same shape: allowed by the mode's contract); fresh ones otherwise
+            reuse = mode == 2 and i >= 8 and seq[i - 2] == F
+            o = outs[i - 2] if reuse else pre[i]
+            if F == 1:
+                engine.set_frames(x1[i % 3], None, H, W, cam, borrow=True)
+            else:
+                engine.set_frames(x3, None, H, W, cam, borrow=True)
+            engine.processImages(N, perm, gt_jp6=gts[F], seed=500 + 7 * i, max_tries=1 << 16, out=o)
+            outs.append(o)
+        engine.joinTail()
+        engine.synchronize()
+        return [{k: v.cpu().numpy().copy() for k, v in o.items()} for o in outs]
+
+    try:
+        plain = run(0)
+        mixed = run(2)
+        # calls 8 and 9 reuse the arrays of calls 6 and 7 in mode 2: compare the calls whose arrays survive (0..5 and 8, 9)
+        for i in list(range(6)) + [8, 9]:
+            assert (plain[i]["refSteps"] == 8).all() and plain[i]["ok"].all()
+            for key in plain[i]:
+                assert np.array_equal(plain[i][key], mixed[i][key]), (i, key)
+    finally:
+        engine.set_option("pi_defer_tail", 0)
