@@ -1384,8 +1384,9 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     HIP_TRY(c, part.reserve((size_t)tiles * N * sizeof(float)));
     // mode 2, which tail stream: consecutive calls write different arrays there, so their tails are independent -- SMALL calls (up to two full-size
     // images' worth of hypothesis x cell pairs: K1 + K2 shorter than the one-wave refinement chain) alternate between two streams and two tails run
-    // side by side; larger calls hide their tail under the next call anyway and stay on the first stream (a process has few hardware queues: a
-    // stream more in use cost configs[3]'s rank step 0.51 -> 0.64 ms in the bench process, whose tails then queued behind K2)
+    // side by side; larger calls hide their tail under the next call anyway and stay on the first stream (measured: with both streams in use for
+    // 8-image calls configs[3]'s rank step went from 0.51 to 0.64 ms in the bench process -- the tails then ran exposed; the cause was not isolated,
+    // GPU_MAX_HW_QUEUES = 8 changes neither number, profiles/r04_hw_queues.txt)
     const int tk = (mode == 2 && (long long)N * (long long)P <= 2ll * 256 * 307200) ? b : 0;
     if (defer && !c->tail_go) HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
     if (defer && !c->tail[tk]) {
