@@ -16,7 +16,6 @@ import torch
 import dsac_amd
 from dsac_amd import synth
 from dsac_amd.capi import lib, ptr, check
-from oracle import oracle as orc  # cv_to_jp6 only (pose convention of the ground truth)
 
 dev = torch.device("cuda:0")
 eng = dsac_amd.Engine(0)
@@ -31,7 +30,7 @@ for (H, W, reps) in ((40, 40, 200), (480, 640, 100)):
         uv = torch.as_tensor(frs[0]["uv"], device=dev) if H == 40 else None
         eng.set_frames(xyz, uv, H, W, frs[0]["cam"], borrow=True) if F > 1 else eng.set_frame(xyz[0], uv, H, W, frs[0]["cam"], borrow=True)
         perm = torch.as_tensor(synth.fast_permutations(P, 8), device=dev)
-        gt = torch.as_tensor(np.stack([orc.cv_to_jp6(f_["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for f_ in frs]), device=dev)
+        gt = torch.as_tensor(np.stack([synth.cv_to_jp6(f_["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for f_ in frs]), device=dev)
         f64 = dict(dtype=torch.float64, device=dev)
         NF = N * F
         o = dict(hyps=torch.zeros(NF, 6, **f64), sampledPoints=torch.zeros(NF, 4, dtype=torch.int32, device=dev), ok=torch.zeros(NF, dtype=torch.uint8, device=dev),

@@ -7,14 +7,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dsac_amd
 from dsac_amd import synth
-from oracle import oracle as orc  # only cv_to_jp6 (pose convention helper) for the ground truth
 
 eng = dsac_amd.Engine(0)
 for (H, W, N, reps) in ((40, 40, 256, 20), (480, 640, 256, 5)):
     fr = synth.chess_like_frame(H, W, seed=1305, quantise_int16=(H == 40))
     eng.set_frame(fr["xyz"], fr["uv"] if H == 40 else None, H, W, fr["cam"])
     perm = synth.fast_permutations(H * W, 8)
-    gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+    gt = synth.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
     t0 = time.perf_counter()
     for i in range(reps):
         fwd = eng.processImage(N=N, seed=1305 + i, perm=perm, gt_jp6=gt)
@@ -25,7 +24,7 @@ for (H, W, N, reps) in ((40, 40, 256, 20), (480, 640, 256, 5)):
 fr = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
 eng.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
 perm = synth.fast_permutations(1600, 8)
-gt = orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
+gt = synth.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0]))
 t0 = time.perf_counter()
 for i in range(10):
     f = eng.processImageDSAC(N=256, seed=7 + i, perm=perm, gt_jp6=gt, draw_u=0.5)
