@@ -507,6 +507,9 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
             if (o.share >= 8) hipLaunchKernelGGL((k_sample_shared<8>), dim3((N + 7) / 8), dim3(512), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
             else hipLaunchKernelGGL((k_sample_shared<4>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         }
+        else if (o.minw >= 2 && H2 == 1 && o.rl == 1 && wpb < 4)  // one lane per attempt at a register budget for two waves per SIMD: 292 B of scratch,
+                                                                  // 61 against 43 us at N = 4096 (profiles/r04_k1_minw.txt) -- a measurement knob, not a default
+            hipLaunchKernelGGL((k_sample<1, 1, false, 2, 1>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else if (o.minw >= 2 && H2 == 1) {
             if (wpb >= 4) hipLaunchKernelGGL((k_sample<4, 1, false, 2>), dim3((N + 3) / 4), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
             else hipLaunchKernelGGL((k_sample<1, 1, false, 2>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, Nf > 0 ? Nf : N);
