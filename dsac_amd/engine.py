@@ -169,6 +169,28 @@ class Engine:
                                                  ptr(scores), ptr(w), ptr(ent), ptr(avg), ptr(ref), ptr(sd), ptr(maps), ptr(out4)))
         return o
 
+    def bindProcessImages(self, hyps_per_frame, perm, out, gt_jp6=None, thr=10.0, max_tries=1 << 20, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5, scale=0.1,
+                          max_inl=100, min_inl=50, err=None):
+        """processImages with every argument but the seed bound once: returns call(seed).  A loop over single images is a 70-80 us launch chain per
+        image; marshalling two dozen buffers through Python per call is host work of the same order.  `out`:
+        dict of preallocated DEVICE buffers with all keys of processImages' result (inlierMaps optional); perm / gt_jp6 / err device buffers too."""
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        keys = ("hyps", "sampledPoints", "ok", "scores", "sfScores", "sfEntropy", "avgHyp", "refAvgHyp", "refSteps")
+        missing = [k for k in keys if out.get(k) is None]
+        if missing or (gt_jp6 is not None and out.get("out4") is None):
+            raise ValueError("bindProcessImages: preallocated buffers needed for %s" % (missing or ["out4"]))
+        keep = (perm, gt_jp6, err, dict(out))  # the closure keeps the buffers alive
+        args = [self._ctx, N, 0, float(thr), int(max_tries), float(clamp), float(tau), float(beta), float(scale), ptr(perm), int(perm.shape[0]), int(max_inl),
+                int(min_inl), ptr(gt_jp6), ptr(out["hyps"]), ptr(out["sampledPoints"]), ptr(out["ok"]), ptr(err), ptr(out["scores"]), ptr(out["sfScores"]),
+                ptr(out["sfEntropy"]), ptr(out["avgHyp"]), ptr(out["refAvgHyp"]), ptr(out["refSteps"]), ptr(out.get("inlierMaps")),
+                ptr(out["out4"]) if gt_jp6 is not None else None]
+        ctx, fn = self._ctx, lib.dsac_process_images
+
+        def call(seed, _keep=keep):
+            args[2] = int(seed) & 0xFFFFFFFFFFFFFFFF
+            check(ctx, fn(*args))
+        return call
+
     def tailWait(self, stream):
         """dsac_tail_wait: `stream` (a torch.cuda.Stream or a raw hipStream_t) waits for the deferred refinement tail in flight and for everything
         enqueued on the engine's stream so far; the engine's own stream is not held up."""

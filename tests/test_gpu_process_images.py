@@ -294,3 +294,38 @@ def test_score_tail_mode_with_small_and_large_calls_mixed(engine, synth):
                 assert np.array_equal(plain[i][key], mixed[i][key]), (i, key)
     finally:
         engine.set_option("pi_defer_tail", 0)
+
+
+def test_bound_process_images_call_equals_the_generic_one(engine, synth):
+    """Engine.bindProcessImages: dsac_process_images with every argument but the seed marshalled once (a loop over single images would otherwise spend as
+    long in Python as on the GPU) -- the same results as the generic call, also with "device_args" set and the tails deferred."""
+    import torch
+    H, W, N = 120, 160, 128
+    dev = torch.device("cuda", 0)
+    fr = synth.chess_like_frame(H, W, seed=77)
+    xyz = torch.from_numpy(fr["xyz"]).to(dev)
+    perm = torch.from_numpy(synth.fast_permutations(H * W, 8)).to(dev)
+    gt = torch.zeros(1, 6, dtype=torch.float64, device=dev)
+    engine.set_frame(xyz, None, H, W, fr["cam"], borrow=True)
+    want = [engine.processImages(N, perm.cpu().numpy(), gt_jp6=np.zeros((1, 6)), seed=40 + i) for i in range(3)]
+    f64 = dict(dtype=torch.float64, device=dev)
+    outs = [dict(hyps=torch.zeros(N, 6, **f64), sampledPoints=torch.zeros(N, 4, dtype=torch.int32, device=dev), ok=torch.zeros(N, dtype=torch.uint8, device=dev),
+                 scores=torch.zeros(N, **f64), sfScores=torch.zeros(N, **f64), sfEntropy=torch.zeros(1, **f64), avgHyp=torch.zeros(1, 6, **f64),
+                 refAvgHyp=torch.zeros(1, 6, **f64), refSteps=torch.zeros(1, dtype=torch.int32, device=dev), out4=torch.zeros(1, 4, **f64)) for _ in range(3)]
+    torch.cuda.synchronize(dev)
+    calls = [engine.bindProcessImages(N, perm, o, gt_jp6=gt) for o in outs]
+    try:
+        engine.set_option("device_args", 1)
+        engine.set_option("pi_defer_tail", 2)
+        for i, c in enumerate(calls):
+            c(40 + i)
+        engine.joinTail()
+        engine.synchronize()
+    finally:
+        engine.set_option("pi_defer_tail", 0)
+        engine.set_option("device_args", 0)
+    for w, o in zip(want, outs):
+        for key in o:
+            assert np.array_equal(np.asarray(w[key]).reshape(-1), o[key].cpu().numpy().reshape(-1)), key
+    with pytest.raises(ValueError):
+        engine.bindProcessImages(N, perm, dict(outs[0], hyps=None), gt_jp6=gt)
