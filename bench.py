@@ -255,6 +255,26 @@ def cpu_baseline(args, fr, N, H, W):
     r40 = 20
     s40, _ = orc.time_forward(N, 1305, f40["xyz"], f40["uv"], 40, 40, f40["cam"], reps=r40)
     out["reference_size"] = {"value": N * r40 / s40, "unit": "hyp/s", "cores": cores, "sample": "%d frames x %d hypotheses x 40x40 int16 map, %.2f s" % (r40, N, s40)}
+    # the REAL reference code (core/cnn_softam.h processImage, compiled from /root/reference by oracle/refbuild against OpenCV stand-ins; the prebuilt
+    # oracle/_ref/*.so travels with the repository) on the same frame size: whole processImage per image -- sampling, 256 error images, soft-inlier score,
+    # softmax, 8 refinement steps, loss.  Context only: the stand-ins are not OpenCV's speed.
+    try:
+        from oracle import reference as _ref
+        if _ref.available():
+            _ref.lib()
+            _ref.set_score_model(10.0, 0.5, 0.1)
+            gt40 = _synth.cv_to_jp6(f40["gt_pose"])
+            _ref.processImage(1305, f40["xyz"], gt40, hyps=N)
+            nref = 4
+            t0 = time.perf_counter()
+            for i in range(nref):
+                _ref.processImage(1306 + i, f40["xyz"], gt40, hyps=N)
+            sref = (time.perf_counter() - t0) / nref
+            out["reference_build"] = {"kind": "reference", "ms_per_image": sref * 1e3, "value": N / sref, "unit": "hyp/s",
+                                      "sample": "%d images x %d hypotheses x 40x40, the reference's own processImage (oracle/_ref/libdsac_ref.so: core/cnn_softam.h "
+                                                "against OpenCV stand-ins), as many threads as its own OpenMP pragmas take" % (nref, N)}
+    except Exception as e:  # noqa: BLE001  (the reference build is optional context)
+        out["reference_build"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
