@@ -873,20 +873,20 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
     const int lane = threadIdx.x & 63;
     if (h >= N) return;
     if (Nf > 0) grad_xyz += (size_t)(h / Nf) * P * 3;  // frame batch: the support cells of hypothesis h lie in frame h / Nf
-    double G[12];
+    // the first 8 x 64 partial rows (all 512 of the persistent main pass) are requested at once, before the pose-only fp64 work below, which then runs
+    // under their latency; rows beyond them (the VALU form's per-tile rows) follow in a plain loop
+    constexpr int PRE = 8;
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f4 pre[PRE][3];
 #pragma unroll
-    for (int i = 0; i < 12; i++) G[i] = 0;
-    for (int t = lane; t < pixel_tiles; t += 64) {
-        const f4* src = reinterpret_cast<const f4*>(G12_part + (poses ? ((size_t)h * pixel_tiles + t) : ((size_t)t * N + h)) * 12);
-        const f4 a = src[0], b = src[1], c = src[2];
-        G[0] += (double)a.x; G[1] += (double)a.y; G[2] += (double)a.z; G[3] += (double)a.w;
-        G[4] += (double)b.x; G[5] += (double)b.y; G[6] += (double)b.z; G[7] += (double)b.w;
-        G[8] += (double)c.x; G[9] += (double)c.y; G[10] += (double)c.z; G[11] += (double)c.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) G[i] += __shfl_xor(G[i], o, 64);
+    for (int k = 0; k < PRE; k++) {
+        const int t = lane + 64 * k;
+        if (t < pixel_tiles) {
+            const f4* src = reinterpret_cast<const f4*>(G12_part + (poses ? ((size_t)h * pixel_tiles + t) : ((size_t)t * N + h)) * 12);
+            pre[k][0] = src[0]; pre[k][1] = src[1]; pre[k][2] = src[2];
+        } else {
+            pre[k][0] = z4; pre[k][1] = z4; pre[k][2] = z4;
+        }
     }
     double Dloc[27];
     float tpf[3] = {0.f, 0.f, 0.f};
@@ -909,6 +909,28 @@ __global__ __launch_bounds__(256) void k_support_scatter(int N, int W, int pixel
                     for (int k = 0; k < 3; k++) v += J[i * 9 + 3 * j + k] * Rre[3 * m + k];
                     Dloc[i * 9 + 3 * j + m] = v;
                 }
+    }
+    double G[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) G[i] = 0;
+#pragma unroll
+    for (int k = 0; k < PRE; k++) {  // same order of additions as one loop over t = lane, lane + 64, ...
+        const f4 a = pre[k][0], b = pre[k][1], c = pre[k][2];
+        G[0] += (double)a.x; G[1] += (double)a.y; G[2] += (double)a.z; G[3] += (double)a.w;
+        G[4] += (double)b.x; G[5] += (double)b.y; G[6] += (double)b.z; G[7] += (double)b.w;
+        G[8] += (double)c.x; G[9] += (double)c.y; G[10] += (double)c.z; G[11] += (double)c.w;
+    }
+    for (int t = lane + 64 * PRE; t < pixel_tiles; t += 64) {
+        const f4* src = reinterpret_cast<const f4*>(G12_part + (poses ? ((size_t)h * pixel_tiles + t) : ((size_t)t * N + h)) * 12);
+        const f4 a = src[0], b = src[1], c = src[2];
+        G[0] += (double)a.x; G[1] += (double)a.y; G[2] += (double)a.z; G[3] += (double)a.w;
+        G[4] += (double)b.x; G[5] += (double)b.y; G[6] += (double)b.z; G[7] += (double)b.w;
+        G[8] += (double)c.x; G[9] += (double)c.y; G[10] += (double)c.z; G[11] += (double)c.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) G[i] += __shfl_xor(G[i], o, 64);
     }
     if (rec_e || poses) {
         // matrix-core main pass: the sums were taken against E = R'X + t' (signed as the kernel held them):
