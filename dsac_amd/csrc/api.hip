@@ -90,6 +90,7 @@ struct dsac_ctx {
     bool pi_scored_rec[2] = {false, false};
     unsigned pi_calls = 0;
     int pi_tail_of[2] = {-1, -1};  // the tail stream the previous call of each parity used (mode 2)
+    int tail_prio = 0;             // DSAC_TAIL_PRIO / "tail_prio": create the tail streams with the highest stream priority (before the first deferred call)
     hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
 
     // measurement hooks: event pairs around the dominant kernels
@@ -286,6 +287,7 @@ int dsac_create(dsac_ctx** out, int device) {
     c->own_stream = true;
     // experiment knobs, per context (dsac_set_option changes them later)
     if (const char* v = getenv("DSAC_K2_VARIANT")) c->k2.variant = atoi(v);
+    if (const char* v = getenv("DSAC_TAIL_PRIO")) c->tail_prio = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K2_ORDER")) c->k2.pixel_minor = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K2_FLAGS")) c->k2.flags = atoi(v);
     if (const char* v = getenv("DSAC_K1_WPB")) c->k1.wpb = atoi(v);
@@ -807,6 +809,10 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
         c->k4_variant = value;
     }
     else if (k == "device_args") c->device_args = value != 0;
+    else if (k == "tail_prio") {
+        if (c->tail[0] || c->tail[1]) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: tail_prio must be set before the first deferred dsac_process_images");
+        c->tail_prio = value != 0;
+    }
     else if (k == "seed_stride") {
         if (value < 1) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: seed_stride must be >= 1");
         c->seed_stride = value;
@@ -1390,7 +1396,13 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     const int tk = (mode == 2 && (long long)N * (long long)P <= 2ll * 256 * 307200) ? b : 0;
     if (defer && !c->tail_go) HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
     if (defer && !c->tail[tk]) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->tail[tk], hipStreamNonBlocking));
+        // the tail's launches are one to a few waves each and latency-bound: with the highest stream priority their workgroups are placed ahead of the
+        // thousands K2 still has pending ("tail_prio" 0: default priority, for the A/B)
+        int lo = 0, hi = 0;
+        if (c->tail_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail[tk], hipStreamNonBlocking, hi));
+        else
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->tail[tk], hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done[tk], hipEventDisableTiming));
     }
     if (mode == 2 && !c->pi_k2done) {

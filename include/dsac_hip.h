@@ -117,11 +117,13 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 this promise is a caller bug with undefined behaviour; 0 (default): detect
  *   "seed_stride"  frame f of a frame batch draws from the random stream of seed + f * seed_stride (default 1).  Images sharded round-robin over W ranks
  *                 (rank r owns images r, r + W, ...) keep the seeds they have in the unsharded loop with seed_stride = W: results do not depend on W
+ *   "tail_prio"   1: the deferred tails' streams are created with the highest stream priority (set before the first deferred dsac_process_images;
+ *                   default 0 -- measured without effect on one GPU, profiles/r04_tail_prio.txt)
  *   "pi_defer_tail" 1: dsac_process_images defers its refinement tail, 2: its score tail (reduction, K3) as well (see dsac_join_tail);
  *                   0 (default): everything in stream order
  *   "k4_variant"  K4 main pass: -1 auto; 0 VALU form; 1 / 2 / 3 / 4 / 5 matrix-core form with 2 / 4 / 5 / 6 / 3 chunks per wave, 6 / 7 its high-occupancy builds (+ 10 x tile code + 100 x workgroups per CU)
  * The environment variables DSAC_K2_VARIANT, DSAC_K2_ORDER, DSAC_K2_FLAGS, DSAC_K1_WPB, DSAC_K1_PRIO, DSAC_K1_HPW, DSAC_K1_MINW, DSAC_K1_RL, DSAC_K1_WIDE, DSAC_K1_SHARE,
- * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT give the initial values at dsac_create. */
+ * DSAC_K1_HORN, DSAC_K1_CUS, DSAC_K4_VARIANT, DSAC_TAIL_PRIO give the initial values at dsac_create. */
 DSAC_API int dsac_set_option(dsac_ctx* ctx, const char* key, int value);
 
 /* ---- device buffers for a host program that has no HIP toolchain --------------------------------------------- */
