@@ -1,5 +1,7 @@
 #!/bin/bash
-# K7 at the end of K6's wave, score tail in one launch: the tests that pin them, then the latency legs of the bench line
+# K7 at the end of K6's wave, score tail in one launch: the tests that pin them, then the latency legs of the bench line.
+# (Historical: the one-launch score tail behind DSAC_FUSE_SCORE_TAIL was measured with this script -- profiles/r04_score_tail_fusion_ab.txt -- and then
+# removed from the library; the variable has no effect any more.)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; REPO=$(pwd); O=gpurun_out/r04fu; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_edge.py tests/test_gpu_process_images.py tests/test_gpu_forward.py tests/test_gpu_shard.py tests/test_gpu_drivers.py tests/test_gpu_host_shim.py tests/test_gpu_pipeline.py tests/test_gpu_timed_configs.py -m gpu -q -x 2>&1 | tail -5 | tee $O/pytest.log
 for fz in 1 0 1 0; do
