@@ -1418,9 +1418,18 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     HIP_TRY(c, dk::sample(c->stream, N, seed, nullptr, c->F, (int)thr, max_tries, d_poses, d_sets, d_ok, c->staged.as<float>(), Nf, c->k1));
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
+    // mode 2: the tail starts behind K2.  The event it waits for rides on K2's own dispatch packet (hipExtLaunchKernelGGL's stop event) -- an event
+    // RECORD between K2 and the next call's K1 is a packet of its own and a ~7 us bubble on the stream that bounds the loop (rank step of configs[3]:
+    // 18.6 us from the end of K2 to the start of the next K1 with the record and the wait below, profiles/r04_rank_timeline_mode2.txt)
+    hipEvent_t k2_done = nullptr;
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, part.as<float>(), ps.k2(), &used, Nf));
+        dk::K2Opts o = ps.k2();
+        if (mode == 2) {
+            if (!o.ev_stop) o.ev_stop = c->pi_k2done;
+            k2_done = o.ev_stop;
+        }
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, part.as<float>(), o, &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
@@ -1431,8 +1440,7 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
         ts = c->tail[tk];
         if (c->pi_tail_of[b] >= 0 && c->pi_tail_of[b] != tk) HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_done[c->pi_tail_of[b]], 0));
         c->pi_tail_of[b] = tk;
-        HIP_TRY(c, hipEventRecord(c->pi_k2done, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(ts, c->pi_k2done, 0));
+        HIP_TRY(c, hipStreamWaitEvent(ts, k2_done, 0));
         HIP_TRY(c, score_tail(ts, hyps_per_frame, frames, used, part.as<float>(), d_scores, scale, d_w, d_ent, d_poses, d_avg));
         HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
         c->pi_scored_rec[b] = true;
