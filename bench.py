@@ -735,7 +735,7 @@ def main(argv=None):
                "note": "one GPU runs exactly rank %d's share of %d ranks (its images, buffers, launch sequence, deferred tail, one-step-late exchange; "
                        "the all-gather of 17 KB per rank replaced by the copy of its own part)" % (rem, Wem)}
         em.close()
-        for key, v in (("device_args", 1), ("seed_stride", world), ("pi_defer_tail", DEFER_MODE)):
+        for key, v in (("seed_stride", world), ("pi_defer_tail", DEFER_MODE)):
             eng0.set_option(key, v)
         return res
 
@@ -789,7 +789,7 @@ def main(argv=None):
         k2_ms += ms
         k2_n += n
     if config3:
-        ok_frac = float(runner.scratch[0]["ok"][:N * len(runner.batches[-1])].float().mean().item())
+        ok_frac = float(runner.scratch[0]["ok"][:N * len(runner.batches[-1])].float().mean().item()) if runner.batches else 1.0  # a rank may own no image
         wsum = float(last[0, 10:].sum().item()) if last is not None else 0.0
     else:
         ok_frac = float(bufs[0]["ok"].float().mean().item()) if not args.kernel_only else 1.0

@@ -42,6 +42,8 @@ EXPORTS = [
     "dsac_loss_frames", "dsac_process_images", "dsac_join_tail", "dsac_select",
     "dsac_device_alloc", "dsac_device_free", "dsac_host_alloc", "dsac_host_free", "dsac_copy_async", "dsac_fill_zero_async", "dsac_tail_wait",
     "dsac_gather_rows",
+    "dsac_softmax_frames", "dsac_process_images_begin", "dsac_process_images_finish",
+    "dsac_refine_fd_sets_frames", "dsac_loss_batch_frames", "dsac_select_frames", "dsac_soft_score_derr",
 ]
 
 
@@ -108,6 +110,13 @@ def _load():
     lib.dsac_fill_zero_async.argtypes = [vp, vp, C.c_size_t]
     lib.dsac_gather_rows.argtypes = [vp, vp, vp, C.c_size_t, i32, vp]
     lib.dsac_process_images.argtypes = [vp, i32, u64, f32, i32, f32, f32, f32, f64, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dsac_refine_fd_sets_frames.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, f32, f32, vp, vp, vp, i32, vp]
+    lib.dsac_loss_batch_frames.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.dsac_select_frames.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]
+    lib.dsac_soft_score_derr.argtypes = [vp, i32, vp, vp, f32, f32, f32, vp]
+    lib.dsac_softmax_frames.argtypes = [vp, i32, i32, vp, f64, vp, vp, vp, vp]
+    lib.dsac_process_images_begin.argtypes = [vp, i32, u64, f32, i32, f32, f32, f32, vp, vp, vp, vp, vp]
+    lib.dsac_process_images_finish.argtypes = [vp, i32, vp, f64, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dsac_backward_path1.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, f32, f32, f32, f64, vp, vp, vp, vp, vp]
     return lib
 

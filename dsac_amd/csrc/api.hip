@@ -90,6 +90,9 @@ struct dsac_ctx {
     bool pi_scored_rec[2] = {false, false};
     unsigned pi_calls = 0;
     int pi_tail_of[2] = {-1, -1};  // the tail stream the previous call of each parity used (mode 2)
+    // dsac_process_images_begin ... dsac_process_images_finish: the pair shares one call parity (which half of the alternating arrays) and one size
+    bool pi_open = false;
+    int pi_open_b = 0, pi_open_N = 0, pi_open_frames = 0;
     int tail_prio = 0;             // DSAC_TAIL_PRIO / "tail_prio": create the tail streams with the highest stream priority (before the first deferred call)
     hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
 
@@ -467,8 +470,10 @@ int dsac_copy_async(dsac_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return fail(c, DSAC_ERR_INVALID, "dsac_copy_async: NULL argument");
     if (bytes == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    // a source on the device may be something a deferred refinement tail is still writing (ref6 / out4 / steps_done / inlier maps)
-    if (is_device_ptr(src)) join_tail(c);
+    // While a deferred tail is in flight the copy is ordered behind it, whichever way it goes: a device SOURCE may be something the tail is still writing
+    // (ref6 / out4 / steps_done / inlier maps), a device DESTINATION something it still reads (the frame's xyz / uv, gt, perm: an upload of the next
+    // frame into the buffer the tail refines against would be a write-after-read race).  join_tail is a no-op without a pending tail.
+    join_tail(c);
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
     return DSAC_OK;
 }
@@ -508,6 +513,7 @@ int dsac_fill_zero_async(dsac_ctx* c, void* dst, size_t bytes) {
     if (!c || (bytes && !dst)) return fail(c, DSAC_ERR_INVALID, "dsac_fill_zero_async: NULL argument");
     if (bytes == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    join_tail(c);  // the buffer may be one a deferred tail still reads or writes (see dsac_copy_async)
     HIP_TRY(c, hipMemsetAsync(dst, 0, bytes, c->stream));
     return DSAC_OK;
 }
@@ -525,7 +531,11 @@ int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, 
                 uint8_t* ok) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_sample: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    // frame batch: N = frames x hypotheses per frame, hypothesis h samples frame h / (N / frames) from the stream of seed + frame * seed_stride
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (frames > 1 && (sets_or_null || N % frames != 0))
+        return fail(c, DSAC_ERR_INVALID, "dsac_sample: with a frame batch N must be frames x (hypotheses per frame) and the sets are drawn here (given sets are "
+                                         "evaluated frame by frame: dsac_set_frame + dsac_sample)");
     if (N < 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample: N >= 0 and poses/sets_out/ok must be non-NULL");
     if (N == 0) return DSAC_OK;
     if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_sample: max_tries must be > 0");
@@ -540,14 +550,17 @@ int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, 
     ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
     ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
     ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
-    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, nullptr, 0, c->k1));
+    HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, nullptr, frames > 1 ? N / frames : 0, c->k1));
     return end_call(c);
 }
 
 int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float* err_or_null, float tau, float beta, double* soft_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_reproject: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_reproject: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_reproject: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    // frame batch: N = frames x hypotheses per frame (a multiple of 128: no hypothesis tile of K2 straddles two frames), hypothesis h scores frame h / Nf
+    const int Nf = c->F.frames > 1 ? N / c->F.frames : 0;
+    if (c->F.frames > 1 && (N % c->F.frames != 0 || Nf % dk::K2_NF_MULTIPLE != 0))
+        return fail(c, DSAC_ERR_INVALID, "dsac_reproject: with a frame batch N must be frames x (a multiple of %d), got %d for %d frames", dk::K2_NF_MULTIPLE, N, c->F.frames);
     if (N < 0 || !poses) return fail(c, DSAC_ERR_INVALID, "dsac_reproject: N >= 0 and poses must be non-NULL");
     if (N == 0 || (!err_or_null && !soft_or_null)) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -577,7 +590,7 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
@@ -585,22 +598,34 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     return end_call(c);
 }
 
-int dsac_softmax(dsac_ctx* c, int N, const double* scores, double scale, double* w, double* entropy_or_null, const double* poses_or_null,
-                 double* avg6_or_null) {
-    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_softmax: ctx is NULL");
-    if (N <= 0 || !scores || !w) return fail(c, DSAC_ERR_INVALID, "dsac_softmax: N > 0 and scores/w must be non-NULL");
-    if ((avg6_or_null != nullptr) != (poses_or_null != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_softmax: avg6 and poses go together");
+static int softmax_common(dsac_ctx* c, const char* who, int frames, int N, const double* scores, double scale, double* w, double* entropy_or_null,
+                          const double* poses_or_null, double* avg6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "%s: ctx is NULL", who);
+    if (N <= 0 || frames <= 0 || !scores || !w) return fail(c, DSAC_ERR_INVALID, "%s: N > 0, frames > 0 and scores/w must be non-NULL", who);
+    if ((long long)N * frames > (1ll << 24)) return fail(c, DSAC_ERR_INVALID, "%s: too many scores", who);
+    if ((avg6_or_null != nullptr) != (poses_or_null != nullptr)) return fail(c, DSAC_ERR_INVALID, "%s: avg6 and poses go together", who);
     HIP_TRY(c, hipSetDevice(c->device));
     begin_call(c);
+    const size_t NT = (size_t)N * frames;
     const double *d_scores, *d_poses;
     double *d_w, *d_ent, *d_avg;
-    ARG_TRY(in_arg(c, scores, (size_t)N, &d_scores));
-    ARG_TRY(in_arg(c, poses_or_null, (size_t)N * 6, &d_poses));
-    ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
-    ARG_TRY(out_arg(c, entropy_or_null, 1, &d_ent));
-    ARG_TRY(out_arg(c, avg6_or_null, 6, &d_avg));
-    HIP_TRY(c, dk::softmax(c->stream, N, d_scores, scale, d_w, d_ent, d_poses, d_avg));
+    ARG_TRY(in_arg(c, scores, NT, &d_scores));
+    ARG_TRY(in_arg(c, poses_or_null, NT * 6, &d_poses));
+    ARG_TRY(out_arg(c, w, NT, &d_w));
+    ARG_TRY(out_arg(c, entropy_or_null, (size_t)frames, &d_ent));
+    ARG_TRY(out_arg(c, avg6_or_null, (size_t)frames * 6, &d_avg));
+    HIP_TRY(c, dk::softmax(c->stream, N, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
     return end_call(c);
+}
+
+int dsac_softmax(dsac_ctx* c, int N, const double* scores, double scale, double* w, double* entropy_or_null, const double* poses_or_null,
+                 double* avg6_or_null) {
+    return softmax_common(c, "dsac_softmax", 1, N, scores, scale, w, entropy_or_null, poses_or_null, avg6_or_null);
+}
+
+int dsac_softmax_frames(dsac_ctx* c, int frames, int hyps_per_frame, const double* scores, double scale, double* w, double* entropy_or_null,
+                        const double* poses_or_null, double* avg6_or_null) {
+    return softmax_common(c, "dsac_softmax_frames", frames, hyps_per_frame, scores, scale, w, entropy_or_null, poses_or_null, avg6_or_null);
 }
 
 static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
@@ -915,7 +940,18 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         c->g6_n = N;
         return end_call(c);
     }
-    const dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant, Nf);
+    dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant, Nf);
+    if (plan.direct && d_grad == grad_xyz && !c->device_args) {
+        // the direct form adds into the caller's buffer with hardware fp64 atomics (unsafeAtomicAdd): those are only defined on ordinary (coarse-grained)
+        // device memory.  Managed / fine-grained memory takes the staged form (partial sums + a reduction launch); a frame batch has no staged form
+        hipPointerAttribute_t attr;
+        const bool plain = hipPointerGetAttributes(&attr, grad_xyz) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        if (!plain) {
+            (void)hipGetLastError();
+            if (frames > 1) return fail(c, DSAC_ERR_INVALID, "%s: on a frame batch grad_xyz must be ordinary device memory (hipMalloc / dsac_device_alloc / torch), not managed memory", who);
+            plan = dk::backward_plan(N, c->F, d_derr, (c->k4_variant < 0 ? 999 : c->k4_variant % 1000) + 1000, Nf);
+        }
+    }
     if (plan.Nf < 0)
         return fail(c, DSAC_ERR_INVALID, "%s: this map / kernel form (k4_variant %d) has no frame-batch mode (needs the matrix-core form: 16-byte aligned buffers, "
                                          "H*W and W multiples of 4)", who, c->k4_variant);
@@ -1062,30 +1098,49 @@ int dsac_loss(dsac_ctx* c, const double* est_cv6, const double* gt_jp6, double* 
     return end_call(c);
 }
 
-int dsac_refine_fd_sets(dsac_ctx* c, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
-                        const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
-                        int32_t* n_obj) {
-    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd_sets: ctx is NULL");
-    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd_sets: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+static int refine_fd_sets_common(dsac_ctx* c, const char* who, int M, const int32_t* sets, const int32_t* frame_of_or_null, const int32_t* perm, int steps, int max_inl,
+                                 int min_inl, float thr, const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels,
+                                 double* J_obj, int cap, int32_t* n_obj) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "%s: ctx is NULL", who);
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "%s: no frame set", who);
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
     if (M < 0 || !sets || !perm || !inlier_maps || !J_set || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
-        return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: NULL argument or negative count");
-    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: need 1 <= max_inl <= 256");
-    if (!(sub_sample > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: sub_sample and eps_obj must be > 0");
+        return fail(c, DSAC_ERR_INVALID, "%s: NULL argument or negative count", who);
+    if (frames > 1 && !frame_of_or_null && M % frames != 0)
+        return fail(c, DSAC_ERR_INVALID, "%s: with a frame batch M must be frames x (hypotheses per frame) -- or give every hypothesis its frame (dsac_refine_fd_sets_frames)", who);
+    if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "%s: need 1 <= max_inl <= 256", who);
+    if (!(sub_sample > 0.f) || !(eps_obj > 0.f)) return fail(c, DSAC_ERR_INVALID, "%s: sub_sample and eps_obj must be > 0", who);
     const int skip = (int)(1 / sub_sample);  // core/cnn.h:933
-    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: sub_sample > 1");
+    if (skip < 1) return fail(c, DSAC_ERR_INVALID, "%s: sub_sample > 1", who);
     if (M == 0) return DSAC_OK;
     const size_t R = 18 + 6 * (size_t)cap, B = R * (size_t)M;
-    if (B > (1u << 26)) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets: M * (18 + 6*cap) = %zu replicas is too many", B);
+    if (B > (1u << 26)) return fail(c, DSAC_ERR_INVALID, "%s: M * (18 + 6*cap) = %zu replicas is too many", who, B);
     HIP_TRY(c, hipSetDevice(c->device));
     begin_call(c);
     const size_t P = (size_t)c->F.P;
-    const int32_t *d_sets, *d_perm, *d_maps;
+    const int32_t *d_sets, *d_perm, *d_maps, *d_fof = nullptr;
     double *d_Js, *d_Jo;
     int32_t *d_px, *d_n;
     ARG_TRY(in_arg(c, sets, (size_t)M * 4, &d_sets));
     ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
     ARG_TRY(in_arg(c, inlier_maps, (size_t)M * P, &d_maps));
+    std::vector<int32_t> implicit_frames;  // pageable host memory: the upload below has left it when hipMemcpyAsync returns
+    if (frames > 1) {
+        if (frame_of_or_null) {
+            if (!is_device_ptr(frame_of_or_null, c))
+                for (int m = 0; m < M; m++)
+                    if (frame_of_or_null[m] < 0 || frame_of_or_null[m] >= frames) return fail(c, DSAC_ERR_INVALID, "%s: frame_of[%d] = %d is not a frame of the batch", who, m, frame_of_or_null[m]);
+            ARG_TRY(in_arg(c, frame_of_or_null, (size_t)M, &d_fof));
+        } else {
+            implicit_frames.resize(M);
+            for (int m = 0; m < M; m++) implicit_frames[m] = m / (M / frames);
+            DevBuf& fb = next_slot(c);
+            HIP_TRY(c, fb.reserve((size_t)M * sizeof(int32_t)));
+            HIP_TRY(c, hipMemcpyAsync(fb.p, implicit_frames.data(), (size_t)M * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));  // the vector goes out of scope with this call
+            d_fof = fb.as<int32_t>();
+        }
+    }
     ARG_TRY(out_arg(c, J_set, (size_t)M * 54, &d_Js));
     ARG_TRY(out_arg(c, obj_pixels, (size_t)M * cap, &d_px));
     ARG_TRY(out_arg(c, J_obj, (size_t)M * cap * 18, &d_Jo));
@@ -1101,11 +1156,26 @@ int dsac_refine_fd_sets(dsac_ctx* c, int M, const int32_t* sets, const int32_t* 
         plan_scratch = ps.as<int32_t>();
     }
     HIP_TRY(c, dk::refine_fd_plan_set(c->stream, d_sets, d_maps, c->F, skip, eps_obj, cap, rp.as<double>(), rx.as<int32_t>(), rv.as<float>(), d_px, d_n, M,
-                                      plan_scratch));
+                                      plan_scratch, d_fof));
     HIP_TRY(c, dk::refine_fd_run_set(c->stream, cap, d_n, rp.as<double>(), d_perm, steps, max_inl, min_inl, thr, rx.as<int32_t>(), rv.as<float>(), c->F,
-                                     ro.as<double>(), M));
+                                     ro.as<double>(), M, d_fof));
     HIP_TRY(c, dk::refine_fd_finish_set(c->stream, ro.as<double>(), d_n, cap, skip, eps_obj, d_Js, d_Jo, M));
     return end_call(c);
+}
+
+int dsac_refine_fd_sets(dsac_ctx* c, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                        const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                        int32_t* n_obj) {
+    return refine_fd_sets_common(c, "dsac_refine_fd_sets", M, sets, nullptr, perm, steps, max_inl, min_inl, thr, inlier_maps, sub_sample, eps_obj, J_set, obj_pixels, J_obj,
+                                 cap, n_obj);
+}
+
+int dsac_refine_fd_sets_frames(dsac_ctx* c, int M, const int32_t* sets, const int32_t* frame_of, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
+                               const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
+                               int32_t* n_obj) {
+    if (c && !frame_of) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_sets_frames: frame_of is NULL");
+    return refine_fd_sets_common(c, "dsac_refine_fd_sets_frames", M, sets, frame_of, perm, steps, max_inl, min_inl, thr, inlier_maps, sub_sample, eps_obj, J_set, obj_pixels,
+                                 J_obj, cap, n_obj);
 }
 
 int dsac_gather_patches(dsac_ctx* c, const uint8_t* bgr, int H, int W, const int32_t* sampling_xy, int n, int patch, float* patches, int32_t* skipped_or_null) {
@@ -1148,7 +1218,10 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
                     const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_all: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_all: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    // frame batch: N = frames x hypotheses per frame, hypothesis h refines against frame h / (N / frames) -- frames x N refinement problems in ONE launch
+    // (core/cnn.h:1155-1215 is the loop over the hypotheses of one image; 16 images x 256 hypotheses are 4096 waves, which fill the chip where 256 do not)
+    const int frames_ra = c->F.frames > 1 ? c->F.frames : 1;
+    if (frames_ra > 1 && N % frames_ra != 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: with a frame batch N must be frames x (hypotheses per frame), got %d for %d frames", N, frames_ra);
     if (N < 0 || !init_poses || !perm || !out_poses || steps < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_refine_all: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
     if (N == 0) return DSAC_OK;
@@ -1166,7 +1239,8 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
     ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)N * P, &d_maps, /*preload=*/false));
     ARG_TRY(out_arg(c, steps_done_or_null, (size_t)N, &d_sd));
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)N * P * sizeof(int32_t), c->stream));
-    HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0));
+    HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
+                          frames_ra > 1 ? N / frames_ra : 0));
     if (d_maps && d_sets) HIP_TRY(c, dk::zero_set_cells(c->stream, N, d_sets, (int)P, d_maps));
     return end_call(c);
 }
@@ -1176,7 +1250,7 @@ int dsac_refine_fd_set(dsac_ctx* c, const int32_t* set4, const int32_t* perm, in
                        int32_t* n_obj) {
     if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refine_fd_set: ctx is NULL");
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_refine_fd_set: no frame set");
-    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: a frame batch is set; only dsac_score_hypotheses_frames works on batches");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: a frame batch is set (one hypothesis: dsac_set_frame of its image, or dsac_refine_fd_sets_frames)");
     if (!set4 || !perm || !inlier_map || !J_set || !obj_pixels || !J_obj || !n_obj || cap < 0 || steps < 0)
         return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: NULL argument or negative count");
     if (max_inl < 1 || max_inl > 256) return fail(c, DSAC_ERR_INVALID, "dsac_refine_fd_set: need 1 <= max_inl <= 256");
@@ -1325,6 +1399,147 @@ int dsac_loss_frames(dsac_ctx* c, int B, const double* est_cv6, const double* gt
     return end_call(c);
 }
 
+int dsac_loss_batch_frames(dsac_ctx* c, int frames, int per_frame, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_loss_batch_frames: ctx is NULL");
+    if (frames < 0 || per_frame <= 0 || !est_cv6 || !gt_jp6 || (!out4 && !J6_or_null)) return fail(c, DSAC_ERR_INVALID, "dsac_loss_batch_frames: NULL argument or bad count");
+    if ((long long)frames * per_frame > (1ll << 26)) return fail(c, DSAC_ERR_INVALID, "dsac_loss_batch_frames: too many estimates");
+    if (frames == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t B = (size_t)frames * per_frame;
+    const double *d_est, *d_gt;
+    double *d_out, *d_J;
+    ARG_TRY(in_arg(c, est_cv6, B * 6, &d_est));
+    ARG_TRY(in_arg(c, gt_jp6, (size_t)frames * 6, &d_gt));
+    ARG_TRY(out_arg(c, out4, B * 4, &d_out));
+    ARG_TRY(out_arg(c, J6_or_null, B * 6, &d_J));
+    HIP_TRY(c, dk::pose_loss(c->stream, (int)B, d_est, d_gt, d_out, d_J, 6, per_frame));
+    return end_call(c);
+}
+
+int dsac_select_frames(dsac_ctx* c, int frames, int N, const double* probs, const double* losses, int loss_stride, const double* u, int32_t* hyp_idx_or_null,
+                       double* expected_loss_or_null, double* score_gradients_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_select_frames: ctx is NULL");
+    if (frames <= 0 || N <= 0 || !probs || !losses || !u || loss_stride < 1) return fail(c, DSAC_ERR_INVALID, "dsac_select_frames: need frames > 0, N > 0, probs, losses, u, loss_stride >= 1");
+    if ((long long)frames * N > (1ll << 24)) return fail(c, DSAC_ERR_INVALID, "dsac_select_frames: too many hypotheses");
+    if (!is_device_ptr(u, c))
+        for (int f = 0; f < frames; f++)
+            if (!(u[f] < 1.0)) return fail(c, DSAC_ERR_INVALID, "dsac_select_frames: u[%d] must be < 1 (negative: the most probable entry)", f);
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t NT = (size_t)frames * N;
+    const double *d_w, *d_l, *d_u;
+    int32_t* d_idx;
+    double *d_e, *d_g;
+    ARG_TRY(in_arg(c, probs, NT, &d_w));
+    ARG_TRY(in_arg(c, losses, NT * loss_stride, &d_l));
+    ARG_TRY(in_arg(c, u, (size_t)frames, &d_u));
+    ARG_TRY(out_arg(c, hyp_idx_or_null, (size_t)frames, &d_idx));
+    ARG_TRY(out_arg(c, expected_loss_or_null, (size_t)frames, &d_e));
+    ARG_TRY(out_arg(c, score_gradients_or_null, NT, &d_g));
+    HIP_TRY(c, dk::dsac_select_frames(c->stream, frames, N, d_w, d_l, loss_stride, d_u, 1e-8, d_idx, d_e, d_g));
+    return end_call(c);
+}
+
+// d_err[h][p] = g[h] * d soft[h] / d err[h][p] = g[h] * (-beta) * s (1 - s),  s = sigmoid(beta (tau - err[h][p])); zero where the residual sits on the clamp
+// (the score no longer depends on it there -- what K4's in-kernel form does, k_backward.hip).  One float4 per lane, the row index from the launch's y.
+namespace {
+__global__ __launch_bounds__(256) void k_soft_derr(int P4, const float4* __restrict__ err, const double* __restrict__ g, float clampv, float tau, float beta,
+                                                   float4* __restrict__ d_err) {
+    const size_t h = blockIdx.y;
+    const float gh = (float)g[h] * (-beta);
+    const float4* e = err + h * (size_t)P4;
+    float4* d = d_err + h * (size_t)P4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P4; i += gridDim.x * blockDim.x) {
+        const float4 v = e[i];
+        float4 o;
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float s = 1.f / (1.f + __expf(-beta * (tau - in[k])));
+            out[k] = in[k] >= clampv ? 0.f : gh * s * (1.f - s);
+        }
+        o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+        d[i] = o;
+    }
+}
+}  // namespace
+
+int dsac_soft_score_derr(dsac_ctx* c, int N, const double* g, const float* err, float clampv, float tau, float beta, float* d_err) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_soft_score_derr: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_soft_score_derr: no frame set (the maps are H*W wide)");
+    if (N < 0 || !g || !err || !d_err || !(beta > 0.f)) return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_derr: NULL argument, negative count or beta <= 0");
+    if (c->F.P % 4 != 0) return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_derr: H*W must be a multiple of 4");
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const size_t P = (size_t)c->F.P;
+    const double* d_g;
+    const float* d_e;
+    float* d_o;
+    ARG_TRY(in_arg(c, g, (size_t)N, &d_g));
+    ARG_TRY(in_arg(c, err, (size_t)N * P, &d_e));
+    ARG_TRY(out_arg(c, d_err, (size_t)N * P, &d_o));
+    if ((reinterpret_cast<uintptr_t>(d_e) | reinterpret_cast<uintptr_t>(d_o)) % 16 != 0) return fail(c, DSAC_ERR_INVALID, "dsac_soft_score_derr: err / d_err must be 16-byte aligned");
+    const int P4 = (int)(P / 4);
+    const unsigned gx = (unsigned)std::min<int>((P4 + 255) / 256, 64);
+    for (int h0 = 0; h0 < N; h0 += 65535) {
+        const int n = std::min(N - h0, 65535);
+        hipLaunchKernelGGL(k_soft_derr, dim3(gx, (unsigned)n), dim3(256), 0, c->stream, P4, reinterpret_cast<const float4*>(d_e + (size_t)h0 * P), d_g + h0, clampv, tau, beta,
+                           reinterpret_cast<float4*>(d_o + (size_t)h0 * P));
+        HIP_TRY(c, hipGetLastError());
+    }
+    return end_call(c);
+}
+
+// ---- shared by dsac_process_images and the begin / finish pair -------------------------------------------------------------------------------
+// Which deferral mode a call runs in: the context's "pi_defer_tail", but only with device-resident arguments -- a host destination is copied back at
+// the end of the call, and a host `perm` / `gt` lives in a staging slot that the next call reuses.
+static int pi_mode(dsac_ctx* c, const void* perm, const void* gt_or_null) {
+    return (c->pending.empty() && is_device_ptr(perm, c) && (!gt_or_null || is_device_ptr(gt_or_null, c))) ? c->pi_defer_tail : 0;
+}
+// mode 2, which tail stream: consecutive calls write different arrays there, so their tails are independent -- SMALL calls (up to two full-size
+// images' worth of hypothesis x cell pairs: K1 + K2 shorter than the one-wave refinement chain) alternate between two streams and two tails run
+// side by side; larger calls hide their tail under the next call anyway and stay on the first stream (measured: with both streams in use for
+// 8-image calls configs[3]'s rank step went from 0.51 to 0.64 ms in the bench process -- the tails then ran exposed; the cause was not isolated,
+// GPU_MAX_HW_QUEUES = 8 changes neither number, profiles/r04_hw_queues.txt)
+static int pi_tail_index(int mode, int b, long long N, long long P) { return (mode == 2 && N * P <= 2ll * 256 * 307200) ? b : 0; }
+// streams and events of the deferred tails, created on first use
+static int pi_tail_setup(dsac_ctx* c, int mode, int tk) {
+    if (mode == 0) return DSAC_OK;
+    if (!c->tail_go) HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
+    if (!c->tail[tk]) {
+        // the tail's launches are one to a few waves each and latency-bound: with the highest stream priority their workgroups are placed ahead of the
+        // thousands K2 still has pending ("tail_prio" 0: default priority, for the A/B)
+        int lo = 0, hi = 0;
+        if (c->tail_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail[tk], hipStreamNonBlocking, hi));
+        else
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->tail[tk], hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done[tk], hipEventDisableTiming));
+    }
+    if (mode == 2 && !c->pi_k2done) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->pi_k2done, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->pi_scored[k], hipEventDisableTiming));
+    }
+    return DSAC_OK;
+}
+// K6 (+ K7 at the end of its wave) of every frame on `ts`; with a deferred tail its completion event is recorded and the tail marked pending
+static int pi_refine_tail(dsac_ctx* c, hipStream_t ts, bool defer, int tk, int frames, const double* d_avg, const int32_t* d_perm, int steps, int max_inl,
+                          int min_inl, float thr, double* d_ref, int32_t* d_maps, int32_t* d_sd, const double* d_gt, double* d_out4) {
+    const size_t P = (size_t)c->F.P;
+    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
+    // K7 rides at the end of K6's wave: the loss of a refined pose is computed by the lane that holds it (one launch less behind the refinement chain)
+    HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
+                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4));
+    if (defer) {
+        HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));
+        c->tail_pending[tk] = true;
+    }
+    return DSAC_OK;
+}
+
 int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clampv, float tau, float beta, double scale,
                         const int32_t* perm, int steps, int max_inl, int min_inl, const double* gt_jp6_or_null, double* poses, int32_t* sets_out, uint8_t* ok,
                         float* err_or_null, double* scores_or_null, double* w, double* entropy, double* avg6, double* ref6, int32_t* steps_done,
@@ -1371,9 +1586,10 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     // too -- K1 of the next call follows K2 of this one directly, and EVERY output of this call except the error images is complete only then.
     // Only with device-resident arguments: a host destination is copied back at the end of this call, and a host `perm` / `gt` lives in a staging
     // slot that the next call reuses.
-    const int mode = (c->pending.empty() && is_device_ptr(perm, c) && (!gt_jp6_or_null || is_device_ptr(gt_jp6_or_null, c))) ? c->pi_defer_tail : 0;
+    const int mode = pi_mode(c, perm, gt_jp6_or_null);
     const bool defer = mode != 0;
     const int b = (int)(c->pi_calls++ & 1u);
+    c->pi_open = false;  // a begin without its finish is abandoned by a whole call
     if (!d_scores) {
         if (mode == 2) {
             HIP_TRY(c, c->pi_scores[b].reserve((size_t)N * sizeof(double)));
@@ -1388,27 +1604,8 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     DevBuf& part = mode == 2 ? c->pi_soft[b] : c->soft_part;
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
     HIP_TRY(c, part.reserve((size_t)tiles * N * sizeof(float)));
-    // mode 2, which tail stream: consecutive calls write different arrays there, so their tails are independent -- SMALL calls (up to two full-size
-    // images' worth of hypothesis x cell pairs: K1 + K2 shorter than the one-wave refinement chain) alternate between two streams and two tails run
-    // side by side; larger calls hide their tail under the next call anyway and stay on the first stream (measured: with both streams in use for
-    // 8-image calls configs[3]'s rank step went from 0.51 to 0.64 ms in the bench process -- the tails then ran exposed; the cause was not isolated,
-    // GPU_MAX_HW_QUEUES = 8 changes neither number, profiles/r04_hw_queues.txt)
-    const int tk = (mode == 2 && (long long)N * (long long)P <= 2ll * 256 * 307200) ? b : 0;
-    if (defer && !c->tail_go) HIP_TRY(c, hipEventCreateWithFlags(&c->tail_go, hipEventDisableTiming));
-    if (defer && !c->tail[tk]) {
-        // the tail's launches are one to a few waves each and latency-bound: with the highest stream priority their workgroups are placed ahead of the
-        // thousands K2 still has pending ("tail_prio" 0: default priority, for the A/B)
-        int lo = 0, hi = 0;
-        if (c->tail_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->tail[tk], hipStreamNonBlocking, hi));
-        else
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->tail[tk], hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->tail_done[tk], hipEventDisableTiming));
-    }
-    if (mode == 2 && !c->pi_k2done) {
-        HIP_TRY(c, hipEventCreateWithFlags(&c->pi_k2done, hipEventDisableTiming));
-        for (int k = 0; k < 2; k++) HIP_TRY(c, hipEventCreateWithFlags(&c->pi_scored[k], hipEventDisableTiming));
-    }
+    const int tk = pi_tail_index(mode, b, N, (long long)P);
+    ARG_TRY(pi_tail_setup(c, mode, tk));
     // the call before the previous one used this half of the alternating buffers (and, by the caller's contract, possibly these output arrays): its K3
     // on the tail stream must have read them.  Two K2 launches have run since -- the event has long completed
     if (mode == 2 && c->pi_scored_rec[b]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pi_scored[b], 0));
@@ -1456,14 +1653,128 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
             ts = c->tail[0];
         }
     }
-    if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
-    // K7 rides at the end of K6's wave: the loss of a refined pose is computed by the lane that holds it (one launch less behind the refinement chain)
-    HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
-                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4));
-    if (defer) {
-        HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));
-        c->tail_pending[tk] = true;
+    ARG_TRY(pi_refine_tail(c, ts, defer, tk, frames, d_avg, d_perm, steps, max_inl, min_inl, thr, d_ref, d_maps, d_sd, d_gt, d_out4));
+    return end_call(c);
+}
+
+// ---- the score-CNN seam of the batched fast path: dsac_process_images cut between K2 and K3 -----------------------------------------------------
+// core/cnn_softam.h:1066-1078 is  getDiffMap x N -> forward(diffMaps) -> softMax : begin leaves the error images of every frame in HBM, the caller's
+// score model (the reference's score CNN; any device code on the context's stream) turns them into frames x hyps_per_frame scores, finish continues
+// with K3 -> K6 -> K7.  The deferral modes of dsac_process_images apply to the pair (the tails start in finish).
+int dsac_process_images_begin(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clampv, float tau, float beta, double* poses,
+                              int32_t* sets_out, uint8_t* ok, float* err, double* soft_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_process_images_begin: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_process_images_begin: no frame set");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (hyps_per_frame <= 0 || (frames > 1 && hyps_per_frame % dk::K2_NF_MULTIPLE != 0))
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images_begin: hyps_per_frame must be positive (a multiple of %d for a frame batch), got %d", dk::K2_NF_MULTIPLE,
+                    hyps_per_frame);
+    if ((long long)hyps_per_frame * frames > (1ll << 24)) return fail(c, DSAC_ERR_INVALID, "dsac_process_images_begin: too many hypotheses");
+    if (!poses || !sets_out || !ok || (!err && !soft_or_null))
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images_begin: poses / sets_out / ok and at least one of err / soft must be non-NULL");
+    if (max_tries <= 0 || c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_process_images_begin: max_tries > 0 and a frame of at least 4 cells needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c, /*keep_tail=*/c->pi_defer_tail != 0);
+    const size_t P = (size_t)c->F.P;
+    const int N = hyps_per_frame * frames, Nf = frames > 1 ? hyps_per_frame : 0;
+    double *d_poses, *d_soft;
+    int32_t* d_sets;
+    uint8_t* d_ok;
+    float* d_err;
+    ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets));
+    ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
+    ARG_TRY(out_arg(c, err, (size_t)N * P, &d_err));
+    ARG_TRY(out_arg(c, soft_or_null, (size_t)N, &d_soft));
+    const int b = (int)(c->pi_calls++ & 1u);
+    c->pi_open = true; c->pi_open_b = b; c->pi_open_N = hyps_per_frame; c->pi_open_frames = frames;
+    // "pi_defer_tail" 2: K3 of the call two back (same half of the caller's alternating arrays) read the poses K1 is about to overwrite
+    if (c->pi_defer_tail == 2 && c->pi_scored_rec[b]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pi_scored[b], 0));
+    const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
+    HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    // the per-tile sums are reduced in stream order below, so the context's one buffer serves every call.  Error images only on a big launch still take
+    // the kernel form with the sigmoid arithmetic (dsac_reproject: it is the faster store schedule) and drop the sums
+    const bool fused_for_err = !d_soft && c->k2.variant < 0 && !(c->k2.flags & (1 << 24)) && (double)N * (double)P * 4.0 > 1.0e9;
+    float* d_part = nullptr;
+    if (d_soft || fused_for_err) {
+        HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
+        d_part = c->soft_part.as<float>();
     }
+    if (fused_for_err && !(beta > 0.f)) { tau = 10.f; beta = 0.5f; }
+    HIP_TRY(c, dk::sample(c->stream, N, seed, nullptr, c->F, (int)thr, max_tries, d_poses, d_sets, d_ok, c->staged.as<float>(), Nf, c->k1));
+    int used = 0;
+    if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
+    {
+        ProfScope ps(c, 0, true);
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used, Nf));
+        ps.commit();
+    }
+    if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
+    if (d_soft) HIP_TRY(c, dk::reduce_soft(c->stream, N, used, d_part, d_soft));
+    return end_call(c);
+}
+
+int dsac_process_images_finish(dsac_ctx* c, int hyps_per_frame, const double* scores, double scale, const int32_t* perm, int steps, int max_inl, int min_inl,
+                               float thr, const double* gt_jp6_or_null, const double* poses, double* w, double* entropy, double* avg6, double* ref6,
+                               int32_t* steps_done, int32_t* inlier_maps_or_null, double* out4_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_process_images_finish: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_process_images_finish: no frame set");
+    const int frames = c->F.frames > 1 ? c->F.frames : 1;
+    if (!c->pi_open || c->pi_open_N != hyps_per_frame || c->pi_open_frames != frames)
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images_finish: no dsac_process_images_begin of %d frame(s) x %d hypotheses is open on this context", frames,
+                    hyps_per_frame);
+    if (!scores || !perm || !poses || !w || !entropy || !avg6 || !ref6 || !steps_done || steps < 0)
+        return fail(c, DSAC_ERR_INVALID, "dsac_process_images_finish: NULL argument or negative step count");
+    if ((out4_or_null != nullptr) != (gt_jp6_or_null != nullptr)) return fail(c, DSAC_ERR_INVALID, "dsac_process_images_finish: out4 and gt_jp6 go together");
+    if (max_inl < 1 || max_inl > 256 || min_inl < 0) return fail(c, DSAC_ERR_INVALID, "dsac_process_images_finish: need 1 <= max_inl <= 256 (got %d), min_inl >= 0", max_inl);
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c, /*keep_tail=*/c->pi_defer_tail != 0);
+    const size_t P = (size_t)c->F.P;
+    const int N = hyps_per_frame * frames;
+    const int32_t* d_perm;
+    const double *d_gt, *d_scores, *d_poses;
+    double *d_w, *d_ent, *d_avg, *d_ref, *d_out4;
+    int32_t *d_sd, *d_maps;
+    ARG_TRY(in_arg(c, perm, (size_t)steps * P, &d_perm));
+    ARG_TRY(in_arg(c, gt_jp6_or_null, (size_t)frames * 6, &d_gt));
+    ARG_TRY(in_arg(c, scores, (size_t)N, &d_scores));
+    ARG_TRY(in_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
+    ARG_TRY(out_arg(c, entropy, (size_t)frames, &d_ent));
+    ARG_TRY(out_arg(c, avg6, (size_t)frames * 6, &d_avg));
+    ARG_TRY(out_arg(c, ref6, (size_t)frames * 6, &d_ref));
+    ARG_TRY(out_arg(c, steps_done, (size_t)frames, &d_sd));
+    ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)frames * P, &d_maps));
+    ARG_TRY(out_arg(c, out4_or_null, (size_t)frames * 4, &d_out4));
+    // the deferral needs every argument in HBM (pi_mode); scores and poses too -- a staged copy lives in a slot the next call reuses
+    const int mode = (is_device_ptr(scores, c) && is_device_ptr(poses, c)) ? pi_mode(c, perm, gt_jp6_or_null) : 0;
+    const bool defer = mode != 0;
+    const int b = c->pi_open_b;
+    c->pi_open = false;
+    const int tk = pi_tail_index(mode, b, N, (long long)P);
+    ARG_TRY(pi_tail_setup(c, mode, tk));
+    hipStream_t ts = c->stream;
+    if (mode == 2) {
+        // K3 as well goes to the tail stream: it starts when the scores are there (an event on the context's stream: the score model ran on it), the
+        // next begin's K1 follows the score model without waiting for K3.  Ordering against earlier tails as in dsac_process_images
+        ts = c->tail[tk];
+        if (c->pi_tail_of[b] >= 0 && c->pi_tail_of[b] != tk) HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_done[c->pi_tail_of[b]], 0));
+        c->pi_tail_of[b] = tk;
+        HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_go, 0));
+        HIP_TRY(c, dk::softmax(ts, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
+        c->pi_scored_rec[b] = true;
+    } else {
+        join_tail(c);  // the previous call's tail reads the soft-argmax poses that K3 is about to overwrite
+        HIP_TRY(c, dk::softmax(c->stream, hyps_per_frame, d_scores, scale, d_w, d_ent, d_poses, d_avg, frames));
+        if (defer) {
+            HIP_TRY(c, hipEventRecord(c->tail_go, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->tail[0], c->tail_go, 0));
+            ts = c->tail[0];
+        }
+    }
+    ARG_TRY(pi_refine_tail(c, ts, defer, tk, frames, d_avg, d_perm, steps, max_inl, min_inl, thr, d_ref, d_maps, d_sd, d_gt, d_out4));
     return end_call(c);
 }
 

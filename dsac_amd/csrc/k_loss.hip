@@ -12,10 +12,10 @@ namespace dk {
 // One lane per estimate (B = 1: maxLoss / dLossMax of the soft-argmax pipeline; B = N: the per-hypothesis losses of
 // expectedMaxLoss, core/cnn.h:137-150, and the per-hypothesis dLossMax of core/train_ransac.cpp:345-349).
 __global__ __launch_bounds__(64) void k_pose_loss(int B, const double* __restrict__ est_all, const double* __restrict__ gt_jp6,
-                                                  double* __restrict__ out4_all, double* __restrict__ J6_all, int gt_stride) {
+                                                  double* __restrict__ out4_all, double* __restrict__ J6_all, int gt_stride, int gt_group) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
-    gt_jp6 += (size_t)b * gt_stride;  // 0: one ground truth for all estimates; 6: one per estimate (a frame batch)
+    gt_jp6 += (size_t)(b / gt_group) * gt_stride;  // stride 0: one ground truth for all estimates; 6: one per group of gt_group estimates (a frame batch)
     const double* est_cv6 = est_all + (size_t)b * 6;
     double* out4 = out4_all ? out4_all + (size_t)b * 4 : nullptr;
     double* J6 = J6_all ? J6_all + (size_t)b * 6 : nullptr;
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(64) void k_pose_loss(int B, const double* __restric
     for (int i = 0; i < 6; i++) J6[i] = J[i];
 }
 
-hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6, int gt_stride) {
+hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6, int gt_stride, int gt_group) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pose_loss, dim3((B + 63) / 64), dim3(64), 0, st, B, est_cv6, gt_jp6, out4, J6, gt_stride);
+    hipLaunchKernelGGL(k_pose_loss, dim3((B + 63) / 64), dim3(64), 0, st, B, est_cv6, gt_jp6, out4, J6, gt_stride, gt_group < 1 ? 1 : gt_group);
     return hipGetLastError();
 }
 
@@ -112,8 +112,17 @@ hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6, const double*
 // One workgroup; the two scalar scans run on one lane (N sequential fp64 additions, the reference's own order), the N x N subtraction on all lanes.
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dsac_select(int N, const double* __restrict__ w, const double* __restrict__ losses, int loss_stride, double u,
-                                                     double eps, int32_t* __restrict__ hyp_idx, double* __restrict__ expected, double* __restrict__ g) {
+                                                     double eps, int32_t* __restrict__ hyp_idx, double* __restrict__ expected, double* __restrict__ g,
+                                                     const double* __restrict__ u_frames) {
     const int tid = threadIdx.x;
+    if (u_frames) {  // image blockIdx.x of a frame batch: its N probabilities / losses / gradients, its own draw
+        const size_t f = blockIdx.x;
+        u = u_frames[f];
+        w += f * N; losses += f * (size_t)N * loss_stride;
+        if (hyp_idx) hyp_idx += f;
+        if (expected) expected += f;
+        if (g) g += f * N;
+    }
     if (tid == 0) {
         double sum = 0;
         for (int i = 0; i < N; i++)
@@ -165,7 +174,14 @@ __global__ __launch_bounds__(256) void k_dsac_select(int N, const double* __rest
 hipError_t dsac_select(hipStream_t st, int N, const double* w, const double* losses, int loss_stride, double u, double eps, int32_t* hyp_idx, double* expected,
                        double* g) {
     if (N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dsac_select, dim3(1), dim3(256), 0, st, N, w, losses, loss_stride, u, eps, hyp_idx, expected, g);
+    hipLaunchKernelGGL(k_dsac_select, dim3(1), dim3(256), 0, st, N, w, losses, loss_stride, u, eps, hyp_idx, expected, g, (const double*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t dsac_select_frames(hipStream_t st, int frames, int N, const double* w, const double* losses, int loss_stride, const double* u, double eps,
+                              int32_t* hyp_idx, double* expected, double* g) {
+    if (N <= 0 || frames <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dsac_select, dim3(frames), dim3(256), 0, st, N, w, losses, loss_stride, 0.0, eps, hyp_idx, expected, g, u);
     return hipGetLastError();
 }
 

@@ -372,10 +372,15 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
                                                int32_t* __restrict__ steps_done, int map_stride, int group, int per_frame,
-                                               const double* __restrict__ loss_gt, double* __restrict__ loss_out4) {
+                                               const double* __restrict__ loss_gt, double* __restrict__ loss_out4,
+                                               const int32_t* __restrict__ frame_of_group) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    if (per_frame > 0) {  // frame batch: one wave per (frame, problem) -- the per-image refinement of test_ransac_softam.cpp:97-157 for F images at once
+    if (frame_of_group) {  // DSAC variant on a frame batch: replica list m = b / group belongs to hypothesis m, which lives in frame frame_of_group[m]
+        const int f = frame_of_group[group > 0 ? b / group : 0];
+        F.xyz += (long long)f * F.xyz_stride;
+        if (F.uv) F.uv += (long long)f * F.uv_stride;
+    } else if (per_frame > 0) {  // frame batch: one wave per (frame, problem) -- the per-image refinement of test_ransac_softam.cpp:97-157 for F images at once
         const int f = b / per_frame;
         F.xyz += (long long)f * F.xyz_stride;
         if (F.uv) F.uv += (long long)f * F.uv_stride;
@@ -471,7 +476,7 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4);
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4, (const int32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -629,13 +634,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* _
                                                                  int skip, float eps_hyp, float eps_obj, int cap, const int32_t* __restrict__ scratch,
                                                                  double* __restrict__ rep_poses, int32_t* __restrict__ rep_px_c,
                                                                  float* __restrict__ rep_value, int32_t* __restrict__ obj_pixels,
-                                                                 int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4, int px_stride) {
+                                                                 int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4, int px_stride,
+                                                                 const int32_t* __restrict__ frame_of) {
     const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
     const int x0 = blockIdx.x * 64, x = x0 + lane;
     double init[6] = {0, 0, 0, 0, 0, 0};
     if (SET) {  // hypothesis m of a batch (blockIdx.y): its set, inlier map, counts and slice of the replica arrays (18 + 6*cap replicas each)
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; inlier_map += m * F.P; scratch += m * F.W * (PLAN_SEGS + 1); rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
+        if (frame_of) F.xyz += (long long)frame_of[m] * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
         if (blockIdx.x == 0 && tid < 18) {
             const int pt = tid / 6, c = (tid % 6) >> 1;
             const int p = min(max(set4[pt], 0), F.P - 1);
@@ -706,7 +713,7 @@ hipError_t refine_fd_plan(hipStream_t st, const double* init_pose, const int32_t
         const int tiles = (F.W + 63) / 64;
         hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles, frames), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
         hipLaunchKernelGGL(k_refine_fd_emit<false>, dim3(tiles, frames), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, scratch,
-                           rep_poses, rep_px_c, rep_value, obj_pixels, n_obj, (const int32_t*)nullptr, px_stride);
+                           rep_poses, rep_px_c, rep_value, obj_pixels, n_obj, (const int32_t*)nullptr, px_stride, (const int32_t*)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_refine_fd_plan, dim3(frames), dim3(PLAN_THREADS), 0, st, init_pose, inlier_map, F, skip, eps_hyp, eps_obj, cap, rep_poses, rep_px_c,
@@ -721,11 +728,11 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     const int R = 12 + 6 * cap;
     if (frames > 1) {  // one replica list per frame: list m = b / R refines against frame m, replicas beyond 12 + 6 * n_obj[m] exit at once
         hipLaunchKernelGGL(k_refine, dim3(R * frames), dim3(64), 0, st, R * frames, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
-                           rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R, (const double*)nullptr, (double*)nullptr);
+                           rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_refine, dim3(R), dim3(64), 0, st, R, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
-                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0, (const double*)nullptr, (double*)nullptr);
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -738,12 +745,14 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan_set(const int32_t* __restrict__ set4, const int32_t* __restrict__ inlier_map, FrameDev F, int skip,
                                                            float eps_obj, int cap, int32_t* __restrict__ rep_px_c, float* __restrict__ rep_value,
-                                                           int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj) {
+                                                           int32_t* __restrict__ obj_pixels, int32_t* __restrict__ n_obj,
+                                                           const int32_t* __restrict__ frame_of) {
     const int lane = threadIdx.x;
     const int P = F.P;
     {   // hypothesis m of a batch (blockIdx.y): its set, inlier map and slice of the replica arrays (18 + 6*cap replicas each)
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; inlier_map += m * P; rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
+        if (frame_of) F.xyz += (long long)frame_of[m] * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
     }
     if (lane < 18) {
         const int pt = lane / 6, c = (lane % 6) >> 1;
@@ -781,10 +790,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan_set(const int32
 // start pose of replica r: P3P (Horn alignment, as OpenCV) of the set read through the replica's perturbation
 __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4,
                                                            const int32_t* __restrict__ rep_px_c, const float* __restrict__ rep_value, FrameDev F,
-                                                           double* __restrict__ rep_poses) {
+                                                           double* __restrict__ rep_poses, const int32_t* __restrict__ frame_of) {
     {
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; rep_px_c += m * R * 2; rep_value += m * R; rep_poses += m * R * 6; n_obj += m;
+        if (frame_of) {
+            const long long f = frame_of[m];
+            F.xyz += f * F.xyz_stride;
+            if (F.uv) F.uv += f * F.uv_stride;
+        }
     }
     // four lanes per replica, one per quartic root (the Horn/Jacobi alignments side by side, as in K5)
     const int r = blockIdx.x * 16 + (threadIdx.x >> 2), root = threadIdx.x & 3;
@@ -823,7 +837,8 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
 }
 
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
-                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M, int32_t* scratch) {
+                              double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M, int32_t* scratch,
+                              const int32_t* frame_of) {
     if (M <= 0) return hipSuccess;
     if (scratch && F.P > PLAN_TILED_MIN_CELLS) {
         // large maps: the tiled two-launch plan of the soft-argmax path, one grid row per hypothesis (round 2 scanned each map with one workgroup, column-major
@@ -831,23 +846,24 @@ hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t
         const int tiles = (F.W + 63) / 64;
         hipLaunchKernelGGL(k_refine_fd_count, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, inlier_map, F, scratch);
         hipLaunchKernelGGL(k_refine_fd_emit<true>, dim3(tiles, M), dim3(PLAN_THREADS), 0, st, (const double*)nullptr, inlier_map, F, skip, 0.f, eps_obj, cap, scratch,
-                           (double*)nullptr, rep_px_c, rep_value, obj_pixels, n_obj, set4, cap);
+                           (double*)nullptr, rep_px_c, rep_value, obj_pixels, n_obj, set4, cap, frame_of);
     } else
-    hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(PLAN_THREADS), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj);
+    hipLaunchKernelGGL(k_refine_fd_plan_set, dim3(1, M), dim3(PLAN_THREADS), 0, st, set4, inlier_map, F, skip, eps_obj, cap, rep_px_c, rep_value, obj_pixels, n_obj, frame_of);
     const int R = 18 + 6 * cap;
-    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 15) / 16, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses);
+    hipLaunchKernelGGL(k_refine_fd_init_set, dim3((R + 15) / 16, M), dim3(64), 0, st, cap, n_obj, set4, rep_px_c, rep_value, F, rep_poses, frame_of);
     return hipGetLastError();
 }
 
 hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M) {
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M,
+                             const int32_t* frame_of) {
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
     const int R = 18 + 6 * cap;
     const long long B = (long long)R * M;
     if (B > 0x7fffffffll) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_refine, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
-                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0, (const double*)nullptr, (double*)nullptr);
+                       rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0, (const double*)nullptr, (double*)nullptr, frame_of);
     return hipGetLastError();
 }
 

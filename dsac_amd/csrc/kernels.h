@@ -128,10 +128,12 @@ hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int
 // scratch: M * refine_fd_plan_scratch_ints(F) int32 (nullptr / small maps: one workgroup per hypothesis scans its map)
 hipError_t refine_fd_plan_set(hipStream_t st, const int32_t* set4, const int32_t* inlier_map, const FrameDev& F, int skip, float eps_obj, int cap,
                               double* rep_poses, int32_t* rep_px_c, float* rep_value, int32_t* obj_pixels, int32_t* n_obj, int M = 1,
-                              int32_t* scratch = nullptr);
+                              int32_t* scratch = nullptr, const int32_t* frame_of = nullptr);
+// frame_of (M int32, device) with a frame batch: hypothesis m lives in frame frame_of[m] (its minimal set, inlier map and replicas read that frame's map)
 // M hypotheses at once (sets M x 4, inlier maps M x H*W, 18 + 6*cap replicas each): one launch of M * (18 + 6*cap) waves
 hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, const double* rep_poses, const int32_t* perm, int steps, int max_inl,
-                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M = 1);
+                             int min_inl, float thr, const int32_t* rep_px_c, const float* rep_value, const FrameDev& F, double* rep_out, int M = 1,
+                             const int32_t* frame_of = nullptr);
 hipError_t refine_fd_finish_set(hipStream_t st, const double* rep_out, const int32_t* n_obj, int cap, int skip, float eps_obj, double* J_set /*M x 6 x 9*/,
                                 double* J_obj, int M = 1);
 // builds the replica list of dRefineHyp/dRefineObj on device, see k_refine.hip
@@ -150,12 +152,16 @@ hipError_t refine_fd_finish(hipStream_t st, const double* rep_out, const int32_t
 
 // ---- k_loss.hip ------------------------------------------------------------------------------------
 // gt_stride: 0 = one ground truth (6 doubles) for all estimates, 6 = one per estimate
+// gt_group: estimates b share the ground truth of index b / gt_group (a frame batch of the DSAC variant: N estimates per frame)
 hipError_t pose_loss(hipStream_t st, int B, const double* est_cv6 /*B x 6*/, const double* gt_jp6, double* out4 /*B x 4*/, double* J6 /*B x 6*/,
-                     int gt_stride = 0);
+                     int gt_stride = 0, int gt_group = 1);
 
 // DSAC variant: draw (core/cnn.h:102-127; u < 0: argmax), expectedMaxLoss (:137-150), the score gradients of dSMScore (:737-742); losses[i * loss_stride]
 hipError_t dsac_select(hipStream_t st, int N, const double* w, const double* losses, int loss_stride, double u, double eps, int32_t* hyp_idx, double* expected,
                        double* g);
+// the same for `frames` images in one launch (a workgroup per image): w / losses / g [frames][N], u / hyp_idx / expected [frames]; u on the device
+hipError_t dsac_select_frames(hipStream_t st, int frames, int N, const double* w, const double* losses, int loss_stride, const double* u, double eps,
+                              int32_t* hyp_idx, double* expected, double* g);
 
 // ---- k_patches.hip ---------------------------------------------------------------------------------
 // n patches of 3 x patch x patch floats (patch, channel, row, column) around sampling_xy[i] = (x, y) of an H x W x 3 BGR image

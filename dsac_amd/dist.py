@@ -149,7 +149,16 @@ class GradientReducer:
     Parameters are grouped into buckets in REVERSE order (the order autograd produces their gradients); a post-accumulate-grad hook counts
     the gradients of a bucket and launches its collective the moment the last one lands -- on the stream the backward runs on, so the
     collective is ordered behind the kernels that produced the gradients and overlaps everything enqueued afterwards (K4, the rest of the
-    backward).  wait() finishes all buckets (average + copy back) and re-arms the hooks for the next step."""
+    backward).  wait() finishes all buckets (average + copy back) and re-arms the hooks for the next step.
+
+    Two consequences of the flat buckets (world size > 1 only; with one rank the reducer does nothing):
+      * every parameter's .grad is a view into its bucket from construction on, and a parameter that received no gradient in a step travels -- and comes
+        back -- as ZEROS, not None.  An optimizer therefore updates it where it would have skipped a None gradient: plain SGD is unaffected, momentum keeps
+        decaying its buffer, weight decay and Adam's moments do act on it.  Freeze such parameters (requires_grad_(False)) before constructing the reducer
+        if that matters.
+      * one backward pass per wait(): a second pass that reaches a bucket before wait() raises (from inside the autograd hook).  For gradient
+        accumulation over several passes, or after a backward that was aborted half-way, call reset() -- it re-arms the hooks without launching
+        anything; with `no_sync()` the hooks only count, the buckets leave at the wait() that follows the last pass."""
 
     def __init__(self, params, average=True, bucket_bytes=64 << 20, group=None, mode="all_reduce"):
         self.params = [p for p in params if p.requires_grad]
@@ -201,6 +210,8 @@ class GradientReducer:
 
     def _make_hook(self, bi):
         def hook(param):
+            if getattr(self, "_hold", False):
+                return  # no_sync(): accumulate only
             self._pending[bi] -= 1
             if self._pending[bi] < 0:
                 raise RuntimeError("GradientReducer: a second backward pass reached bucket %d before wait() finished the first one "
@@ -223,6 +234,35 @@ class GradientReducer:
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         return n
+
+    def reset(self):
+        """Re-arm the hooks without sending anything: drops the arrival counts of a backward pass that was aborted (or whose gradients are to be discarded).
+        Buckets already in flight are waited for first -- their collectives were issued on every rank."""
+        if not self.enabled:
+            return
+        self.handle.wait()
+        self.handle = GradientReduce()
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+
+    class _NoSync:
+        def __init__(self, red):
+            self.red = red
+
+        def __enter__(self):
+            self.red._hold = True
+            return self.red
+
+        def __exit__(self, *a):
+            self.red._hold = False
+            if self.red.enabled:  # the passes inside only accumulated: arrival counts start over, the next pass (or wait()) sends the buckets
+                self.red._pending = [len(b) for b in self.red.buckets]
+                self.red._next = 0
+
+    def no_sync(self):
+        """Context for gradient accumulation: backward passes inside accumulate into the flat buckets without launching collectives; the buckets leave with
+        the first pass after the context (or at wait())."""
+        return GradientReducer._NoSync(self)
 
     def close(self):
         for h in self._hooks:

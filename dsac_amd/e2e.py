@@ -224,3 +224,63 @@ class TrainStep:
         self.opt_obj.step()
         self.opt_score.step()
         return out
+
+
+class ScoredFrameBatch:
+    """The reference's score CNN on the BATCHED fast path: F sub-sampled frames per launch chain, forward and backward.
+
+        forward   dsac_process_images_begin (K1 + K2 of all F frames -> F*N error images in one HBM tensor)  ->  ScoreNet on that tensor in place
+                  (core/cnn_softam.h:1066-1078: getDiffMap x N -> forward(diffMaps) -> softMax)  ->  dsac_process_images_finish (K3 per frame, K6, K7)
+        backward  dsac_backward_path1 on the batch (dLossMax -> dRefine -> dPNP -> softmax backward: g, F*N score gradients)  ->  ScoreNet.backward
+                  (clamped at 0.1, train_score_softam.lua:97) gives dErr (n, y, x)  ->  dsac_score_backward on the batch (K4; core/train_ransac_softam.cpp:
+                  378-383)  ->  F x H*W x 3 scene-coordinate gradients in HBM.
+
+    The engine runs on torch's current stream: the three parties are ordered by the stream alone, nothing leaves the GPU, the host never waits.  Frame f
+    draws from the random stream of seed + f, so every frame's result equals the per-image path (TrainStep.forward_backward with seed + f)."""
+
+    def __init__(self, device=0, frames=8, hyps=256, ref_steps=8, inlier_count=100, thr=10.0, sub_sample=0.01, cam=(525.0, 525.0, 320.0, 240.0), score_net=None,
+                 H=CNN_OBJ_PATCHSIZE, W=CNN_OBJ_PATCHSIZE, engine=None):
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.F, self.N, self.H, self.W, self.P = frames, hyps, H, W, H * W
+        self.ref_steps, self.inlier_count, self.thr, self.sub_sample, self.cam = ref_steps, inlier_count, thr, sub_sample, cam
+        self.score_net = (score_net or ScoreNet()).to(self.dev)
+        self.engine = engine or Engine(device, stream=torch.cuda.current_stream(self.dev))
+        F, N, P = frames, hyps, self.P
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.poses, self.sets, self.ok = torch.zeros(F * N, 6, **f64), torch.zeros(F * N, 4, dtype=torch.int32, device=self.dev), torch.zeros(F * N, dtype=torch.uint8, device=self.dev)
+        self.err = torch.zeros(F * N, 1, H, W, dtype=torch.float32, device=self.dev)
+        self.res = dict(sfScores=torch.zeros(F * N, **f64), sfEntropy=torch.zeros(F, **f64), avgHyp=torch.zeros(F, 6, **f64), refAvgHyp=torch.zeros(F, 6, **f64),
+                        refSteps=torch.zeros(F, dtype=torch.int32, device=self.dev), inlierMaps=torch.zeros(F, P, dtype=torch.int32, device=self.dev), out4=torch.zeros(F, 4, **f64))
+        self.grad_xyz = torch.zeros(F, P, 3, **f64)
+        self.dpnp, self.g = torch.zeros(F * N, 6, 12, **f64), torch.zeros(F * N, **f64)
+
+    def forward(self, xyz, uv, gt_jp6, perm, seed=1305, uv_per_frame=True):
+        """xyz F x P x 3 float32 (device), uv F x P x 2 (or P x 2 shared) float32 (device), gt_jp6 F x 6 float64 (device), perm ref_steps x P int32 (device)."""
+        eng, F, N = self.engine, self.F, self.N
+        self._in = (xyz, uv, gt_jp6, perm)  # borrowed by the engine until the backward has run
+        eng.set_frames(xyz, uv, self.H, self.W, self.cam, uv_per_frame=uv_per_frame, borrow=True)
+        eng.processImagesBegin(N, self.err, seed=seed, thr=self.thr, out=(self.poses, self.sets, self.ok))
+        self._err_in = self.err.detach().requires_grad_(True)  # same storage: the score CNN reads what K2 wrote
+        self._scores = self.score_net(self._err_in)
+        self.scores = self._scores.detach().double().contiguous()
+        eng.processImagesFinish(N, self.scores, perm, self.poses, gt_jp6=gt_jp6, scale=1.0, thr=self.thr, max_inl=self.inlier_count, out=self.res)
+        return self.res
+
+    def backward(self, quirk_transpose=False):
+        """Leaves dLoss/d(scene coordinates) of every frame in self.grad_xyz (F x P x 3) and the score CNN's parameter gradients in .grad."""
+        from .capi import lib, ptr, check
+        eng, F, N, P, H, W = self.engine, self.F, self.N, self.P, self.H, self.W
+        xyz, uv, gt, perm = self._in
+        ctx = eng._ctx
+        self.grad_xyz.zero_()
+        r = self.res
+        check(ctx, lib.dsac_backward_path1(ctx, F * N, ptr(self.poses), ptr(self.sets), ptr(r["sfScores"]), ptr(r["avgHyp"]), ptr(r["refAvgHyp"]), ptr(gt), ptr(perm),
+                                           int(perm.shape[0]), int(self.inlier_count), 50, float(int(self.thr)), ptr(r["inlierMaps"]), float(self.sub_sample), 0.001, 2.0, 1.0,
+                                           ptr(self.dpnp), ptr(self.grad_xyz), ptr(self.g), None, None))
+        self._scores.backward(gradient=self.g.float().clamp_(-CLAMP_E2E, CLAMP_E2E))
+        d = self._err_in.grad.reshape(F * N, H, W)
+        # reference-exact seam: gradient images read back transposed (lua_calls.h:329-335) together with dScore's x*cols*3 + y*3 columns -- both or neither
+        d_err = (d.transpose(1, 2) if quirk_transpose else d).reshape(F * N, P).contiguous()
+        eng.dScore(self.poses, self.sets, d_err, dpnp=self.dpnp, quirk_transpose=quirk_transpose, grad=self.grad_xyz)
+        return self.grad_xyz

@@ -191,6 +191,92 @@ class Engine:
             check(ctx, fn(*args))
         return call
 
+    # ---- the score-CNN seam of the batched fast path (dsac_process_images_begin / _finish) ---------------------------------------------
+    def processImagesBegin(self, hyps_per_frame, err, seed=1305, thr=10.0, max_tries=1 << 20, clamp=CNN_OBJ_MAXINPUT, tau=10.0, beta=0.5, soft=None, out=None):
+        """First half of processImage for every frame set with set_frame / set_frames (cnn_softam.h:1010-1069): K1 sample + P3P, K2 -> the F*N error
+        images in `err` (F*N x H*W float32, where the reference's score CNN reads them: lua_calls.h:98-104); soft (F*N float64, optional) receives the
+        soft-inlier sums as well.  out = (poses F*N x 6, sets F*N x 4, ok F*N) preallocated or None; returns it."""
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        if out is None:
+            out = (np.zeros((F * N, 6)), np.zeros((F * N, 4), np.int32), np.zeros(F * N, np.uint8))
+        poses, sets_out, ok = out
+        check(self._ctx, lib.dsac_process_images_begin(self._ctx, N, int(seed) & 0xFFFFFFFFFFFFFFFF, float(thr), int(max_tries), float(clamp), float(tau), float(beta),
+                                                       ptr(poses), ptr(sets_out), ptr(ok), ptr(err), ptr(soft)))
+        return out
+
+    def processImagesFinish(self, hyps_per_frame, scores, perm, poses, gt_jp6=None, scale=1.0, thr=10.0, max_inl=100, min_inl=50, want_inlier_maps=False, out=None):
+        """Second half (cnn_softam.h:1078-1179) from the score model's output: K3 per frame on scale * scores (F*N float64), the refinement of every
+        frame's soft-argmax pose (K6) and its loss (K7).  poses: what processImagesBegin returned.  Returns dict(sfScores, sfEntropy F, avgHyp F x 6,
+        refAvgHyp F x 6, refSteps F[, inlierMaps F x P][, out4 F x 4]); `out` may hold preallocated buffers under the same keys."""
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        perm = _np(perm, np.int32)
+        o = dict(out) if out is not None else {}
+        def buf(key, shape, dtype=np.float64):
+            if key not in o or o[key] is None:
+                o[key] = np.zeros(shape, dtype)
+            return o[key]
+        w, ent = buf("sfScores", F * N), buf("sfEntropy", F)
+        avg, ref, sd = buf("avgHyp", (F, 6)), buf("refAvgHyp", (F, 6)), buf("refSteps", F, np.int32)
+        maps = buf("inlierMaps", (F, self.P), np.int32) if (want_inlier_maps or o.get("inlierMaps") is not None) else None
+        gt = _np(np.asarray(gt_jp6, dtype=np.float64).reshape(F, 6), np.float64) if isinstance(gt_jp6, (np.ndarray, list, tuple)) else gt_jp6
+        out4 = buf("out4", (F, 4)) if gt is not None else None
+        check(self._ctx, lib.dsac_process_images_finish(self._ctx, N, ptr(_np(scores, np.float64)), float(scale), ptr(perm), int(perm.shape[0]), int(max_inl), int(min_inl),
+                                                        float(thr), ptr(gt), ptr(_np(poses, np.float64)), ptr(w), ptr(ent), ptr(avg), ptr(ref), ptr(sd), ptr(maps), ptr(out4)))
+        return o
+
+    def softMaxFrames(self, scores, hyps_per_frame, scale=1.0, poses=None, out=None):
+        """K3 for F independent groups of hyps_per_frame scores in one launch (dsac_softmax_frames).  Returns (w F*N, entropy F, avg6 F x 6 or None)."""
+        N = int(hyps_per_frame)
+        F = int(scores.shape[0]) // N
+        if out is None:
+            out = (np.zeros(F * N), np.zeros(F), np.zeros((F, 6)) if poses is not None else None)
+        w, ent, avg = out
+        check(self._ctx, lib.dsac_softmax_frames(self._ctx, F, N, ptr(_np(scores, np.float64)), float(scale), ptr(w), ptr(ent),
+                                                 ptr(_np(poses, np.float64)) if poses is not None else None, ptr(avg)))
+        return w, ent, avg
+
+    def processImagesScored(self, hyps_per_frame, perm, score_fn, gt_jp6=None, seed=1305, thr=10.0, max_tries=1 << 20, clamp=CNN_OBJ_MAXINPUT, max_inl=100,
+                            min_inl=50, scale=1.0, err=None, want_inlier_maps=False, out=None):
+        """processImage of every frame with the reference's own kind of score: score_fn(err) -> F*N scores, err the F*N x H x W float32 error images
+        as a torch DEVICE tensor that K2 has just written (nothing crosses PCIe: the reference pushes the same maps to Lua number by number,
+        lua_calls.h:89-105).  score_fn runs on the engine's stream when the engine was made on torch's current stream (Engine(stream=...)); its result
+        may be any floating torch tensor on the device.  perm / gt_jp6: device tensors or host arrays (host arrays are uploaded).  Returns the dict of
+        processImages with torch device tensors (plus "diffMaps")."""
+        import torch
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        dev = torch.device("cuda", self.device)
+        o = dict(out) if out is not None else {}
+        # everything torch does here -- allocations, uploads, the score model -- goes onto the ENGINE's stream, whichever stream that is: the launches of
+        # begin, the score model and finish are then ordered by the stream alone
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(self.stream), device=dev)):
+            def buf(key, shape, dtype=torch.float64):
+                if o.get(key) is None:
+                    o[key] = torch.zeros(shape, dtype=dtype, device=dev)
+                return o[key]
+            hyps, sets, ok = buf("hyps", (F * N, 6)), buf("sampledPoints", (F * N, 4), torch.int32), buf("ok", F * N, torch.uint8)
+            if err is None:
+                err = torch.empty(F * N, self.H, self.W, dtype=torch.float32, device=dev)
+            perm_d = perm if hasattr(perm, "data_ptr") else torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32), device=dev)
+            gt_d = None if gt_jp6 is None else (gt_jp6 if hasattr(gt_jp6, "data_ptr") else
+                                                torch.as_tensor(np.ascontiguousarray(np.asarray(gt_jp6, dtype=np.float64).reshape(F, 6)), device=dev))
+            for key, shape, dt in (("sfScores", F * N, torch.float64), ("sfEntropy", F, torch.float64), ("avgHyp", (F, 6), torch.float64),
+                                   ("refAvgHyp", (F, 6), torch.float64), ("refSteps", F, torch.int32)):
+                buf(key, shape, dt)
+            if want_inlier_maps:
+                buf("inlierMaps", (F, self.P), torch.int32)
+            if gt_d is not None:
+                buf("out4", (F, 4))
+            self.processImagesBegin(N, err, seed=seed, thr=thr, max_tries=max_tries, clamp=clamp, out=(hyps, sets, ok))
+            scores = score_fn(err.view(F * N, self.H, self.W))
+            if not hasattr(scores, "data_ptr"):
+                scores = torch.as_tensor(np.ascontiguousarray(scores, dtype=np.float64))
+            scores = scores.detach().to(device=dev, dtype=torch.float64).reshape(F * N).contiguous()
+            o["scores"] = scores
+            self.processImagesFinish(N, scores, perm_d, hyps, gt_jp6=gt_d, scale=scale, thr=thr, max_inl=max_inl, min_inl=min_inl, out=o)
+        o["diffMaps"] = err
+        self._keep_scored = (perm_d, gt_d, scores)  # alive until the launches that read them have run (the next call replaces them)
+        return o
+
     def tailWait(self, stream):
         """dsac_tail_wait: `stream` (a torch.cuda.Stream or a raw hipStream_t) waits for the deferred refinement tail in flight and for everything
         enqueued on the engine's stream so far; the engine's own stream is not held up."""
@@ -565,16 +651,31 @@ class Engine:
                      beta=0.5, alpha=0.1, score_fn=None, keep_err=False, max_tries=1 << 20):
         """Forward pass of processImage (cnn_softam.h:960-1179) on the frame set with set_frame: sample N
         hypotheses, score them, soft-argmax, refine, evaluate.  Scores are alpha * soft-inlier counts unless
-        score_fn(err N x H x W float32) -> N float64 is given (the seam where the reference's score CNN sits,
-        cnn_softam.h:1072).  `perm` = refSteps x P pixel permutations (the reference's pixelIdxs)."""
+        score_fn(err) -> N scores is given (the seam where the reference's score CNN sits, cnn_softam.h:1072): err is the N x H x W float32
+        error images as a torch DEVICE tensor (processImagesScored: the maps never leave HBM), the result a torch tensor or an array.
+        `perm` = refSteps x P pixel permutations (the reference's pixelIdxs)."""
+        if score_fn is not None:
+            # the score-CNN seam (cnn_softam.h:1066-1078) on device tensors: K1 + K2 write the error images into HBM, score_fn reads them there, K3 / K6 / K7
+            # continue from its scores -- dsac_process_images_begin / _finish; only the small results come back (round 4 shipped the N x H x W error images
+            # through host NumPy here: 314 MB per 640 x 480 image)
+            r = self.processImagesScored(N, np.ascontiguousarray(perm[:refSteps], dtype=np.int32) if perm is not None else np.zeros((0, self.P), np.int32),
+                                         score_fn, gt_jp6=gt_jp6, seed=seed, thr=thr, max_tries=max_tries, max_inl=inlierCount, min_inl=minInliers,
+                                         want_inlier_maps=True)
+            self.synchronize()
+            h = {k: v.cpu().numpy() for k, v in r.items() if k != "diffMaps"}
+            out = dict(hyps=h["hyps"], sampledPoints=h["sampledPoints"], ok=h["ok"], scores=h["scores"], score_scale=1.0, sfScores=h["sfScores"],
+                       sfEntropy=float(h["sfEntropy"][0]), avgHyp=h["avgHyp"][0], diffMaps=r["diffMaps"] if keep_err else None, soft=None,
+                       refAvgHyp=h["refAvgHyp"][0], refSteps=int(h["refSteps"][0]), inlierMap=h["inlierMaps"][0],
+                       pixelIdxs=np.ascontiguousarray(perm[:refSteps], dtype=np.int32) if perm is not None else None)
+            if gt_jp6 is not None:
+                o4 = h["out4"][0]
+                out.update(loss=o4[0], rotErr=o4[1], tErr=o4[2], correct=bool(o4[3] > 0.5))
+            return out
         poses, sets, ok = self.sample(N, seed=seed, thr=thr, max_tries=max_tries)
-        err = np.zeros((N, self.P), np.float32) if (keep_err or score_fn is not None) else None
+        err = np.zeros((N, self.P), np.float32) if keep_err else None
         soft = np.zeros(N)
         self.reproject(poses, err=err, soft=soft, tau=tau, beta=beta)
-        if score_fn is not None:
-            scores, scale = np.ascontiguousarray(score_fn(err.reshape(N, self.H, self.W)), dtype=np.float64), 1.0
-        else:
-            scores, scale = soft, alpha
+        scores, scale = soft, alpha
         w, ent, avg = self.softMax(scores, scale, poses)
         out = dict(hyps=poses, sampledPoints=sets, ok=ok, scores=scores, score_scale=scale, sfScores=w, sfEntropy=float(ent[0]), avgHyp=avg,
                    diffMaps=err, soft=soft)
@@ -610,7 +711,8 @@ class Engine:
             J = self.dPNP(fwd["sampledPoints"])
             grad, g = self.path1AndSoftmaxBackward(v6, fwd["sfScores"], fwd["hyps"], fwd["sampledPoints"], J, grad=grad)
         if d_scores_fn is not None:
-            d_err = np.ascontiguousarray(d_scores_fn(g), dtype=np.float32).reshape(len(g), self.P)
+            d_err = d_scores_fn(g)  # N x H*W float32: a torch device tensor is read in place by K4, an array is uploaded
+            d_err = d_err.reshape(len(g), self.P).contiguous() if hasattr(d_err, "data_ptr") else np.ascontiguousarray(d_err, dtype=np.float32).reshape(len(g), self.P)
             grad = self.dScore(fwd["hyps"], fwd["sampledPoints"], d_err, dpnp=J, quirk_transpose=quirk_transpose, grad=grad)
         else:
             grad = self.dSoftScore(fwd["hyps"], fwd["sampledPoints"], g * fwd["score_scale"], tau=tau, beta=beta, dpnp=J,

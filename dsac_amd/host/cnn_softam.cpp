@@ -41,7 +41,14 @@ void Context::check(int rc, const char* what) {
     if (rc != DSAC_OK) throw Error(rc, std::string(what) + ": " + dsac_last_error(ctx_));
 }
 void Context::synchronize() { check(dsac_synchronize(ctx_), "dsac_synchronize"); }
-void Context::setOption(const char* key, int value) { check(dsac_set_option(ctx_, key, value), "dsac_set_option"); }
+void Context::setOption(const char* key, int value) {
+    check(dsac_set_option(ctx_, key, value), "dsac_set_option");
+    options_[key] = value;
+}
+int Context::option(const char* key, int unset) const {
+    const auto it = options_.find(key);
+    return it == options_.end() ? unset : it->second;
+}
 void* Context::deviceAlloc(size_t bytes) { void* p = nullptr; check(dsac_device_alloc(ctx_, bytes, &p), "dsac_device_alloc"); return p; }
 void Context::deviceFree(void* p) noexcept { (void)dsac_device_free(ctx_, p); }
 void* Context::hostAlloc(size_t bytes) { void* p = nullptr; check(dsac_host_alloc(ctx_, bytes, &p), "dsac_host_alloc"); return p; }
@@ -265,9 +272,10 @@ namespace {
 // dsac_set_option("device_args", 1) for the calls of a scope whose pointer arguments all live in HBM; back to argument detection on leaving it -- the
 // context is shared with Frame, whose calls take host arrays
 struct DeviceArgsScope {
-    dsac_ctx* c;
-    explicit DeviceArgsScope(dsac_ctx* ctx) : c(ctx) { (void)dsac_set_option(c, "device_args", 1); }
-    ~DeviceArgsScope() { (void)dsac_set_option(c, "device_args", 0); }
+    Context& C;
+    int before;  // what the context's user had set: restored on leaving the scope (round 4 reset it to 0 and so clobbered a caller's own setting)
+    explicit DeviceArgsScope(Context& ctx) : C(ctx), before(ctx.option("device_args", 0)) { if (!before) C.setOption("device_args", 1); }
+    ~DeviceArgsScope() { if (!before) { try { C.setOption("device_args", 0); } catch (...) {} } }
     DeviceArgsScope(const DeviceArgsScope&) = delete;
     DeviceArgsScope& operator=(const DeviceArgsScope&) = delete;
 };
@@ -307,6 +315,8 @@ void FrameBatch::setFrame(int f, const float* estObj, const Hypothesis& poseGT, 
     if (opt_.sampling != (sampling != nullptr)) throw Error(DSAC_ERR_INVALID, "FrameBatch::setFrame: a sampling table goes with FrameBatchOptions::sampling, and only with it");
     const size_t P = (size_t)H_ * W_;
     const std::vector<double> g = poseGT.getRodVecAndTrans();
+    // a deferred tail of the previous processImages may still refine against this buffer: dsac_copy_async orders every copy behind a tail in flight (since
+    // round 5, whichever way the copy goes), so the uploads below are safe right after a deferred call (tests/test_gpu_host_shim.py)
     xyz_.upload(estObj, P * 3, (size_t)f * P * 3);
     if (sampling) uv_.upload(sampling, P * 2, (size_t)f * P * 2);
     gt_.upload(g.data(), 6, (size_t)f * 6);
@@ -327,7 +337,7 @@ void FrameBatch::processImages(int first, int count, uint64_t seedOfFrame0, int 
     C_.check(dsac_set_frames(c, count, xyz_.data() + f0 * P * 3, opt_.sampling ? uv_.data() + f0 * P * 2 : nullptr, opt_.sampling ? 1 : 0, H_, W_, cam_.fx, cam_.fy, cam_.cx,
                              cam_.cy, flags), "dsac_set_frames");
     C_.setBound(this);
-    const DeviceArgsScope devArgs(c);  // every argument below lives in HBM: no pointer query per argument
+    const DeviceArgsScope devArgs(C_);  // every argument below lives in HBM: no pointer query per argument
     const int rcP = dsac_process_images(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, alpha, perm_.data(),
                                  refSteps_, inlierCount, 50, gt_.data() + f0 * 6, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, ok_.data() + f0 * N,
                                  opt_.errorImages ? err_.data() : nullptr, scores_.data() + f0 * N, w_.data() + f0 * N, entropy_.data() + f0, avg_.data() + f0 * 6,
@@ -343,11 +353,7 @@ void FrameBatch::backward(int first, int count, int inlierThreshold2D, int inlie
         if (!done_[f]) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: processImages has not run on a frame of the range");
     const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
     dsac_ctx* c = C_.get();
-    if (grad_.size() == 0) {
-        grad_.resize(C_, (size_t)F_ * P * 3);
-        dpnp_.resize(C_, (size_t)maxCall_ * N * 72);
-        g_.resize(C_, (size_t)maxCall_ * N);
-    }
+    ensureBackwardBuffers();
     unsigned flags = DSAC_FRAME_BORROW;
     if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;
     // any entry point but dsac_process_images orders the stream behind a deferred tail: the refined poses and inlier maps are complete for what follows
@@ -355,7 +361,7 @@ void FrameBatch::backward(int first, int count, int inlierThreshold2D, int inlie
                              cam_.cy, flags), "dsac_set_frames");
     C_.setBound(this);
     double* grad = grad_.data() + f0 * P * 3;
-    const DeviceArgsScope devArgs(c);
+    const DeviceArgsScope devArgs(C_);
     C_.check(dsac_fill_zero_async(c, grad, (size_t)count * P * 3 * sizeof(double)), "dsac_fill_zero_async");
     const int n = count * N_;
     // path I and the softmax backward (train_ransac_softam.cpp:294-376); g comes back scaled by alpha: the score is alpha x the soft-inlier count
@@ -367,6 +373,108 @@ void FrameBatch::backward(int first, int count, int inlierThreshold2D, int inlie
     C_.check(dsac_soft_score_backward(c, n, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, g_.data(), (float)CNN_OBJ_MAXINPUT, tau, beta, dpnp_.data(), 0u, grad),
              "dsac_soft_score_backward");
     lastFirst_ = 0; lastCount_ = 0;  // the stream is ordered behind every tail now
+}
+
+// ---- the score-CNN seam on the batch ----------------------------------------------------------------------------------------------------
+void FrameBatch::bindRange(int first, int count) {
+    const size_t P = (size_t)H_ * W_, f0 = (size_t)first;
+    unsigned flags = DSAC_FRAME_BORROW;
+    if (opt_.quantiseInt16) flags |= DSAC_FRAME_QUANTISE_INT16;  // in place; idempotent
+    C_.check(dsac_set_frames(C_.get(), count, xyz_.data() + f0 * P * 3, opt_.sampling ? uv_.data() + f0 * P * 2 : nullptr, opt_.sampling ? 1 : 0, H_, W_, cam_.fx, cam_.fy,
+                             cam_.cx, cam_.cy, flags), "dsac_set_frames");
+    C_.setBound(this);
+}
+
+void FrameBatch::scoreImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, float tau, float beta) {
+    if (first < 0 || count <= 0 || first + count > F_ || count > maxCall_) throw Error(DSAC_ERR_INVALID, "FrameBatch::scoreImages: bad frame range");
+    if (!opt_.errorImages) throw Error(DSAC_ERR_INVALID, "FrameBatch::scoreImages: the batch was made without FrameBatchOptions::errorImages");
+    const size_t N = (size_t)N_, f0 = (size_t)first;
+    dsac_ctx* c = C_.get();
+    C_.setOption("pi_defer_tail", opt_.deferTail ? (opt_.deferScoreTail ? 2 : 1) : 0);
+    if (opt_.deferTail && opt_.deferScoreTail && first < lastFirst_ + lastCount_ && lastFirst_ < first + count) C_.check(dsac_join_tail(c), "dsac_join_tail");
+    lastFirst_ = first; lastCount_ = count;
+    if (soft_.size() == 0) soft_.resize(C_, (size_t)maxCall_ * N);
+    bindRange(first, count);
+    const DeviceArgsScope devArgs(C_);
+    C_.check(dsac_process_images_begin(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, poses_.data() + f0 * N * 6,
+                                       sets_.data() + f0 * N * 4, ok_.data() + f0 * N, err_.data(), soft_.data()),
+             "dsac_process_images_begin");
+    seamFirst_ = first; seamCount_ = count;
+}
+
+void FrameBatch::finishImages(int first, int count, const double* scoresDevice, int inlierThreshold2D, int inlierCount, double scale) {
+    if (first != seamFirst_ || count != seamCount_) throw Error(DSAC_ERR_INVALID, "FrameBatch::finishImages: the range is not the one scoreImages ran on");
+    if (!scoresDevice) throw Error(DSAC_ERR_INVALID, "FrameBatch::finishImages: scores is NULL");
+    const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
+    dsac_ctx* c = C_.get();
+    const DeviceArgsScope devArgs(C_);
+    C_.check(dsac_process_images_finish(c, N_, scoresDevice, scale, perm_.data(), refSteps_, inlierCount, 50, (float)inlierThreshold2D, gt_.data() + f0 * 6,
+                                        poses_.data() + f0 * N * 6, w_.data() + f0 * N, entropy_.data() + f0, avg_.data() + f0 * 6, ref_.data() + f0 * 6,
+                                        stepsDone_.data() + f0, opt_.inlierMaps ? maps_.data() + f0 * P : nullptr, out4_.data() + f0 * 4),
+             "dsac_process_images_finish");
+    for (int f = first; f < first + count; f++) done_[f] = 1;
+}
+
+void FrameBatch::processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, const ScoreModel& model, float tau, float beta) {
+    if (!model.forward) throw Error(DSAC_ERR_INVALID, "FrameBatch::processImages: the score model has no forward function");
+    scoreImages(first, count, seedOfFrame0, inlierThreshold2D, tau, beta);  // (tau, beta): the soft-inlier sums scoreImages leaves on the side (softInlierModel reads them)
+    const double* scores = model.forward(err_.data(), count * N_, H_, W_);  // core/cnn_softam.h:1072
+    finishImages(first, count, scores, inlierThreshold2D, inlierCount, model.scale);
+}
+
+ScoreModel FrameBatch::softInlierModel(float tau, float beta, double alpha) {
+    ScoreModel m;
+    m.scale = alpha;
+    // scoreImages evaluated the sums with its own (tau, beta): the model's must be the same pair (the defaults are)
+    m.forward = [this](const float*, int, int, int) { return soft_.data(); };
+    m.backward = [this, tau, beta](const double* g, const float* err, int nMaps, int, int) -> const float* {
+        const size_t P = (size_t)H_ * W_;
+        if (dErr_.size() == 0) dErr_.resize(C_, (size_t)maxCall_ * N_ * P);
+        const DeviceArgsScope devArgs(C_);
+        C_.check(dsac_soft_score_derr(C_.get(), nMaps, g, err, (float)CNN_OBJ_MAXINPUT, tau, beta, dErr_.data()), "dsac_soft_score_derr");
+        return dErr_.data();
+    };
+    return m;
+}
+
+void FrameBatch::ensureBackwardBuffers() {
+    if (grad_.size() != 0) return;
+    const size_t P = (size_t)H_ * W_, N = (size_t)N_;
+    grad_.resize(C_, (size_t)F_ * P * 3);
+    dpnp_.resize(C_, (size_t)maxCall_ * N * 72);
+    g_.resize(C_, (size_t)maxCall_ * N);
+}
+
+void FrameBatch::backward(int first, int count, int inlierThreshold2D, int inlierCount, float subSampleFactor, const ScoreModel& model, bool referenceIndexQuirk) {
+    if (first < 0 || count <= 0 || first + count > F_ || count > maxCall_) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: bad frame range");
+    if (!opt_.inlierMaps) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: the batch was made without FrameBatchOptions::inlierMaps");
+    if (!model.backward) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: the score model has no backward function");
+    if (first != seamFirst_ || count != seamCount_) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: the error images in HBM belong to another frame range");
+    for (int f = first; f < first + count; f++)
+        if (!done_[f]) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: processImages has not run on a frame of the range");
+    const size_t P = (size_t)H_ * W_, N = (size_t)N_, f0 = (size_t)first;
+    dsac_ctx* c = C_.get();
+    ensureBackwardBuffers();
+    bindRange(first, count);  // any entry point but dsac_process_images orders the stream behind a deferred tail
+    double* grad = grad_.data() + f0 * P * 3;
+    const int n = count * N_;
+    {
+        const DeviceArgsScope devArgs(C_);
+        C_.check(dsac_fill_zero_async(c, grad, (size_t)count * P * 3 * sizeof(double)), "dsac_fill_zero_async");
+        // path I and the softmax backward (train_ransac_softam.cpp:294-376): g = dLoss / d(scale * score); the model's scores enter scaled
+        C_.check(dsac_backward_path1(c, n, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, w_.data() + f0 * N, avg_.data() + f0 * 6, ref_.data() + f0 * 6,
+                                     gt_.data() + f0 * 6, perm_.data(), refSteps_, inlierCount, 50, (float)inlierThreshold2D, maps_.data() + f0 * P, subSampleFactor, 0.001f,
+                                     2.f, model.scale, dpnp_.data(), grad, g_.data(), nullptr, nullptr),
+                 "dsac_backward_path1");
+    }
+    const float* dErr = model.backward(g_.data(), err_.data(), n, H_, W_);  // train_ransac_softam.cpp:378-381
+    if (!dErr) throw Error(DSAC_ERR_INVALID, "FrameBatch::backward: the score model returned no gradient images");
+    {
+        const DeviceArgsScope devArgs(C_);
+        C_.check(dsac_score_backward(c, n, poses_.data() + f0 * N * 6, sets_.data() + f0 * N * 4, dErr, dpnp_.data(), referenceIndexQuirk ? DSAC_BWD_QUIRK_TRANSPOSE : 0u, grad),
+                 "dsac_score_backward");  // :382-383
+    }
+    lastFirst_ = 0; lastCount_ = 0;
 }
 
 std::vector<double> FrameBatch::gradients(int f) {

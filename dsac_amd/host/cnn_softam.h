@@ -22,6 +22,8 @@
 // computed on the CPU here -- without a gfx950 device the Frame constructor throws.
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -66,6 +68,7 @@ public:
     void check(int rc, const char* what);
     void synchronize();
     void setOption(const char* key, int value);
+    int option(const char* key, int unset = 0) const;  // the value last given to setOption (the C ABI has no getter; scopes that change a knob restore it from here)
     // HBM / page-locked host buffers and stream-ordered copies (dsac_device_alloc, dsac_host_alloc, dsac_copy_async)
     void* deviceAlloc(size_t bytes);
     void deviceFree(void* p) noexcept;
@@ -80,6 +83,7 @@ public:
 private:
     dsac_ctx* ctx_ = nullptr;
     const void* bound_ = nullptr;
+    std::map<std::string, int> options_;
 };
 
 // A typed buffer in HBM, freed with its owner.  upload / download are ordered on the context's stream; download() waits for the data.
@@ -196,6 +200,17 @@ struct FrameBatchOptions {
                                // core/cnn_softam.h:283-309, draws them per image); false: the full-resolution grid, cell (x, y) at pixel (x, y)
 };
 
+// The score model at the seam of the batched path -- the reference's score CNN (core/cnn_softam.h:1072: forward(diffMaps); core/train_ransac_softam.cpp:
+// 378-383: backward -> dScore), or anything else that turns error images into scores.  Both functions are called with DEVICE pointers and must enqueue their
+// work on the engine's stream (dsac_get_stream) or order themselves against it; the pointers they return must stay valid until the batch's next call.
+//   forward : nMaps x H*W float32 error images (hypothesis-major, each map row-major: the order of core/lua_calls.h:98-104) -> nMaps scores (double)
+//   backward: nMaps score gradients (double) and the same error images -> nMaps x H*W float32 gradient images, (n, y, x) order
+struct ScoreModel {
+    std::function<const double*(const float* errDevice, int nMaps, int H, int W)> forward;
+    std::function<const float*(const double* scoreGradientsDevice, const float* errDevice, int nMaps, int H, int W)> backward;
+    double scale = 1.0;  // softMax(scale * scores)
+};
+
 class FrameBatch {
 public:
     FrameBatch(Context& ctx, int frames, int H, int W, const Camera& cam, int objHyps, int refSteps, const std::vector<int32_t>& pixelIdxs,
@@ -206,6 +221,16 @@ public:
     // enqueue processImage for frames [first, first + count), count <= maxFramesPerCall; returns immediately
     void processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f,
                        double alpha = 0.1);
+    // ---- the same with the score taken from OUTSIDE the library (the score-CNN seam; needs FrameBatchOptions::errorImages) ----
+    // scoreImages: K1 + K2 of the range -> error images in HBM (errorImagesDevice) and, on the side, the soft-inlier sums (softInlierSumsDevice);
+    // finishImages: K3 on scale * scores, the refinement and the loss.  processImages(.., model) = scoreImages -> model.forward -> finishImages.
+    void scoreImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, float tau = 10.f, float beta = 0.5f);
+    void finishImages(int first, int count, const double* scoresDevice, int inlierThreshold2D, int inlierCount, double scale = 1.0);
+    void processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, const ScoreModel& model, float tau = 10.f, float beta = 0.5f);
+    const double* softInlierSumsDevice() const { return soft_.data(); }  // of the most recent scoreImages, count*objHyps
+    // the soft-inlier score dressed as an external model (forward: the sums scoreImages left; backward: dsac_soft_score_derr) -- the stand-in a host without
+    // device code uses to drive the seam end to end; results equal the built-in score's to fp32 rounding
+    ScoreModel softInlierModel(float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
     // convenience: all frames in calls of maxFramesPerCall
     void processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
     void synchronize();  // joins the deferred tail and waits
@@ -220,6 +245,12 @@ public:
     // frame f's scene coordinates (H*W x 3 doubles, what the reference hands to the scene-coordinate CNN's backward, :412) stays in HBM
     // (gradientsDevice); returns immediately.  count * objHyps hypotheses: objHyps a multiple of 16 and at most 256 when count > 1.
     void backward(int first, int count, int inlierThreshold2D, int inlierCount, float subSampleFactor, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
+    // ... with the score model's own backward between the softmax backward and dScore (train_ransac_softam.cpp:378-383): path I -> score gradients ->
+    // model.backward -> gradient images -> dsac_score_backward on the batch.  The range must be the one of the most recent processImages(.., model) /
+    // scoreImages (its error images are what the model differentiates).  referenceIndexQuirk: dScore's transposed columns (cnn_softam.h:628,641); the
+    // model then has to hand the images over transposed as the Lua bridge does (lua_calls.h:329-335).
+    void backward(int first, int count, int inlierThreshold2D, int inlierCount, float subSampleFactor, const ScoreModel& model, bool referenceIndexQuirk = false);
+    const double* scoreGradientsDevice() const { return g_.data(); }  // of the most recent backward, count*objHyps
     const double* gradientsDevice(int f) const { return grad_.data() + (size_t)f * H_ * W_ * 3; }
     std::vector<double> gradients(int f);  // waits, copies frame f's gradient back
     // device-to-device: frame `srcFrame` of another batch of the same geometry becomes frame `dstFrame` of this one (coordinate map + ground truth),
@@ -239,6 +270,11 @@ private:
     DeviceArray<uint8_t> ok_;
     DeviceArray<double> gt_, poses_, scores_, w_, entropy_, avg_, ref_, out4_;
     DeviceArray<double> grad_, dpnp_, g_;  // training: F x H*W x 3 gradient, maxCall x objHyps x 72 dPNP, maxCall x objHyps score gradients
+    DeviceArray<double> soft_;             // the seam: soft-inlier sums of the most recent scoreImages (maxCall x objHyps)
+    DeviceArray<float> dErr_;              // softInlierModel's gradient images (maxCall x objHyps x H*W), allocated on first use
+    int seamFirst_ = -1, seamCount_ = 0;   // the range whose error images err_ holds
+    void bindRange(int first, int count);
+    void ensureBackwardBuffers();
     std::vector<uint8_t> done_;
 };
 

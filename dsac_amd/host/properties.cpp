@@ -68,6 +68,7 @@ bool GlobalProperties::readArguments(std::vector<std::string> argv) {
         if (s == "-passes") { eP.passes = std::atoi(next().c_str()); std::cout << "passes over the data set: " << eP.passes << "\n"; continue; }
         if (s == "-warmup") { eP.warmupMs = std::atoi(next().c_str()); std::cout << "warm-up: " << eP.warmupMs << " ms\n"; continue; }
         if (s == "-gradstats") { eP.gradStats = std::atoi(next().c_str()); std::cout << "gradient statistics every: " << eP.gradStats << "\n"; continue; }
+        if (s == "-seam") { eP.seam = std::atoi(next().c_str()) != 0; std::cout << "external score model through the seam: " << eP.seam << "\n"; continue; }
         if (s == "-defer") { eP.defer = std::atoi(next().c_str()); std::cout << "deferred tails: " << eP.defer << "\n"; continue; }
         if (s == "-errimg") { eP.errorImages = std::atoi(next().c_str()) != 0; std::cout << "error images: " << eP.errorImages << "\n"; continue; }
         std::cout << "unkown argument: " << argv[i] << "\n";  // (sic) core/properties.cpp:264

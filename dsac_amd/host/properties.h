@@ -51,6 +51,9 @@ struct EngineParameters {
     int warmupMs = 0;                 // -warmup : run untimed (and unlogged) passes / rounds for this many milliseconds first -- a GPU that idled while the host made
                                       //           or loaded the data set needs ~0.3 s of work before its clock has settled (batch paths only)
     int gradStats = 1;                // -gradstats : the training program prints / logs the gradient statistics every this many rounds (0: never; -batch only)
+    bool seam = false;                // -seam   : 1 = the score comes from OUTSIDE the library through the score-CNN seam of the batch path (FrameBatch::processImages /
+                                      //           backward with a ScoreModel: error images out, scores in, score gradients out, gradient images in -- cnn_softam.h:1066-1078,
+                                      //           train_ransac_softam.cpp:378-383); the model of these programs is the soft-inlier score dressed as an external one
     int defer = 2;                    // -defer  : 0 batches in stream order, 1 refinement tail of a batch under the next batch, 2 score tail too (dsac_hip.h "pi_defer_tail")
 };
 

@@ -69,12 +69,26 @@ int main(int argc, const char* argv[]) {
             FrameBatch data(engine, (int)trainingDataset.size(), H, W, camMat, objHyps, refSteps, perms, 1, dataOpt);  // storage only: the resident training set
             for (size_t i = 0; i < trainingDataset.size(); i++) data.setFrame((int)i, trainingDataset[i].estObj.data(), trainingDataset[i].poseGT, dataOpt.sampling ? trainingDataset[i].sampling.data() : nullptr);
             FrameBatchOptions stepOpt;
-            stepOpt.errorImages = gp->eP.errorImages;
+            stepOpt.errorImages = gp->eP.errorImages || gp->eP.seam;  // the seam is the error images
             stepOpt.inlierMaps = true;
             stepOpt.sampling = dataOpt.sampling;
             stepOpt.deferTail = false;  // the backward pass follows the forward pass of the same frames: nothing to run the tail under
             FrameBatch step(engine, F, H, W, camMat, objHyps, refSteps, perms, F, stepOpt);
             engine.synchronize();
+            // -seam 1: the score of a round comes from outside the library -- error images out, scores in (FrameBatch::processImages with a ScoreModel:
+            // cnn_softam.h:1066-1078), score gradients out, gradient images in (FrameBatch::backward with it: train_ransac_softam.cpp:378-383).  A trainer with a
+            // score CNN on the device plugs its forward / backward in here; this program's model is the soft-inlier score dressed as an external one.
+            const ScoreModel scoreModel = step.softInlierModel(gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+            const bool seam = gp->eP.seam;
+            auto forwardBackward = [&](unsigned long long seed) {
+                if (seam) {
+                    step.processImages(0, F, seed, inlierThreshold2D, refInlierCount, scoreModel, gp->eP.tau, gp->eP.beta);
+                    step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, scoreModel, gp->eP.indexQuirk);
+                } else {
+                    step.processImages(0, F, seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                    step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                }
+            };
             const int statsEvery = gp->eP.gradStats;
             {   // -warmup: untimed, unlogged rounds on frames drawn from a generator of their own (the training sequence below is not disturbed)
                 std::mt19937 warmRng(7);
@@ -82,8 +96,7 @@ int main(int argc, const char* argv[]) {
                     std::vector<int32_t> ids(F);
                     for (int k = 0; k < F; k++) ids[k] = (int32_t)(std::uniform_int_distribution<int>(0, (int)trainingDataset.size() - 1)(warmRng));
                     step.gatherFramesFrom(data, ids);
-                    step.processImages(0, F, gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
-                    step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                    forwardBackward(gp->eP.seed);
                     engine.synchronize();
                 }
             }
@@ -94,8 +107,7 @@ int main(int argc, const char* argv[]) {
                 std::vector<int32_t> ids(F);
                 for (int k = 0; k < F; k++) ids[k] = (int32_t)(std::uniform_int_distribution<int>(0, (int)trainingDataset.size() - 1)(frameRng));
                 step.gatherFramesFrom(data, ids);  // device-to-device, one launch per array
-                step.processImages(0, F, gp->eP.seed + 7919ull * round, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
-                step.backward(0, F, inlierThreshold2D, refInlierCount, refSubSample, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                forwardBackward(gp->eP.seed + 7919ull * round);
                 if (round >= 1) timedRounds++;
                 const bool stats = statsEvery > 0 && round % statsEvery == 0;
                 if (!stats && round != trainingRounds) continue;  // nothing of this round is needed on the host: the next one is enqueued behind it
@@ -134,7 +146,7 @@ int main(int argc, const char* argv[]) {
             const double ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
             if (timedRounds > 0)
                 std::cout << "Timing: " << timedRounds << " rounds x " << F << " frames x " << objHyps << " hypotheses, " << W << "x" << H
-                          << " coordinate maps, forward + backward device-resident: " << ms * 1e3 / timedRounds << " us per round = "
+                          << " coordinate maps, forward + backward device-resident" << (seam ? " (score through the external seam)" : "") << ": " << ms * 1e3 / timedRounds << " us per round = "
                           << ms * 1e3 / timedRounds / F << " us per frame (gradient statistics every " << statsEvery << " rounds)" << std::endl;
             trainFile.close();
             gradFile.close();

@@ -27,13 +27,15 @@ from .capi import check, lib, ptr
 
 class ShardRunner:
     def __init__(self, engine, stream, device, frames_of, n_images, rank, world, N, H, W, cam, perm, gt_of=None, batch=16, group=None, emulate=False,
-                 seed0=1305, seed_per_step=64, write_err=True, defer=True, host_copy=False, err_buffer=None):
+                 seed0=1305, seed_per_step=None, write_err=True, defer=True, host_copy=False, err_buffer=None):
         """frames_of(i) -> H*W x 3 float32 coordinate map of image i (host array); gt_of(i) -> jp 6-vector or None (zeros).  perm: refSteps x H*W int32
         (device tensor).  group: the process group of the sharding when world > 1 and not emulate."""
         self.eng, self.st, self.dev = engine, stream, device
         self.rank, self.world, self.N, self.H, self.W, self.cam = rank, world, N, H, W, cam
         self.P = H * W
-        self.n_images, self.seed0, self.seed_per_step = n_images, seed0, seed_per_step
+        # image i of step s samples from seed0 + seed_per_step * s + i: the stride must cover the images (64 was configs[3]'s count, hard-wired until round 5:
+        # seeds of consecutive steps collided beyond 64 images)
+        self.n_images, self.seed0, self.seed_per_step = n_images, seed0, (max(64, n_images) if seed_per_step is None else int(seed_per_step))
         self.mine = ddist.shard_images(n_images, rank, world)
         self.B = max(1, min(batch, max(1, len(self.mine))))
         if self.B > 1 and N % 128 != 0:
@@ -89,7 +91,10 @@ class ShardRunner:
                                               ptr(s["soft"][:n]), ptr(w_v[j0:j0 + nb]), ptr(s["ent"][:nb]), ptr(s["avg"][:nb]), ptr(ref_v[j0:j0 + nb]),
                                               ptr(s["sd"][:nb]), None, ptr(out4_v[j0:j0 + nb])])
         self._seed_base = [self.mine[idx[0]] for idx in self.batches]
-        engine.set_option("device_args", 1)  # every argument above lives in HBM
+        # "device_args" (no pointer query per argument) is set around the bound calls of a step only -- the engine may serve other callers with host arrays
+        # between steps (round 4 left it on for the runner's lifetime)
+        self._dev_args_on = (ctx, b"device_args", 1)
+        self._dev_args_off = (ctx, b"device_args", 0)
 
     # -- one step ---------------------------------------------------------------------------------------------------------------------------
     def _launch_gather(self, slot):
@@ -125,14 +130,19 @@ class ShardRunner:
         ctx = self.eng._ctx
         seed0 = self.seed0 + self.seed_per_step * i
         t1 = time.perf_counter(); T["slot_wait"] += t1 - t0; t0 = t1
+        if self.batches:
+            lib.dsac_set_option(*self._dev_args_on)
         for bi in range(len(self.batches)):
             check(ctx, lib.dsac_set_frames(*self._set_frames_args[bi]))
             a = self._process_args[k][bi]
             a[2] = (seed0 + self._seed_base[bi]) & 0xFFFFFFFFFFFFFFFF
             # the reference's whole per-image unit (test_ransac_softam.cpp:97-157 -> processImage): K1, K2, K3, 8 refinement steps, loss
             check(ctx, lib.dsac_process_images(*a))
+        if self.batches:
+            lib.dsac_set_option(*self._dev_args_off)
+            self.eng.frames = len(self.batches[-1])
+        # a rank without images (n_images < world) has nothing to launch but still takes part in every gather: the exchange above runs for it too
         T["process_images"] += time.perf_counter() - t0
-        self.eng.frames = len(self.batches[-1])
         self._last_slot = k
         self.steps_done += 1
 
@@ -158,5 +168,5 @@ class ShardRunner:
         self.eng.joinTail()
         self.eng.synchronize()
         self.gs.synchronize()
-        for key, v in (("device_args", 0), ("seed_stride", 1), ("pi_defer_tail", 0)):
+        for key, v in (("seed_stride", 1), ("pi_defer_tail", 0)):
             self.eng.set_option(key, v)

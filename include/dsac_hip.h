@@ -160,8 +160,11 @@ DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_
  * every per-image argument (start / refined pose, ground truth, inlier map, J_hyp, obj_pixels, J_obj, n_obj, dL, v6) holds one slice per frame, grad_xyz
  * is frames x H*W x 3, and every stage is ONE launch over all frames; the results equal `frames` single-frame calls bit for bit
  * (core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what the data-parallel step of SURVEY.md 5 puts on one GPU).  The score
- * backward needs 16 | hypotheses per frame <= 256 for a batch.  Every other call (dsac_sample, dsac_reproject, dsac_score_hypotheses, the DSAC-variant
- * calls) reports DSAC_ERR_INVALID while a batch is set. */
+ * backward needs 16 | hypotheses per frame <= 256 for a batch.  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
+ * here), dsac_reproject (128 | hypotheses per frame), dsac_softmax_frames, and the pair dsac_process_images_begin / dsac_process_images_finish, the
+ * score-CNN seam of the batched fast path -- and so do the DSAC-variant calls (dsac_refine_all, dsac_refine_fd_sets, dsac_loss_batch, dsac_select_frames).
+ * What still reports DSAC_ERR_INVALID while a batch is set: dsac_score_hypotheses (use dsac_score_hypotheses_frames), dsac_sample with GIVEN sets,
+ * dsac_refine_fd_set (one hypothesis: use dsac_refine_fd_sets), and the fp64 parity mode of dsac_score_backward. */
 DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
                     float cx, float cy, unsigned flags);
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).
@@ -195,6 +198,11 @@ DSAC_API int dsac_reproject(dsac_ctx* ctx, int N, const double* poses, float cla
  * w = softmax(scale * scores); entropy in bits; avg6 = sum_h w_h * poses[h].  entropy/avg6/poses may be NULL. */
 DSAC_API int dsac_softmax(dsac_ctx* ctx, int N, const double* scores, double scale, double* w, double* entropy_or_null,
                  const double* poses_or_null, double* avg6_or_null);
+/* The same for `frames` independent groups of hyps_per_frame consecutive scores in ONE launch (a workgroup per frame): scores / w / poses
+ * [frames][hyps_per_frame], entropy [frames], avg6 [frames][6].  Needs no frame to be set -- K3 reads scores and poses only.  This is the K3 of a
+ * frame batch whose scores come from a score model outside the library (core/cnn_softam.h:1072-1078: forward(diffMaps) -> softMax). */
+DSAC_API int dsac_softmax_frames(dsac_ctx* ctx, int frames, int hyps_per_frame, const double* scores, double scale, double* w, double* entropy_or_null,
+                        const double* poses_or_null, double* avg6_or_null);
 
 /* ---- K1 + K2 + K3 in one call: the hypothesis-scoring half of processImage ------------------------ */
 /* Replaces core/cnn_softam.h:1010-1094 with the soft-inlier score in the place of the score CNN (:1072):
@@ -233,7 +241,12 @@ DSAC_API int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, dou
  * core/train_ransac_softam.cpp:382-383:  grad_xyz[p] += sum_h ( d_err[h][p] * dProjectdObj(h,p) )
  * and, for the 4 support pixels of h, += (sum_p d_err[h][p] * dProjectdHyp(h,p)) * dPNP(h).
  * poses are the cv poses of the hypotheses (as re-solved at :597-598); dpnp N x 72 or NULL (computed
- * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into. */
+ * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into.
+ * Determinism: with one hypothesis tile (N <= 256) or a frame batch the main pass adds into grad_xyz with hardware fp64 atomics -- a cell receives at most
+ * two such additions per call (a pixel tile split between two workgroups) on top of the value it held, so two runs may differ in the last bit of a cell;
+ * dsac_set_option("k4_variant", 1000 + v) (1999: automatic form) is the staged, bit-reproducible form (fp32 partial sums + a reduction launch; single
+ * frame only).  The atomics need ordinary device memory: a managed / fine-grained grad_xyz takes the staged form by itself, and is refused on a frame
+ * batch; under "device_args" = 1 the caller's promise includes that. */
 DSAC_API int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
                         unsigned flags, double* grad_xyz);
 /* The backward calls need fx == fy: the reference's Jacobians use the single focal length camMat(0,0) for both axes
@@ -247,6 +260,14 @@ DSAC_API int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, cons
  * (no N x P read).  g = dLoss/d soft[h]. */
 DSAC_API int dsac_soft_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const double* g, float clamp, float tau,
                              float beta, const double* dpnp_or_null, unsigned flags, double* grad_xyz);
+
+/* The soft-inlier score as an EXTERNAL score model, backward half: the gradient images a score model hands to dsac_score_backward
+ * (core/train_ransac_softam.cpp:378-383: backward -> dScore), written out for the soft-inlier score -- d_err[h][p] = g[h] * (-beta) s (1 - s),
+ * s = sigmoid(beta (tau - err[h][p])), 0 where err sits on the clamp; err / d_err N x H*W float32 (16-byte aligned, 4 | H*W), g N doubles.
+ * With dsac_process_images_begin's `soft` output as the forward half, a host without device code of its own (the C++ programs of dsac_amd/host)
+ * drives the whole score-CNN seam -- error images out, scores in, score gradients out, gradient images in -- and must reproduce the built-in
+ * dsac_soft_score_backward to fp32 rounding (tests/test_gpu_seam.py, train_ransac_softam -seam 1). */
+DSAC_API int dsac_soft_score_derr(dsac_ctx* ctx, int N, const double* g, const float* err, float clamp, float tau, float beta, float* d_err);
 
 /* The per-hypothesis 1 x 6 pose gradients of the most recent dsac_score_backward / dsac_soft_score_backward call on
  * this context: G6[h] = sum over cells of d_err[h][p] * dProjectdHyp(p) (the accumulation of core/cnn_softam.h:631-632
@@ -278,6 +299,9 @@ DSAC_API int dsac_refine_fd(dsac_ctx* ctx, const double* init_pose, const int32_
  * shared steps x H*W permutation (every hypothesis re-seeds the same default std::mt19937, :1169).  inlier_maps
  * (N x H*W int32, zeroed here) receives one hit-count map per hypothesis; with sets (N x 4) the cells of each
  * hypothesis' own minimal set are cleared afterwards (:1208-1214). */
+/* Frame batch (round 5; core/cnn.h:1154-1230 for F images at once -- SURVEY.md 8(f)1: "the natural way to fill the GPU"): N = frames x hypotheses per
+ * frame, hypothesis h refines against frame h / (N / frames); init_poses / sets / out_poses / steps_done frame-major, inlier_maps N x H*W.  ONE launch of
+ * N waves; equals `frames` single-frame calls bit for bit. */
 DSAC_API int dsac_refine_all(dsac_ctx* ctx, int N, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                     const int32_t* sets_or_null, double* out_poses, int32_t* inlier_maps_or_null, int32_t* steps_done_or_null);
 /* Replaces dRefine core/cnn.h:854-990 for ONE hypothesis given by its minimal set: the refinement restarts from P3P of
@@ -293,9 +317,17 @@ DSAC_API int dsac_refine_fd_set(dsac_ctx* ctx, const int32_t* set4, const int32_
 DSAC_API int dsac_refine_fd_sets(dsac_ctx* ctx, int M, const int32_t* sets, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                         const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj, int cap,
                         int32_t* n_obj);
+/* Frame batch: with dsac_refine_fd_sets M must be frames x (hypotheses per frame), hypothesis m lives in frame m / (M / frames).  The trainer differentiates
+ * only the hypotheses that carry weight (core/train_ransac.cpp:318: probability > 1e-4), a different number per image: dsac_refine_fd_sets_frames takes
+ * frame_of[m] (M int32, host or device) -- the frame hypothesis m was sampled from -- and runs all M * (18 + 6*cap) replicas of all images in one launch. */
+DSAC_API int dsac_refine_fd_sets_frames(dsac_ctx* ctx, int M, const int32_t* sets, const int32_t* frame_of, const int32_t* perm, int steps, int max_inl, int min_inl,
+                               float thr, const int32_t* inlier_maps, float sub_sample, float eps_obj, double* J_set, int32_t* obj_pixels, double* J_obj,
+                               int cap, int32_t* n_obj);
 /* maxLoss / dLossMax for B estimates against one ground truth: the losses[] of expectedMaxLoss core/cnn.h:137-150 and
  * the per-hypothesis dLossMax of core/train_ransac.cpp:345-349.  out4 is B x 4, J6 B x 6 (layouts of dsac_loss). */
 DSAC_API int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
+/* The same for a frame batch: frames x per_frame estimates (frame-major), estimate b against the ground truth of frame b / per_frame (gt_jp6 frames x 6). */
+DSAC_API int dsac_loss_batch_frames(dsac_ctx* ctx, int frames, int per_frame, const double* est_cv6, const double* gt_jp6, double* out4, double* J6_or_null);
 /* DSAC variant, the three small reductions over the N hypotheses of an image on the device (one launch, no host round trip):
  *   hyp_idx        = draw(probs)                 core/cnn.h:102-127: entries below EPS = 1e-8 skipped, the entry whose cumulative probability
  *                                                first exceeds u * sum (u in [0, 1) supplied by the caller in place of drand); u < 0: the most
@@ -305,6 +337,9 @@ DSAC_API int dsac_loss_batch(dsac_ctx* ctx, int B, const double* est_cv6, const 
  * losses[i * loss_stride]: loss_stride = 4 reads the first column of dsac_loss_batch's out4 in place. */
 DSAC_API int dsac_select(dsac_ctx* ctx, int N, const double* probs, const double* losses, int loss_stride, double u, int32_t* hyp_idx_or_null,
                 double* expected_loss_or_null, double* score_gradients_or_null);
+/* ... for `frames` images in one launch (a workgroup per image): probs / losses / score_gradients [frames][N], u / hyp_idx / expected_loss [frames]. */
+DSAC_API int dsac_select_frames(dsac_ctx* ctx, int frames, int N, const double* probs, const double* losses, int loss_stride, const double* u,
+                       int32_t* hyp_idx_or_null, double* expected_loss_or_null, double* score_gradients_or_null);
 
 /* ---- producer side: patch gather for the scene-coordinate CNN ----------------------------------------------------- */
 /* Replaces the patch assembly of getCoordImg core/cnn_softam.h:224-254 in the table layout of pushMaps core/lua_calls.h:63-80:
@@ -359,6 +394,28 @@ DSAC_API int dsac_process_images(dsac_ctx* ctx, int hyps_per_frame, uint64_t see
  * refinement chains of images i and i + 1 run side by side and the loop is bound by K1 + K2: 173 us per image in order, 122 with mode 1, 81 with
  * mode 2 (profiles/r04_two_tails_ab.txt).  Results are the same bit for bit in all three modes (tests/test_gpu_process_images.py). */
 DSAC_API int dsac_join_tail(dsac_ctx* ctx);
+
+/* ---- the score-CNN seam of the batched fast path ------------------------------------------------------------------------------------------
+ * dsac_process_images cut where the reference calls its score CNN (core/cnn_softam.h:1066-1078: getDiffMap x N -> forward(diffMaps) -> softMax;
+ * core/lua_calls.h:89-105 pushes the N error images to Lua number by number).  For every frame set with dsac_set_frame / dsac_set_frames:
+ *   dsac_process_images_begin   K1 sample + P3P, K2 -> err [frames * hyps_per_frame][H*W] in the caller's HBM buffer, the order the reference hands the
+ *                               maps to the CNN (and, if soft is non-NULL, the soft-inlier sums as well); poses / sets_out / ok as dsac_process_images.
+ *   ... the caller's score model turns err into scores [frames * hyps_per_frame] (doubles) -- on the context's stream (dsac_set_stream adopts torch's),
+ *       or with its own ordering against it ...
+ *   dsac_process_images_finish  K3 per frame on scale * scores (softmax / entropy / soft-argmax pose of `poses`), K6 the refinement of every frame, K7 the
+ *                               loss -- arguments and outputs as the second half of dsac_process_images.
+ * Frame f draws from the random stream of seed + f * seed_stride; scores equal to the soft-inlier sums (begin's `soft`) and scale = the score scale give
+ * the results of dsac_process_images bit for bit (tests/test_gpu_seam.py).  "pi_defer_tail" applies to the pair: 1 = K6 / K7 run on the tail stream under
+ * the NEXT begin's K1 / K2; 2 = K3 as well (it starts behind an event the finish call records on the context's stream, i.e. behind the score model);
+ * ordering of the outputs, dsac_join_tail / dsac_tail_wait and the rule that consecutive calls are given different arrays in mode 2 are those of
+ * dsac_process_images.  One pair at a time per context: finish must follow its begin with the same frames and hyps_per_frame (another
+ * dsac_process_images or begin abandons an open begin).  The backward half of the seam is dsac_score_backward with the score model's d_err
+ * (core/train_ransac_softam.cpp:378-383) -- on a frame batch since round 4. */
+DSAC_API int dsac_process_images_begin(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta,
+                              double* poses, int32_t* sets_out, uint8_t* ok, float* err, double* soft_or_null);
+DSAC_API int dsac_process_images_finish(dsac_ctx* ctx, int hyps_per_frame, const double* scores, double scale, const int32_t* perm, int steps, int max_inl,
+                               int min_inl, float thr, const double* gt_jp6_or_null, const double* poses, double* w, double* entropy, double* avg6,
+                               double* ref6, int32_t* steps_done, int32_t* inlier_maps_or_null, double* out4_or_null);
 /* The same dependency for ANOTHER stream: `hip_stream` (a hipStream_t of the context's device) waits for the deferred tail that is in flight -- and
  * thereby for the dsac_process_images call it belongs to and everything the context's stream held before that call (the tail starts behind that call's
  * K3); the context's own stream is not held up, nothing is inserted into it, and the tail stays pending for it.  This is how a consumer of the tail's

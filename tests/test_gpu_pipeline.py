@@ -79,18 +79,20 @@ def test_process_image_full_resolution_with_score_fn(engine, orc, synth, frame_f
     perm = synth.fast_permutations(fr["H"] * fr["W"], 8)
     gt_jp6 = orc.cv_to_jp6(fr["gt_pose"])
 
-    def score_fn(err):  # higher score for smaller mean error
-        return -0.5 * err.reshape(err.shape[0], -1).mean(axis=1).astype(np.float64)
+    def score_fn(err):  # higher score for smaller mean error.  The engine hands over a torch DEVICE tensor (the maps stay in HBM), the oracle check an array
+        e = err.reshape(err.shape[0], -1)
+        return -0.5 * (e.double().mean(dim=1) if hasattr(e, "data_ptr") else e.astype(np.float64).mean(axis=1))
 
     fwd = engine.processImage(N=64, seed=7, perm=perm, gt_jp6=gt_jp6, score_fn=score_fn)
     ref_err = orc.get_diff_maps(fwd["hyps"], fr["xyz"], fr["uv"], fr["H"], fr["W"], fr["cam"])
     wr = orc.softMax(score_fn(ref_err))
-    margin("a4", "processImage 40x40: softmax weights vs the oracle's from the same poses (BASELINE.md 3)", np.abs(fwd["sfScores"] - wr).max(), 1e-4)
+    margin("a4", "processImage 640x480 with a score function on the device-resident error images: softmax weights vs the oracle's from the same poses (BASELINE.md 3)", np.abs(fwd["sfScores"] - wr).max(), 1e-4)
     assert fwd["rotErr"] < 1.0 and fwd["tErr"] < 20.0 and fwd["correct"]
 
-    def d_scores_fn(g):  # backward of the linear 'CNN': d score / d err = -0.5 / P
+    def d_scores_fn(g):  # backward of the linear 'CNN': d score / d err = -0.5 / P -- returned as a device tensor, which K4 reads in place
+        import torch
         P = fr["H"] * fr["W"]
-        return np.broadcast_to((g * (-0.5 / P))[:, None], (len(g), P)).astype(np.float32)
+        return torch.as_tensor(g * (-0.5 / P), dtype=torch.float32, device="cuda")[:, None].expand(len(g), P).contiguous()
 
     bwd = engine.backward(fwd, gt_jp6, d_scores_fn=d_scores_fn)
     assert np.isfinite(bwd["grad"]).all() and np.abs(bwd["grad"]).max() > 0
