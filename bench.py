@@ -129,7 +129,8 @@ def parse_args(argv=None):
     ap.add_argument("--kernel-only", action="store_true", help="time K2 alone on random poses (BASELINE.json configs[2] with --hyps 4096)")
     ap.add_argument("--k2-mode", choices=("both", "err", "soft"), default="both", help="K2 outputs: error images and/or soft-inlier sums")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="config3 on ONE GPU: besides the whole 64-image step, time exactly the share rank --emulate-rank of W ranks would run (8 images at "
+                    help="default workload on ONE GPU: fill the line's `strong` object (configs[3], 64 images fixed) from the emulation of one rank of W.  "
+                         "config3 on ONE GPU: besides the whole 64-image step, time exactly the share rank --emulate-rank of W ranks would run (8 images at "
                          "W = 8; its gather replaced by the rank's own part) and report per_rank_ms next to one_gpu_ms / W -> predicted efficiency")
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true", help="exercise launch / shard / gather / reporting without touching a GPU (CPU tests, gloo)")
@@ -323,6 +324,179 @@ def host_driver_leg(N, H, W, device=0, images=64, batch=16, passes=6):
         return res
 
 
+def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_world=0, emulate_rank=0, err_buffer=None):
+    """north_star's multi-GPU claim inside the command the driver runs: BASELINE.json configs[3] -- 64 images x --hyps hypotheses FIXED, sharded round-robin
+    over the ranks (core/test_ransac_softam.cpp:97-230: independent images), every image through the whole processImage, the 64 x (10 + N) result rows
+    exchanged with ONE all_gather_into_tensor per step over RCCL inside the timed region (dsac_amd.shard.ShardRunner).  Returns the `strong` object of
+    the JSON line (rank 0; None elsewhere):
+        one_gpu_ms   rank 0 ALONE runs all 64 images per step (same process, same engine, before the ranks run their shares; the others wait)
+        per_rank_ms  every rank runs its share, barrier + max over ranks, the gather of step i beside step i + 1 as in production
+        speedup = one_gpu_ms / per_rank_ms, efficiency = speedup / ranks
+        collective_bytes_per_step, collective_exposed_us (the same steps with the gather replaced by the copy of the rank's own part, subtracted)
+    world == 1 with emulate_world > 1: the same fields from the one-GPU emulation of rank `emulate_rank` of `emulate_world` (a prediction, flagged)."""
+    import torch
+    import dsac_amd
+    from dsac_amd import synth
+    from dsac_amd.shard import ShardRunner
+    N, H, W = args.hyps, args.height, args.width
+    P = H * W
+    if N % 128 != 0:
+        return {"refused": "configs[3] needs --hyps to be a multiple of 128"} if rank == 0 else None
+    if world > 1 and backend != "nccl":
+        # the claim is about RCCL over xGMI: a run whose ranks talk over gloo measures something else -- no number rather than a wrong one
+        return {"refused": "the ranks did not join an RCCL process group (backend %s%s): no strong-scaling measurement" %
+                           (backend, ("; " + BACKEND_NOTE) if BACKEND_NOTE else "")} if rank == 0 else None
+    dev = torch.device("cuda", local_rank)
+    st = torch.cuda.Stream(device=dev)
+    eng = dsac_amd.Engine(local_rank, stream=st)
+    cam = synth.chess_like_frame(8, 8, seed=1)["cam"]
+    perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    cache = {}
+
+    def frames_of(i):
+        if i not in cache:
+            cache[i] = synth.chess_like_frame(H, W, seed=1305 + i)["xyz"]  # SURVEY.md 8(d) config 4: seeds 1305 + i
+        return cache[i]
+    B = max(1, args.frames_per_step)
+    K = max(args.steps, 20)
+
+    def barrier():
+        eng.synchronize()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    def rmax(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(runner, base, together=True):
+        """settle (--prewarm-ms), then K steps + drain (between barriers when the ranks run together): seconds per step on this rank, the last step's rows"""
+        t_pre, n = time.perf_counter(), 0
+        while n < max(5, args.warmup) or (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            runner.step(base + (n % 90))
+            n += 1
+            if n % 16 == 0:
+                eng.synchronize()
+        runner.drain()
+        if together:
+            barrier()
+        else:
+            eng.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            runner.step(base + 100 + i)
+        rows = runner.drain()
+        eng.synchronize()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / K, rows
+
+    out = None
+    # ---- one GPU, all 64 images: rank 0 alone (the other ranks' GPUs idle; they wait at the next barrier)
+    one_s, err_shared = None, err_buffer
+    if rank == 0:
+        r1 = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, 0, 1, N, H, W, cam, perm3, batch=B, emulate=True, defer=2, err_buffer=err_buffer)
+        one_s, _ = timed(r1, 0, together=False)
+        err_shared = r1.err
+        r1.close()
+        del r1
+    if world > 1:
+        # ---- every rank its share, the real exchange
+        rr = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, cam, perm3, batch=B, defer=2, err_buffer=err_shared)
+        barrier()
+        per_s, rows = timed(rr, 1000)
+        barrier()
+        per_s = rmax(per_s)
+        per_rank, Dw = rr.ex.per, rr.ex.D
+        rr.close()
+        # ---- the same steps without the collective (the rank's own part copied instead): what the gather adds to a step
+        re_ = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, cam, perm3, batch=B, emulate=True, defer=2, err_buffer=err_shared)
+        barrier()
+        noex_s, _ = timed(re_, 2000)
+        barrier()
+        noex_s = rmax(noex_s)
+        re_.close()
+        if rank == 0:
+            ws = rows[:, 10:].sum(1)
+            ok = bool(((ws - 1.0).abs() < 1e-9).all()) and bool(torch.isfinite(rows[:, :10]).all()) and bool((rows[:, 6] > 0).all())
+            # rank-count independence: the gathered rows of the sharded run are the rows of the one-GPU run of the same step (same seeds per image)
+            out = {"workload": "BASELINE.json configs[3]: %d images x %d hypotheses x %dx%d FIXED, image i on rank i mod %d, whole processImage per image, "
+                               "result rows (refined pose 6 + loss 4 + N weights) exchanged by one all_gather_into_tensor per step" % (CONFIG3_IMAGES, N, W, H, world),
+                   "ranks_joined": world, "backend": "RCCL (torch.distributed nccl)", "steps": K, "images_per_rank_step": CONFIG3_IMAGES // world,
+                   "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s, "efficiency": one_s / per_s / world,
+                   "collective_bytes_per_step": int(world * per_rank * Dw * 8), "per_rank_ms_without_collective": noex_s * 1e3,
+                   "collective_exposed_us": max(0.0, (per_s - noex_s) * 1e6), "rows_ok": ok,
+                   "how": "one_gpu_ms: rank 0 alone, all 64 images per step, before the ranks ran their shares (same process and engine); per_rank_ms: every rank "
+                          "its share, barrier + max over ranks, %d steps, the gather of step i on a side stream beside step i + 1" % K}
+    elif emulate_world > 1:
+        Wem, rem = emulate_world, emulate_rank % emulate_world
+        em = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, rem, Wem, N, H, W, cam, perm3, batch=B, emulate=True, defer=2, err_buffer=err_shared)
+        per_s, rows = timed(em, 1000)
+        out = {"workload": "BASELINE.json configs[3]: %d images x %d hypotheses x %dx%d FIXED; ONE GPU runs exactly the share of rank %d of %d (its images, "
+                           "buffers, launch sequence, deferred tails; the all-gather replaced by the copy of its own part)" % (CONFIG3_IMAGES, N, W, H, rem, Wem),
+               "emulated": True, "ranks_joined": 1, "backend": "none (one process: a PREDICTION of what %d ranks would show, not a measurement)" % Wem,
+               "steps": K, "images_per_rank_step": len(em.mine), "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s,
+               "efficiency": one_s / per_s / Wem, "collective_bytes_per_step": int(Wem * em.ex.per * em.ex.D * 8), "collective_exposed_us": None,
+               "rows_ok": bool(torch.isfinite(rows[em.mine]).all())}
+        em.close()
+    elif rank == 0:
+        out = {"workload": "BASELINE.json configs[3] on one GPU", "ranks_joined": 1, "one_gpu_ms": one_s * 1e3, "steps": K}
+    eng.close()
+    return out
+
+
+def dry_strong(args, rank, world, dist):
+    """The `strong` object of the line with a stand-in for the engine (CPU, gloo): the exchange, the rank-0-alone run, the max over ranks and the field
+    set are the real code paths of strong_scaling_leg; the "work" of an image is a sleep.  Returns the object on rank 0."""
+    import torch
+    from dsac_amd import dist as ddist
+    N, K = args.hyps, max(args.steps, 3)
+    per_image_s = 2e-4
+
+    def run(r, w, group):
+        mine = ddist.shard_images(CONFIG3_IMAGES, r, w)
+        ex = ddist.FrameResultExchange(CONFIG3_IMAGES, r, w, (6, 4, N), torch.device("cpu"), group=group, local_only=group is None)
+        t0 = time.perf_counter()
+        for i in range(K):
+            k = i & 1
+            if i >= 1:
+                ex.wait(k)
+                ex.launch(1 - k)
+            ref_v, out4_v, w_v = ex.views(k)
+            for j, img in enumerate(mine):
+                ref_v[j] = float(img)
+                out4_v[j] = float(i)
+                w_v[j] = 1.0 / N
+            time.sleep(per_image_s * len(mine))
+        k = (K - 1) & 1
+        if K >= 2:
+            ex.wait(1 - k)
+        ex.launch(k)
+        ex.wait(k)
+        return (time.perf_counter() - t0) / K, ex.frames(k), ex
+    one_s = None
+    if rank == 0:
+        one_s, _, _ = run(0, 1, None)
+    if dist is not None:
+        dist.barrier()
+    Wsh = world if world > 1 else args.emulate_world
+    per_s, rows, ex = run(rank if world > 1 else args.emulate_rank % Wsh, Wsh, (dist.group.WORLD if world > 1 else None))
+    if dist is not None:
+        t = torch.tensor([per_s], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_s = float(t.item())
+    if rank != 0:
+        return None
+    ok = bool(torch.equal(rows[:, 0], torch.arange(CONFIG3_IMAGES, dtype=torch.float64))) if world > 1 else True
+    return {"workload": "DRY RUN of BASELINE.json configs[3] (stand-in engine): %d images fixed over %d rank(s)" % (CONFIG3_IMAGES, Wsh), "dry_run": True,
+            "emulated": world == 1, "ranks_joined": world, "backend": ("gloo (dry run)" if world > 1 else "none"), "steps": K,
+            "images_per_rank_step": CONFIG3_IMAGES // Wsh, "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s,
+            "efficiency": one_s / per_s / Wsh, "collective_bytes_per_step": int(Wsh * ex.per * ex.D * 8), "collective_exposed_us": None, "rows_ok": ok}
+
+
 def run_dry(args, rank, world, dist):
     """No GPU: the rank/shard/gather plumbing and the JSON contract with a stand-in for the engine (CPU tests)."""
     import torch
@@ -364,6 +538,9 @@ def run_dry(args, rank, world, dist):
         elapsed = time.perf_counter() - t0
         total = N * args.frames_per_step * K * world
         scaling, per_step = "weak", args.frames_per_step * world
+    strong = None
+    if args.workload == "frames" and (world > 1 or args.emulate_world > 1):
+        strong = dry_strong(args, rank, world, dist)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -372,7 +549,8 @@ def run_dry(args, rank, world, dist):
         print(json.dumps({"metric": "hypotheses scored/sec over 640x480 coord map", "value": total / elapsed, "unit": "hyp/s", "n_gpus": world, "steps": K,
                           "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "DRY RUN (no GPU work): %s" % args.workload, "frames_per_step_all_ranks": per_step}}), flush=True)
+                          "config": {"workload": "DRY RUN (no GPU work): %s" % args.workload, "frames_per_step_all_ranks": per_step},
+                          **({"strong": strong} if strong is not None else {})}), flush=True)
 
 
 def run_config5(args, rank, local_rank, world, backend, dist):
@@ -588,14 +766,27 @@ def main(argv=None):
         eng.profile_enable(stride > 0, stride=max(1, stride))
         engines.append((eng, st))
     NB = N * B  # hypotheses per launch and context
+    # The default step hides its score tail: dsac_set_option("pi_defer_tail", 2) -- the reduction of the per-tile sums and K3 of step i run on the engine's
+    # tail stream beside K1 of step i + 1 (include/dsac_hip.h, dsac_score_hypotheses_frames).  Consecutive steps then write alternating result arrays
+    # (one error-image buffer: only K2 touches it).  DSAC_BENCH_NO_DEFER=1: everything in stream order, as until round 4 (the A/B).
+    defer_tail = bool(batched and not config3 and not pipelined and n_ctx == 1 and not os.environ.get("DSAC_BENCH_NO_DEFER"))
+    if defer_tail:
+        n_buf = 2
     for i in range(0 if config3 else n_buf):
         bufs.append(dict(
             poses=torch.zeros(NB, 6, dtype=torch.float64, device=dev), sets=torch.zeros(NB, 4, dtype=torch.int32, device=dev),
-            ok=torch.zeros(NB, dtype=torch.uint8, device=dev), err=torch.empty(NB, P, dtype=torch.float32, device=dev),
+            ok=torch.zeros(NB, dtype=torch.uint8, device=dev),
+            err=bufs[0]["err"] if (defer_tail and i > 0) else torch.empty(NB, P, dtype=torch.float32, device=dev),
             soft=torch.zeros(NB, dtype=torch.float64, device=dev), w=torch.zeros(NB, dtype=torch.float64, device=dev),
             ent=torch.zeros(B, dtype=torch.float64, device=dev), avg=torch.zeros(B, 6, dtype=torch.float64, device=dev)))
     for b in bufs:
         b["err"].zero_()  # first touch of the 2.5 GB of error images happens here, not in a timed launch
+    defer_on = [False]
+
+    def set_defer(on):
+        defer_on[0] = bool(on and defer_tail)
+        engines[0][0].set_option("pi_defer_tail", 2 if defer_on[0] else 0)  # a change of mode orders the stream behind a tail in flight
+    set_defer(True)
     gated = (n_ctx == 2 and args.overlap == "gated")
     if gated:
         # K2 launches of the two contexts run back to back (never overlapping each other); K1 / K3 of one frame overlap K2 of the other
@@ -671,7 +862,7 @@ def main(argv=None):
         if staged:
             return step_staged(i)
         eng, _ = engines[i % n_ctx]
-        b = bufs[i % n_ctx]
+        b = bufs[(i & 1) if defer_on[0] else (i % n_ctx)]
         if batched:
             # three launches for B frames: K1 over B*N waves, K2 over B*N error images, K3 with one workgroup per frame
             eng.scoreHypothesesFrames(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1,
@@ -788,6 +979,24 @@ def main(argv=None):
         ms, n = eng.profile_read(0, reset=True)
         k2_ms += ms
         k2_n += n
+    # the same K steps again, a few times: the spread of the step time on this box (the timed region above is ONE sample of K steps)
+    repeats = None
+    if rank == 0 and not config3 and not distributed:
+        reps = []
+        for _ in range(5):
+            sync_all()
+            tr = time.perf_counter()
+            for i in range(K):
+                step(ctr)
+                ctr += 1
+            sync_all()
+            reps.append((time.perf_counter() - tr) / K * 1e3)
+        repeats = {"n": len(reps), "steps_each": K, "ms_per_step_min": min(reps), "ms_per_step_max": max(reps), "ms_per_step_median": sorted(reps)[len(reps) // 2],
+                   "note": "the timed region re-run 5 times after the line's own measurement, same process (box-to-box the same binary differs by several per cent)"}
+        for eng, _ in engines:
+            eng.profile_read(0, reset=True)
+    if not config3:
+        set_defer(False)  # the side measurements below reuse one set of result arrays: stream order
     if config3:
         ok_frac = float(runner.scratch[0]["ok"][:N * len(runner.batches[-1])].float().mean().item()) if runner.batches else 1.0  # a rank may own no image
         wsum = float(last[0, 10:].sum().item()) if last is not None else 0.0
@@ -1033,8 +1242,37 @@ def main(argv=None):
                     procB(5 + i)
                 eng.synchronize()
                 procimg[key] = {"us_per_image": (time.perf_counter() - tp) / nb_ / Bf * 1e6, "images": nb_ * Bf, "refine_steps_done_min": int(sdB.min().item())}
+            # the same batch through the score-CNN seam (cnn_softam.h:1066-1078): dsac_process_images_begin leaves the error images in HBM, the scores come
+            # from OUTSIDE (here: the soft-inlier sums begin wrote on the side, standing in for a score model's output), dsac_process_images_finish continues
+            def procS(i):
+                o = outB2 if (i & 1) else outB
+                eng.processImagesBegin(N, b["err"], seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, soft=o["scores"],
+                                       out=(o["hyps"], o["sampledPoints"], o["ok"]))
+                eng.processImagesFinish(N, o["scores"], permB, o["hyps"], gt_jp6=gtB, scale=0.1, thr=10.0, out=o)
+            for key, defer in (("%dx%d_batch_of_%d_external_scores" % (W, H, Bf), 0),
+                               ("%dx%d_batch_of_%d_external_scores_score_and_refinement_under_the_next_batch" % (W, H, Bf), 2)):
+                eng.set_option("pi_defer_tail", defer)
+                for i in range(5):
+                    procS(i)
+                eng.synchronize()
+                tp = time.perf_counter()
+                for i in range(nb_):
+                    procS(5 + i)
+                eng.synchronize()
+                procimg[key] = {"us_per_image": (time.perf_counter() - tp) / nb_ / Bf * 1e6, "images": nb_ * Bf, "refine_steps_done_min": int(sdB.min().item()),
+                                "what": "dsac_process_images_begin -> scores from outside (the soft-inlier sums as a stand-in) -> dsac_process_images_finish"}
             eng.set_option("pi_defer_tail", 0)
         eng.profile_read(0, reset=True)
+
+    # north_star's multi-GPU claim in the driver's own command: with --gpus N > 1 the line carries a `strong` object -- configs[3] (64 images fixed) sharded
+    # over the N ranks, the result rows exchanged over RCCL inside the timed region -- next to the weak-scaling `value`; on one GPU --emulate-world W fills
+    # the same fields from the emulation of one rank's share
+    strong = None
+    if not config3 and not args.kernel_only and args.k2_mode == "both" and (world > 1 or args.emulate_world > 1):
+        for b_ in bufs[1:]:
+            b_["err"] = None  # the leg's runners write into the first context's error-image buffer; drop the others
+        strong = strong_scaling_leg(args, rank, local_rank, world, backend, dist if distributed else None, emulate_world=args.emulate_world,
+                                    emulate_rank=args.emulate_rank, err_buffer=bufs[0]["err"] if (batched and bufs[0]["err"] is not None) else None)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -1084,7 +1322,9 @@ def main(argv=None):
                        "hypotheses_per_frame": N, "frame": [H, W], "frames_per_step": CONFIG3_IMAGES if config3 else B, "streams_per_gpu": n_ctx,
                        "overlap": ("in-context software pipeline: K1(i+1) || K2,K3(i), alternating frame batches" if pipelined else
                                    "K2 launches serialised across 2 contexts, K1/K3 overlap them" if gated else "sampling stage || scoring stage" if staged
-                                   else ("frames round-robin" if n_ctx > 1 else "none")),
+                                   else ("frames round-robin" if n_ctx > 1 else
+                                         ("score tail of step i (reduction of the per-tile sums + K3) on the tail stream beside K1 of step i + 1 "
+                                          "(pi_defer_tail = 2); K1 -> K2 in stream order" if defer_tail else "none"))),
                        "parallelism": "images sharded over %d GPU(s), no data-path collective%s%s" %
                                       (world, "; results gathered on rank 0" if config3 else "", ("; " + BACKEND_NOTE) if BACKEND_NOTE else ""),
                        "prewarm_steps_untimed": n_pre, "accepted_fraction": ok_frac, "softmax_sum": wsum},
@@ -1101,6 +1341,8 @@ def main(argv=None):
             "rates": {"per_image_hyp_s": value, "kernel_only_k2_hyp_s": (N * frames_per_launch / k2_avg_s * world) if k2_avg_s > 0 else None,
                       "unit": "hyp/s", "note": "per_image = whole step (K1 sample+P3P, K2, soft reduce, K3); kernel_only = hypotheses per K2 launch / its duration"},
         }
+        if repeats is not None:
+            out["repeats"] = repeats
         if soft_only is not None:
             out["soft_only"] = soft_only
         if single is not None:
@@ -1111,6 +1353,8 @@ def main(argv=None):
             out["process_image"] = procimg
         if emulation is not None:
             out["emulation"] = emulation
+        if strong is not None:
+            out["strong"] = strong
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fr, N, H, W)
         if (not args.no_host_driver and world == 1 and not config3 and not args.kernel_only and args.k2_mode == "both" and not args.no_single_frame

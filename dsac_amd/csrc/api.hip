@@ -628,6 +628,9 @@ int dsac_softmax_frames(dsac_ctx* c, int frames, int hyps_per_frame, const doubl
     return softmax_common(c, "dsac_softmax_frames", frames, hyps_per_frame, scores, scale, w, entropy_or_null, poses_or_null, avg6_or_null);
 }
 
+static int pi_tail_index(int mode, int b, long long N, long long P);
+static int pi_tail_setup(dsac_ctx* c, int mode, int tk);
+
 static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, float clampv, float tau,
                                    float beta, double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null,
                                    double* w, double* entropy_or_null, double* avg6_or_null) {
@@ -638,7 +641,12 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     if (!sets_or_null && max_tries <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: max_tries must be > 0");
     if (!sets_or_null && c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_score_hypotheses: frame has fewer than 4 cells");
     HIP_TRY(c, hipSetDevice(c->device));
-    begin_call(c);
+    // "pi_defer_tail" = 2 on a frame batch with device-resident arguments: the score tail (reduction of the per-tile sums + K3: two small launches that
+    // leave the chip idle while they run in order) goes to the tail stream, K1 of the NEXT call follows K2 of this one without a gap -- the contract of
+    // dsac_process_images' mode 2: scores / w / entropy / avg6 (and poses / sets / ok, which K3 reads) are complete after dsac_join_tail / another entry
+    // point / dsac_synchronize, consecutive calls are given different arrays (the error images may be the same buffer: only K2 touches them)
+    const bool want_defer = Nf > 0 && c->pi_defer_tail == 2 && !sets_or_null;
+    begin_call(c, /*keep_tail=*/want_defer);
     const size_t P = (size_t)c->F.P;
     const int32_t* d_sets_in;
     double *d_poses, *d_scores, *d_w, *d_ent, *d_avg;
@@ -654,13 +662,52 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     ARG_TRY(out_arg(c, w, (size_t)N, &d_w));
     ARG_TRY(out_arg(c, entropy_or_null, (size_t)frames, &d_ent));
     ARG_TRY(out_arg(c, avg6_or_null, (size_t)frames * 6, &d_avg));
+    const bool defer = want_defer && c->pending.empty();  // every output in HBM: nothing to copy back at the end of this call
+    if (want_defer && !defer) join_tail(c);
+    const int b = defer ? (int)(c->pi_calls++ & 1u) : 0;
+    if (defer) c->pi_open = false;
     if (!d_scores) {
-        DevBuf& s = next_slot(c);
-        HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
-        d_scores = s.as<double>();
+        if (defer) {
+            HIP_TRY(c, c->pi_scores[b].reserve((size_t)N * sizeof(double)));
+            d_scores = c->pi_scores[b].as<double>();
+        } else {
+            DevBuf& s = next_slot(c);
+            HIP_TRY(c, s.reserve((size_t)N * sizeof(double)));
+            d_scores = s.as<double>();
+        }
     }
     const int tiles = dk::reproject_num_pixel_tiles(c->F.P);
     HIP_TRY(c, c->staged.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float)));
+    if (defer) {
+        DevBuf& part = c->pi_soft[b];
+        HIP_TRY(c, part.reserve((size_t)tiles * N * sizeof(float)));
+        const int tk = pi_tail_index(2, b, N, (long long)P);
+        ARG_TRY(pi_tail_setup(c, 2, tk));
+        if (c->pi_scored_rec[b]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->pi_scored[b], 0));  // K3 of the call two back read this half's arrays
+        HIP_TRY(c, dk::sample(c->stream, N, seed, nullptr, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>(), Nf, c->k1));
+        int used_d = 0;
+        if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
+        hipEvent_t k2_done = nullptr;
+        {
+            ProfScope ps(c, 0, true);
+            dk::K2Opts o = ps.k2();
+            if (!o.ev_stop) o.ev_stop = c->pi_k2done;  // the tail's start rides on K2's own dispatch packet: no record between K2 and the next K1
+            k2_done = o.ev_stop;
+            HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, part.as<float>(), o, &used_d, Nf));
+            ps.commit();
+        }
+        if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
+        hipStream_t ts = c->tail[tk];
+        if (c->pi_tail_of[b] >= 0 && c->pi_tail_of[b] != tk) HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_done[c->pi_tail_of[b]], 0));
+        c->pi_tail_of[b] = tk;
+        HIP_TRY(c, hipStreamWaitEvent(ts, k2_done, 0));
+        HIP_TRY(c, score_tail(ts, Nf, frames, used_d, part.as<float>(), d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg));
+        HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
+        c->pi_scored_rec[b] = true;
+        HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));
+        c->tail_pending[tk] = true;
+        return DSAC_OK;
+    }
     HIP_TRY(c, c->soft_part.reserve((size_t)tiles * N * sizeof(float)));
     // K1 writes the poses AND their staged K2 records (no separate pose_prep launch)
     HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, c->staged.as<float>(), Nf, c->k1));

@@ -312,12 +312,14 @@ class FrameResultExchange:
     world / rank are those of the SHARDING; without a process group of that size (one process: world 1, or a one-GPU emulation of rank r of W) the
     collective is replaced by the copy of the local buffer into its own part -- the rank's half of the gather."""
 
-    def __init__(self, n_images, rank, world, widths, device, dtype=torch.float64, group=None, slots=2, pin_host=False):
+    def __init__(self, n_images, rank, world, widths, device, dtype=torch.float64, group=None, slots=2, pin_host=False, local_only=False):
+        """local_only: never a collective, whatever process group exists -- the one-GPU emulation of a rank, or rank 0 running the whole job alone while
+        the other ranks of an initialised group wait (group=None would otherwise mean the default group)."""
         self.n, self.rank, self.world, self.group = int(n_images), int(rank), int(world), group
         self.per = (self.n + self.world - 1) // self.world
         self.widths = tuple(int(w) for w in widths)
         self.D = sum(self.widths)
-        self.real = _world(group) > 1
+        self.real = (not local_only) and _world(group) > 1
         if self.real and _world(group) != self.world:
             raise ValueError("FrameResultExchange: the process group has %d ranks, the sharding %d" % (_world(group), self.world))
         self.local = [torch.zeros(self.per * self.D, dtype=dtype, device=device) for _ in range(slots)]

@@ -54,7 +54,7 @@ class ShardRunner:
             import torch.distributed as tdist
             group = tdist.group.WORLD
         self.ex = ddist.FrameResultExchange(n_images, rank, world, (6, 4, N), device, group=group if (world > 1 and not emulate) else None,
-                                            pin_host=(device.type == "cuda"))
+                                            pin_host=(device.type == "cuda"), local_only=(emulate or world == 1))
         NB = N * self.B
         # per-hypothesis outputs nobody gathers.  Two sets: with the score tail deferred K3 of a call still reads its poses / scores while K1 of the
         # next call runs, so consecutive calls alternate (dsac_hip.h, "pi_defer_tail" 2)

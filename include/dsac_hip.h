@@ -170,7 +170,12 @@ DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const 
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).
  * Frame f draws from the stream of seed + f, so the result equals `frames` single-frame calls with seeds seed, seed + 1, ...
  * hyps_per_frame must be a multiple of 128.  Outputs are frame-major: poses / sets_out / ok / scores / w [frames][hyps_per_frame],
- * err [frames*hyps_per_frame][H*W], entropy [frames], avg6 [frames][6]. */
+ * err [frames*hyps_per_frame][H*W], entropy [frames], avg6 [frames][6].
+ * With dsac_set_option("pi_defer_tail", 2) and device-resident arguments the score tail (reduction of the per-tile sums, K3) runs on the tail stream
+ * beside K1 of the NEXT call, which follows this call's K2 without a gap (the two small launches otherwise leave the chip idle: 12 of 946 us per
+ * 16-frame step).  The contract is dsac_process_images' mode 2: everything but the error images is ordered on the context's stream only after
+ * dsac_join_tail / another entry point / dsac_synchronize, and consecutive calls are given different arrays for poses / sets_out / ok / scores / w /
+ * entropy / avg6 (the error images may share one buffer).  Results are the same bit for bit (tests/test_gpu_process_images.py). */
 DSAC_API int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uint64_t seed, float thr, int max_tries, float clamp, float tau, float beta,
                                  double scale, double* poses, int32_t* sets_out, uint8_t* ok, float* err_or_null, double* scores_or_null, double* w,
                                  double* entropy_or_null, double* avg6_or_null);

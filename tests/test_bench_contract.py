@@ -113,6 +113,34 @@ def test_gpus_flag_launches_the_ranks_itself():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
     assert d["config"]["frames_per_step_all_ranks"] == 32  # 16 frames per rank
+    # round 5: with more than one rank the SAME line carries north_star's strong-scaling claim -- configs[3], 64 images fixed, sharded, the result rows
+    # exchanged by the backend inside the timed region -- next to the weak-scaling value
+    _check_strong(d["strong"], ranks=2, shards=2)
+
+
+STRONG_FIELDS = ("workload", "ranks_joined", "backend", "steps", "images_per_rank_step", "one_gpu_ms", "per_rank_ms", "speedup", "efficiency",
+                 "collective_bytes_per_step", "collective_exposed_us", "rows_ok")
+
+
+def _check_strong(s, ranks, shards):
+    for k in STRONG_FIELDS:
+        assert k in s, k
+    assert s["ranks_joined"] == ranks and s["images_per_rank_step"] == 64 // shards and s["rows_ok"] is True
+    assert s["one_gpu_ms"] > 0 and s["per_rank_ms"] > 0 and abs(s["speedup"] - s["one_gpu_ms"] / s["per_rank_ms"]) < 1e-9 * s["speedup"]
+    assert abs(s["efficiency"] - s["speedup"] / shards) < 1e-12
+    assert s["collective_bytes_per_step"] == shards * (64 // shards) * (10 + 256) * 8  # ranks x rows per rank x (6 + 4 + N) doubles
+
+
+def test_one_gpu_emulation_fills_the_same_strong_fields():
+    """--gpus 1 --emulate-world 8: the one-GPU box's line carries the same object, flagged as an emulation (a prediction, not a measurement)."""
+    r = _run_bench("--gpus", "1", "--steps", "3", "--dry-run", "--emulate-world", "8")
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak"
+    _check_strong(d["strong"], ranks=1, shards=8)
+    assert d["strong"]["emulated"] is True
+    r = _run_bench("--gpus", "1", "--steps", "3", "--dry-run")
+    assert "strong" not in _json_line(r.stdout)
 
 
 def test_config3_shards_64_images_and_gathers_them():

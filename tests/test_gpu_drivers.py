@@ -146,3 +146,27 @@ def test_device_resident_training_rounds_equal_the_per_image_loop(tmp_path):
     l3 = np.loadtxt(os.path.join(str(tmp_path / "t3"), "ransac_training_loss_train_obj.lua.txt")).reshape(-1, 3)
     assert l3.shape == (4, 3) and np.isfinite(l3).all() and (l3[:, 1] > 0).all()
     assert np.isfinite(grads["3"]).all() and (grads["3"][:, 1] > 0).all()
+
+
+@pytest.mark.parametrize("mw,mh,batch", [(64, 48, 3), (40, 40, 2)])
+def test_training_rounds_through_the_external_score_seam(tmp_path, mw, mh, batch):
+    """train_ransac_softam -batch F -seam 1: every round's score comes from OUTSIDE the library through the seam of the batch path -- error images out
+    (dsac_process_images_begin), scores in (dsac_process_images_finish), score gradients out (dsac_backward_path1), gradient images in (dsac_score_backward
+    on the batch): core/cnn_softam.h:1066-1078 and core/train_ransac_softam.cpp:378-383 for F frames per launch chain.  The program's model is the
+    soft-inlier score dressed as an external one, so the run must reproduce -seam 0 (the built-in score): the forward bit for bit (same log text), the
+    gradient statistics to the fp32 rounding of the explicit gradient images."""
+    logs, grads = {}, {}
+    for seam in ("0", "1"):
+        d = tmp_path / ("s" + seam)
+        d.mkdir()
+        cmd = [os.path.join(HOST, "train_ransac_softam"), "-synth", "4", "-mw", str(mw), "-mh", str(mh), "-rI", "128", "-rounds", "3", "-batch", str(batch), "-gradstats", "1",
+               "-seam", seam]
+        out = subprocess.run(cmd, cwd=str(d), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert ("score through the external seam" in out.stdout) == (seam == "1")
+        logs[seam] = open(os.path.join(str(d), "ransac_training_loss_train_obj.lua.txt")).read()
+        grads[seam] = np.loadtxt(os.path.join(str(d), "ransac_training_grad_train_obj.lua.txt")).reshape(-1, 5)
+    assert logs["1"] == logs["0"]
+    assert grads["1"].shape == grads["0"].shape == (4, 5) and (grads["0"][:, 1] > 0).all()
+    assert np.array_equal(grads["1"][:, 0], grads["0"][:, 0]) and np.abs(grads["1"][:, 4] - grads["0"][:, 4]).max() <= 2
+    assert np.allclose(grads["1"][:, 1:4], grads["0"][:, 1:4], rtol=1e-4, atol=0)

@@ -230,3 +230,121 @@ def test_process_image_with_a_device_score_function_keeps_the_maps_in_hbm(engine
     fwd = engine.processImage(N=64, seed=7, perm=perm, gt_jp6=orc.cv_to_jp6(fr["gt_pose"]), score_fn=score_fn, keep_err=True)
     assert seen["cuda"] and seen["shape"] == (64, fr["H"], fr["W"]) and isinstance(fwd["diffMaps"], torch.Tensor) and fwd["diffMaps"].data_ptr() == seen["ptr"]
     assert fwd["correct"] and fwd["refSteps"] == 8
+
+
+@pytest.mark.parametrize("H,W,F,N", [(40, 40, 1, 64), (48, 64, 3, 128)])
+def test_soft_inlier_gradient_images_reproduce_the_in_kernel_form(engine, synth, H, W, F, N):
+    """dsac_soft_score_derr (the soft-inlier score's backward written out as the gradient images a score model hands to dScore) + dsac_score_backward ==
+    dsac_soft_score_backward (the same derivative formed inside K4), to fp32 rounding; and the images equal the formula evaluated in numpy."""
+    from dsac_amd.capi import lib, ptr, check
+    P = H * W
+    frames = [synth.chess_like_frame(H, W, seed=40 + f, quantise_int16=(H == 40)) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv, cam = frames[0]["uv"], frames[0]["cam"]
+    if F > 1:
+        engine.set_frames(xyz, uv, H, W, cam)
+    else:
+        engine.set_frame(xyz[0], uv, H, W, cam)
+    err, soft = np.zeros((F * N, P), np.float32), np.zeros(F * N)
+    poses, sets, ok = engine.processImagesBegin(N, err, seed=3, soft=soft)
+    g = np.random.default_rng(1).standard_normal(F * N) * 1e-2
+    d_err = np.zeros((F * N, P), np.float32)
+    check(engine._ctx, lib.dsac_soft_score_derr(engine._ctx, F * N, ptr(g), ptr(err), 100.0, 10.0, 0.5, ptr(d_err)))
+    e = err.astype(np.float64)
+    s = 1.0 / (1.0 + np.exp(-0.5 * (10.0 - e)))
+    want = np.where(e >= 100.0, 0.0, g[:, None] * (-0.5) * s * (1.0 - s))
+    margin("(f)2", "dsac_soft_score_derr vs the formula in numpy: max |d| / max |d_err|", np.abs(d_err - want).max() / np.abs(want).max(), 1e-5)
+    J = engine.dPNP(sets)
+    a = engine.dScore(poses, sets, d_err, dpnp=J)
+    b = engine.dSoftScore(poses, sets, g, tau=10.0, beta=0.5, dpnp=J)
+    margin("(f)2", "explicit gradient images through dsac_score_backward vs the in-kernel soft-score backward: max |d| / max |g|", np.abs(a - b).max() / np.abs(b).max(), 1e-4)
+
+
+def test_upload_right_after_a_deferred_call_waits_for_the_tail(synth, orc):
+    """dsac_copy_async / dsac_fill_zero_async into memory a deferred tail still reads (the borrowed frame, the ground truth) are ordered behind
+    that tail -- the refinement of call i must see frame i, not the frame uploaded for call i + 1."""
+    import torch
+    import dsac_amd
+    from dsac_amd.capi import lib, ptr, check
+    dev = torch.device("cuda", 0)
+    H, W, N = 480, 640, 256
+    P = H * W
+    fa, fb = synth.chess_like_frame(H, W, seed=11), synth.chess_like_frame(H, W, seed=12)
+    perm = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
+    gts = [torch.from_numpy(orc.cv_to_jp6(f["gt_pose"])).to(dev).view(1, 6) for f in (fa, fb)]
+    xa, xb = torch.from_numpy(fa["xyz"]).to(dev), torch.from_numpy(fb["xyz"]).to(dev)
+    with dsac_amd.Engine(0) as eng:
+        want = []
+        for x, gt in ((xa, gts[0]), (xb, gts[1])):  # in order, each frame on its own
+            eng.set_frame(x, None, H, W, fa["cam"], borrow=True)
+            o = _dev_bufs(torch, dev, 1, N, P)
+            eng.processImages(N, perm, gt_jp6=gt, seed=5, out=o)
+            eng.synchronize()
+            want.append({k: v.clone() for k, v in o.items()})
+        buf = xa.clone()      # ONE frame buffer, refilled between the calls
+        gt_buf = gts[0].clone()
+        outs = [_dev_bufs(torch, dev, 1, N, P) for _ in range(2)]
+        for mode in (1, 2):
+            eng.set_option("pi_defer_tail", mode)
+            for rep in range(3):
+                check(eng._ctx, lib.dsac_copy_async(eng._ctx, ptr(buf), ptr(xa), P * 12))
+                check(eng._ctx, lib.dsac_copy_async(eng._ctx, ptr(gt_buf), ptr(gts[0]), 48))
+                eng.set_frame(buf, None, H, W, fa["cam"], borrow=True)
+                eng.processImages(N, perm, gt_jp6=gt_buf, seed=5, out=outs[0])
+                # the tail of that call (K6 on one wave: ~100 us) is still refining against `buf` when the next frame is uploaded into it
+                check(eng._ctx, lib.dsac_copy_async(eng._ctx, ptr(buf), ptr(xb), P * 12))
+                check(eng._ctx, lib.dsac_copy_async(eng._ctx, ptr(gt_buf), ptr(gts[1]), 48))
+                eng.set_frame(buf, None, H, W, fa["cam"], borrow=True)
+                eng.processImages(N, perm, gt_jp6=gt_buf, seed=5, out=outs[1])
+                eng.joinTail()
+                eng.synchronize()
+                for k in want[0]:
+                    assert torch.equal(outs[0][k], want[0][k]) and torch.equal(outs[1][k], want[1][k]), (k, mode, rep)
+        eng.set_option("pi_defer_tail", 0)
+
+
+def test_score_hypotheses_frames_with_the_score_tail_deferred(synth):
+    """dsac_score_hypotheses_frames under "pi_defer_tail" = 2 (the bench's default step since round 5): the reduction of the per-tile sums and K3 of call i
+    run on the tail stream beside K1 of call i + 1; alternating result arrays, one error-image buffer.  Every call's results equal the in-order call's."""
+    import torch
+    import dsac_amd
+    dev = torch.device("cuda", 0)
+    H, W, F, N = 480, 640, 4, 128
+    P = H * W
+    frames = [synth.chess_like_frame(H, W, seed=30 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+
+    def bufs():
+        f64 = dict(dtype=torch.float64, device=dev)
+        return (torch.zeros(F * N, 6, **f64), torch.zeros(F * N, 4, dtype=torch.int32, device=dev), torch.zeros(F * N, dtype=torch.uint8, device=dev),
+                torch.zeros(F * N, **f64), torch.zeros(F * N, **f64), torch.zeros(F, **f64), torch.zeros(F, 6, **f64))
+    err = torch.empty(F * N, P, dtype=torch.float32, device=dev)
+    with dsac_amd.Engine(0) as eng:
+        eng.set_frames(xyz, None, H, W, frames[0]["cam"], borrow=True)
+        want = []
+        for i in range(4):
+            o = bufs()
+            eng.scoreHypothesesFrames(N, seed=100 + i, err=err, out=o)
+            eng.synchronize()
+            want.append([t.clone() for t in o] + [err.clone()] if i == 3 else [t.clone() for t in o])
+        eng.set_option("pi_defer_tail", 2)
+        sets = [bufs(), bufs()]
+        got = []
+        for i in range(4):
+            eng.scoreHypothesesFrames(N, seed=100 + i, err=err, out=sets[i & 1])
+            if i >= 1:  # call i - 1's arrays are complete once call i's launches are ordered behind its tail: join, then copy them out in stream order
+                pass
+        eng.joinTail()
+        eng.synchronize()
+        # the last two calls' arrays are intact (calls 2 and 3); the error images are those of call 3
+        for i in (2, 3):
+            for a, b in zip(sets[i & 1], want[i][:7]):
+                assert torch.equal(a, b), i
+        assert torch.equal(err, want[3][7])
+        # with the SAME arrays every call the contract is broken on purpose nowhere: the in-order mode is what a caller with one set of arrays uses
+        eng.set_option("pi_defer_tail", 0)
+        o = bufs()
+        eng.scoreHypothesesFrames(N, seed=103, err=err, out=o)
+        eng.synchronize()
+        for a, b in zip(o, want[3][:7]):
+            assert torch.equal(a, b)
