@@ -373,6 +373,8 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    host_enqueue = [0.0]
+
     def timed(runner, base, together=True):
         """settle (--prewarm-ms), then K steps + drain (between barriers when the ranks run together): seconds per step on this rank, the last step's rows"""
         t_pre, n = time.perf_counter(), 0
@@ -386,9 +388,12 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
             barrier()
         else:
             eng.synchronize()
+        for key in runner.host_us:
+            runner.host_us[key] = 0.0
         t0 = time.perf_counter()
         for i in range(K):
             runner.step(base + 100 + i)
+        host_enqueue[0] = (time.perf_counter() - t0) / K  # the host never waits inside a step: this is what enqueueing one costs
         rows = runner.drain()
         eng.synchronize()
         torch.cuda.synchronize(dev)
@@ -400,6 +405,7 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
     if rank == 0:
         r1 = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, 0, 1, N, H, W, cam, perm3, batch=B, emulate=True, defer=2, err_buffer=err_buffer)
         one_s, _ = timed(r1, 0, together=False)
+        one_host = host_enqueue[0]
         err_shared = r1.err
         r1.close()
         del r1
@@ -408,6 +414,7 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
         rr = ShardRunner(eng, st, dev, frames_of, CONFIG3_IMAGES, rank, world, N, H, W, cam, perm3, batch=B, defer=2, err_buffer=err_shared)
         barrier()
         per_s, rows = timed(rr, 1000)
+        host_ex = host_enqueue[0]
         barrier()
         per_s = rmax(per_s)
         per_rank, Dw = rr.ex.per, rr.ex.D
@@ -428,7 +435,7 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
                    "ranks_joined": world, "backend": "RCCL (torch.distributed nccl)", "steps": K, "images_per_rank_step": CONFIG3_IMAGES // world,
                    "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s, "efficiency": one_s / per_s / world,
                    "collective_bytes_per_step": int(world * per_rank * Dw * 8), "per_rank_ms_without_collective": noex_s * 1e3,
-                   "collective_exposed_us": max(0.0, (per_s - noex_s) * 1e6), "rows_ok": ok,
+                   "collective_exposed_us": max(0.0, (per_s - noex_s) * 1e6), "rows_ok": ok, "host_enqueue_ms_per_step_rank0": host_ex * 1e3,
                    "how": "one_gpu_ms: rank 0 alone, all 64 images per step, before the ranks ran their shares (same process and engine); per_rank_ms: every rank "
                           "its share, barrier + max over ranks, %d steps, the gather of step i on a side stream beside step i + 1" % K}
     elif emulate_world > 1:
@@ -440,7 +447,8 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
                "emulated": True, "ranks_joined": 1, "backend": "none (one process: a PREDICTION of what %d ranks would show, not a measurement)" % Wem,
                "steps": K, "images_per_rank_step": len(em.mine), "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s,
                "efficiency": one_s / per_s / Wem, "collective_bytes_per_step": int(Wem * em.ex.per * em.ex.D * 8), "collective_exposed_us": None,
-               "rows_ok": bool(torch.isfinite(rows[em.mine]).all())}
+               "rows_ok": bool(torch.isfinite(rows[em.mine]).all()), "host_enqueue_ms_per_step": host_enqueue[0] * 1e3, "one_gpu_host_enqueue_ms_per_step": one_host * 1e3,
+               "host_enqueue_us_by_phase": {k_: v_ / K * 1e6 for k_, v_ in em.host_us.items()}}
         em.close()
     elif rank == 0:
         out = {"workload": "BASELINE.json configs[3] on one GPU", "ranks_joined": 1, "one_gpu_ms": one_s * 1e3, "steps": K}

@@ -215,9 +215,10 @@ struct ProfScope {
         on = attached ? true : hipEventRecord(p.a, c->stream) == hipSuccess;
     }
     // the K2 options of this call: the context's, plus the event pair when this launch is sampled
-    dk::K2Opts k2() const {
+    dk::K2Opts k2(const double* poses64 = nullptr) const {
         dk::K2Opts o = c->k2;
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
+        o.poses64 = poses64;  // the cv poses of this launch: what the precise form ("k2_flags" bit 25) projects with
         return o;
     }
     void commit() { launched = true; }
@@ -590,7 +591,7 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(d_poses), &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
@@ -690,7 +691,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
         hipEvent_t k2_done = nullptr;
         {
             ProfScope ps(c, 0, true);
-            dk::K2Opts o = ps.k2();
+            dk::K2Opts o = ps.k2(d_poses);
             if (!o.ev_stop) o.ev_stop = c->pi_k2done;  // the tail's start rides on K2's own dispatch packet: no record between K2 and the next K1
             k2_done = o.ev_stop;
             HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, part.as<float>(), o, &used_d, Nf));
@@ -715,7 +716,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(), &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(d_poses), &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));
@@ -826,7 +827,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     int used = 0;
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, ps.k2(), &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, ps.k2(poses), &used, Nf));
         ps.commit();
     }
     HIP_TRY(c, hipEventRecord(c->slot_free[slot], c->stream));
@@ -1668,7 +1669,7 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     hipEvent_t k2_done = nullptr;
     {
         ProfScope ps(c, 0, true);
-        dk::K2Opts o = ps.k2();
+        dk::K2Opts o = ps.k2(d_poses);
         if (mode == 2) {
             if (!o.ev_stop) o.ev_stop = c->pi_k2done;
             k2_done = o.ev_stop;
@@ -1753,7 +1754,7 @@ int dsac_process_images_begin(dsac_ctx* c, int hyps_per_frame, uint64_t seed, fl
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
         ProfScope ps(c, 0, true);
-        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(), &used, Nf));
+        HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(d_poses), &used, Nf));
         ps.commit();
     }
     if (c->k2_record) HIP_TRY(c, hipEventRecord(c->k2_record, c->stream));

@@ -868,6 +868,129 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------------
+// K2, PRECISE form (round 5; dsac_set_option("k2_flags", bit 25)).  The reference projects in double (core/cnn_softam.h:319-362: cv::projectPoints of a
+// float point under a double pose) and rounds the residual to float at the end; the fast forms above carry fp32 records into an fp32 matrix-core
+// transform, whose four roundings at the magnitude of the partial sums (f * R.X ~ 1e6, z ~ 3e3) are what the suite measures as up to 5.9e-4 px on cells
+// close to the camera plane (profiles/r04_final2_parity_margins.txt) -- inside the stated 1e-3, but with a margin of 1.7x, and with a softmax weight in
+// a tie of two unrelated hypotheses moving by an estimated 2.3e-4 (stated: 1e-4).  This form evaluates the reference's own arithmetic: the pose records
+// in fp64 (Rodrigues of the cv pose in the workgroup's prologue, intrinsics folded in -- no staged fp32 record at all), the rigid transform as three
+// chains of three v_fma_f64 per (hypothesis, cell) -- fp64 FMA issues at the rate of an unpacked fp32 FMA on this chip --, the perspective division in
+// fp64 through one Newton step on v_rcp_f32's seed, and ONE rounding to float of each image-plane difference; only |d| = sqrt(du^2 + dv^2), the clamp and
+// the sigmoid stay in fp32.  Measured residual error against the oracle: see profiles/r05_k2_precise_ab.txt.  Cost: 27 % more issue cycles per pair than
+// the matrix-core form (priced), hidden only in part by the store schedule -- a parity mode, not the default.
+// Layout: the VALU form's (lane = 4 consecutive cells, hypothesis loop over an LDS tile of records; a wave store is 1 KiB of one error-image row).
+// --------------------------------------------------------------------------------------------------
+template <int HT, bool ERR, bool SOFT, bool UV>
+__global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __restrict__ poses, const float* __restrict__ xyz, const float* __restrict__ uv,
+                                                               float* __restrict__ err, float* __restrict__ soft_part, int N, int P, int W, int PT,
+                                                               float fx, float fy, float cx, float cy, float clampv, float kA, float kB, int Nf,
+                                                               long long xyz_stride, long long uv_stride) {
+    const int b = blockIdx.x;
+    const int q = b >> 3, PTG = (PT + 7) >> 3;
+    const int ht = q / PTG, pt = (q % PTG) * 8 + (b & 7);  // XCD-aware, pixel tiles innermost
+    if (pt >= PT) return;
+    const int h0 = ht * HT;
+    const int nh = min(HT, N - h0);
+    const int tid = threadIdx.x;
+    {
+        const int frame = h0 / Nf;
+        xyz += (long long)frame * xyz_stride;
+        if (UV) uv += (long long)frame * uv_stride;
+    }
+    __shared__ __attribute__((aligned(16))) double s_rec[HT * 12];
+    __shared__ float s_red[SOFT ? (K2_THREADS / 64) * HT : 1];
+    if (tid < nh) {  // record of hypothesis h0 + tid: [fx R0 | fx t0 ; fy R1 | fy t1 ; R2 | t2] in double
+        const double* ps = poses + (size_t)(h0 + tid) * 6;
+        double r[3] = {ps[0], ps[1], ps[2]}, R[9];
+        dm::rodrigues_v2m<false>(r, R, nullptr);
+        double* o = s_rec + tid * 12;
+        const double dfx = fx, dfy = fy;
+        o[0] = dfx * R[0]; o[1] = dfx * R[1]; o[2] = dfx * R[2]; o[3] = dfx * ps[3];
+        o[4] = dfy * R[3]; o[5] = dfy * R[4]; o[6] = dfy * R[5]; o[7] = dfy * ps[4];
+        o[8] = R[6]; o[9] = R[7]; o[10] = R[8]; o[11] = ps[5];
+    }
+    const int p0 = (pt * K2_THREADS + tid) * 4;
+    const bool valid = p0 < P;  // P % 4 == 0
+    double X[4], Y[4], Z[4], pu[4], pv[4];
+    if (valid) {
+        const f4* src = reinterpret_cast<const f4*>(xyz + (size_t)p0 * 3);
+        const f4 a = src[0], bb = src[1], c = src[2];
+        X[0] = a.x; Y[0] = a.y; Z[0] = a.z;
+        X[1] = a.w; Y[1] = bb.x; Z[1] = bb.y;
+        X[2] = bb.z; Y[2] = bb.w; Z[2] = c.x;
+        X[3] = c.y; Y[3] = c.z; Z[3] = c.w;
+        if (UV) {
+            const f4* su = reinterpret_cast<const f4*>(uv + (size_t)p0 * 2);
+            const f4 u0 = su[0], u1 = su[1];
+            pu[0] = (double)u0.x - (double)cx; pv[0] = (double)u0.y - (double)cy; pu[1] = (double)u0.z - (double)cx; pv[1] = (double)u0.w - (double)cy;
+            pu[2] = (double)u1.x - (double)cx; pv[2] = (double)u1.y - (double)cy; pu[3] = (double)u1.z - (double)cx; pv[3] = (double)u1.w - (double)cy;
+        } else {
+            const int y = p0 / W, x = p0 - y * W;  // 4 | W for the implicit grid of this form: the four cells share a row
+#pragma unroll
+            for (int k = 0; k < 4; k++) { pu[k] = (double)(x + k) - (double)cx; pv[k] = (double)y - (double)cy; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { X[k] = Y[k] = 0.0; Z[k] = 1.0; pu[k] = pv[k] = 0.0; }
+    }
+    __syncthreads();
+    float* erow = ERR ? err + (size_t)h0 * P + p0 : nullptr;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int h = 0; h < nh; h++) {
+        const double* sp = s_rec + h * 12;
+        const double a0 = sp[0], a1 = sp[1], a2 = sp[2], a3 = sp[3], b0 = sp[4], b1 = sp[5], b2 = sp[6], b3 = sp[7], c0 = sp[8], c1 = sp[9], c2 = sp[10], c3 = sp[11];
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double xc = fma(a0, X[k], fma(a1, Y[k], fma(a2, Z[k], a3)));
+            const double yc = fma(b0, X[k], fma(b1, Y[k], fma(b2, Z[k], b3)));
+            const double zc = fma(c0, X[k], fma(c1, Y[k], fma(c2, Z[k], c3)));
+            // 1 / zc in double: v_rcp_f32's 1-ulp seed, two Newton steps (2^-23 -> 2^-46 -> below double's rounding for this purpose); projectPoints: z = Z ? 1/Z : 1
+            double iz = (double)__builtin_amdgcn_rcpf((float)zc);
+            iz = fma(fma(-zc, iz, 1.0), iz, iz);
+            iz = fma(fma(-zc, iz, 1.0), iz, iz);
+            iz = (zc == 0.0) ? 1.0 : iz;
+            const float du = (float)fma(-xc, iz, pu[k]);  // cell position minus projection: one rounding to float, like the reference's Point2f difference
+            const float dv = (float)fma(-yc, iz, pv[k]);
+            e[k] = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
+        }
+        if (ERR && valid) __builtin_nontemporal_store(f4{e[0], e[1], e[2], e[3]}, reinterpret_cast<f4*>(erow + (size_t)h * P));
+        if (SOFT) {
+            const f2 s2 = soft_inlier2(f2{e[0], e[1]}, kA, kB) + soft_inlier2(f2{e[2], e[3]}, kA, kB);
+            const float s = wave_sum(valid ? s2.x + s2.y : 0.f);
+            if (lane == 0) s_red[wave * HT + h] = s;
+        }
+    }
+    if (SOFT) {
+        __syncthreads();
+        if (tid < nh) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < K2_THREADS / 64; w++) s += s_red[w * HT + tid];
+            soft_part[(size_t)pt * N + h0 + tid] = s;
+        }
+    }
+}
+
+template <int HT>
+static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* poses, const FrameDev& F, float clampv, float* err, float kA, float kB,
+                                        float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB) {
+    const int PT = (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4);
+    const int NTa = (N + HT - 1) / HT;
+    const int grid = ((PT + 7) / 8) * 8 * NTa;
+    if (tiles_used) *tiles_used = PT;
+    const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
+#define DSAC_K2P(E, S, U)                                                                                                                       \
+    hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
+                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride)
+    if (ERR && SOFT) { if (UV) DSAC_K2P(true, true, true); else DSAC_K2P(true, true, false); }
+    else if (ERR) { if (UV) DSAC_K2P(true, false, true); else DSAC_K2P(true, false, false); }
+    else if (SOFT) { if (UV) DSAC_K2P(false, true, true); else DSAC_K2P(false, true, false); }
+#undef DSAC_K2P
+    return hipGetLastError();
+}
+
 bool reproject_variant_known(int v) {
     return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77);
 }
@@ -918,6 +1041,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     // timing events (dsac_profile_enable): attached to the kernel's own dispatch (hipExtLaunchKernelGGL) instead of two event records on the
     // stream, which cost ~7 us of bubble each (one 640x480 frame: 100 us per step with them, 86 without)
     hipEvent_t evA = opts.ev_start, evB = opts.ev_stop;
+    // the precise form (k2_flags bit 25): needs the cv poses themselves, 16-byte vectors and -- on the implicit grid -- four cells of a lane in one row
+    if ((opts.flags & K2_FLAG_PRECISE) && opts.poses64 && vec && (F.uv || F.W % 4 == 0)) {
+        const double nhp = (double)N * (double)F.P;
+        // hypothesis tile by size as the VALU forms: 32 for big launches, 16 for a single small frame (more workgroups)
+        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, evA, evB)
+                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, evA, evB);
+    }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
 #define DSAC_VA(PX_, HT_, SP_) launch_reproject<PX_, HT_, SP_>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, pm, kf, evA, evB)

@@ -34,7 +34,9 @@ struct K2Opts {
     int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
     int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // per call: timing events attached to the K2 dispatch itself (profiling), else null
+    const double* poses64 = nullptr;  // per call: the cv poses (N x 6 doubles) the staged records were made from -- the precise form (flags bit 25) works from these
 };
+constexpr int K2_FLAG_PRECISE = 1 << 25;  // k2_flags: the fp64 projection of the reference (k_reproject_prec) instead of the fp32 matrix-core transform
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
 // Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of K2_NF_MULTIPLE = 128 then: no

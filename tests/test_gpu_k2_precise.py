@@ -1,0 +1,103 @@
+"""K2's PRECISE mode (round 5; dsac_set_option("k2_flags", 1 << 25)): the reference's own arithmetic -- the projection in double, one rounding to float
+of each image-plane difference (core/cnn_softam.h:319-362) -- instead of the fp32 matrix-core transform.  What it buys, against the oracle at the TIMED
+shapes: residuals within 2e-4 px (the fast forms: 5.9e-4 of the stated 1e-3) and softmax weights within the stated 1e-4 also in a tie,
+where the fast forms are asserted at 1e-3 only (tests/test_gpu_timed_configs.py)."""
+import numpy as np
+import pytest
+
+from conftest import excl_clamp_edge, margin
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+P = H * W
+TAU, BETA, SCALE, CLAMP = 10.0, 0.5, 0.1, 100.0
+PRECISE = 1 << 25
+
+
+@pytest.fixture()
+def precise_engine(engine):
+    engine.set_option("k2_variant", -1)
+    engine.set_option("k2_flags", PRECISE)
+    yield engine
+    engine.set_option("k2_flags", 0)
+
+
+def test_residuals_and_tied_weights_at_640x480(precise_engine, orc, synth):
+    eng = precise_engine
+    fr = synth.chess_like_frame(H, W, seed=1305 + 1000)
+    uv, cam = synth.pixel_grid(H, W), fr["cam"]
+    eng.set_frame(fr["xyz"], None, H, W, cam)
+    poses, sets, ok = eng.sample(256, seed=4711, thr=10.0, max_tries=1 << 16)
+    err, soft = np.zeros((256, P), np.float32), np.zeros(256)
+    eng.reproject(poses, err=err, soft=soft, tau=TAU, beta=BETA)
+    ref = orc.get_diff_maps(poses, fr["xyz"], uv, H, W, cam)
+    m = excl_clamp_edge(err, ref, CLAMP)
+    margin("a3", "K2 PRECISE mode, residuals at 640x480 x 256 hypotheses (all cells): max |err - oracle| px", np.abs(err - ref)[m].max(), 2e-4, stated=1e-3)
+    # the fast form on the same poses, for the record (asserted at 1e-3 elsewhere)
+    eng.set_option("k2_flags", 0)
+    err_f, soft_f = np.zeros((256, P), np.float32), np.zeros(256)
+    eng.reproject(poses, err=err_f, soft=soft_f, tau=TAU, beta=BETA)
+    eng.set_option("k2_flags", PRECISE)
+    fast = np.abs(err_f - ref)[excl_clamp_edge(err_f, ref, CLAMP)].max()
+    print("fast form on the same poses: %.2e px; precise: %.2e px" % (fast, np.abs(err - ref)[m].max()))
+    # scores: 307 200 sigmoids each.  The weights of two hypotheses in a tie move by w (1 - w) * scale * (error of their score DIFFERENCE) <= 0.25 * 0.1 * 2 max|d score|
+    soft_ref = orc.soft_inlier(ref, TAU, BETA)
+    ds = np.abs(soft - soft_ref).max()
+    margin("a4", "K2 PRECISE mode: bound on a softmax weight's error in a tie of ANY two of the 256 hypotheses (0.25 x scale x 2 max|score - oracle|), scale 0.1",
+           0.25 * SCALE * 2 * ds, 1e-4)
+    print("max |score - oracle|: precise %.2e, fast %.2e (scores ~%.0f)" % (ds, np.abs(soft_f - soft_ref).max(), soft_ref.max()))
+    # ... and the constructed tie of tests/test_gpu_timed_configs.py at the STATED tolerance
+    best = int(np.argmax(soft))
+    tie = poses.copy()
+    tie[(best + 1) % 256] = poses[best] + np.array([1e-9, -1e-9, 1e-9, 1e-6, 1e-6, -1e-6])
+    s2 = eng.softInlierScores(tie, tau=TAU, beta=BETA)
+    w, _, _ = eng.softMax(s2, SCALE)
+    s2_ref = orc.soft_inlier(orc.get_diff_maps(tie, fr["xyz"], uv, H, W, cam), TAU, BETA)
+    w_ref = orc.softMax(SCALE * s2_ref)
+    assert np.sort(w_ref)[-2] > 0.2
+    margin("a4", "K2 PRECISE mode: softmax weights at 640x480 in a TIE of the two best hypotheses, scale 0.1: max |w - oracle|", np.abs(w - w_ref).max(), 1e-4)
+
+
+def test_bench_shape_and_every_entry_point(precise_engine, orc, synth):
+    """16 frames x 256 hypotheses through dsac_score_hypotheses_frames, dsac_process_images and the begin / finish pair with the flag set: one kernel, the
+    same error images bit for bit; sampled rows within 2e-4 px of the oracle."""
+    import torch
+    eng = precise_engine
+    dev = torch.device("cuda", 0)
+    F, N = 16, 256
+    frames = [synth.chess_like_frame(H, W, seed=1305 + 1000 + f) for f in range(F)]
+    xyz = torch.from_numpy(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))).to(dev)
+    cam, uv = frames[0]["cam"], synth.pixel_grid(H, W)
+    eng.set_frames(xyz, None, H, W, cam, borrow=True)
+    f64 = dict(dtype=torch.float64, device=dev)
+    err = torch.empty(F * N, P, dtype=torch.float32, device=dev)
+    out = (torch.zeros(F * N, 6, **f64), torch.zeros(F * N, 4, dtype=torch.int32, device=dev), torch.zeros(F * N, dtype=torch.uint8, device=dev), torch.zeros(F * N, **f64),
+           torch.zeros(F * N, **f64), torch.zeros(F, **f64), torch.zeros(F, 6, **f64))
+    eng.profile_enable(True, stride=1)
+    eng.scoreHypothesesFrames(N, seed=4711, thr=10.0, max_tries=1 << 16, err=err, out=out)
+    eng.synchronize()
+    ms, n = eng.profile_read(0, reset=True)
+    eng.profile_enable(False)
+    ph, sf = out[0].cpu().numpy(), out[3].cpu().numpy()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for f in range(0, F, 3):
+        rows = f * N + rng.choice(N, 6, replace=False)
+        got = err[torch.as_tensor(rows, device=dev)].cpu().numpy()
+        ref = orc.get_diff_maps(ph[rows], frames[f]["xyz"], uv, H, W, cam)
+        m = excl_clamp_edge(got, ref, CLAMP)
+        worst = max(worst, np.abs(got - ref)[m].max())
+    margin("a3", "K2 PRECISE mode at the bench shape (16 x 256 x 640x480, sampled rows): max |err - oracle| px", worst, 2e-4, stated=1e-3)
+    print("precise K2 at the bench shape: %.1f us per launch" % (ms * 1e3))
+    # the other entry points launch the same kernel on the same poses
+    err2 = torch.empty(F * N, P, dtype=torch.float32, device=dev)
+    soft2 = torch.zeros(F * N, **f64)
+    p2 = (torch.zeros(F * N, 6, **f64), torch.zeros(F * N, 4, dtype=torch.int32, device=dev), torch.zeros(F * N, dtype=torch.uint8, device=dev))
+    eng.processImagesBegin(N, err2, seed=4711, thr=10.0, max_tries=1 << 16, soft=soft2, out=p2)
+    eng.synchronize()
+    assert torch.equal(p2[0], out[0]) and torch.equal(err2, err) and torch.equal(soft2, out[3])
+    err2.zero_()
+    eng.reproject(out[0], N=F * N, err=err2)
+    eng.synchronize()
+    assert torch.equal(err2, err)
