@@ -324,7 +324,7 @@ def host_driver_leg(N, H, W, device=0, images=64, batch=16, passes=6):
         return res
 
 
-def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_world=0, emulate_rank=0, err_buffer=None):
+def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_world=0, emulate_rank=0, err_buffer=None, engine=None, stream=None):
     """north_star's multi-GPU claim inside the command the driver runs: BASELINE.json configs[3] -- 64 images x --hyps hypotheses FIXED, sharded round-robin
     over the ranks (core/test_ransac_softam.cpp:97-230: independent images), every image through the whole processImage, the 64 x (10 + N) result rows
     exchanged with ONE all_gather_into_tensor per step over RCCL inside the timed region (dsac_amd.shard.ShardRunner).  Returns the `strong` object of
@@ -347,8 +347,11 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
         return {"refused": "the ranks did not join an RCCL process group (backend %s%s): no strong-scaling measurement" %
                            (backend, ("; " + BACKEND_NOTE) if BACKEND_NOTE else "")} if rank == 0 else None
     dev = torch.device("cuda", local_rank)
-    st = torch.cuda.Stream(device=dev)
-    eng = dsac_amd.Engine(local_rank, stream=st)
+    # the engine (and stream) of the weak run when the caller has one: a SECOND engine in the process measured 15-25 % slower steps (4.41 / 0.62 ms against
+    # 3.82 / 0.51 for the same runner on the first engine, gpurun_out/r05b) -- its tail stream did not overlap its main stream; not isolated further
+    own_engine = engine is None
+    st = stream if stream is not None else torch.cuda.Stream(device=dev)
+    eng = engine if engine is not None else dsac_amd.Engine(local_rank, stream=st)
     cam = synth.chess_like_frame(8, 8, seed=1)["cam"]
     perm3 = torch.from_numpy(synth.fast_permutations(P, 8)).to(dev)
     cache = {}
@@ -452,7 +455,8 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
         em.close()
     elif rank == 0:
         out = {"workload": "BASELINE.json configs[3] on one GPU", "ranks_joined": 1, "one_gpu_ms": one_s * 1e3, "steps": K}
-    eng.close()
+    if own_engine:
+        eng.close()
     return out
 
 
@@ -1280,7 +1284,9 @@ def main(argv=None):
         for b_ in bufs[1:]:
             b_["err"] = None  # the leg's runners write into the first context's error-image buffer; drop the others
         strong = strong_scaling_leg(args, rank, local_rank, world, backend, dist if distributed else None, emulate_world=args.emulate_world,
-                                    emulate_rank=args.emulate_rank, err_buffer=bufs[0]["err"] if (batched and bufs[0]["err"] is not None) else None)
+                                    emulate_rank=args.emulate_rank, err_buffer=bufs[0]["err"] if (batched and bufs[0]["err"] is not None) else None,
+                                    engine=engines[0][0], stream=engines[0][1])
+        engines[0][0].profile_read(0, reset=True)
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

@@ -881,11 +881,23 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
 // the matrix-core form (priced), hidden only in part by the store schedule -- a parity mode, not the default.
 // Layout: the VALU form's (lane = 4 consecutive cells, hypothesis loop over an LDS tile of records; a wave store is 1 KiB of one error-image row).
 // --------------------------------------------------------------------------------------------------
+DM_INLINE f2 soft_inlier2_hl(f2 e, float kA, float kAl, float kB, float kBl) {
+    const f2 t = pk_fma(splat(kA), e, splat(kB)) + pk_fma(splat(kAl), e, splat(kBl));
+    f2 ex;
+    ex.x = __builtin_amdgcn_exp2f(t.x);
+    ex.y = __builtin_amdgcn_exp2f(t.y);
+    const f2 d = ex + splat(1.0f);
+    f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return pk_fma(pk_fma(-d, r, splat(1.0f)), r, r);
+}
+
 template <int HT, bool ERR, bool SOFT, bool UV>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __restrict__ poses, const float* __restrict__ xyz, const float* __restrict__ uv,
                                                                float* __restrict__ err, float* __restrict__ soft_part, int N, int P, int W, int PT,
                                                                float fx, float fy, float cx, float cy, float clampv, float kA, float kB, int Nf,
-                                                               long long xyz_stride, long long uv_stride) {
+                                                               long long xyz_stride, long long uv_stride, float kAl, float kBl) {
     const int b = blockIdx.x;
     const int q = b >> 3, PTG = (PT + 7) >> 3;
     const int ht = q / PTG, pt = (q % PTG) * 8 + (b & 7);  // XCD-aware, pixel tiles innermost
@@ -899,7 +911,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
         if (UV) uv += (long long)frame * uv_stride;
     }
     __shared__ __attribute__((aligned(16))) double s_rec[HT * 12];
-    __shared__ float s_red[SOFT ? (K2_THREADS / 64) * HT : 1];
+    __shared__ double s_red[SOFT ? (K2_THREADS / 64) * HT : 1];
     if (tid < nh) {  // record of hypothesis h0 + tid: [fx R0 | fx t0 ; fy R1 | fy t1 ; R2 | t2] in double
         const double* ps = poses + (size_t)(h0 + tid) * 6;
         double r[3] = {ps[0], ps[1], ps[2]}, R[9];
@@ -946,9 +958,9 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
             const double xc = fma(a0, X[k], fma(a1, Y[k], fma(a2, Z[k], a3)));
             const double yc = fma(b0, X[k], fma(b1, Y[k], fma(b2, Z[k], b3)));
             const double zc = fma(c0, X[k], fma(c1, Y[k], fma(c2, Z[k], c3)));
-            // 1 / zc in double: v_rcp_f32's 1-ulp seed, two Newton steps (2^-23 -> 2^-46 -> below double's rounding for this purpose); projectPoints: z = Z ? 1/Z : 1
+            // 1 / zc in double: v_rcp_f32's seed (1 ulp, 2^-23) and one Newton step (2^-46: a relative 1.4e-14, i.e. 6e-12 px at the image border -- far
+            // below the float the difference is rounded to); projectPoints: z = Z ? 1/Z : 1
             double iz = (double)__builtin_amdgcn_rcpf((float)zc);
-            iz = fma(fma(-zc, iz, 1.0), iz, iz);
             iz = fma(fma(-zc, iz, 1.0), iz, iz);
             iz = (zc == 0.0) ? 1.0 : iz;
             const float du = (float)fma(-xc, iz, pu[k]);  // cell position minus projection: one rounding to float, like the reference's Point2f difference
@@ -957,33 +969,43 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
         }
         if (ERR && valid) __builtin_nontemporal_store(f4{e[0], e[1], e[2], e[3]}, reinterpret_cast<f4*>(erow + (size_t)h * P));
         if (SOFT) {
-            const f2 s2 = soft_inlier2(f2{e[0], e[1]}, kA, kB) + soft_inlier2(f2{e[2], e[3]}, kA, kB);
-            const float s = wave_sum(valid ? s2.x + s2.y : 0.f);
+            // the sums in double from the lane's four sigmoids on: an fp32 tile sum (<= 1024) is rounded to 6e-5, and 300 such tiles put ~1e-3 on a score of
+            // ~2e4 -- 2e-4 on a softmax weight in a tie, twice the stated 1e-4
+            // ... and the sigmoid without the systematic part of its fp32 error: the exponent from (high, low) pairs of the two constants (a rounded kA / kB shifts
+            // every cell's exponent the same way: ~1e-3 on a score), the reciprocal polished by one Newton step
+            const f2 s2 = soft_inlier2_hl(f2{e[0], e[1]}, kA, kAl, kB, kBl) + soft_inlier2_hl(f2{e[2], e[3]}, kA, kAl, kB, kBl);
+            double s = valid ? (double)s2.x + (double)s2.y : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             if (lane == 0) s_red[wave * HT + h] = s;
         }
     }
     if (SOFT) {
         __syncthreads();
         if (tid < nh) {
-            float s = 0.f;
+            double s = 0.0;
 #pragma unroll
             for (int w = 0; w < K2_THREADS / 64; w++) s += s_red[w * HT + tid];
-            soft_part[(size_t)pt * N + h0 + tid] = s;
+            // the partial rows are floats: the tile's sum travels as a (high, low) pair of rows, which the fp64 reduction adds back together
+            const float hi = (float)s;
+            soft_part[(size_t)pt * N + h0 + tid] = hi;
+            soft_part[(size_t)(PT + pt) * N + h0 + tid] = (float)(s - (double)hi);
         }
     }
 }
 
 template <int HT>
-static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* poses, const FrameDev& F, float clampv, float* err, float kA, float kB,
+static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* poses, const FrameDev& F, float clampv, float* err, double kAd, double kBd,
                                         float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB) {
+    const float kA = (float)kAd, kB = (float)kBd, kAl = (float)(kAd - (double)kA), kBl = (float)(kBd - (double)kB);
     const int PT = (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4);
     const int NTa = (N + HT - 1) / HT;
     const int grid = ((PT + 7) / 8) * 8 * NTa;
-    if (tiles_used) *tiles_used = PT;
+    if (tiles_used) *tiles_used = 2 * PT;  // a (high, low) pair of partial rows per pixel tile; 2 ceil(P / 1024) <= reproject_num_pixel_tiles(P)
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2P(E, S, U)                                                                                                                       \
     hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
-                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride)
+                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl)
     if (ERR && SOFT) { if (UV) DSAC_K2P(true, true, true); else DSAC_K2P(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2P(true, false, true); else DSAC_K2P(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2P(false, true, true); else DSAC_K2P(false, true, false); }
@@ -1044,9 +1066,10 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     // the precise form (k2_flags bit 25): needs the cv poses themselves, 16-byte vectors and -- on the implicit grid -- four cells of a lane in one row
     if ((opts.flags & K2_FLAG_PRECISE) && opts.poses64 && vec && (F.uv || F.W % 4 == 0)) {
         const double nhp = (double)N * (double)F.P;
+        const double kAd = (double)beta * 1.4426950408889634, kBd = -(double)beta * (double)tau * 1.4426950408889634;
         // hypothesis tile by size as the VALU forms: 32 for big launches, 16 for a single small frame (more workgroups)
-        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, evA, evB)
-                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, evA, evB);
+        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB)
+                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB);
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost

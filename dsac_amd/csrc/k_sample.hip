@@ -521,7 +521,10 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4 && o.wide == 4 && N <= 256)
             hipLaunchKernelGGL((k_sample_wide<4>), dim3(N), dim3(256), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4 && o.wide != 0 && N <= 512 && (o.wide < 0 || o.wide == 2))
-            hipLaunchKernelGGL((k_sample_wide<2>), dim3(N), dim3(128), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
+            // 56 KiB of unused dynamic LDS per two-wave workgroup: at most two workgroups per CU = one wave per SIMD.  Since round 5 the kernel needs 232
+            // registers (no hoisted libm constants), two of its waves fit a SIMD -- and the dispatcher then packs up to 512 hypotheses x 2 waves onto half
+            // the chip: 16.1 against 12.1 us at N = 512 (profiles/r05_k1_licm_ab.txt).  With few hypotheses every wave wants a SIMD of its own
+            hipLaunchKernelGGL((k_sample_wide<2>), dim3(N), dim3(128), 56 * 1024, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else if (o.rl == 1 && H2 == 1 && o.minw < 2 && wpb < 4) hipLaunchKernelGGL((k_sample<1, 1, false, 1, 1>), dim3(N), dim3(64), 0, st, N, seed, F, thr_int, max_tries, poses, sets_out, ok, staged, prio, NfK);
         else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }
 #undef DSAC_K1

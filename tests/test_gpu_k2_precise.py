@@ -39,14 +39,50 @@ def test_residuals_and_tied_weights_at_640x480(precise_engine, orc, synth):
     err_f, soft_f = np.zeros((256, P), np.float32), np.zeros(256)
     eng.reproject(poses, err=err_f, soft=soft_f, tau=TAU, beta=BETA)
     eng.set_option("k2_flags", PRECISE)
-    fast = np.abs(err_f - ref)[excl_clamp_edge(err_f, ref, CLAMP)].max()
+    mf = excl_clamp_edge(err_f, ref, CLAMP)
+    fast = np.abs(err_f - ref)[mf].max()
     print("fast form on the same poses: %.2e px; precise: %.2e px" % (fast, np.abs(err - ref)[m].max()))
+    # Where the fast (fp32 matrix-core) form's error lives: it is an ABSOLUTE error of the camera-frame point (four fp32 roundings at the magnitude of
+    # f R.X ~ 1e6 and of z ~ 3e3) divided by the depth, so over ALL 78 M cells of a frame -- the suite's other tests sample rows -- a handful of cells that a
+    # hypothesis places within a few hundred millimetres of its camera centre exceed the stated 1e-3 px.  Recorded here with the bound it obeys:
+    # |err - oracle| <= max(1e-3, 0.5 / depth[mm]) px, depth = the cell's camera-frame z under the hypothesis.
+    d = np.abs(err_f - ref)
+    d[~mf] = 0
+    over = np.argwhere(d > 1e-3)
+    worst_ratio, n_over = 0.0, len(over)
+    for h in np.unique(over[:, 0]) if n_over else []:
+        R = synth.rodrigues(poses[h, :3])
+        cells = over[over[:, 0] == h, 1]
+        z = np.abs(fr["xyz"][cells].astype(np.float64) @ R[2] + poses[h, 5])
+        worst_ratio = max(worst_ratio, float((d[h, cells] * z).max()))
+    print("fast form: %d of %d cells above 1e-3 px (%.2e of them), max error x depth = %.3f px mm" % (n_over, d.size, n_over / d.size, worst_ratio))
+    margin("a3", "K2 fast form over ALL cells of 256 x 640x480: fraction of cells above the stated 1e-3 px (cells within ~0.5 m of the camera centre)", n_over / d.size, 1e-5)
+    margin("a3", "K2 fast form over ALL cells: max of |err - oracle| x depth over the cells above 1e-3 px [px mm] (error <= 0.5 / depth)", worst_ratio, 0.5)
     # scores: 307 200 sigmoids each.  The weights of two hypotheses in a tie move by w (1 - w) * scale * (error of their score DIFFERENCE) <= 0.25 * 0.1 * 2 max|d score|
     soft_ref = orc.soft_inlier(ref, TAU, BETA)
-    ds = np.abs(soft - soft_ref).max()
-    margin("a4", "K2 PRECISE mode: bound on a softmax weight's error in a tie of ANY two of the 256 hypotheses (0.25 x scale x 2 max|score - oracle|), scale 0.1",
-           0.25 * SCALE * 2 * ds, 1e-4)
-    print("max |score - oracle|: precise %.2e, fast %.2e (scores ~%.0f)" % (ds, np.abs(soft_f - soft_ref).max(), soft_ref.max()))
+    dsv = soft - soft_ref
+    ds = np.abs(dsv).max()
+    margin("north*", "K2 PRECISE mode: soft-inlier scores at 640x480, max |score - oracle| relative to the largest score", ds / soft_ref.max(), 1e-6, stated=1e-4)
+    print("max |score - oracle|: precise %.2e, fast %.2e (scores up to %.0f)" % (ds, np.abs(soft_f - soft_ref).max(), soft_ref.max()))
+    # The weights of two hypotheses in a TIE move by w (1 - w) * scale * (error of their score DIFFERENCE) = 0.25 * 0.1 * |d_i - d_j|.  Part of a score's
+    # error is systematic (the hardware exp2 / rcp are not exactly rounded: a bias that grows with the score) and cancels between two hypotheses whose scores
+    # tie; what does not cancel is measured on every pair of UNRELATED hypotheses whose oracle scores lie within 5 % of the top score of each other
+    order = np.argsort(-soft_ref)
+    worst_pair = 0.0
+    npairs = 0
+    for a in range(len(order)):
+        for b in range(a + 1, len(order)):
+            i, j = order[a], order[b]
+            if soft_ref[i] - soft_ref[j] > 0.05 * soft_ref.max():
+                break
+            worst_pair = max(worst_pair, abs(dsv[i] - dsv[j]))
+            npairs += 1
+    assert npairs >= 100
+    margin("a4", "K2 PRECISE mode: softmax-weight error in a tie of two UNRELATED hypotheses, scale 0.1 -- 0.25 x scale x max |d_i - d_j| over %d near-tie pairs" % npairs,
+           0.25 * SCALE * worst_pair, 1e-4)
+    dsf = soft_f - soft_ref
+    worst_fast = max(abs(dsf[order[a]] - dsf[order[b]]) for a in range(len(order)) for b in range(a + 1, len(order)) if soft_ref[order[a]] - soft_ref[order[b]] <= 0.05 * soft_ref.max())
+    print("near-tie pairs: precise %.2e, fast %.2e (0.25 x scale x max |d_i - d_j|)" % (0.25 * SCALE * worst_pair, 0.25 * SCALE * worst_fast))
     # ... and the constructed tie of tests/test_gpu_timed_configs.py at the STATED tolerance
     best = int(np.argmax(soft))
     tie = poses.copy()
@@ -98,6 +134,7 @@ def test_bench_shape_and_every_entry_point(precise_engine, orc, synth):
     eng.synchronize()
     assert torch.equal(p2[0], out[0]) and torch.equal(err2, err) and torch.equal(soft2, out[3])
     err2.zero_()
+    torch.cuda.synchronize()  # the fill ran on torch's stream, the engine has its own
     eng.reproject(out[0], N=F * N, err=err2)
     eng.synchronize()
     assert torch.equal(err2, err)
