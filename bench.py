@@ -1107,10 +1107,31 @@ def main(argv=None):
         eng.synchronize()
         e1 = min(e1, time.perf_counter() - t1)
         eng.profile_enable(True, stride=1)
+        # ... and the same loop with the score tail of frame i beside K1 of frame i + 1 ("pi_defer_tail" 2, alternating result arrays)
+        b2 = bufs[1] if len(bufs) > 1 else {k_: (torch.zeros_like(v_) if k_ != "err" else v_) for k_, v_ in b.items()}
+
+        def one_d(i):
+            bb = b2 if (i & 1) else b
+            eng.scoreHypotheses(N, seed=seed_of(i), thr=10.0, max_tries=1 << 16, clamp=100.0, tau=10.0, beta=0.5, scale=0.1, err=b["err"][:N],
+                                out=(bb["poses"][:N], bb["sets"][:N], bb["ok"][:N], bb["soft"][:N], bb["w"][:N], bb["ent"][:1], bb["avg"][0]))
+        eng.profile_enable(False)
+        eng.set_option("pi_defer_tail", 2)
+        for i in range(20):
+            one_d(i)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n1):
+            one_d(20 + i)
+        eng.synchronize()
+        e1d = time.perf_counter() - t1
+        eng.set_option("pi_defer_tail", 0)
+        eng.profile_enable(True, stride=1)
         k2_1 = ms1 / max(1, c1) * 1e-3
         ab1 = algorithmic_bytes_k2(N, P, explicit_uv=False)
         single = {"workload": "BASELINE.json configs[1] literally: ONE %dx%d frame x %d hypotheses per step (K1 -> K2 -> K3, one context, no overlap)" % (W, H, N),
                   "value": N * n1 / e1, "unit": "hyp/s", "steps": n1, "us_per_frame": e1 / n1 * 1e6,
+                  "score_tail_under_the_next_frame": {"value": N * n1 / e1d, "unit": "hyp/s", "us_per_frame": e1d / n1 * 1e6,
+                                                      "what": "the same loop with dsac_set_option(pi_defer_tail, 2): reduction + K3 of frame i beside K1 of frame i + 1"},
                   "roofline": {"kernel": "k_reproject (K2)", "achieved": ab1 / k2_1 / 1e9 if k2_1 > 0 else 0.0, "unit": "GB/s",
                                "frac": (ab1 / k2_1 / 1e9 / HBM_PEAK_GBS) if k2_1 > 0 else 0.0, "avg_launch_us": k2_1 * 1e6, "launches_timed": c1,
                                "algorithmic_bytes_per_launch": ab1}}

@@ -646,7 +646,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     // leave the chip idle while they run in order) goes to the tail stream, K1 of the NEXT call follows K2 of this one without a gap -- the contract of
     // dsac_process_images' mode 2: scores / w / entropy / avg6 (and poses / sets / ok, which K3 reads) are complete after dsac_join_tail / another entry
     // point / dsac_synchronize, consecutive calls are given different arrays (the error images may be the same buffer: only K2 touches them)
-    const bool want_defer = Nf > 0 && c->pi_defer_tail == 2 && !sets_or_null;
+    const bool want_defer = c->pi_defer_tail == 2 && !sets_or_null;  // frame batches and (since the single-frame loop of configs[1] pays the same tail) one frame alike
     begin_call(c, /*keep_tail=*/want_defer);
     const size_t P = (size_t)c->F.P;
     const int32_t* d_sets_in;
@@ -702,7 +702,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
         if (c->pi_tail_of[b] >= 0 && c->pi_tail_of[b] != tk) HIP_TRY(c, hipStreamWaitEvent(ts, c->tail_done[c->pi_tail_of[b]], 0));
         c->pi_tail_of[b] = tk;
         HIP_TRY(c, hipStreamWaitEvent(ts, k2_done, 0));
-        HIP_TRY(c, score_tail(ts, Nf, frames, used_d, part.as<float>(), d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg));
+        HIP_TRY(c, score_tail(ts, Nf > 0 ? Nf : N, frames, used_d, part.as<float>(), d_scores, scale, d_w, d_ent, avg6_or_null ? d_poses : nullptr, d_avg));
         HIP_TRY(c, hipEventRecord(c->pi_scored[b], ts));
         c->pi_scored_rec[b] = true;
         HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));

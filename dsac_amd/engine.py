@@ -619,6 +619,40 @@ class Engine:
                        tErr=float(L["tErr"][hyp_idx]), correct=bool(L["correct"][hyp_idx]))
         return out
 
+    def processImagesDSAC(self, hyps_per_frame, perm, gt_jp6, seed=1305, u=None, thr=10.0, max_tries=1 << 20, inlierCount=100, minInliers=50, tau=10.0, beta=0.5,
+                          alpha=0.1, want_inlier_maps=True, want_gradients=True):
+        """Forward pass of the DSAC variant's processImage (core/cnn.h:1000-1240) for EVERY frame set with set_frames, device-resident, one launch per
+        stage: K1 + K2 (soft-inlier scores) of all frames, K3 per frame, the refinement of ALL F * N hypotheses in one launch (dsac_refine_all: F * N waves --
+        SURVEY.md 8(f)1), their losses against each frame's ground truth (dsac_loss_batch_frames), selection / expected loss / dSMScore per frame
+        (dsac_select_frames; u: F draws in [0, 1) or None for the most probable hypothesis).  perm / gt_jp6: device tensors or arrays.  Returns a dict of
+        torch device tensors."""
+        import torch
+        F, N = getattr(self, "frames", 1), int(hyps_per_frame)
+        dev = torch.device("cuda", self.device)
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(self.stream), device=dev)):
+            f64 = dict(dtype=torch.float64, device=dev)
+            perm_d = perm if hasattr(perm, "data_ptr") else torch.as_tensor(np.ascontiguousarray(perm, dtype=np.int32), device=dev)
+            gt_d = gt_jp6 if hasattr(gt_jp6, "data_ptr") else torch.as_tensor(np.ascontiguousarray(np.asarray(gt_jp6, dtype=np.float64).reshape(F, 6)), device=dev)
+            u_d = torch.full((F,), -1.0, **f64) if u is None else torch.as_tensor(np.ascontiguousarray(u, dtype=np.float64).reshape(F), device=dev)
+            hyps, sets, ok = torch.zeros(F * N, 6, **f64), torch.zeros(F * N, 4, dtype=torch.int32, device=dev), torch.zeros(F * N, dtype=torch.uint8, device=dev)
+            soft, w, ent = torch.zeros(F * N, **f64), torch.zeros(F * N, **f64), torch.zeros(F, **f64)
+            ref, sd = torch.zeros(F * N, 6, **f64), torch.zeros(F * N, dtype=torch.int32, device=dev)
+            maps = torch.zeros(F * N, self.P, dtype=torch.int32, device=dev) if want_inlier_maps else None
+            out4 = torch.zeros(F * N, 4, **f64)
+            idx, eloss = torch.zeros(F, dtype=torch.int32, device=dev), torch.zeros(F, **f64)
+            g = torch.zeros(F * N, **f64) if want_gradients else None
+            ctx = self._ctx
+            check(ctx, lib.dsac_process_images_begin(ctx, N, int(seed) & 0xFFFFFFFFFFFFFFFF, float(thr), int(max_tries), float(CNN_OBJ_MAXINPUT), float(tau), float(beta),
+                                                     ptr(hyps), ptr(sets), ptr(ok), None, ptr(soft)))
+            check(ctx, lib.dsac_softmax_frames(ctx, F, N, ptr(soft), float(alpha), ptr(w), ptr(ent), None, None))
+            check(ctx, lib.dsac_refine_all(ctx, F * N, ptr(hyps), ptr(perm_d), int(perm_d.shape[0]), int(inlierCount), int(minInliers), float(int(thr)), ptr(sets), ptr(ref),
+                                           ptr(maps), ptr(sd)))
+            check(ctx, lib.dsac_loss_batch_frames(ctx, F, N, ptr(ref), ptr(gt_d), ptr(out4), None))
+            check(ctx, lib.dsac_select_frames(ctx, F, N, ptr(w), ptr(out4), 4, ptr(u_d), ptr(idx), ptr(eloss), ptr(g)))
+        self._keep_dsac = (perm_d, gt_d, u_d)
+        return dict(hyps=hyps, sampledPoints=sets, ok=ok, scores=soft, score_scale=alpha, sfScores=w, sfEntropy=ent, refHyps=ref, refSteps=sd, inlierMaps=maps, out4=out4,
+                    hypIdx=idx, expectedLoss=eloss, scoreOutputGradients=g)
+
     def backwardDSAC(self, fwd, gt_jp6, d_scores_fn=None, thr=10.0, inlierCount=100, minInliers=50, tau=10.0, beta=0.5, sub_sample=0.01, min_prob=1e-4):
         """Backward section of the DSAC trainer (core/train_ransac.cpp:303-399): dE[loss]/d(scene coordinates), P x 3.
         Path I: sum_h w_h dLossMax(ref_h) . dRefine_h (hypotheses with w_h <= 1e-4 skipped, :318); path II: dSMScore (core/cnn.h:

@@ -171,7 +171,7 @@ DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const 
  * Frame f draws from the stream of seed + f, so the result equals `frames` single-frame calls with seeds seed, seed + 1, ...
  * hyps_per_frame must be a multiple of 128.  Outputs are frame-major: poses / sets_out / ok / scores / w [frames][hyps_per_frame],
  * err [frames*hyps_per_frame][H*W], entropy [frames], avg6 [frames][6].
- * With dsac_set_option("pi_defer_tail", 2) and device-resident arguments the score tail (reduction of the per-tile sums, K3) runs on the tail stream
+ * With dsac_set_option("pi_defer_tail", 2) and device-resident arguments (dsac_score_hypotheses without given sets as well) the score tail (reduction of the per-tile sums, K3) runs on the tail stream
  * beside K1 of the NEXT call, which follows this call's K2 without a gap (the two small launches otherwise leave the chip idle: 12 of 946 us per
  * 16-frame step).  The contract is dsac_process_images' mode 2: everything but the error images is ordered on the context's stream only after
  * dsac_join_tail / another entry point / dsac_synchronize, and consecutive calls are given different arrays for poses / sets_out / ok / scores / w /

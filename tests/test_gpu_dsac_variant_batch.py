@@ -85,3 +85,30 @@ def test_dsac_variant_on_a_frame_batch_equals_single_frame_calls(engine, orc, sy
     with pytest.raises(Exception):
         check(ctx, lib.dsac_refine_fd_sets_frames(ctx, len(sel2), ptr(np.ascontiguousarray(sets[sel2])), ptr(bad), ptr(perm), 8, 100, 50, 10.0,
                                                   ptr(np.ascontiguousarray(maps_b[sel2])), 0.05, 2.0, ptr(Js3), ptr(px3), ptr(Jo3), cap, ptr(n3)))
+
+
+def test_device_resident_dsac_forward_of_a_frame_batch(engine, orc, synth):
+    """Engine.processImagesDSAC (F images per launch chain, everything in HBM) against the per-image, host-orchestrated Engine.processImageDSAC: same
+    hypotheses and minimal sets bit for bit, the same refined hypotheses, selection and expected loss up to the fp32 rounding of the soft-inlier scores
+    (the batch scores with K1's own staged records, the per-image path re-stages the poses through dsac_reproject)."""
+    H, W, F, N = 40, 40, 3, 128
+    frames = [synth.chess_like_frame(H, W, seed=1500 + f, quantise_int16=True) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv, cam = frames[0]["uv"], frames[0]["cam"]
+    perm = synth.fast_permutations(H * W, 8)
+    gts = np.stack([orc.cv_to_jp6(fr["gt_pose"] + np.array([0.01, -0.02, 0.01, 5.0, -8.0, 12.0])) for fr in frames])
+    u = np.array([0.25, 0.6, 0.9])
+    engine.set_frames(xyz, uv, H, W, cam)
+    b = engine.processImagesDSAC(N, perm, gts, seed=70, u=u)
+    engine.synchronize()
+    b = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in b.items()}
+    for f in range(F):
+        engine.set_frame(xyz[f], uv, H, W, cam)
+        s = engine.processImageDSAC(N=N, seed=70 + f, perm=perm, gt_jp6=gts[f], draw_u=float(u[f]))
+        sl = slice(f * N, (f + 1) * N)
+        assert np.array_equal(b["hyps"][sl], s["hyps"]) and np.array_equal(b["sampledPoints"][sl], s["sampledPoints"])
+        assert np.array_equal(b["refHyps"][sl], s["refHyps"]) and np.array_equal(b["refSteps"][sl], s["refSteps"]) and np.array_equal(b["inlierMaps"][sl], s["inlierMaps"])
+        assert np.array_equal(b["out4"][sl, 0], s["losses"])
+        assert np.abs(b["sfScores"][sl] - s["sfScores"]).max() <= 1e-5
+        assert abs(b["expectedLoss"][f] - s["expectedLoss"]) <= 1e-4 * max(1.0, abs(s["expectedLoss"]))
+        assert np.abs(b["scoreOutputGradients"][sl] - s["scoreOutputGradients"]).max() <= 1e-4 * max(1.0, np.abs(s["scoreOutputGradients"]).max())
