@@ -224,6 +224,8 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
     for (int k = 0; k < NP; k++) { gxy[k] = f2{0.f, 0.f}; gz[k] = 0.f; }
 
     float* gout = G12_part + ((size_t)(pt * (K4_THREADS / 64) + wave) * N + h0) * 12;
+    // which of the 12 per-hypothesis sums this lane holds after wave_sum12 (-1: none)
+    const int gslot = ((lane & 12) == 0 && (lane & 3) != 3) ? 6 * (lane >> 5) + 3 * ((lane >> 4) & 1) + ((lane & 3) == 0 ? 0 : (lane & 3) == 2 ? 1 : 2) : -1;
     for (int h = 0; h < nh; h++) {
         // all sign bookkeeping and pairing was done once per hypothesis in k_backward_prep: the loop below has no negations
         // (on packed operands they cost register moves), (E.x, -E.y) yields (du, dv) and (C0, -C1, -C2) directly, the accumulators
@@ -233,13 +235,8 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
         const f2 c0 = {q0.x, q0.y}, c1 = {q0.z, q0.w}, c2 = {q1.x, q1.y}, c3 = {q1.z, q1.w};
         const f2 r0xy = {q3.x, q3.y}, nr1xy = {q3.z, q3.w}, nr2xy = {q4.x, q4.y};
         const float r0z = q4.z, nr1z = q4.w, nr2z = q5.x;
-        // The 12 sums of the hypothesis over this lane's cells, in DOUBLE since round 5: G[3 i + c] = sum C_i X_c, G[9 + i] = sum C_i.  The products of a
-        // coefficient with raw coordinates (thousands of millimetres) nearly cancel over the image for some hypotheses; accumulated in fp32 (per lane, then
-        // six fp32 levels of the wave reduction) one hypothesis in 128 of the 640 x 480 test case came out at 2.6e-3 of its largest sum, beyond the stated
-        // 1e-3 (tests/test_gpu_backward_big.py).  This form is the fallback for maps that cannot be read as 16-byte vectors: accuracy before speed.
-        double Gd[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) Gd[k] = 0.0;
+        // G pairs: Ga[i] = C_i * (X, Y)  ;  Gb[i] = C_i * (Z, 1)
+        f2 Ga[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}}, Gb[3] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < PXG; j++) {
             float wv[PXL];
@@ -287,30 +284,14 @@ __global__ __launch_bounds__(K4_THREADS) void k_score_backward(const float* __re
                 const float nC2 = (de.x + de.y) * (wfz * iz);     // -C2
                 gxy[i] = __builtin_elementwise_fma(r0xy, f2{Cn.x, Cn.x}, __builtin_elementwise_fma(nr1xy, f2{Cn.y, Cn.y}, __builtin_elementwise_fma(nr2xy, f2{nC2, nC2}, gxy[i])));
                 gz[i] = fmaf(r0z, Cn.x, fmaf(nr1z, Cn.y, fmaf(nr2z, nC2, gz[i])));
-                {
-                    const double C0 = (double)Cn.x, C1 = -(double)Cn.y, C2 = -(double)nC2, Xd = (double)Xi, Yd = (double)Yi, Zd = (double)Zi;
-                    Gd[0] = fma(C0, Xd, Gd[0]); Gd[1] = fma(C0, Yd, Gd[1]); Gd[2] = fma(C0, Zd, Gd[2]);
-                    Gd[3] = fma(C1, Xd, Gd[3]); Gd[4] = fma(C1, Yd, Gd[4]); Gd[5] = fma(C1, Zd, Gd[5]);
-                    Gd[6] = fma(C2, Xd, Gd[6]); Gd[7] = fma(C2, Yd, Gd[7]); Gd[8] = fma(C2, Zd, Gd[8]);
-                    Gd[9] += C0; Gd[10] += C1; Gd[11] += C2;
-                }
+                Ga[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, xy[i], Ga[0]); Gb[0] = __builtin_elementwise_fma(f2{Cn.x, Cn.x}, zw[i], Gb[0]);
+                Ga[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, xy[i], Ga[1]); Gb[1] = __builtin_elementwise_fma(f2{Cn.y, Cn.y}, zw[i], Gb[1]);   // -C1 sums
+                Ga[2] = __builtin_elementwise_fma(f2{nC2, nC2}, xy[i], Ga[2]);   Gb[2] = __builtin_elementwise_fma(f2{nC2, nC2}, zw[i], Gb[2]);     // -C2 sums
             }
         }
-        // wave reduction in double (butterfly over the 64 lanes), the totals rounded to float once per (wave, hypothesis) row; the finish kernel adds the
-        // rows in double again
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            double v = Gd[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            Gd[k] = v;
-        }
-        if (lane < 12) {
-            double tot = Gd[0];
-#pragma unroll
-            for (int k = 1; k < 12; k++) tot = (lane == k) ? Gd[k] : tot;
-            gout[(size_t)h * 12 + lane] = (float)tot;
-        }
+        float G[12] = {Ga[0].x, Ga[0].y, Gb[0].x, -Ga[1].x, -Ga[1].y, -Gb[1].x, -Ga[2].x, -Ga[2].y, -Gb[2].x, Gb[0].y, -Gb[1].y, -Gb[2].y};
+        const float tot = wave_sum12(G, lane);
+        if (gslot >= 0) gout[(size_t)h * 12 + gslot] = tot;
     }
 
 #pragma unroll

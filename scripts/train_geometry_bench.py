@@ -22,9 +22,12 @@ eng = dsac_amd.Engine(0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 ctx = eng._ctx
 N = 256
+ONLY = os.environ.get("DSAC_TGB_ONLY")  # e.g. "480x640x16": one configuration (for rocprofv3 --stats of exactly that chain)
 for (H, W, reps) in ((40, 40, 200), (480, 640, 100)):
     P = H * W
     for F in (1, 8, 16):
+        if ONLY and ONLY != "%dx%dx%d" % (H, W, F):
+            continue
         frs = [synth.chess_like_frame(H, W, seed=1305 + f, quantise_int16=(H == 40)) for f in range(F)]
         xyz = torch.as_tensor(np.ascontiguousarray(np.stack([f_["xyz"] for f_ in frs])), device=dev)
         uv = torch.as_tensor(frs[0]["uv"], device=dev) if H == 40 else None
