@@ -897,7 +897,7 @@ template <int HT, bool ERR, bool SOFT, bool UV>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __restrict__ poses, const float* __restrict__ xyz, const float* __restrict__ uv,
                                                                float* __restrict__ err, float* __restrict__ soft_part, int N, int P, int W, int PT,
                                                                float fx, float fy, float cx, float cy, float clampv, float kA, float kB, int Nf,
-                                                               long long xyz_stride, long long uv_stride, float kAl, float kBl) {
+                                                               long long xyz_stride, long long uv_stride, float kAl, float kBl, int rec32) {
     const int b = blockIdx.x;
     const int q = b >> 3, PTG = (PT + 7) >> 3;
     const int ht = q / PTG, pt = (q % PTG) * 8 + (b & 7);  // XCD-aware, pixel tiles innermost
@@ -921,6 +921,12 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
         o[0] = dfx * R[0]; o[1] = dfx * R[1]; o[2] = dfx * R[2]; o[3] = dfx * ps[3];
         o[4] = dfy * R[3]; o[5] = dfy * R[4]; o[6] = dfy * R[5]; o[7] = dfy * ps[4];
         o[8] = R[6]; o[9] = R[7]; o[10] = R[8]; o[11] = ps[5];
+        // diagnostic (k2_flags bit 26): the records rounded to float as the fast forms stage them, everything else exact -- isolates what the fp32 RECORD alone
+        // costs (tests/test_gpu_k2_precise.py: it is the bulk of the fast form's score error, a systematic shift of all of a hypothesis' projections)
+        if (rec32) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) o[k] = (double)(float)o[k];
+        }
     }
     const int p0 = (pt * K2_THREADS + tid) * 4;
     const bool valid = p0 < P;  // P % 4 == 0
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
 
 template <int HT>
 static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* poses, const FrameDev& F, float clampv, float* err, double kAd, double kBd,
-                                        float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB) {
+                                        float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB, int rec32) {
     const float kA = (float)kAd, kB = (float)kBd, kAl = (float)(kAd - (double)kA), kBl = (float)(kBd - (double)kB);
     const int PT = (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4);
     const int NTa = (N + HT - 1) / HT;
@@ -1005,7 +1011,7 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2P(E, S, U)                                                                                                                       \
     hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
-                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl)
+                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl, rec32)
     if (ERR && SOFT) { if (UV) DSAC_K2P(true, true, true); else DSAC_K2P(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2P(true, false, true); else DSAC_K2P(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2P(false, true, true); else DSAC_K2P(false, true, false); }
@@ -1068,8 +1074,9 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         const double nhp = (double)N * (double)F.P;
         const double kAd = (double)beta * 1.4426950408889634, kBd = -(double)beta * (double)tau * 1.4426950408889634;
         // hypothesis tile by size as the VALU forms: 32 for big launches, 16 for a single small frame (more workgroups)
-        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB)
-                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB);
+        const int rec32 = (opts.flags >> 26) & 1;
+        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32)
+                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32);
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost

@@ -197,3 +197,76 @@ def test_frame_result_exchange_single_process_emulation():
     assert ex.wait(0)
     f = ex.frames(0)
     assert f.shape == (10, 12) and f[[1, 4, 7]][:, 0].tolist() == [1.0, 4.0, 7.0] and not f[[0, 2, 3, 5, 6, 8, 9]].any()
+
+
+def _worker_r5(rank, world, port, q):
+    """Round-5 additions: GradientReducer.no_sync() / reset(), and an exchange that stays local although a process group exists."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from dsac_amd import dist as ddist
+    ddist.init(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    red = ddist.GradientReducer(net.parameters(), bucket_bytes=64)
+    x1, x2 = torch.full((5, 4), float(rank + 1)), torch.full((3, 4), float(2 * rank + 1))
+    # reference: the mean over the ranks of the ACCUMULATED local gradients of two passes
+    ref = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    ref.load_state_dict(net.state_dict())
+    ref(x1).sum().backward()
+    ref(x2).sum().backward()
+    want = []
+    for p in ref.parameters():
+        g = p.grad.clone()
+        dist.all_reduce(g)
+        want.append((g / world).numpy().copy())
+    # accumulation: the first pass inside no_sync() launches nothing, the second pass sends the buckets
+    with red.no_sync():
+        net(x1).sum().backward()
+        inside = red.handle.collectives
+    net(x2).sum().backward()
+    n = red.wait()
+    got = [p.grad.numpy().copy() for p in net.parameters()]
+    # an aborted backward: arrival counts are stale; reset() re-arms the hooks without sending anything, the next step works
+    for p in net.parameters():
+        p.grad.zero_()
+    list(net.parameters())[-1].grad.add_(1.0)  # stands for a partially run backward
+    red._pending[0] -= 1
+    red.reset()
+    for p in net.parameters():
+        p.grad.zero_()
+    net(x1).sum().backward()
+    n2 = red.wait()
+    red.close()
+    # local-only exchange while the group exists (rank 0 alone runs the whole job: bench.py's strong leg)
+    ok_local = True
+    if rank == 0:
+        ex = ddist.FrameResultExchange(5, 0, 1, (2, 3), torch.device("cpu"), local_only=True)
+        a, b = ex.views(0)
+        a[:] = 1.0
+        b[:] = 2.0
+        ex.launch(0)
+        ex.wait(0)
+        fr = ex.frames(0)
+        ok_local = bool((fr[:, :2] == 1.0).all() and (fr[:, 2:] == 2.0).all()) and not ex.real
+    dist.barrier()
+    q.put((rank, inside, n, got, want, n2, ok_local))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_reducer_accumulation_reset_and_local_only_exchange_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_r5, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, inside, n, got, want, n2, ok_local in out:
+        assert inside == 0 and n >= 2 and n2 == n and ok_local
+        for g, w in zip(got, want):
+            assert np.allclose(g, w, rtol=1e-12, atol=1e-12)
