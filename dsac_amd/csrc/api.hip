@@ -49,7 +49,7 @@ struct dsac_ctx {
     DevBuf frame_xyz, frame_uv;
 
     // scratch, one buffer per role so that calls can be chained without aliasing
-    DevBuf staged, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
+    DevBuf staged, staged_lo, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
     int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
     // staging for host-pointer arguments: slots are bump-allocated per call.  A deque: next_slot() hands out references that
     // must stay valid while further slots are appended within the same call
@@ -219,6 +219,7 @@ struct ProfScope {
         dk::K2Opts o = c->k2;
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
         o.poses64 = poses64;  // the cv poses of this launch: what the precise form ("k2_flags" bit 25) projects with
+        o.staged_lo = (poses64 && (o.flags & dk::K2_FLAG_RECLO)) ? c->staged_lo.as<float>() : nullptr;  // filled by k2_records_lo() before the launch
         return o;
     }
     void commit() { launched = true; }
@@ -230,6 +231,14 @@ struct ProfScope {
         if (hipEventRecord(p.b, c->stream) == hipSuccess) c->ev[which].push_back(p);
     }
 };
+
+// "k2_flags" bit 27: the low parts of the N staged records, derived from the cv poses on `st` right in front of the K2 launch that reads them
+static hipError_t k2_records_lo(dsac_ctx* c, hipStream_t st, int N, const double* d_poses) {
+    if (!(c->k2.flags & dk::K2_FLAG_RECLO) || !d_poses || N <= 0) return hipSuccess;
+    hipError_t e = c->staged_lo.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float));
+    if (e != hipSuccess) return e;
+    return dk::pose_prep_lo(st, N, d_poses, c->F, c->staged_lo.as<float>());
+}
 
 #define ARG_TRY(expr)                \
     do {                             \
@@ -313,7 +322,7 @@ void dsac_destroy(dsac_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->frame_xyz.release(); c->frame_uv.release();
-    c->staged.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
+    c->staged.release(); c->staged_lo.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
     c->grad_part.release(); c->g12_part.release(); c->g6.release();
     for (auto& s : c->slots) s.release();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
@@ -590,6 +599,7 @@ int dsac_reproject(dsac_ctx* c, int N, const double* poses, float clampv, float*
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
+        HIP_TRY(c, k2_records_lo(c, c->stream, N, d_poses));
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(d_poses), &used, Nf));
         ps.commit();
@@ -690,6 +700,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
         if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
         hipEvent_t k2_done = nullptr;
         {
+            HIP_TRY(c, k2_records_lo(c, c->stream, N, d_poses));
             ProfScope ps(c, 0, true);
             dk::K2Opts o = ps.k2(d_poses);
             if (!o.ev_stop) o.ev_stop = c->pi_k2done;  // the tail's start rides on K2's own dispatch packet: no record between K2 and the next K1
@@ -715,6 +726,7 @@ static int score_hypotheses_common(dsac_ctx* c, int N, int Nf, uint64_t seed, co
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
+        HIP_TRY(c, k2_records_lo(c, c->stream, N, d_poses));
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, c->soft_part.as<float>(), ps.k2(d_poses), &used, Nf));
         ps.commit();
@@ -826,6 +838,7 @@ int dsac_score_sampled(dsac_ctx* c, int slot, float clampv, float tau, float bet
     if (c->slot_reduced_recorded[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->slot_reduced[slot], 0));  // partials of frame i-2 consumed
     int used = 0;
     {
+        HIP_TRY(c, k2_records_lo(c, c->stream, N, poses));
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->slot_staged[slot].as<float>(), SF, clampv, err_or_null, tau, beta, part, ps.k2(poses), &used, Nf));
         ps.commit();
@@ -1668,6 +1681,7 @@ int dsac_process_images(dsac_ctx* c, int hyps_per_frame, uint64_t seed, float th
     // 18.6 us from the end of K2 to the start of the next K1 with the record and the wait below, profiles/r04_rank_timeline_mode2.txt)
     hipEvent_t k2_done = nullptr;
     {
+        HIP_TRY(c, k2_records_lo(c, c->stream, N, d_poses));
         ProfScope ps(c, 0, true);
         dk::K2Opts o = ps.k2(d_poses);
         if (mode == 2) {
@@ -1753,6 +1767,7 @@ int dsac_process_images_begin(dsac_ctx* c, int hyps_per_frame, uint64_t seed, fl
     int used = 0;
     if (c->k2_wait) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->k2_wait, 0));
     {
+        HIP_TRY(c, k2_records_lo(c, c->stream, N, d_poses));
         ProfScope ps(c, 0, true);
         HIP_TRY(c, dk::reproject(c->stream, N, c->staged.as<float>(), c->F, clampv, d_err, tau, beta, d_part, ps.k2(d_poses), &used, Nf));
         ps.commit();

@@ -38,6 +38,28 @@ __global__ __launch_bounds__(256) void k_pose_prep(int N, const double* __restri
     o[8] = (float)R[6]; o[9] = (float)R[7]; o[10] = (float)R[8]; o[11] = (float)t2;
 }
 
+// What the float records leave behind: lo = (float)(A - (double)(float)A) for the twelve entries of k_pose_prep's record (the same fp64 arithmetic, so
+// the pair is consistent with the records K1 stages itself).  k2_flags bit 27.
+__global__ __launch_bounds__(256) void k_pose_prep_lo(int N, const double* __restrict__ poses, float fx, float fy, float* __restrict__ staged_lo) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= N) return;
+    double r[3] = {poses[6 * h], poses[6 * h + 1], poses[6 * h + 2]};
+    double R[9];
+    dm::rodrigues_v2m<false>(r, R, nullptr);
+    const double dfx = fx, dfy = fy;
+    const double A[12] = {dfx * R[0], dfx * R[1], dfx * R[2], dfx * poses[6 * h + 3], dfy * R[3], dfy * R[4], dfy * R[5], dfy * poses[6 * h + 4],
+                          R[6], R[7], R[8], poses[6 * h + 5]};
+    float* o = staged_lo + (size_t)h * POSE_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[k] = (float)(A[k] - (double)(float)A[k]);
+}
+
+hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_lo) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pose_prep_lo, dim3((N + 255) / 256), dim3(256), 0, st, N, poses, F.fx, F.fy, staged_lo);
+    return hipGetLastError();
+}
+
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_pose_prep, dim3((N + 255) / 256), dim3(256), 0, st, N, poses, F.fx, F.fy, staged);
@@ -279,17 +301,33 @@ DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, res
 //   3. soft-inlier sigmoid packed over PIXEL pairs of one hypothesis, accumulated per hypothesis.
 // Z == 0 detection of the fast path: zacc accumulates iz^2 -- rcp(0) = inf sticks (as would a NaN), anything finite stays finite unless
 // |z| < 5e-20, which only sends the wave down the (always exact) slow path once more.
-template <bool EXACT_Z, bool SOFT>
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+// The low parts of the pose records through the matrix core as well (k2_flags bit 27): per 1 024 pairs twelve v_mfma_f32_16x16x16_f16 chained through
+// the accumulator of the fp32 ones, D = A_lo 2^16 . B 2^-16 + (A_hi . B).  Only the k = 0..3 slice of the 16-deep fp16 product is used (the operands of the
+// lanes 16..63 are zero).  What it removes is the SYSTEMATIC part of the fast form's error -- the fp32 rounding of a hypothesis' record shifts all of its
+// projections the same way, which is 96 % of its score error; the correction (<= half an ulp of the record times the coordinate)
+// is often below the ulp of the sum it is added to, and survives in expectation, which is all a sum over 300 000 cells needs.
+struct LoOps { h4 x, y, z; };
+template <bool EXACT_Z, bool SOFT, bool LO = false>
 DM_INLINE bool hp_chunk(float ax, float ay, float az, const float (&Bm)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4],
-                        f2 (&sloc)[4]) {
+                        f2 (&sloc)[4], const LoOps* lo = nullptr, const h4* B16 = nullptr) {
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     f2 qq[4][2];
     f2 zacc = splat(0.f);
 #pragma unroll
     for (int m = 0; m < 4; m++) {
-        const f4 nx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, Bm[m], z4, 0, 0, 0);
-        const f4 ny = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, Bm[m], z4, 0, 0, 0);
-        const f4 dz = __builtin_amdgcn_mfma_f32_16x16x4f32(az, Bm[m], z4, 0, 0, 0);
+        // LO: the correction FIRST, as the accumulator the fp32 products are added onto.  The other order loses it: a finished fp32 sum sits on its grid, and
+        // adding less than half an ulp returns the same number every time (measured: only 60 % of the error gone); added to the exact first product inside
+        // the fused multiply-add it shifts the value BEFORE the rounding, which then keeps it in expectation
+        f4 cx4 = z4, cy4 = z4, cz4 = z4;
+        if (LO) {
+            cx4 = __builtin_amdgcn_mfma_f32_16x16x16f16(lo->x, B16[m], z4, 0, 0, 0);
+            cy4 = __builtin_amdgcn_mfma_f32_16x16x16f16(lo->y, B16[m], z4, 0, 0, 0);
+            cz4 = __builtin_amdgcn_mfma_f32_16x16x16f16(lo->z, B16[m], z4, 0, 0, 0);
+        }
+        const f4 nx = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, Bm[m], cx4, 0, 0, 0);
+        const f4 ny = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, Bm[m], cy4, 0, 0, 0);
+        const f4 dz = __builtin_amdgcn_mfma_f32_16x16x4f32(az, Bm[m], cz4, 0, 0, 0);
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) {
             const f2 x = pr ? f2{nx.z, nx.w} : f2{nx.x, nx.y};
@@ -498,12 +536,12 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
 // component, L2-resident -- no LDS image, no barrier before the first MFMA), the pixel positions of the implicit grid from a
 // wave-uniform row / column (W % 64 == 0), and the only barrier is the one before the 16 NG partial soft sums leave the workgroup.
 // --------------------------------------------------------------------------------------------------
-template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW>
+template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW, bool LO = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                              const float* __restrict__ uv, float* __restrict__ err,
                                                              float* __restrict__ soft_part, int N, int P, int W, int PT, float cx, float cy,
                                                              float clampv, float kA, float kB, int kflags, int Nf, long long xyz_stride,
-                                                             long long uv_stride) {
+                                                             long long uv_stride, const float* __restrict__ staged_lo = nullptr) {
     constexpr int HT = 16 * NG;
     const int b = blockIdx.x;
     int ht, pt;
@@ -556,14 +594,44 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             Bm[ch][m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
         }
     }
+    // LO: the fp16 B operands of every (chunk, m) -- (X, Y, Z, 1) 2^-16 of pixel column c in the lanes of row 0, zero elsewhere.  Row 0 holds X itself;
+    // Y and Z come over from rows 1 and 2 with one lane swap each
+    h4 B16[LO ? CHW : 1][4];
+    if (LO) {
+#pragma unroll
+        for (int ch = 0; ch < CHW; ch++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const unsigned v = __builtin_bit_cast(unsigned, Bm[ch][m]);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // [1]: row 0 <- row 1
+                const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // [1]: rows 0, 1 <- rows 2, 3
+                const unsigned u16 = r16[1], u32 = r32[1];
+                const float s = 1.52587890625e-05f;  // 2^-16
+                const float X = Bm[ch][m] * s, Y = __builtin_bit_cast(float, u16) * s, Z = __builtin_bit_cast(float, u32) * s;
+                const bool r0 = g == 0;
+                // the constant 1 of the translation column travels as 2^-8 (its record entry as lo 2^8): 2^-16 is a SUBNORMAL half, which the matrix core
+                // flushes -- measured: with it the translation's correction, the largest of the four, was simply missing
+                B16[ch][m] = h4{(_Float16)(r0 ? X : 0.f), (_Float16)(r0 ? Y : 0.f), (_Float16)(r0 ? Z : 0.f), (_Float16)(r0 ? 0.00390625f : 0.f)};
+            }
+    }
     // A operands: with up to two groups all of them are loaded up front; with four they are fetched one group ahead (two register sets instead of
     // four: the 128-register build of the <64 hypotheses, 256 pixels> form needs the six registers)
     constexpr bool A_AHEAD = NG > 2;
     float ax[NG], ay[NG], az[NG];
+    LoOps alo[LO ? NG : 1];
     auto load_A = [&](int gi) {
         const int hyp = min(16 * gi + c, nh - 1);  // beyond the ragged end: repeat the last valid hypothesis (never stored)
         const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
         ax[gi] = rec[0]; ay[gi] = rec[4]; az[gi] = rec[8];
+        if (LO) {
+            // the records' low parts x 2^16 (x and y rows negated like the high parts), k = 0..3 of hypothesis c in the lanes of row 0
+            const f4* rl = reinterpret_cast<const f4*>(staged_lo + (size_t)(h0 + hyp) * POSE_STRIDE);
+            const float S = (g == 0) ? 65536.f : 0.f, T = (g == 0) ? 256.f : 0.f;  // rotation entries x 2^16 against coordinates x 2^-16, translation x 2^8 against 2^-8
+            const f4 lx = rl[0], ly = rl[1], lz = rl[2];
+            alo[gi].x = h4{(_Float16)(-lx.x * S), (_Float16)(-lx.y * S), (_Float16)(-lx.z * S), (_Float16)(-lx.w * T)};
+            alo[gi].y = h4{(_Float16)(-ly.x * S), (_Float16)(-ly.y * S), (_Float16)(-ly.z * S), (_Float16)(-ly.w * T)};
+            alo[gi].z = h4{(_Float16)(lz.x * S), (_Float16)(lz.y * S), (_Float16)(lz.z * S), (_Float16)(lz.w * T)};
+        }
     };
 #pragma unroll
     for (int gi = 0; gi < (A_AHEAD ? 1 : NG); gi++) load_A(gi);
@@ -620,8 +688,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             if (kflags & 2) {  // store schedule alone (measurement)
                 ev[0] = ev[1] = ev[2] = ev[3] = f4{nax, nay, az[gi], (float)ch};
                 sloc[0] = sloc[1] = sloc[2] = sloc[3] = splat(0.f);
-            } else if (__builtin_expect(__any(hp_chunk<false, SOFT>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
-                (void)hp_chunk<true, SOFT>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc);
+            } else if (__builtin_expect(__any(hp_chunk<false, SOFT, LO>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0])), 0)) {
+                (void)hp_chunk<true, SOFT, LO>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0]);
             }
             if (SOFT) {
                 const f2 vf = splat(valid[ch] ? 1.0f : 0.0f);
@@ -846,9 +914,9 @@ static hipError_t launch_reproject_ps(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
-template <int NG, int CHW, int WAVES, bool PW, int MINW = 1>
+template <int NG, int CHW, int WAVES, bool PW, int MINW = 1, bool LO = false>
 static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
-                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB) {
+                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB, const float* staged_lo = nullptr) {
     constexpr int HT = 16 * NG;
     const int tile = WAVES * CHW * 64;
     static_assert(PW || WAVES > 1, "one-wave workgroups write per-wave partial sums");
@@ -859,8 +927,8 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
     const bool G64 = !UV && (F.W & 63) == 0;
 #define DSAC_K2S(E, S, U, G)                                                                                                               \
-    hipExtLaunchKernelGGL((k_reproject_st<NG, CHW, WAVES, PW, E, S, U, G, MINW>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, \
-                          soft_part, N, F.P, F.W, PT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride)
+    hipExtLaunchKernelGGL((k_reproject_st<NG, CHW, WAVES, PW, E, S, U, G, MINW, LO>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, \
+                          soft_part, N, F.P, F.W, PT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride, staged_lo)
     if (ERR && SOFT) { if (UV) DSAC_K2S(true, true, true, false); else if (G64) DSAC_K2S(true, true, false, true); else DSAC_K2S(true, true, false, false); }
     else if (ERR) { if (UV) DSAC_K2S(true, false, true, false); else if (G64) DSAC_K2S(true, false, false, true); else DSAC_K2S(true, false, false, false); }
     else if (SOFT) { if (UV) DSAC_K2S(false, true, true, false); else if (G64) DSAC_K2S(false, true, false, true); else DSAC_K2S(false, true, false, false); }
@@ -1020,7 +1088,7 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
 }
 
 bool reproject_variant_known(int v) {
-    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77);
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 83);
 }
 
 // the largest count of partial-sum rows over all forms: one row per 64-pixel wave chunk, and the per-wave-sum forms with several waves per workgroup write
@@ -1077,6 +1145,17 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         const int rec32 = (opts.flags >> 26) & 1;
         return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32)
                            : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32);
+    }
+    // records in two pieces (k2_flags bit 27): the one-wave streaming form <64 hypotheses, 256 pixels> with the fp16 correction instructions, whatever the size
+    if ((opts.flags & K2_FLAG_RECLO) && opts.staged_lo && vec && (opts.variant < 0 || (opts.variant >= 80 && opts.variant <= 83))) {
+#define DSAC_LO(NG_, CH_, MW_) launch_reproject_st<NG_, CH_, 1, true, MW_, true>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, opts.staged_lo)
+        switch (opts.variant) {  // k2_variant 80..83 with the flag: the register / occupancy trades of this form (A/B); -1: the measured one
+            case 80: return DSAC_LO(4, 4, 3);   // <64 hypotheses, 256 pixels>, 3 waves per SIMD (92 B of scratch)
+            case 82: return DSAC_LO(4, 2, 4);   // <64, 128>, 4 waves per SIMD
+            case 83: return DSAC_LO(2, 4, 3);   // <32, 256>, 3 waves per SIMD
+            case 81: default: return DSAC_LO(4, 4, 2);  // <64, 256>, 2 waves per SIMD, no scratch: the fastest of the four (profiles/r05_k2_reclo_ab.txt)
+        }
+#undef DSAC_LO
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
@@ -1143,7 +1222,8 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 55: return DSAC_ST(4, 1, 4, true);
         case 56: return DSAC_ST(2, 4, 4, true);
         case 57: return DSAC_ST(4, 2, 4, true);
-        case 58: return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
+        case 58: case 80: case 81: case 82: case 83:  // 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
+            return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
         case 59: return launch_reproject_st<2, 4, 1, true, 5>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <2,4,1>, >= 5 waves per SIMD
         case 65: return launch_reproject_st<4, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,4> per-wave sums
         case 66: return launch_reproject_st<4, 4, 2, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,2>

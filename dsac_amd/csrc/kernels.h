@@ -26,6 +26,7 @@ constexpr int POSE_STRIDE = 12;
 // ---- k_forward.hip ---------------------------------------------------------------------------------
 // fp64 Rodrigues of N cv poses -> staged float records.
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
+hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_lo);  // what the float records leave behind
 
 // K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
 // Launch knobs of K2; they live in the context (read once from the environment in dsac_create), never in process-wide state.
@@ -34,8 +35,10 @@ struct K2Opts {
     int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
     int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // per call: timing events attached to the K2 dispatch itself (profiling), else null
+    const float* staged_lo = nullptr;  // per call: the low parts of the staged records (pose_prep_lo), for flags bit 27
     const double* poses64 = nullptr;  // per call: the cv poses (N x 6 doubles) the staged records were made from -- the precise form (flags bit 25) works from these
 };
+constexpr int K2_FLAG_RECLO = 1 << 27;    // k2_flags: pose records in two pieces -- the low parts through fp16 matrix-core instructions chained onto the fp32 ones
 constexpr int K2_FLAG_PRECISE = 1 << 25;  // k2_flags: the fp64 projection of the reference (k_reproject_prec) instead of the fp32 matrix-core transform
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).

@@ -102,7 +102,7 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  * None of them changes a result beyond rounding; -1 / the default is the measured policy.  Unknown keys are DSAC_ERR_INVALID.
  *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
  *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
- *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments); bits 16-19 / 20-23: error-images-only streaming forms idle for that many units of 64 / 16 clocks after a chunk's stores (pacing experiment); bit 24: error images only on a big launch do NOT take the fused kernel; bit 25 (0x2000000): PRECISE -- K2 projects as the reference does, in double (fp64 pose records from the cv poses, fp64 transform and perspective division, one rounding to float of each image-plane difference; core/cnn_softam.h:319-362): residuals within 2e-4 px of the oracle at 640 x 480 where the fp32 matrix-core forms reach 6e-4, softmax weights in a tie of unrelated hypotheses within the stated 1e-4; 15-25 % slower (profiles/r05_k2_precise_ab.txt), every call that launches K2 honours it; bit 26 (with bit 25, diagnostic): the precise form with ONLY its pose records rounded to float -- isolates what the fp32 record costs (it is 96 % of the fast forms' score error)
+ *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments); bits 16-19 / 20-23: error-images-only streaming forms idle for that many units of 64 / 16 clocks after a chunk's stores (pacing experiment); bit 24: error images only on a big launch do NOT take the fused kernel; bit 25 (0x2000000): PRECISE -- K2 projects as the reference does, in double (fp64 pose records from the cv poses, fp64 transform and perspective division, one rounding to float of each image-plane difference; core/cnn_softam.h:319-362): residuals within 2e-4 px of the oracle at 640 x 480 where the fp32 matrix-core forms reach 6e-4, softmax weights in a tie of unrelated hypotheses within the stated 1e-4; 15-25 % slower (profiles/r05_k2_precise_ab.txt), every call that launches K2 honours it; bit 27 (0x8000000): RECORDS IN TWO PIECES -- the fast matrix-core form with the low parts of the pose records carried through twelve fp16 matrix-core instructions per 1 024 pairs chained onto the fp32 ones: measured: 85 % of the fast form's score error gone (0.112 -> 0.017 on scores of 1.5e5; softmax weights in a tie of unrelated hypotheses 4.4e-3 -> 7.2e-4) for +16 % of K2's time (profiles/r05_k2_reclo_ab.txt) -- a middle mode that does NOT reach the stated 1e-4 in ties (bit 25 does); k2_variant 80..83 select its register / occupancy trades; bit 26 (with bit 25, diagnostic): the precise form with ONLY its pose records rounded to float -- isolates what the fp32 record costs (it is 96 % of the fast forms' score error)
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_rl"       lanes per sampling attempt: 1 (default) = one lane per attempt, the quartic's roots in sequence, 64 attempts per round and
  *                 hypothesis; 4 = one lane per root, 16 attempts per round (the form the wpb / hpw / minw / share knobs below act on)

@@ -16,6 +16,11 @@ H, W = 480, 640
 P = H * W
 dev = torch.device("cuda", 0)
 PRECISE = 1 << 25
+RECLO = 1 << 27
+MODES = [("default", 0, -1), ("precise", PRECISE, -1), ("reclo<64,256,3w>", RECLO, 80), ("reclo<64,256,2w>", RECLO, 81), ("reclo<64,128,4w>", RECLO, 82),
+         ("reclo<32,256,3w>", RECLO, 83)]
+if os.environ.get("DSAC_AB_MODES"):
+    MODES = [m for m in MODES if m[0].split("<")[0] in os.environ["DSAC_AB_MODES"].split(",")]
 
 
 def bytes_k2(N, frames=1, err=True):
@@ -55,7 +60,8 @@ def main():
     print("# K2 precise mode A/B (scripts/r05_k2_precise_ab.py), us per launch, HIP events on the K2 dispatch, alternating default / precise on one box")
     rows = []
     for rnd in range(3):
-        for name, flags in (("default", 0), ("precise", PRECISE)):
+        for name, flags, var in MODES:
+            eng.set_option("k2_variant", var)
             eng.set_option("k2_flags", flags)
             us = timed(eng, lambda: eng.scoreHypothesesFrames(N, seed=7, max_tries=1 << 16, err=err, out=out))
             rows.append(("16 x 256 x 640x480, err + soft", name, us, bytes_k2(N, F) / us / 1e3))
@@ -64,7 +70,8 @@ def main():
     eng.set_frame(torch.from_numpy(fr["xyz"]).to(dev), None, H, W, fr["cam"], borrow=True)
     soft = torch.zeros(4096, **f64)
     for rnd in range(2):
-        for name, flags in (("default", 0), ("precise", PRECISE)):
+        for name, flags, var in MODES:
+            eng.set_option("k2_variant", var)
             eng.set_option("k2_flags", flags)
             us = timed(eng, lambda: eng.reproject(rp, N=4096, err=err, soft=soft), reps=8)
             rows.append(("configs[2] N = 4096, err + soft", name, us, bytes_k2(4096) / us / 1e3))
@@ -73,8 +80,9 @@ def main():
             us = timed(eng, lambda: eng.reproject(rp, N=4096, soft=soft), reps=8)
             rows.append(("configs[2] N = 4096, soft only (no stores)", name, us, float("nan")))
     eng.set_option("k2_flags", 0)
+    eng.set_option("k2_variant", -1)
     for r in rows:
-        print("%-44s %-8s %8.1f us   %6.0f GB/s (algorithmic bytes)" % r)
+        print("%-44s %-18s %8.1f us   %6.0f GB/s (algorithmic bytes)" % r)
     eng.close()
 
 
