@@ -320,7 +320,12 @@ int dsac_create(dsac_ctx** out, int device) {
 void dsac_destroy(dsac_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // drain every stream that may still read the context's buffers (a deferred tail runs K6 / K7 against the frame) before anything is freed
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 2; k++)
+        if (c->tail[k]) (void)hipStreamSynchronize(c->tail[k]);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     c->frame_xyz.release(); c->frame_uv.release();
     c->staged.release(); c->staged_lo.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
     c->grad_part.release(); c->g12_part.release(); c->g6.release();

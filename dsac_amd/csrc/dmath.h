@@ -200,7 +200,7 @@ DM_INLINE int roots3(double a, double b, double c, double d, double& x0, double&
         x2 = 2 * sqrt_Q * cos((theta + 4 * 3.14159265358979323846) / 3.0) - b_a_3;
         return 3;
     }
-    const double AD = cbrt(fabs(Rr) + sqrt(D)) * (Rr > 0 ? 1 : (Rr < 0 ? -1 : 0));
+    const double AD = pow(fabs(Rr) + sqrt(D), 1.0 / 3.0) * (Rr > 0 ? 1 : (Rr < 0 ? -1 : 0));
     const double BD = (AD == 0) ? 0 : -Q / AD;
     x0 = AD + BD - b_a_3;
     return 1;
@@ -398,6 +398,73 @@ DM_INLINE void align3_horn(const double M[3][3], const double X[3][3], double R[
 }
 
 // ------------------------------------------------------------------------------------------------
+// Horn's least-squares alignment of three correspondences in CLOSED FORM: the optimum OpenCV's Jacobi sweeps converge to, without the
+// sweeps.  The centred cross-covariance S of three points has rank 2 (three centred vectors are linearly dependent), so the spectrum of
+// Horn's 4x4 matrix N is {+-(s1 + s2), +-(s1 - s2)} with s1 >= s2 the non-zero singular values of S, and its largest eigenvalue is
+//     lambda = sqrt(|S|_F^2 + 2 |cof S|_F)          (s1^2 + s2^2 = |S|_F^2,  s1 s2 = |cof S|_F for a rank-2 matrix)
+// -- sums of squares only, no cancellation.  The eigenvector is a column of adj(N - lambda I) (= c q q^T: every column is a multiple of
+// q; the one with the largest diagonal entry is the best conditioned).  Against numpy's eigh on 20 000 random triangles, congruent or
+// not, thin ones included: rotation / translation within 5e-12 (scripts/micro/horn_closed_form.py).  This is what K1 aligns with since
+// round 5: when the P3P lengths of a root are inconsistent (near a double root of the quartic) the triad and the least-squares solution
+// are different poses -- by pixels on ill-conditioned minimal sets -- and a different pose accepts a different minimal set
+// (profiles/r05_k1_alignment.txt).
+// ------------------------------------------------------------------------------------------------
+DM_INLINE void align3_lsq(const double M[3][3], const double X[3][3], double R[9], double T[3]) {
+    // fused multiply-adds are welcome here, whatever the file is built with: this is not OpenCV's rounding sequence, it is the optimum itself
+#pragma clang fp contract(fast)
+    const double third = 1.0 / 3.0;
+    double Cs[3], Ce[3], x[3][3], m[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        Ce[j] = (M[0][j] + M[1][j] + M[2][j]) * third;
+        Cs[j] = (X[0][j] + X[1][j] + X[2][j]) * third;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { x[k][j] = X[k][j] - Cs[j]; m[k][j] = M[k][j] - Ce[j]; }
+    }
+    double s[9];  // 3 x OpenCV's s (the scale drops out of the eigenvector)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) s[a * 3 + j] = x[0][a] * m[0][j] + x[1][a] * m[1][j] + x[2][a] * m[2][j];
+    double f2 = 0, c2 = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) f2 += s[i] * s[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const double k = s[i1 * 3 + j1] * s[i2 * 3 + j2] - s[i1 * 3 + j2] * s[i2 * 3 + j1];
+            c2 += k * k;
+        }
+    const double lam = sqrt(f2 + 2 * sqrt(c2));
+    const double a00 = s[0] + s[4] + s[8] - lam, a11 = s[0] - s[4] - s[8] - lam, a22 = s[4] - s[8] - s[0] - lam, a33 = s[8] - s[0] - s[4] - lam;
+    const double a01 = s[5] - s[7], a02 = s[6] - s[2], a03 = s[1] - s[3], a12 = s[3] + s[1], a13 = s[6] + s[2], a23 = s[7] + s[5];
+    // adjugate of the symmetric 4x4 through its 2x2 minors (rows 0-1: m*, rows 2-3: n*)
+    const double m0 = a00 * a11 - a01 * a01, m1 = a00 * a12 - a01 * a02, m2 = a00 * a13 - a01 * a03;
+    const double m3 = a01 * a12 - a11 * a02, m4 = a01 * a13 - a11 * a03, m5 = a02 * a13 - a12 * a03;
+    const double n5 = a22 * a33 - a23 * a23, n4 = a12 * a33 - a13 * a23, n3 = a12 * a23 - a13 * a22;
+    const double n2 = a02 * a33 - a03 * a23, n1 = a02 * a23 - a03 * a22;
+    const double b00 = a11 * n5 - a12 * n4 + a13 * n3, b11 = a00 * n5 - a02 * n2 + a03 * n1;
+    const double b22 = a03 * m4 - a13 * m2 + a33 * m0, b33 = a02 * m3 - a12 * m1 + a22 * m0;
+    const double b01 = -a01 * n5 + a02 * n4 - a03 * n3, b02 = a13 * m5 - a23 * m4 + a33 * m3, b03 = -a12 * m5 + a22 * m4 - a23 * m3;
+    const double b12 = -a03 * m5 + a23 * m2 - a33 * m1, b13 = a02 * m5 - a22 * m2 + a23 * m1, b23 = -a02 * m4 + a12 * m2 - a23 * m0;
+    double q0 = b00, q1 = b01, q2 = b02, q3 = b03, best = fabs(b00);
+    if (fabs(b11) > best) { best = fabs(b11); q0 = b01; q1 = b11; q2 = b12; q3 = b13; }
+    if (fabs(b22) > best) { best = fabs(b22); q0 = b02; q1 = b12; q2 = b22; q3 = b23; }
+    if (fabs(b33) > best) { q0 = b03; q1 = b13; q2 = b23; q3 = b33; }
+    const double inv = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    q0 *= inv; q1 *= inv; q2 *= inv; q3 *= inv;
+    const double q02 = q0 * q0, q12 = q1 * q1, q22 = q2 * q2, q32 = q3 * q3;
+    const double q0_1 = q0 * q1, q0_2 = q0 * q2, q0_3 = q0 * q3, q1_2 = q1 * q2, q1_3 = q1 * q3, q2_3 = q2 * q3;
+    R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q1_2 - q0_3); R[2] = 2. * (q1_3 + q0_2);
+    R[3] = 2. * (q1_2 + q0_3); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q2_3 - q0_1);
+    R[6] = 2. * (q1_3 - q0_2); R[7] = 2. * (q2_3 + q0_1); R[8] = q02 + q32 - q12 - q22;
+#pragma unroll
+    for (int i = 0; i < 3; i++) T[i] = Ce[i] - (R[i * 3] * Cs[0] + R[i * 3 + 1] * Cs[1] + R[i * 3 + 2] * Cs[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // solvePnP(CV_P3P): 4 correspondences -> cv pose.  X: 4 object points (float, mm), uv: 4 pixel positions.
 // Split in two so that the (up to four) quartic roots can be evaluated either in sequence by one lane
 // (p3p) or by four neighbouring lanes in parallel (p3p_setup + p3p_eval_root, used by K1).
@@ -493,11 +560,15 @@ DM_INLINE bool p3p_eval_root(const P3PSetup& S, const float X[4][3], const float
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 3; j++) Xw[i][j] = X[i][j];
-    if (HORN) align3_horn(M, Xw, Rc, Tc);
+    if (HORN) align3_horn(M, Xw, Rc, Tc);   // OpenCV's own iteration (Jacobi sweeps), rounding and all
     else {
+#ifdef DSAC_ALIGN_TRIAD                     // rounds 1-4: exact only for congruent triangles (kept for the A/B of profiles/r05_k1_alignment.txt)
         double Ew[9];
         triad(Xw, Ew);
         align3(M, Xw, Ew, Rc, Tc);
+#else
+        align3_lsq(M, Xw, Rc, Tc);          // the same least-squares optimum in closed form
+#endif
     }
     const double X30 = X[3][0], X31 = X[3][1], X32 = X[3][2];
     const double X3p = Rc[0] * X30 + Rc[1] * X31 + Rc[2] * X32 + Tc[0];

@@ -574,8 +574,13 @@ __global__ __launch_bounds__(128) void k_dpnp(int N, const int32_t* __restrict__
         dm::P3PSetup S;
         if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
             const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
-            // Horn alignment as in OpenCV: the difference quotient amplifies the method's rounding
+            // the least-squares alignment, like OpenCV: the difference quotient amplifies whatever an alignment that is not the optimum (the triad of
+            // rounds 1-4: 5e-2) adds.  Closed form since round 5; -DDSAC_K5_ALIGN_JACOBI: OpenCV's own Jacobi sweeps (the long pole of a solve)
+#ifdef DSAC_K5_ALIGN_JACOBI
             cand = dm::p3p_eval_root<true>(S, X, uv, K, x, Rc, Tc, reproj);
+#else
+            cand = dm::p3p_eval_root<false>(S, X, uv, K, x, Rc, Tc, reproj);
+#endif
         }
     }
     const int win = dm::best_root_of_quad(cand, reproj);  // -1: no root -> safeSolvePnP's zero pose

@@ -57,8 +57,9 @@ def pixel_grid(H, W, full_h=480, full_w=640, stratified_rng=None, patch=42):
 
 
 def chess_like_frame(H=480, W=640, seed=1305, cam=CAM_7SCENES, noise_mm=20.0, outlier_frac=0.3, quantise_int16=False,
-                     stratified=True):
-    """Returns dict(xyz (P,3) f32 mm, uv (P,2) f32, gt_pose (6,) f64 cv-convention rvec|tvec[mm], H, W, cam)."""
+                     stratified=True, grid_uv=False):
+    """Returns dict(xyz (P,3) f32 mm, uv (P,2) f32, gt_pose (6,) f64 cv-convention rvec|tvec[mm], H, W, cam).
+    grid_uv: pixel positions u = x, v = y whatever the map size (what the kernels generate themselves when a frame is set without positions)."""
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = cam
     axis = rng.normal(size=3)
@@ -67,7 +68,7 @@ def chess_like_frame(H=480, W=640, seed=1305, cam=CAM_7SCENES, noise_mm=20.0, ou
     rvec = axis * ang
     tvec = (rng.uniform(-1, 1, size=3) + np.array([0, 0, 2.5])) * 1000.0
     R = rodrigues(rvec)
-    uv = pixel_grid(H, W, stratified_rng=rng if stratified else None)
+    uv = pixel_grid(H, W, H, W) if grid_uv else pixel_grid(H, W, stratified_rng=rng if stratified else None)
     P = H * W
     depth = rng.uniform(800.0, 3500.0, size=P)
     Xc = np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth, depth], -1)

@@ -193,3 +193,105 @@ def test_loss_at_the_end_of_the_refinement_wave_equals_k7(engine, synth):
         b = engine.processImages(N, perm, gt_jp6=gts, seed=9)
         assert (b["refSteps"] == 8).all() and np.isfinite(b["out4"]).all() and (b["out4"][:, 0] > 0).all()
         assert np.array_equal(engine.maxLossFrames(b["refAvgHyp"], gts)["out4"], b["out4"]), (F, N)
+
+
+def test_misuse_of_the_seam_and_batch_entry_points_is_rejected(engine, frame40):
+    """dsac_process_images_begin / _finish, dsac_softmax_frames, dsac_loss_batch_frames, dsac_select_frames, dsac_soft_score_derr: every misuse is an
+    error code with a message, never a launch on bad sizes; the context stays usable afterwards."""
+    import ctypes
+    C = dsac_amd.capi
+    lib, ptr = C.lib, C.ptr
+    fr = frame40
+    P = 1600
+    ctx = engine._ctx
+    xyz = np.stack([fr["xyz"], fr["xyz"]])
+    engine.set_frames(xyz, fr["uv"], 40, 40, fr["cam"])
+    perm = np.stack([np.random.default_rng(i).permutation(P).astype(np.int32) for i in range(8)])
+    err = np.zeros((2 * 128, P), np.float32)
+
+    def invalid(fn, code=C.DSAC_ERR_INVALID):
+        with pytest.raises(C.DsacError) as ei:
+            fn()
+        assert ei.value.code == code and str(ei.value)
+
+    invalid(lambda: engine.processImagesBegin(100, err))                      # a batch needs a multiple of 128 hypotheses per frame
+    invalid(lambda: engine.processImagesBegin(128, err, max_tries=0))
+    invalid(lambda: engine.processImagesBegin(0, err))
+    # finish without a begin, and with a begin of another size
+    sc = np.zeros(2 * 128)
+    invalid(lambda: engine.processImagesFinish(128, sc, perm, np.zeros((256, 6))))
+    poses, sets, ok = engine.processImagesBegin(128, err)
+    invalid(lambda: engine.processImagesFinish(256, np.zeros(512), perm, np.zeros((512, 6))))
+    invalid(lambda: engine.processImagesFinish(128, sc, perm, poses, max_inl=1000))
+    # ... the open begin is still there: the matching finish goes through, a second finish does not
+    r = engine.processImagesFinish(128, sc, perm, poses, gt_jp6=np.zeros((2, 6)))
+    assert np.allclose(r["sfScores"].reshape(2, 128).sum(1), 1.0)
+    invalid(lambda: engine.processImagesFinish(128, sc, perm, poses))
+
+    w = np.zeros(256)
+    ent = np.zeros(2)
+    invalid(lambda: C.check(ctx, lib.dsac_softmax_frames(ctx, 0, 128, ptr(sc), 1.0, ptr(w), ptr(ent), None, None)))
+    invalid(lambda: C.check(ctx, lib.dsac_softmax_frames(ctx, 2, 0, ptr(sc), 1.0, ptr(w), ptr(ent), None, None)))
+    invalid(lambda: C.check(ctx, lib.dsac_softmax_frames(ctx, 2, 128, None, 1.0, ptr(w), ptr(ent), None, None)))
+
+    est, gt, out4 = np.zeros((256, 6)), np.zeros((2, 6)), np.zeros((256, 4))
+    invalid(lambda: C.check(ctx, lib.dsac_loss_batch_frames(ctx, 2, 0, ptr(est), ptr(gt), ptr(out4), None)))
+    invalid(lambda: C.check(ctx, lib.dsac_loss_batch_frames(ctx, 2, 128, ptr(est), ptr(gt), None, None)))
+    invalid(lambda: C.check(ctx, lib.dsac_loss_batch_frames(ctx, 2, 128, ptr(est), None, ptr(out4), None)))
+
+    probs = np.full(256, 1.0 / 128)
+    idx, el, g = np.zeros(2, np.int32), np.zeros(2), np.zeros(256)
+    invalid(lambda: C.check(ctx, lib.dsac_select_frames(ctx, 2, 128, ptr(probs), ptr(out4), 4, ptr(np.array([0.5, 1.0])), ptr(idx), ptr(el), ptr(g))))
+    invalid(lambda: C.check(ctx, lib.dsac_select_frames(ctx, 2, 128, ptr(probs), ptr(out4), 0, ptr(np.array([0.5, 0.5])), ptr(idx), ptr(el), ptr(g))))
+    invalid(lambda: C.check(ctx, lib.dsac_select_frames(ctx, 0, 128, ptr(probs), ptr(out4), 4, ptr(np.array([0.5, 0.5])), ptr(idx), ptr(el), ptr(g))))
+    C.check(ctx, lib.dsac_select_frames(ctx, 2, 128, ptr(probs), ptr(out4), 4, ptr(np.array([0.5, -1.0])), ptr(idx), ptr(el), ptr(g)))
+    assert idx[0] == 64 and idx[1] == 0   # u = 0.5 of a uniform distribution: the first key above 64/128 (binary-exact sums); u < 0: the first maximum
+
+    d_err = np.zeros_like(err)
+    invalid(lambda: C.check(ctx, lib.dsac_soft_score_derr(ctx, 256, ptr(g), ptr(err), 100.0, 10.0, 0.0, ptr(d_err))))
+    invalid(lambda: C.check(ctx, lib.dsac_soft_score_derr(ctx, -1, ptr(g), ptr(err), 100.0, 10.0, 0.5, ptr(d_err))))
+    invalid(lambda: C.check(ctx, lib.dsac_soft_score_derr(ctx, 256, None, ptr(err), 100.0, 10.0, 0.5, ptr(d_err))))
+    # refine_fd_sets on a batch: M must split into the frames, or every hypothesis names its frame
+    sets3 = np.zeros((3, 4), np.int32)
+    invalid(lambda: engine.dRefineSets(sets3, perm, np.zeros((3, P), np.int32)))
+    # the context is still good
+    engine.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
+    p, s, okk = engine.sample(8)
+    assert okk.all()
+
+
+def test_contexts_give_their_memory_back(frame40, synth):
+    """dsac_destroy releases everything a context allocated (frame, staging slots, tail streams, events): forty create / use / destroy rounds, with a
+    deferred tail pending at destruction in every other one, leave the device's free memory where it was."""
+    import torch
+    fr = frame40
+    perm = synth.fast_permutations(1600, 8)
+
+    def one_round(k):
+        e = dsac_amd.Engine(0)
+        if k & 1:
+            e.set_option("pi_defer_tail", 2)
+        xyz = np.stack([fr["xyz"]] * 3)
+        e.set_frames(xyz, fr["uv"], 40, 40, fr["cam"])
+        dev = torch.device("cuda", 0)
+        out = dict(hyps=torch.zeros(384, 6, dtype=torch.float64, device=dev), sampledPoints=torch.zeros(384, 4, dtype=torch.int32, device=dev),
+                   ok=torch.zeros(384, dtype=torch.uint8, device=dev), scores=torch.zeros(384, dtype=torch.float64, device=dev),
+                   sfScores=torch.zeros(384, dtype=torch.float64, device=dev), sfEntropy=torch.zeros(3, dtype=torch.float64, device=dev),
+                   avgHyp=torch.zeros(3, 6, dtype=torch.float64, device=dev), refAvgHyp=torch.zeros(3, 6, dtype=torch.float64, device=dev),
+                   refSteps=torch.zeros(3, dtype=torch.int32, device=dev), out4=torch.zeros(3, 4, dtype=torch.float64, device=dev))
+        e.processImages(128, torch.from_numpy(perm).to(dev), gt_jp6=torch.zeros(3, 6, dtype=torch.float64, device=dev), seed=k, out=out)
+        e.close()  # with the tail of the call still in flight when k is odd
+        torch.cuda.synchronize()
+        return out["refSteps"].cpu().numpy()
+
+    one_round(0)
+    one_round(1)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for k in range(40):
+        sd = one_round(k)
+        assert (sd == 8).all()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 <= 8 << 20, "device memory went from %d to %d bytes free over 40 contexts" % (free0, free1)

@@ -132,6 +132,31 @@ def test_softmax_entropy_avg(engine, orc):
     assert np.abs(w - orc.softMax(0.1 * scores)).max() <= 1e-12
 
 
+def test_sample_parity_in_an_ill_conditioned_window(engine, orc, synth):
+    """A 101 x 76 window in the corner of a 640 x 480 camera (cells at u < 101, v < 76: 11 degrees of view, 25 degrees off the axis): Gao's P3P is
+    ill-conditioned on most minimal sets there, its lengths come out inconsistent, and the accepted set then depends on HOW the triangle is aligned
+    and on every rounding of the solve.  Rounds 1-4 (orthonormal triad, fused multiply-adds) accepted a different set than the oracle for 1-1.5 % of the
+    hypotheses here; with the least-squares alignment in closed form and the solve built without contraction (round 5) the sets are the oracle's, and
+    the poses agree to 1e-9 but for the 1-2 per mille whose conditioning amplifies an ulp of acos / cos / pow."""
+    differing = total = 0
+    within, beyond = [], []
+    for thr, int16 in ((2.0, True), (5.0, False), (10.0, True)):
+        for f in range(2):
+            fr = synth.chess_like_frame(76, 101, seed=36128 + f, quantise_int16=int16, grid_uv=True)
+            engine.set_frame(fr["xyz"], None, 76, 101, fr["cam"])
+            pg, sg, okg = engine.sample(1024, seed=850736128 + f, thr=thr, max_tries=4096)
+            pr, sr, okr, _ = orc.sample(1024, 850736128 + f, fr["xyz"], fr["uv"], 76, 101, fr["cam"], thr=thr, max_tries=4096)
+            bad = (sg != sr).any(1) | (okg != okr)
+            differing += int(bad.sum())
+            total += 1024
+            dp = np.abs(pg[~bad] - pr[~bad]).max(1)
+            within.append((dp <= 1e-9).mean())
+            beyond.append((dp > 1e-6).mean())
+    margin("a1", "K1 in an ill-conditioned window: fraction of hypotheses whose accepted minimal set is the oracle's", 1.0 - differing / total, 0.999, at_least=True)
+    margin("a2", "K1 in an ill-conditioned window: fraction of poses within 1e-9 (rad | mm) of the oracle's", min(within), 0.97, at_least=True)
+    margin("a2", "K1 in an ill-conditioned window: fraction of poses beyond 1e-6 of the oracle's", max(beyond), 5e-3)
+
+
 def test_sample_parity(engine, orc, frame40, frame_full):
     for fr, N, seed in ((frame40, 256, 1305), (frame_full, 256, 99)):
         _set(engine, fr)
