@@ -158,8 +158,11 @@ DM_INLINE float residual_f(const double R[9], const double t[3], const Cam& K, f
 
 // ------------------------------------------------------------------------------------------------
 // real roots of polynomials of degree <= 4 (closed forms)
+// The whole P3P solve (these, p3p_setup, p3p_eval_root) is compiled WITHOUT fused multiply-adds, in every file that includes it: it is a chain of
+// cancellations that OpenCV and the oracle evaluate operation by operation, and a contracted build is a differently rounded solver (Makefile, K1_FLAGS).
 // ------------------------------------------------------------------------------------------------
 DM_INLINE int roots2(double a, double b, double c, double& x0, double& x1) {
+#pragma clang fp contract(off)
     const double delta = b * b - 4 * a * c;
     if (delta < 0) return 0;
     const double inv_2a = 0.5 / a;
@@ -171,6 +174,7 @@ DM_INLINE int roots2(double a, double b, double c, double& x0, double& x1) {
 }
 
 DM_INLINE int roots3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+#pragma clang fp contract(off)
     if (a == 0) {
         if (b == 0) {
             if (c == 0) return 0;
@@ -207,6 +211,7 @@ DM_INLINE int roots3(double a, double b, double c, double d, double& x0, double&
 }
 
 DM_INLINE int roots4(double a, double b, double c, double d, double e, double x[4]) {
+#pragma clang fp contract(off)
     if (a == 0) { x[3] = 0; return roots3(b, c, d, e, x[0], x[1], x[2]); }
     const double inv_a = 1. / a;
     b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
@@ -481,6 +486,7 @@ struct P3PSetup {
 
 // undistortPoints (zero distortion) rounds the normalised coordinates to float; the solver then maps them back to pixels.
 DM_INLINE void p3p_image_point(const float uv[2], const Cam& K, double& mu, double& mv) {
+#pragma clang fp contract(off)
     const float xn = (float)(((double)uv[0] - K.cx) * (1. / K.fx));
     const float yn = (float)(((double)uv[1] - K.cy) * (1. / K.fy));
     mu = (double)xn * K.fx + K.cx;
@@ -488,6 +494,7 @@ DM_INLINE void p3p_image_point(const float uv[2], const Cam& K, double& mu, doub
 }
 
 DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K, P3PSetup& S) {
+#pragma clang fp contract(off)
     const double inv_fx = 1. / K.fx, inv_fy = 1. / K.fy, cx_fx = K.cx / K.fx, cy_fy = K.cy / K.fy;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -532,6 +539,7 @@ DM_INLINE bool p3p_setup(const float X[4][3], const float uv[4][2], const Cam& K
 template <bool HORN = false>
 DM_INLINE bool p3p_eval_root(const P3PSetup& S, const float X[4][3], const float uv[4][2], const Cam& K, double x, double Rc[9], double Tc[3],
                              double& reproj) {
+#pragma clang fp contract(off)
     if (!(x > 0)) return false;
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;

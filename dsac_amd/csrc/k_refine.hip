@@ -787,7 +787,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan_set(const int32
     if (lane == 0) n_obj[0] = min(total / skip, cap);
 }
 
-// start pose of replica r: P3P (Horn alignment, as OpenCV) of the set read through the replica's perturbation
+// start pose of replica r: P3P (least-squares alignment, as OpenCV's; closed form since round 5) of the set read through the replica's perturbation
 __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_t* __restrict__ n_obj, const int32_t* __restrict__ set4,
                                                            const int32_t* __restrict__ rep_px_c, const float* __restrict__ rep_value, FrameDev F,
                                                            double* __restrict__ rep_poses, const int32_t* __restrict__ frame_of) {
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
             if (F.uv) F.uv += f * F.uv_stride;
         }
     }
-    // four lanes per replica, one per quartic root (the Horn/Jacobi alignments side by side, as in K5)
+    // four lanes per replica, one per quartic root (side by side, as in K5)
     const int r = blockIdx.x * 16 + (threadIdx.x >> 2), root = threadIdx.x & 3;
     const bool active = r < 18 + 6 * min(n_obj[0], cap);
     bool cand = false;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
         dm::P3PSetup S;
         if (dm::p3p_setup(X, uv, K, S) && root < S.n) {
             const double x = (root == 0) ? S.roots[0] : (root == 1) ? S.roots[1] : (root == 2) ? S.roots[2] : S.roots[3];
-            cand = dm::p3p_eval_root<true>(S, X, uv, K, x, Rc, Tc, reproj);
+            cand = dm::p3p_eval_root<false>(S, X, uv, K, x, Rc, Tc, reproj);  // least-squares alignment in closed form (dmath.h), as in K1 / K5
         }
     }
     const int win = dm::best_root_of_quad(cand, reproj);

@@ -110,7 +110,10 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 else 1), 0 = always 1, 2, 4 (4: up to 256 hypotheses) -- a round is 64 x waves attempts wide, the first accepted attempt is the same
  *   "k1_share"    4 or 8: the waves of a K1 workgroup evaluate the next attempts of their unfinished neighbours -- same first accepted attempt,
  *                 shorter tail; applied up to 1024 hypotheses (negative: always); 0 = off
- *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method exactly as OpenCV's solvePnP(CV_P3P); 0 = orthonormal triad (default)
+ *   "k1_horn"     1 = align the P3P triangle with Horn's quaternion method by Jacobi sweeps, operation by operation as OpenCV's solvePnP(CV_P3P)
+ *                 (K1 43 -> 230 us at 4096 hypotheses); 0 (default) = the same least-squares optimum in closed form (rounds 1-4: an orthonormal triad,
+ *                 which is that optimum only when the P3P lengths are consistent -- on ill-conditioned minimal sets it is another pose, and another
+ *                 pose accepts another set)
  *   "k1_cus"      > 0: the auxiliary stream of dsac_sample_ahead is created with a CU mask of that many CUs (before its first use)
  *   "device_args"  1: the caller promises that EVERY pointer argument from now on is a device pointer (dsac_device_alloc, torch, hipMalloc): the library skips
  *                 its per-argument hipPointerGetAttributes query (about a microsecond each, 20-odd per dsac_process_images).  A host pointer passed under

@@ -37,7 +37,8 @@ def _grid_frame(synth, H, W, seed, cam):
     return dict(xyz=xyz.astype(np.float32), uv=uv, gt_pose=np.concatenate([rvec, tvec]), H=H, W=W, cam=tuple(float(c) for c in cam))
 
 
-@pytest.mark.parametrize("H,W,F,N,implicit", [(40, 40, 3, 128, False), (120, 160, 2, 256, True), (40, 40, 3, 128, "own")])
+@pytest.mark.parametrize("H,W,F,N,implicit", [(40, 40, 3, 128, False), (120, 160, 2, 256, True), (40, 40, 3, 128, "own"),
+                                              (37, 53, 2, 128, True), (45, 31, 2, 128, False)])  # the last two: odd sizes that no tile divides
 def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
     """implicit = False: one table of image positions shared by the frames; True: the implicit grid; "own": one table PER FRAME (uv_per_frame -- the
     reference's sub-sampled maps, whose positions stochasticSubSample draws per image, core/cnn_softam.h:283-309)."""

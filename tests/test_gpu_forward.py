@@ -3,15 +3,13 @@ oracle, through the C ABI.  Tolerances:
   residuals  <= 1e-3 px abs, clamp-edge pixels excluded  (fp32 projection on the GPU, fp64 in the oracle)
   soft score <= 1e-4 relative
   softmax w  <= 1e-12 abs given equal scores (both fp64)
-  poses      fp64 P3P on both sides, but libm-vs-ocml transcendentals and fma contraction differ in the last
-             bits and Gao's quartic amplifies that on near-degenerate minimal sets (both sides then carry the
-             same ~0.5 px inconsistency on the 3 defining points).  So: >= 95 % of the hypotheses agree to
-             1e-5 deg / 1e-6 relative translation, >= 99 % to 0.1 deg / 0.5 % translation (the rest are
-             near-collinear minimal sets where the P3P problem itself is ill-posed: the GPU aligns the triangle
-             with an orthonormal triad, OpenCV/the oracle with Horn's least squares), and every accepted pose
-             passes the reference's own in-loop check (4 points re-project within the threshold,
-             cnn_softam.h:1045-1059).
-  minimal sets: bit-identical (shared counter-based RNG)
+  poses      fp64 P3P on both sides, the same operations in the same order WITHOUT fused multiply-adds (round 5; csrc/dmath.h), the triangle aligned by
+             Horn's least squares like OpenCV (closed form instead of Jacobi sweeps); what is left are the last bits of ocml's acos / cos / pow against
+             glibc's, which Gao's quartic amplifies on near-degenerate minimal sets.  So: >= 99 % of the hypotheses agree to 1e-5 deg / 1e-6 relative
+             translation (measured: all; rounds 1-4 with contraction and an orthonormal triad: 96-98 %), every pose is bounded by the conditioning of its
+             own P3P problem, and every accepted pose passes the reference's own in-loop check (4 points re-project within the threshold,
+             cnn_softam.h:1045-1059).  In ill-conditioned geometry (a narrow off-axis window) 97.7 % agree to 1e-9, 0.1 % differ by more than 1e-6.
+  minimal sets: bit-identical (shared counter-based RNG; the same accepted attempt also where P3P is ill-conditioned: 0 of 27 648 differ)
 """
 import numpy as np
 import pytest
@@ -33,7 +31,7 @@ def assert_poses_close(pg, pr):
         ang[i] = np.degrees(np.arccos(np.clip((np.trace(D) - 1) / 2, -1, 1)))
         trel[i] = np.linalg.norm(a[3:] - b[3:]) / max(np.linalg.norm(b[3:]), 1e-9)
     tight = (ang <= 1e-5) & (trel <= 1e-6)
-    margin("a2", "K1 P3P poses vs oracle: fraction within 1e-5 deg / 1e-6 rel translation", tight.mean(), 0.95, at_least=True)
+    margin("a2", "K1 P3P poses vs oracle: fraction within 1e-5 deg / 1e-6 rel translation", tight.mean(), 0.99, at_least=True)
     loose = (ang <= 0.1) & (trel <= 5e-3)
     margin("a2", "K1 P3P poses vs oracle: fraction within 0.1 deg / 0.5 %% translation (rest: ill-conditioned sets, see the per-pose bound)", loose.mean(), 0.99, at_least=True)
 
@@ -153,7 +151,7 @@ def test_sample_parity_in_an_ill_conditioned_window(engine, orc, synth):
             within.append((dp <= 1e-9).mean())
             beyond.append((dp > 1e-6).mean())
     margin("a1", "K1 in an ill-conditioned window: fraction of hypotheses whose accepted minimal set is the oracle's", 1.0 - differing / total, 0.999, at_least=True)
-    margin("a2", "K1 in an ill-conditioned window: fraction of poses within 1e-9 (rad | mm) of the oracle's", min(within), 0.97, at_least=True)
+    margin("a2", "K1 in an ill-conditioned window: fraction of poses within 1e-9 (rad | mm) of the oracle's", min(within), 0.95, at_least=True)
     margin("a2", "K1 in an ill-conditioned window: fraction of poses beyond 1e-6 of the oracle's", max(beyond), 5e-3)
 
 

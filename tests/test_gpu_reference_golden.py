@@ -47,7 +47,7 @@ def test_hypotheses_from_the_references_minimal_sets(eng, g):
     assert ok.all() and np.array_equal(sets, g["sets"])  # every set the reference accepted is accepted
     d = np.array([pose_delta(a, b) for a, b in zip(poses, g["hyps"])])
     tight = (d[:, 0] <= 1e-5) & (d[:, 1] <= 1e-6)
-    margin("a2", "golden frames (REAL reference): P3P poses from the reference's minimal sets, fraction within 1e-5 deg / 1e-6", tight.mean(), 0.95, at_least=True)
+    margin("a2", "golden frames (REAL reference): P3P poses from the reference's minimal sets, fraction within 1e-5 deg / 1e-6", tight.mean(), 0.99, at_least=True)
     assert ((d[:, 0] <= 0.1) & (d[:, 1] <= 5e-3)).mean() >= 0.99, (tight.mean(), d.max(0))
 
 
@@ -86,7 +86,9 @@ def test_jacobians(eng, g):
     J = eng.dPNP(g["sets"][:8])
     rel = np.array([np.abs(J[h] - g["dPNP8"][h]).max() / max(1.0, np.abs(g["dPNP8"][h]).max()) for h in range(8)])
     margin("a11", "golden frames (REAL reference): dPNP of 8 sets, median max-rel", np.median(rel), 1e-5)
-    margin("a11", "golden frames (REAL reference): dPNP of 8 sets, worst max-rel (ill-conditioned set; SURVEY 8(c) allows 1e-3 on well-conditioned ones)", rel.max(), 5e-2, stated=1e-3)
+    # 5e-2 until round 5: the P3P solve was built with fused multiply-adds and its replicas could land on another side of an ill-conditioned set's rounding;
+    # without contraction the worst of the 8 sets reads 4.4e-6 and the stated tolerance holds for all of them
+    margin("a11", "golden frames (REAL reference): dPNP of 8 sets, worst max-rel (SURVEY 8(c): 1e-3)", rel.max(), 1e-3)
     J_hyp, px, J_obj = eng.dRefine(g["avgHyp"], g["pixelIdxs"], g["inlierMap"], max_inl=int(g["inlier_count"]), thr=float(g["thr"]),
                                    sub_sample=float(g["sub_sample"]))
     margin("a14", "golden frames (REAL reference): dRefineHyp, max abs error / (1e-3 max|J| + 1e-6)", np.abs(J_hyp - g["dRefineHyp"]).max() / (1e-6 + 1e-3 * np.abs(g["dRefineHyp"]).max()), 1.0)
