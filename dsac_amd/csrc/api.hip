@@ -1007,39 +1007,56 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         return end_call(c);
     }
     dk::K4Plan plan = dk::backward_plan(N, c->F, d_derr, c->k4_variant, Nf);
-    if (plan.direct && d_grad == grad_xyz && !c->device_args) {
-        // the direct form adds into the caller's buffer with hardware fp64 atomics (unsafeAtomicAdd): those are only defined on ordinary (coarse-grained)
-        // device memory.  Managed / fine-grained memory takes the staged form (partial sums + a reduction launch); a frame batch has no staged form
+    // the direct form adds into the caller's buffer with hardware fp64 atomics (unsafeAtomicAdd): those are only defined on ordinary (coarse-grained)
+    // device memory.  Managed / fine-grained memory takes the staged form (partial sums + a reduction launch; on a frame batch: frame by frame, below)
+    const int staged_variant = (c->k4_variant < 0 ? 999 : c->k4_variant % 1000) + 1000;
+    bool plain = true;
+    if (d_grad == grad_xyz && !c->device_args) {
         hipPointerAttribute_t attr;
-        const bool plain = hipPointerGetAttributes(&attr, grad_xyz) == hipSuccess && attr.type == hipMemoryTypeDevice;
-        if (!plain) {
-            (void)hipGetLastError();
-            if (frames > 1) return fail(c, DSAC_ERR_INVALID, "%s: on a frame batch grad_xyz must be ordinary device memory (hipMalloc / dsac_device_alloc / torch), not managed memory", who);
-            plan = dk::backward_plan(N, c->F, d_derr, (c->k4_variant < 0 ? 999 : c->k4_variant % 1000) + 1000, Nf);
-        }
+        plain = hipPointerGetAttributes(&attr, grad_xyz) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        if (!plain) (void)hipGetLastError();
     }
-    if (plan.Nf < 0)
-        return fail(c, DSAC_ERR_INVALID, "%s: this map / kernel form (k4_variant %d) has no frame-batch mode (needs the matrix-core form: 16-byte aligned buffers, "
-                                         "H*W and W multiples of 4)", who, c->k4_variant);
+    if (plan.direct && !plain) plan = dk::backward_plan(N, c->F, d_derr, staged_variant, Nf);  // Nf < 0 for a batch: frame by frame
     // Round 4, the fused stage (plan.fused): two launches instead of four -- the main pass derives its hypothesis records from the poses in its prologue
     // and (one hypothesis tile: plan.direct) adds the gradient straight into grad_xyz, the finish kernel derives dR/drod itself.  The round-3 staging
     // (k_backward_prep -> main -> k_grad_reduce -> k_support_scatter) remains for the VALU form and behind k4_variant + 1000.
-    if (!plan.fused) {
-        HIP_TRY(c, c->bwd_staged.reserve(((size_t)N * dk::BWD_STRIDE + (size_t)((N + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
-        HIP_TRY(c, c->dRdH.reserve((size_t)N * dk::BWD_DRDH * sizeof(double)));
-    }
-    if (!plan.direct) HIP_TRY(c, c->grad_part.reserve((size_t)plan.NT * plan.glayers * P * 3 * sizeof(float)));
-    HIP_TRY(c, c->g12_part.reserve((size_t)plan.rows * N * 12 * sizeof(float)));
     HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
-    if (!plan.fused) HIP_TRY(c, dk::backward_prep(c->stream, N, d_poses, c->F, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
-    {
-        ProfScope ps(c, 1);
-        HIP_TRY(c, dk::score_backward(c->stream, N, c->bwd_staged.as<float>(), c->F, d_derr, d_g, clampv, tau, beta, c->grad_part.as<float>(),
-                                      c->g12_part.as<float>(), plan, d_poses, d_grad, flags));
+    auto run = [&](int n, const dk::FrameDev& Fd, const dk::K4Plan& pl, size_t h0, size_t cell0, int nf) -> int {  // hypotheses h0 .. h0 + n - 1, gradient rows from cell0
+        if (!pl.fused) {
+            HIP_TRY(c, c->bwd_staged.reserve(((size_t)n * dk::BWD_STRIDE + (size_t)((n + 15) / 16) * 384) * sizeof(float)));  // records + the K4 LDS image
+            HIP_TRY(c, c->dRdH.reserve((size_t)n * dk::BWD_DRDH * sizeof(double)));
+        }
+        if (!pl.direct) HIP_TRY(c, c->grad_part.reserve((size_t)pl.NT * pl.glayers * P * 3 * sizeof(float)));
+        HIP_TRY(c, c->g12_part.reserve((size_t)pl.rows * n * 12 * sizeof(float)));
+        const double* ps = d_poses + h0 * 6;
+        double* gr = d_grad + cell0 * 3;
+        if (!pl.fused) HIP_TRY(c, dk::backward_prep(c->stream, n, ps, Fd, c->bwd_staged.as<float>(), c->dRdH.as<double>()));
+        {
+            ProfScope ps1(c, 1);
+            HIP_TRY(c, dk::score_backward(c->stream, n, c->bwd_staged.as<float>(), Fd, d_derr ? d_derr + h0 * P : nullptr, d_g ? d_g + h0 : nullptr, clampv, tau, beta,
+                                          c->grad_part.as<float>(), c->g12_part.as<float>(), pl, ps, gr, flags));
+        }
+        HIP_TRY(c, dk::score_backward_finish(c->stream, n, Fd, c->grad_part.as<float>(), pl.direct ? 0 : pl.NT * pl.glayers, c->g12_part.as<float>(), pl.rows,
+                                             c->dRdH.as<double>(), d_dpnp + h0 * 72, d_sets + h0 * 4, flags, gr, c->g6.as<double>() + h0 * 6,
+                                             (pl.variant > 0 && !pl.fused) ? c->bwd_staged.as<float>() : nullptr, pl.fused ? ps : nullptr, nf));
+        return DSAC_OK;
+    };
+    if (plan.Nf < 0) {
+        // a frame batch on a map the matrix-core form cannot read as vectors (H*W or W not a multiple of 4, unaligned buffers): frame by frame through the
+        // single-frame forms, the scratch buffers reused in stream order -- F times the launches, the same numbers as F single-frame calls
+        for (int f = 0; f < frames; f++) {
+            dk::FrameDev Fd = c->F;
+            Fd.frames = 1;
+            Fd.xyz = c->F.xyz + (size_t)f * c->F.xyz_stride;
+            if (Fd.uv) Fd.uv = c->F.uv + (size_t)f * c->F.uv_stride;
+            Fd.xyz_stride = Fd.uv_stride = 0;
+            const dk::K4Plan pf = dk::backward_plan(Nf, Fd, d_derr ? d_derr + (size_t)f * Nf * P : nullptr, plain ? c->k4_variant : staged_variant, 0);
+            if (pf.Nf < 0) return fail(c, DSAC_ERR_INVALID, "%s: no kernel form for this map (k4_variant %d)", who, c->k4_variant);
+            ARG_TRY(run(Nf, Fd, pf, (size_t)f * Nf, (size_t)f * P, 0));
+        }
+    } else {
+        ARG_TRY(run(N, c->F, plan, 0, 0, Nf));
     }
-    HIP_TRY(c, dk::score_backward_finish(c->stream, N, c->F, c->grad_part.as<float>(), plan.direct ? 0 : plan.NT * plan.glayers, c->g12_part.as<float>(), plan.rows,
-                                         c->dRdH.as<double>(), d_dpnp, d_sets, flags, d_grad, c->g6.as<double>(),
-                                         (plan.variant > 0 && !plan.fused) ? c->bwd_staged.as<float>() : nullptr, plan.fused ? d_poses : nullptr, Nf));
     c->g6_n = N;
     return end_call(c);
 }

@@ -163,7 +163,9 @@ DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_
  * every per-image argument (start / refined pose, ground truth, inlier map, J_hyp, obj_pixels, J_obj, n_obj, dL, v6) holds one slice per frame, grad_xyz
  * is frames x H*W x 3, and every stage is ONE launch over all frames; the results equal `frames` single-frame calls bit for bit
  * (core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what the data-parallel step of SURVEY.md 5 puts on one GPU).  The score
- * backward needs 16 | hypotheses per frame <= 256 for a batch.  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
+ * backward needs 16 | hypotheses per frame <= 256 for a batch; on maps its matrix-core form cannot read as vectors (H*W or -- with the implicit grid --
+ * W not a multiple of 4, buffers not 16-byte aligned) and with the staged forms ("k4_variant" 0 or >= 1000) it runs frame by frame inside the call
+ * (F times the launches, the results of F single-frame calls).  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
  * here), dsac_reproject (128 | hypotheses per frame), dsac_softmax_frames, and the pair dsac_process_images_begin / dsac_process_images_finish, the
  * score-CNN seam of the batched fast path -- and so do the DSAC-variant calls (dsac_refine_all, dsac_refine_fd_sets, dsac_loss_batch, dsac_select_frames).
  * What still reports DSAC_ERR_INVALID while a batch is set: dsac_score_hypotheses (use dsac_score_hypotheses_frames), dsac_sample with GIVEN sets,
@@ -252,8 +254,8 @@ DSAC_API int dsac_dpnp(dsac_ctx* ctx, int N, const int32_t* sets, float eps, dou
  * internally with eps = 0.1f).  grad_xyz is H*W x 3 doubles, ACCUMULATED into.
  * Determinism: with one hypothesis tile (N <= 256) or a frame batch the main pass adds into grad_xyz with hardware fp64 atomics -- a cell receives at most
  * two such additions per call (a pixel tile split between two workgroups) on top of the value it held, so two runs may differ in the last bit of a cell;
- * dsac_set_option("k4_variant", 1000 + v) (1999: automatic form) is the staged, bit-reproducible form (fp32 partial sums + a reduction launch; single
- * frame only).  The atomics need ordinary device memory: a managed / fine-grained grad_xyz takes the staged form by itself, and is refused on a frame
+ * dsac_set_option("k4_variant", 1000 + v) (1999: automatic form) is the staged, bit-reproducible form (fp32 partial sums + a reduction launch; on a frame batch
+ * it runs frame by frame).  The atomics need ordinary device memory: a managed / fine-grained grad_xyz takes the staged form by itself, and is refused on a frame
  * batch; under "device_args" = 1 the caller's promise includes that. */
 DSAC_API int dsac_score_backward(dsac_ctx* ctx, int N, const double* poses, const int32_t* sets, const float* d_err, const double* dpnp_or_null,
                         unsigned flags, double* grad_xyz);

@@ -135,3 +135,47 @@ def dpnp_substitution_frame(engine, orc, fr, xyz_f, uv, H, W, cam, sets, coef6):
     with dsac_amd.Engine(0) as e2:
         e2.set_frame(xyz_f, uv, H, W, cam)
         return dpnp_substitution(e2, orc, fr, sets, coef6)
+
+
+def test_score_backward_into_managed_memory(engine, synth):
+    """The main pass of K4 adds into grad_xyz with hardware fp64 atomics, which are only defined on ordinary device memory: a MANAGED gradient buffer
+    (hipMallocManaged) takes the staged form by itself -- on one frame and, frame by frame, on a batch -- and receives the same gradient (to the fp32
+    grouping of the partial sums) as a torch device tensor does."""
+    import ctypes
+    import torch
+    from dsac_amd.capi import lib, ptr, check
+    hip = ctypes.CDLL("libamdhip64.so")
+    H, W, F, N = 40, 40, 2, 128
+    P = H * W
+    dev = torch.device("cuda", 0)
+    frames = [synth.chess_like_frame(H, W, seed=610 + f, quantise_int16=True) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv, cam = frames[0]["uv"], frames[0]["cam"]
+    rng = np.random.default_rng(11)
+    d_err = torch.from_numpy((rng.standard_normal((F * N, P)) * 1e-3).astype(np.float32)).to(dev)
+    managed = ctypes.c_void_p()
+    nbytes = F * P * 3 * 8
+    assert hip.hipMallocManaged(ctypes.byref(managed), ctypes.c_size_t(nbytes), ctypes.c_uint(1)) == 0
+    try:
+        view = np.ctypeslib.as_array(ctypes.cast(managed, ctypes.POINTER(ctypes.c_double)), shape=(F * P, 3))
+        for nf in (1, F):
+            if nf == 1:
+                engine.set_frame(xyz[0], uv, H, W, cam)
+            else:
+                engine.set_frames(xyz, uv, H, W, cam)
+            poses, sets, ok = engine.sample(nf * N, seed=3)
+            poses_d, sets_d = torch.from_numpy(poses).to(dev), torch.from_numpy(sets).to(dev)
+            J = torch.from_numpy(np.asarray(engine.dPNP(sets))).to(dev)
+            ref = torch.zeros(nf * P, 3, dtype=torch.float64, device=dev)
+            check(engine._ctx, lib.dsac_score_backward(engine._ctx, nf * N, ptr(poses_d), ptr(sets_d), ptr(d_err[:nf * N]), ptr(J), 0, ptr(ref)))
+            engine.synchronize()
+            view[:] = 0.0
+            check(engine._ctx, lib.dsac_score_backward(engine._ctx, nf * N, ptr(poses_d), ptr(sets_d), ptr(d_err[:nf * N]), ptr(J), 0, managed.value))
+            engine.synchronize()
+            torch.cuda.synchronize()
+            r = ref.cpu().numpy()
+            assert np.abs(r).max() > 0
+            margin("a9", "K4 into a managed gradient buffer (staged form; %d frame(s)) vs into device memory: max |d| / max |g|" % nf,
+                   np.abs(view[:nf * P] - r).max() / np.abs(r).max(), 1e-5)
+    finally:
+        hip.hipFree(managed)

@@ -108,3 +108,65 @@ def test_random_shape(engine, orc, synth, k, H, W, F, N, implicit_uv, int16, thr
         R1, t1 = orc.cv2our(b["refAvgHyp"][f])
         loss_o = orc.maxLoss(R1, t1, orc.rodrigues_vec2mat(gts[f][:3]), gts[f][3:])
         margin("a7", "random shapes: loss vs oracle, relative", abs(loss_o - b["out4"][f][0]) / max(1.0, loss_o), 1e-9)
+
+
+def _stream_cases():
+    rng = np.random.default_rng(7919)
+    out = []
+    for k in range(8):
+        out.append((k, int(rng.integers(6, 90)), int(rng.integers(6, 140)), int(rng.integers(1, 7)), int(rng.choice([128, 256])), int(rng.choice([1, 3, 8])),
+                    int(rng.choice([1, 2])), bool(rng.integers(0, 2)), int(rng.integers(1, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("k,H,W,F,N,steps,mode,copy_frames,seed", _stream_cases())
+def test_random_shape_as_a_stream_of_batches(synth, k, H, W, F, N, steps, mode, copy_frames, seed):
+    """Four batches of different frames in a row with the tails deferred ("pi_defer_tail" 1 / 2), every buffer on the device, the frames either borrowed
+    or COPIED by dsac_set_frames right behind a call whose tail still reads the previous ones (the copy must wait for it): equal to the same four calls
+    on host arrays in stream order, bit for bit -- on random map sizes, batch sizes and refinement step counts (1, 3, 8)."""
+    import torch
+    import dsac_amd
+    P = H * W
+    dev = torch.device("cuda", 0)
+    cam = synth.CAM_7SCENES
+    perm = synth.fast_permutations(P, steps)
+    max_inl, min_inl = (100, 50) if P >= 400 else (20, 8)
+    batches = []
+    for b in range(4):
+        frames = [synth.chess_like_frame(H, W, seed=seed % 100000 + 10 * b + f) for f in range(F)]
+        batches.append(np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames])))
+    uv = synth.chess_like_frame(H, W, seed=1)["uv"]
+    gts = np.zeros((F, 6))
+    gts[:, 5] = 2500.0
+    keys = ("hyps", "sampledPoints", "ok", "scores", "sfScores", "sfEntropy", "avgHyp", "refAvgHyp", "refSteps", "out4", "inlierMaps")
+
+    with dsac_amd.Engine(0) as e:
+        plain = []
+        for b in range(4):
+            e.set_frames(batches[b], uv, H, W, cam)
+            plain.append(e.processImages(N, perm, gt_jp6=gts, seed=seed + b, want_inlier_maps=True, max_inl=max_inl, min_inl=min_inl, max_tries=4096))
+
+    def bufs():
+        n = F * N
+        return dict(hyps=torch.zeros(n, 6, dtype=torch.float64, device=dev), sampledPoints=torch.zeros(n, 4, dtype=torch.int32, device=dev),
+                    ok=torch.zeros(n, dtype=torch.uint8, device=dev), scores=torch.zeros(n, dtype=torch.float64, device=dev),
+                    sfScores=torch.zeros(n, dtype=torch.float64, device=dev), sfEntropy=torch.zeros(F, dtype=torch.float64, device=dev),
+                    avgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev), refAvgHyp=torch.zeros(F, 6, dtype=torch.float64, device=dev),
+                    refSteps=torch.zeros(F, dtype=torch.int32, device=dev), out4=torch.zeros(F, 4, dtype=torch.float64, device=dev),
+                    inlierMaps=torch.zeros(F, P, dtype=torch.int32, device=dev))
+
+    with dsac_amd.Engine(0) as e:
+        e.set_option("pi_defer_tail", mode)
+        perm_d, gts_d, uv_d = torch.from_numpy(perm).to(dev), torch.from_numpy(gts).to(dev), torch.from_numpy(uv).to(dev)
+        xyz_d = [torch.from_numpy(x).to(dev) for x in batches]
+        outs = [bufs() for _ in range(4)]
+        torch.cuda.synchronize(dev)
+        for b in range(4):
+            # copy_frames: the context copies the coordinates into its own buffer -- behind the tail of the previous call, which reads that buffer
+            e.set_frames(xyz_d[b], uv_d, H, W, cam, borrow=not copy_frames)
+            e.processImages(N, perm_d, gt_jp6=gts_d, seed=seed + b, out=outs[b], max_inl=max_inl, min_inl=min_inl, max_tries=4096)
+        e.joinTail()
+        e.synchronize()
+        for b in range(4):
+            for key in keys:
+                assert np.array_equal(plain[b][key], outs[b][key].cpu().numpy()), (b, key)
