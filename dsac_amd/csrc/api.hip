@@ -962,9 +962,9 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "%s: no frame set", who);
     const int frames = c->F.frames > 1 ? c->F.frames : 1;
     const int Nf = frames > 1 ? N / frames : 0;
-    if (frames > 1 && (N % frames != 0 || Nf % 16 != 0 || Nf > 256))
-        return fail(c, DSAC_ERR_INVALID, "%s: with a frame batch N must be frames x (hypotheses per frame: a multiple of 16, at most 256), got %d for %d frames", who, N, frames);
-    if (frames > 1 && (flags & DSAC_BWD_PARITY_FP64)) return fail(c, DSAC_ERR_INVALID, "%s: the fp64 parity mode works on one frame", who);
+    // one launch for all frames needs 16 | hypotheses per frame <= 256; any other count, and the fp64 parity mode, run frame by frame below
+    if (frames > 1 && (N % frames != 0 || Nf <= 0))
+        return fail(c, DSAC_ERR_INVALID, "%s: with a frame batch N must be frames x (hypotheses per frame), got %d for %d frames", who, N, frames);
     // the reference's jp-convention Jacobians use one focal length, f = camMat(0,0), for both axes (core/cnn_softam.h:406,466);
     // a camera with fx != fy would make this backward inconsistent with the forward kernels, which honour both
     if (c->F.fx != c->F.fy) return fail(c, DSAC_ERR_INVALID, "%s: needs fx == fy (got %g, %g): dProjectdObj / dProjectdHyp use a single focal length", who,
@@ -975,7 +975,7 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
     const bool parity = (flags & DSAC_BWD_PARITY_FP64) != 0;
     if ((flags & DSAC_BWD_QUIRK_ROT_WRITEBACK) && !parity)
         return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_QUIRK_ROT_WRITEBACK needs DSAC_BWD_PARITY_FP64 (the write-back is a sequential recurrence)", who);
-    if (parity && (!d_err || (long long)N * c->F.P > (1ll << 26)))
+    if (parity && (!d_err || (long long)(frames > 1 ? Nf : N) * c->F.P > (1ll << 26)))
         return fail(c, DSAC_ERR_INVALID, "%s: DSAC_BWD_PARITY_FP64 takes a d_err volume with N*H*W <= 2^26 (reference-sized maps)", who);
     if (N == 0) return DSAC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -997,12 +997,25 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, s.as<double>(), Nf));
         d_dpnp = s.as<double>();
     }
+    auto frame_view = [&](int f) {  // frame f of a batch as a single frame
+        dk::FrameDev Fd = c->F;
+        Fd.frames = 1;
+        Fd.xyz = c->F.xyz + (size_t)f * c->F.xyz_stride;
+        if (Fd.uv) Fd.uv = c->F.uv + (size_t)f * c->F.uv_stride;
+        Fd.xyz_stride = Fd.uv_stride = 0;
+        return Fd;
+    };
     if (parity) {
-        // fp64 parity mode: the reference's evaluation order, optional rotation write-back (quirk 7)
+        // fp64 parity mode: the reference's evaluation order, optional rotation write-back (quirk 7); a batch frame by frame (the scratch reused in stream order)
+        const int n1 = frames > 1 ? Nf : N;
         DevBuf& jac = next_slot(c);
-        HIP_TRY(c, jac.reserve((size_t)N * P * 3 * sizeof(double)));
+        HIP_TRY(c, jac.reserve((size_t)n1 * P * 3 * sizeof(double)));
         HIP_TRY(c, c->g6.reserve((size_t)N * 6 * sizeof(double)));
-        HIP_TRY(c, dk::score_backward_parity(c->stream, N, d_poses, c->F, d_derr, d_dpnp, d_sets, flags, jac.as<double>(), d_grad, c->g6.as<double>()));
+        for (int f = 0; f < frames; f++) {
+            const size_t h0 = (size_t)f * n1;
+            HIP_TRY(c, dk::score_backward_parity(c->stream, n1, d_poses + h0 * 6, frames > 1 ? frame_view(f) : c->F, d_derr + h0 * P, d_dpnp + h0 * 72, d_sets + h0 * 4, flags,
+                                                 jac.as<double>(), d_grad + (size_t)f * P * 3, c->g6.as<double>() + h0 * 6));
+        }
         c->g6_n = N;
         return end_call(c);
     }
@@ -1042,14 +1055,10 @@ static int score_backward_common(dsac_ctx* c, const char* who, int N, const doub
         return DSAC_OK;
     };
     if (plan.Nf < 0) {
-        // a frame batch on a map the matrix-core form cannot read as vectors (H*W or W not a multiple of 4, unaligned buffers): frame by frame through the
-        // single-frame forms, the scratch buffers reused in stream order -- F times the launches, the same numbers as F single-frame calls
+        // a frame batch on a map the matrix-core form cannot read as vectors (H*W or W not a multiple of 4, unaligned buffers), or with a hypothesis count
+        // per frame that is not a multiple of 16 up to 256: frame by frame through the single-frame forms, the scratch buffers reused in stream order -- F times the launches, the same numbers as F single-frame calls
         for (int f = 0; f < frames; f++) {
-            dk::FrameDev Fd = c->F;
-            Fd.frames = 1;
-            Fd.xyz = c->F.xyz + (size_t)f * c->F.xyz_stride;
-            if (Fd.uv) Fd.uv = c->F.uv + (size_t)f * c->F.uv_stride;
-            Fd.xyz_stride = Fd.uv_stride = 0;
+            const dk::FrameDev Fd = frame_view(f);
             const dk::K4Plan pf = dk::backward_plan(Nf, Fd, d_derr ? d_derr + (size_t)f * Nf * P : nullptr, plain ? c->k4_variant : staged_variant, 0);
             if (pf.Nf < 0) return fail(c, DSAC_ERR_INVALID, "%s: no kernel form for this map (k4_variant %d)", who, c->k4_variant);
             ARG_TRY(run(Nf, Fd, pf, (size_t)f * Nf, (size_t)f * P, 0));

@@ -163,13 +163,13 @@ DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_
  * every per-image argument (start / refined pose, ground truth, inlier map, J_hyp, obj_pixels, J_obj, n_obj, dL, v6) holds one slice per frame, grad_xyz
  * is frames x H*W x 3, and every stage is ONE launch over all frames; the results equal `frames` single-frame calls bit for bit
  * (core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what the data-parallel step of SURVEY.md 5 puts on one GPU).  The score
- * backward needs 16 | hypotheses per frame <= 256 for a batch; on maps its matrix-core form cannot read as vectors (H*W or -- with the implicit grid --
- * W not a multiple of 4, buffers not 16-byte aligned) and with the staged forms ("k4_variant" 0 or >= 1000) it runs frame by frame inside the call
- * (F times the launches, the results of F single-frame calls).  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
+ * backward is ONE launch for all frames when 16 | hypotheses per frame <= 256; with any other count, on maps its matrix-core form cannot read as vectors
+ * (H*W or -- with the implicit grid -- W not a multiple of 4, buffers not 16-byte aligned), with the staged forms ("k4_variant" 0 or >= 1000) and in the
+ * fp64 parity mode it runs frame by frame inside the call (F times the launches, the results of F single-frame calls).  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
  * here), dsac_reproject (128 | hypotheses per frame), dsac_softmax_frames, and the pair dsac_process_images_begin / dsac_process_images_finish, the
  * score-CNN seam of the batched fast path -- and so do the DSAC-variant calls (dsac_refine_all, dsac_refine_fd_sets, dsac_loss_batch, dsac_select_frames).
  * What still reports DSAC_ERR_INVALID while a batch is set: dsac_score_hypotheses (use dsac_score_hypotheses_frames), dsac_sample with GIVEN sets,
- * dsac_refine_fd_set (one hypothesis: use dsac_refine_fd_sets), and the fp64 parity mode of dsac_score_backward. */
+ * dsac_refine_fd_set (one hypothesis: use dsac_refine_fd_sets). */
 DSAC_API int dsac_set_frames(dsac_ctx* ctx, int frames, const float* xyz, const float* uv_or_null, int uv_per_frame, int H, int W, float fx, float fy,
                     float cx, float cy, unsigned flags);
 /* dsac_score_hypotheses for every frame of the batch in three launches (K1, K2, K3 over frames x hyps_per_frame hypotheses).

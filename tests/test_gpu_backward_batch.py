@@ -126,7 +126,7 @@ def test_backward_on_a_frame_batch(engine, orc, synth, H, W, F, N, implicit):
         margin("a8", "frame batch: dLossMax of every frame vs oracle", np.abs(b["dL"][f] - dL).max() / max(1.0, np.abs(dL).max()), 1e-8)
     engine.set_frames(xyz, uv, H, W, cam, uv_per_frame=own)
     with pytest.raises(Exception):
-        engine.dSoftScore(fwd["hyps"][:F * N - 8], fwd["sampledPoints"][:F * N - 8], np.zeros(F * N - 8))  # not frames x (a multiple of 16)
+        engine.dSoftScore(fwd["hyps"][:F * N - 7], fwd["sampledPoints"][:F * N - 7], np.zeros(F * N - 7))  # not frames x (hypotheses per frame)
 
 
 def dpnp_substitution_frame(engine, orc, fr, xyz_f, uv, H, W, cam, sets, coef6):
@@ -179,3 +179,44 @@ def test_score_backward_into_managed_memory(engine, synth):
                    np.abs(view[:nf * P] - r).max() / np.abs(r).max(), 1e-5)
     finally:
         hip.hipFree(managed)
+
+
+@pytest.mark.parametrize("Nf", [120, 384])
+def test_score_backward_on_a_batch_with_any_hypothesis_count_and_in_parity_mode(engine, orc, synth, Nf):
+    """One launch for all frames needs 16 | hypotheses per frame <= 256.  Other counts (120: not a multiple of 16; 384: two hypothesis tiles) and the fp64
+    parity mode run frame by frame inside the call: the batch's gradient and pose sums equal the single-frame calls' -- bit for bit in parity mode
+    (a sequential fp64 recurrence; the single-frame mode is pinned against the oracle in tests/test_gpu_backward.py), to the last bit of the fp64 atomics
+    otherwise."""
+    H, W, F = 40, 40, 3
+    P = H * W
+    frames = [synth.chess_like_frame(H, W, seed=770 + f, quantise_int16=True) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv, cam = frames[0]["uv"], frames[0]["cam"]
+    rng = np.random.default_rng(Nf)
+    d_err = (rng.standard_normal((F * Nf, P)) * 1e-3).astype(np.float32)
+    engine.set_frames(xyz, uv, H, W, cam)
+    poses, sets, ok = engine.sample(F * Nf, seed=9) if Nf % 128 == 0 else (None, None, None)
+    if poses is None:  # dsac_sample on a batch draws whole 128-hypothesis groups; any count: frame by frame
+        ps, ss = [], []
+        for f in range(F):
+            engine.set_frame(xyz[f], uv, H, W, cam)
+            p1, s1, o1 = engine.sample(Nf, seed=9 + f)
+            ps.append(p1); ss.append(s1)
+        poses, sets = np.concatenate(ps), np.concatenate(ss)
+        engine.set_frames(xyz, uv, H, W, cam)
+    J = np.asarray(engine.dPNP(sets))
+    g_b = engine.dScore(poses, sets, d_err, dpnp=J)
+    G6_b = engine.lastPoseGradients(F * Nf)
+    g_p = engine.dScore(poses, sets, d_err, dpnp=J, parity_fp64=True) if Nf <= 128 else None
+    for f in range(F):
+        hs, cs = slice(f * Nf, (f + 1) * Nf), slice(f * P, (f + 1) * P)
+        engine.set_frame(xyz[f], uv, H, W, cam)
+        g1 = engine.dScore(poses[hs], sets[hs], d_err[hs], dpnp=J[hs])
+        G6_1 = engine.lastPoseGradients(Nf)
+        margin("a15", "frame batch with %d hypotheses per frame (frame by frame inside the call) vs single-frame calls, K4 gradient: max |d| / max |g|" % Nf,
+               np.abs(g_b[cs] - g1).max() / np.abs(g1).max(), 1e-12)
+        assert np.array_equal(G6_b[hs], G6_1)
+        if g_p is not None:
+            gp1 = engine.dScore(poses[hs], sets[hs], d_err[hs], dpnp=J[hs], parity_fp64=True)
+            assert np.array_equal(g_p[cs], gp1)
+        engine.set_frames(xyz, uv, H, W, cam)
