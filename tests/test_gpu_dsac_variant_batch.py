@@ -9,7 +9,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("H,W,F,N,own_uv", [(40, 40, 3, 64, True), (48, 64, 4, 32, False), (480, 640, 2, 16, None)])
+@pytest.mark.parametrize("H,W,F,N,own_uv", [(40, 40, 3, 64, True), (48, 64, 4, 32, False), (480, 640, 2, 16, None),
+                                            (37, 53, 2, 24, False), (23, 77, 3, 40, True)])  # the last two: odd sizes, counts no tile divides
 def test_dsac_variant_on_a_frame_batch_equals_single_frame_calls(engine, orc, synth, H, W, F, N, own_uv):
     from dsac_amd.capi import lib, ptr, check
     P = H * W
