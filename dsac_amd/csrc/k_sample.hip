@@ -107,8 +107,9 @@ DM_INLINE bool draw_set(const FrameDev& F, uint64_t key, uint32_t attempt, int32
 // measured (scripts/k1_bench.py, 640x480 synthetic frame): N=2048 takes 65 us with HPW=1, 91 us with 2, 183 us with 4 -- a
 // hypothesis needs ~20 attempts here (4 noisy inliers rarely re-project the 4th point within 10 px), so the 16 attempt lanes
 // of HPW=1 are busy and fewer lanes per hypothesis only serialise.  HPW=1 stays the default; the knob is for easy frames.
-// HORN: align the P3P triangle with Horn's quaternion method (4x4 Jacobi) as OpenCV does instead of the orthonormal triad --
-// the parity mode (poses equal the oracle's to rounding also on near-degenerate sets); several times slower, the triad is the default.
+// HORN: align the P3P triangle by OpenCV's own iteration -- Horn's quaternion method through Jacobi sweeps of the 4x4 matrix -- instead of the
+// closed form of the same least-squares optimum (dmath.h align3_lsq, the default since round 5; rounds 1-4: an orthonormal triad): 43 -> 230 us at
+// 4096 hypotheses, kept as the literal restatement for comparisons.
 // MINW: minimum waves per SIMD the register allocation must leave room for (1: 288 registers, no scratch; 2: 256 registers + 140 B of
 // scratch per lane, two waves share a SIMD and hide each other's fp64 dependency chains)
 // RL: lanes per attempt.  4 = one lane per quartic root (16 attempts per round and hypothesis); 1 = one lane per ATTEMPT, its roots in

@@ -59,7 +59,7 @@ hipError_t softmax(hipStream_t st, int N, const double* scores, double scale, do
 // Nf > 0 (frame batch): hypothesis h belongs to frame h / Nf and draws from the stream of (seed + frame, h % Nf), i.e. exactly
 // what a single-frame call with seed + frame would draw.
 // Launch knobs of K1 (context state like K2Opts): waves per workgroup (DSAC_K1_WPB in {1, 4, 8}), wave priority (DSAC_K1_PRIO 0..3),
-// hypotheses per wave (DSAC_K1_HPW in {1, 2, 4}), Horn alignment of the P3P triangle as in OpenCV instead of the triad (DSAC_K1_HORN).
+// hypotheses per wave (DSAC_K1_HPW in {1, 2, 4}), OpenCV's Jacobi sweeps for the alignment of the P3P triangle instead of the closed form (DSAC_K1_HORN).
 struct K1Opts {
     int wpb = 1, prio = 3, hpw = 1, minw = 1;  // minw: minimum waves per SIMD of the register allocation (DSAC_K1_MINW)
     bool share_always = false;  // share beyond 1024 hypotheses as well (DSAC_K1_SHARE < 0)

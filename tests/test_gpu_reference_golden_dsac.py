@@ -30,7 +30,7 @@ def test_forward_selection_refinement_expected_loss(engine, g):
     assert fwd["ok"].all()
     assert np.abs(fwd["sfScores"] - g["sfScores"]).max() <= 1e-4 and abs(fwd["sfEntropy"] - float(g["sfEntropy"])) <= 2e-3
     assert fwd["hypIdx"] == int(g["hypIdx"])
-    # refinement restarts from the engine's own P3P poses (triad alignment): compare where LM converged from both starts
+    # refinement restarts from the engine's own P3P poses: compare where LM converged from both starts
     close = np.isclose(fwd["refHyps"], g["refHyps"], rtol=1e-5, atol=1e-6).all(1)
     assert close.mean() >= 0.9, close.mean()
     same_maps = np.array([np.array_equal(a, b) for a, b in zip(fwd["inlierMaps"], g["inlierMaps"])])
