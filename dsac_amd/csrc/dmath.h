@@ -204,7 +204,11 @@ DM_INLINE int roots3(double a, double b, double c, double d, double& x0, double&
         x2 = 2 * sqrt_Q * cos((theta + 4 * 3.14159265358979323846) / 3.0) - b_a_3;
         return 3;
     }
+#ifdef DSAC_P3P_CBRT  // A/B only (profiles/r05_k1_cost.txt): OpenCV writes the cube root as pow(x, 1/3), and ocml's pow is closer to glibc's than its cbrt
+    const double AD = cbrt(fabs(Rr) + sqrt(D)) * (Rr > 0 ? 1 : (Rr < 0 ? -1 : 0));
+#else
     const double AD = pow(fabs(Rr) + sqrt(D), 1.0 / 3.0) * (Rr > 0 ? 1 : (Rr < 0 ? -1 : 0));
+#endif
     const double BD = (AD == 0) ? 0 : -Q / AD;
     x0 = AD + BD - b_a_3;
     return 1;
