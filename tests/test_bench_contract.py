@@ -52,7 +52,9 @@ def test_committed_bench_line_has_the_contract_fields(name):
         ext, own = pi["640x480_batch_of_16_external_scores"]["us_per_image"], pi["640x480_batch_of_16"]["us_per_image"]
         assert abs(ext - own) < 0.08 * own  # within a few per cent of the built-in one
         assert d["host_driver"]["training"]["us_per_frame_without_error_images"] < d["host_driver"]["training"]["us_per_frame"]
-        assert d["rates"]["per_image_hyp_s"] / d["rates"]["kernel_only_k2_hyp_s"] >= 0.935
+        # 0.939-0.942 with the score tail hidden (the first closing run of round 5); K1 then took on OpenCV's arithmetic and alignment (+7 us on the
+        # critical path, profiles/r05_k1_cost.txt): 0.931-0.937
+        assert d["rates"]["per_image_hyp_s"] / d["rates"]["kernel_only_k2_hyp_s"] >= 0.925
         st = json.loads(open(os.path.join(ROOT, "profiles", "r05_final_bench_em8_rank0.json")).read().strip().splitlines()[-1])["strong"]
         _check_strong(st, ranks=1, shards=8)
         assert st["emulated"] is True and 6.0 < st["speedup"] <= 8.0
