@@ -115,16 +115,12 @@ def test_seam_against_the_oracle(setup, orc, quirk):
     got = ts.grad_xyz.cpu().numpy()
     scale = np.abs(grad_o).max()
     assert scale > 0
-    # the oracle re-solves P3P from the sets; on the 1-2 % of ill-conditioned sets its pose differs from K1's (tests/test_gpu_forward.py bounds that
-    # by the conditioning of each set), which moves dScore's contribution of those hypotheses: compare on the cells no such hypothesis dominates
+    # the oracle re-solves P3P from the sets.  Until round 5 its pose differed from K1's on the 1-2 % of ill-conditioned sets and this test compared a 0.9
+    # quantile over cells; with OpenCV's arithmetic and alignment in K1 (csrc/dmath.h) every pose agrees and the comparison is the maximum over all cells
     p3p_o = np.stack([orc.solve_p3p(xyz[s_], uvh[s_], cam)[1] for s_ in sets])
     same = np.abs(p3p_o - poses).max(1) <= 1e-6 * np.maximum(1.0, np.abs(poses).max(1))
-    assert same.mean() >= 0.9
-    if same.all():
-        margin("(f)2", "score-CNN seam: scene-coordinate gradient through the CNN's own autograd vs the oracle's chain, max / max|g|", np.abs(got - grad_o).max() / scale, 1e-5)
-    else:
-        rel = np.abs(got - grad_o).max(1) / scale
-        margin("(f)2", "score-CNN seam: gradient, 0.9 quantile over cells (an ill-conditioned P3P set differs between K1 and the oracle)", np.quantile(rel, 0.9), 1e-5)
+    assert same.all(), "K1 poses that differ from the oracle's P3P of the same sets: %s" % np.flatnonzero(~same)
+    margin("(f)2", "score-CNN seam: scene-coordinate gradient through the CNN's own autograd vs the oracle's chain, max / max|g|", np.abs(got - grad_o).max() / scale, 1e-5)
 
 
 def test_step_with_the_reference_architectures(synth, frame40, orc):

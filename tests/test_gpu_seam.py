@@ -207,12 +207,9 @@ def test_score_net_through_the_batched_seam(synth, orc, quirk):
     assert scale > 0
     p3p_o = np.stack([orc.solve_p3p(xyz[s_], uvh[s_], cam)[1] for s_ in sets])
     same = np.abs(p3p_o - poses).max(1) <= 1e-6 * np.maximum(1.0, np.abs(poses).max(1))
-    assert same.mean() >= 0.9
+    assert same.all(), "K1 poses that differ from the oracle's P3P of the same sets: %s" % np.flatnonzero(~same)  # all of them agree since round 5 (csrc/dmath.h)
     rel = np.abs(got - grad_o).max(1) / scale
-    if same.all():
-        margin("(f)2", "batched seam: scene-coordinate gradient through the CNN's own autograd vs the oracle's chain, max / max|g|", rel.max(), 1e-5)
-    else:
-        margin("(f)2", "batched seam: gradient, 0.9 quantile over cells (an ill-conditioned P3P set differs between K1 and the oracle)", np.quantile(rel, 0.9), 1e-5)
+    margin("(f)2", "batched seam: scene-coordinate gradient through the CNN's own autograd vs the oracle's chain, max / max|g|", rel.max(), 1e-5)
     sb.engine.close()
 
 
