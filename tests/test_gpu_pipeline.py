@@ -56,6 +56,9 @@ def test_process_image_and_backward_reference_size(engine, orc, synth, frame40):
     # refinement steps happen to walk: the gradient would be the round-off of the central differences on both sides)
     bwd = engine.backward(fwd, gt_jp6, sub_sample=0.2)
     ref_grad, dL, v6, g, coef6 = oracle_backward(orc, fr, fwd, gt_jp6, sub_sample=0.2)
+    # the oracle's chain as it stands, its own dPNP included: K5 agrees with it to 3e-8 on well-conditioned sets since round 5 (the solve rounds like
+    # OpenCV's), so the substitution below -- needed while the two dPNP could differ by 1e-4 ... 5e-2 -- only removes the ill-conditioned sets' share
+    margin("a15", "end-to-end training gradient (40x40) vs the oracle's chain WITHOUT substituting the engine's dPNP: max-rel", np.abs(bwd["grad"] - ref_grad).max() / np.abs(ref_grad).max(), 1e-5)
     ref_grad = ref_grad + dpnp_substitution(engine, orc, fr, fwd["sampledPoints"], coef6)
     assert np.abs(bwd["dLoss_dRef"] - dL).max() <= 1e-8 * max(1.0, np.abs(dL).max())
     # v6 = dLoss/dRef . dRefineHyp: when the refinement converges to the same optimum from every start, dRefineHyp is the round-off of its
