@@ -98,7 +98,7 @@ def test_synthetic_run_and_config_precedence(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("mw,mh,k,rI,batch,defer", [(64, 48, 5, 128, 4, 2), (640, 480, 3, 256, 2, 1), (64, 48, 5, 128, 1, 2)])
+@pytest.mark.parametrize("mw,mh,k,rI,batch,defer", [(64, 48, 5, 128, 4, 2), (640, 480, 3, 256, 2, 1), (64, 48, 5, 128, 1, 2), (53, 37, 5, 128, 3, 2)])
 def test_batched_evaluation_equals_the_per_image_loop(tmp_path, mw, mh, k, rI, batch, defer):
     """The fast path of the C++ surface (FrameBatch: the data set resident in HBM, `batch` images per launch chain, refinement tail -- defer = 2: and score tail -- of a chain
     under the next one, three passes enqueued back to back) writes the
@@ -120,7 +120,8 @@ def test_batched_evaluation_equals_the_per_image_loop(tmp_path, mw, mh, k, rI, b
     assert err.shape[0] == k and (err[:, 3] < 5).all() and (err[:, 2] < 50).all()
 
 
-def test_device_resident_training_rounds_equal_the_per_image_loop(tmp_path):
+@pytest.mark.parametrize("mw,mh", [(64, 48), (53, 37)])  # 53 x 37: no tile divides it -- the batched score backward runs frame by frame inside the call
+def test_device_resident_training_rounds_equal_the_per_image_loop(tmp_path, mw, mh):
     """train_ransac_softam -batch 1: the training set resident in HBM, every round's frame copied device-to-device into the step's FrameBatch, forward and
     backward as one launch chain each (FrameBatch::processImages / backward), gradients left in HBM.  Round by round the same frame and the same seed
     as the reference-shaped per-image loop (Frame::processImage / Frame::backward with host arrays): the training log is the same text, the gradient
@@ -129,7 +130,7 @@ def test_device_resident_training_rounds_equal_the_per_image_loop(tmp_path):
     for mode in ("loop", "1", "3"):
         d = tmp_path / ("t" + mode)
         d.mkdir()
-        cmd = [os.path.join(HOST, "train_ransac_softam"), "-synth", "4", "-mw", "64", "-mh", "48", "-rI", "128", "-rounds", "3"]
+        cmd = [os.path.join(HOST, "train_ransac_softam"), "-synth", "4", "-mw", str(mw), "-mh", str(mh), "-rI", "128", "-rounds", "3"]
         if mode != "loop":
             cmd += ["-batch", mode, "-gradstats", "1", "-warmup", "20"]
         out = subprocess.run(cmd, cwd=str(d), capture_output=True, text=True, timeout=600)
