@@ -95,6 +95,9 @@ struct dsac_ctx {
     int pi_open_b = 0, pi_open_N = 0, pi_open_frames = 0;
     int tail_prio = 0;             // DSAC_TAIL_PRIO / "tail_prio": create the tail streams with the highest stream priority (before the first deferred call)
     hipEvent_t xs_event = nullptr;                      // dsac_tail_wait: the context's stream as seen by another stream
+    // dsac_backward_path1: K5 (dPNP needs nothing but the minimal sets) on a side stream beside the finite-difference replica chain of K6
+    hipStream_t bwd_side = nullptr;
+    hipEvent_t bwd_fork = nullptr, bwd_join = nullptr;
 
     // measurement hooks: event pairs around the dominant kernels
     bool profiling = false;
@@ -352,6 +355,9 @@ void dsac_destroy(dsac_ctx* c) {
     for (int k = 0; k < 2; k++)
         if (c->pi_scored[k]) (void)hipEventDestroy(c->pi_scored[k]);
     if (c->xs_event) (void)hipEventDestroy(c->xs_event);
+    if (c->bwd_side) { (void)hipStreamSynchronize(c->bwd_side); (void)hipStreamDestroy(c->bwd_side); }
+    if (c->bwd_fork) (void)hipEventDestroy(c->bwd_fork);
+    if (c->bwd_join) (void)hipEventDestroy(c->bwd_join);
     for (int k = 0; k < 2; k++) for (auto& p : c->ev[k]) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1438,6 +1444,14 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
         HIP_TRY(c, sd.reserve((size_t)N * 72 * sizeof(double)));
         d_dpnp = sd.as<double>();
     }
+    // K5 on a side stream: dPNP (:344-349) depends on nothing but the minimal sets, and the chain below contains K6's finite-difference replicas -- one
+    // LM chain long (~100 us) with most of the chip idle: the 24 x N P3P solves run beside it (round 5: the 40 x 40, 16-frame training round 381 -> 364 us).
+    // Forked behind everything enqueued so far (the staged arguments, earlier readers of the dPNP buffer), joined before its first reader.
+    if (!c->bwd_side) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->bwd_side, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->bwd_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->bwd_join, hipEventDisableTiming));
+    }
     // dLossMax at the refined pose (train_ransac_softam.cpp:301-304), one ground truth per frame
     HIP_TRY(c, dk::pose_loss(c->stream, frames, d_ref, d_gt, s_out4, s_dL, 6));
     // dRefineObj / dRefineHyp as one batch of finite-difference replicas (:307-341)
@@ -1448,11 +1462,22 @@ int dsac_backward_path1(dsac_ctx* c, int N, const double* poses, const int32_t* 
         plan_scratch = ps.as<int32_t>();
     }
     HIP_TRY(c, dk::refine_fd_plan(c->stream, d_avg, d_map, c->F, skip, eps_hyp, eps_obj, cap, s_rp, s_rx, s_rv, s_px, s_n, plan_scratch, frames, cap));
+    // the two cross-stream hand-overs cost ~7 us each (profiles/r05_k5_side_stream.txt): worth it from about 3 000 minimal sets (K5: 10 ns per set)
+    const bool k5_beside = N >= 3072;
+    if (k5_beside) HIP_TRY(c, hipEventRecord(c->bwd_fork, c->stream));  // the fork point is the end of the plan: K5 becomes eligible together with the replicas ...
     HIP_TRY(c, dk::refine_fd_run(c->stream, cap, s_n, s_rp, d_perm, steps, max_inl, min_inl, thr, s_rx, s_rv, c->F, s_ro, frames));
+    // ... but is enqueued behind them: the replicas' few hundred waves take their SIMDs first, K5's thousands fill in around them (launched in front,
+    // K5 held every wave slot for its first 20 us and the chain started late: 127 against 101 us, nothing gained)
+    if (k5_beside) {
+        HIP_TRY(c, hipStreamWaitEvent(c->bwd_side, c->bwd_fork, 0));
+        HIP_TRY(c, dk::dpnp(c->bwd_side, N, d_sets, c->F, 0.1f, d_dpnp, Nf));
+        HIP_TRY(c, hipEventRecord(c->bwd_join, c->bwd_side));
+    }
     HIP_TRY(c, dk::refine_fd_finish(c->stream, s_ro, s_n, cap, skip, eps_hyp, eps_obj, s_Jh, s_Jo, frames));
     HIP_TRY(c, dk::path1_assemble(c->stream, s_dL, s_Jh, s_px, s_Jo, s_n, cap, (int)P, d_grad, s_v6, frames, cap));
     // sum_h w_h dPNP_h to the support points and the softmax backward (:344-376)
-    HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp, Nf));
+    if (k5_beside) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->bwd_join, 0));
+    else HIP_TRY(c, dk::dpnp(c->stream, N, d_sets, c->F, 0.1f, d_dpnp, Nf));
     HIP_TRY(c, dk::path1_softmax_backward(c->stream, Nf, c->F.P, s_v6, d_w, d_poses, d_sets, d_dpnp, d_grad, d_g, g_scale, frames));
     return end_call(c);
 }

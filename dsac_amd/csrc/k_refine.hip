@@ -376,6 +376,8 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
                                                const int32_t* __restrict__ frame_of_group) {
     const int b = blockIdx.x;
     if (b >= B) return;
+    // a latency chain on one wave: whatever shares its SIMD (K5 beside the replicas in dsac_backward_path1, K1 / K2 beside a deferred tail) issues after it
+    __builtin_amdgcn_s_setprio(3);
     if (frame_of_group) {  // DSAC variant on a frame batch: replica list m = b / group belongs to hypothesis m, which lives in frame frame_of_group[m]
         const int f = frame_of_group[group > 0 ? b / group : 0];
         F.xyz += (long long)f * F.xyz_stride;
