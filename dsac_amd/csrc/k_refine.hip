@@ -124,6 +124,18 @@ DM_INLINE void wave_allsum32(double (&v)[32], double* s_out) {
 // Solve of the symmetric positive definite 6x6 system A x = b (upper triangle of A, row-major 6x6) by L D L^T: six reciprocals and no
 // square root on the dependent chain (a Cholesky factorisation has 6 square roots and 27 divisions there).  OpenCV uses an SVD
 // pseudo-inverse here; identical for full-rank normal equations.
+// 1 / d for the pivots: v_rcp_f64 and two Newton steps (relative error ~1e-16, half the dependent latency of the IEEE division sequence -- six of them sit
+// on the solve's critical path); the oracle solves the same system by Gaussian elimination, the agreement is 1e-13 either way
+DM_INLINE double drcp(double d) {
+#ifdef DSAC_K6_IEEE_DIV
+    return 1.0 / d;
+#else
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+#endif
+}
 DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
     double L[36], W[36], inv[6];  // W[i][j] = L[i][j] * D[j]
     bool ok = true;
@@ -133,7 +145,7 @@ DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
 #pragma unroll
         for (int k = 0; k < j; k++) d -= L[j * 6 + k] * W[j * 6 + k];
         ok = ok && (d > 0.0);
-        inv[j] = 1.0 / d;
+        inv[j] = drcp(d);
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double t = A[j * 6 + i];
@@ -205,7 +217,7 @@ DM_INLINE double lm_eval(int n, const float* s_X, const float* s_uv, double* s_r
             const double Xc = R[0] * M[h][0] + R[1] * M[h][1] + R[2] * M[h][2] + p[3];
             const double Yc = R[3] * M[h][0] + R[4] * M[h][1] + R[5] * M[h][2] + p[4];
             const double Zc = R[6] * M[h][0] + R[7] * M[h][1] + R[8] * M[h][2] + p[5];
-            const double z = (Zc != 0.0) ? 1. / Zc : 1.;
+            const double z = (Zc != 0.0) ? drcp(Zc) : 1.;
             const double xx = Xc * z, yy = Yc * z;
             const double du = xx * K.fx + K.cx - (double)s_uv[ic * 2];
             const double dv = yy * K.fy + K.cy - (double)s_uv[ic * 2 + 1];
