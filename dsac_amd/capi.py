@@ -44,6 +44,7 @@ EXPORTS = [
     "dsac_gather_rows",
     "dsac_softmax_frames", "dsac_process_images_begin", "dsac_process_images_finish",
     "dsac_refine_fd_sets_frames", "dsac_loss_batch_frames", "dsac_select_frames", "dsac_soft_score_derr",
+    "dsac_refstream_init", "dsac_refstream_discard", "dsac_sample_refstream",
 ]
 
 
@@ -117,6 +118,9 @@ def _load():
     lib.dsac_softmax_frames.argtypes = [vp, i32, i32, vp, f64, vp, vp, vp, vp]
     lib.dsac_process_images_begin.argtypes = [vp, i32, u64, f32, i32, f32, f32, f32, vp, vp, vp, vp, vp]
     lib.dsac_process_images_finish.argtypes = [vp, i32, vp, f64, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dsac_refstream_init.argtypes = [vp, u32, i32]
+    lib.dsac_refstream_discard.argtypes = [vp, i32, C.c_ulonglong]
+    lib.dsac_sample_refstream.argtypes = [vp, i32, f32, C.c_longlong, vp, vp, vp, vp, vp]
     lib.dsac_backward_path1.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, f32, f32, f32, f64, vp, vp, vp, vp, vp]
     return lib
 

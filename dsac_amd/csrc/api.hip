@@ -2,6 +2,7 @@
 // pointer handling, and the launch sequences.  No CPU compute path exists in this library.
 #include "../../include/dsac_hip.h"
 #include "kernels.h"
+#include "refstream.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdarg>
@@ -12,6 +13,13 @@
 #include <deque>
 #include <string>
 #include <vector>
+// std::uniform_int_distribution of the libstdc++ this library is built against: GCC >= 11 draws by Lemire's method, older ones by scaling and division
+// (refstream.h); "refstream_mode" overrides
+#if defined(_GLIBCXX_RELEASE) && _GLIBCXX_RELEASE < 11
+#define DSAC_RS_DEFAULT_MODE 1
+#else
+#define DSAC_RS_DEFAULT_MODE 0
+#endif
 
 namespace {
 
@@ -49,7 +57,9 @@ struct dsac_ctx {
     DevBuf frame_xyz, frame_uv;
 
     // scratch, one buffer per role so that calls can be chained without aliasing
-    DevBuf staged, staged_lo, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
+    DevBuf rs_states, rs_scratch, rs_small;  // the reference's random streams (dsac_refstream_init) and the scratch of a sampling window
+    int rs_threads = 0, rs_mode = DSAC_RS_DEFAULT_MODE;
+    DevBuf staged, staged_lo, staged_split, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
     int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
     // staging for host-pointer arguments: slots are bump-allocated per call.  A deque: next_slot() hands out references that
     // must stay valid while further slots are appended within the same call
@@ -223,6 +233,7 @@ struct ProfScope {
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
         o.poses64 = poses64;  // the cv poses of this launch: what the precise form ("k2_flags" bit 25) projects with
         o.staged_lo = (poses64 && (o.flags & dk::K2_FLAG_RECLO)) ? c->staged_lo.as<float>() : nullptr;  // filled by k2_records_lo() before the launch
+        o.split = (poses64 && (o.flags & dk::K2_FLAG_EXACT) && dk::pose_split_exponent(c->F) <= 13) ? c->staged_split.as<char>() : nullptr;  // likewise
         return o;
     }
     void commit() { launched = true; }
@@ -237,6 +248,12 @@ struct ProfScope {
 
 // "k2_flags" bit 27: the low parts of the N staged records, derived from the cv poses on `st` right in front of the K2 launch that reads them
 static hipError_t k2_records_lo(dsac_ctx* c, hipStream_t st, int N, const double* d_poses) {
+    if ((c->k2.flags & dk::K2_FLAG_EXACT) && d_poses && N > 0 && dk::pose_split_exponent(c->F) <= 13) {  // "k2_flags" bit 28: the split records of the exact-transform form
+        hipError_t e = c->staged_split.reserve(dk::pose_split_bytes(N));
+        if (e != hipSuccess) return e;
+        e = dk::pose_prep_split(st, N, d_poses, c->F, c->staged_split.as<char>());
+        if (e != hipSuccess) return e;
+    }
     if (!(c->k2.flags & dk::K2_FLAG_RECLO) || !d_poses || N <= 0) return hipSuccess;
     hipError_t e = c->staged_lo.reserve((size_t)N * dk::POSE_STRIDE * sizeof(float));
     if (e != hipSuccess) return e;
@@ -330,7 +347,7 @@ void dsac_destroy(dsac_ctx* c) {
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     c->frame_xyz.release(); c->frame_uv.release();
-    c->staged.release(); c->staged_lo.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
+    c->staged.release(); c->staged_lo.release(); c->staged_split.release(); c->rs_states.release(); c->rs_scratch.release(); c->rs_small.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
     c->grad_part.release(); c->g12_part.release(); c->g6.release();
     for (auto& s : c->slots) s.release();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
@@ -572,6 +589,94 @@ int dsac_sample(dsac_ctx* c, int N, uint64_t seed, const int32_t* sets_or_null, 
     ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
     ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
     HIP_TRY(c, dk::sample(c->stream, N, seed, d_sets_in, c->F, (int)thr, max_tries, d_poses, d_sets_out, d_ok, nullptr, frames > 1 ? N / frames : 0, c->k1));
+    return end_call(c);
+}
+
+// ---- K1 in the reference's own random stream (core/thread_rand.cpp:40-69) -----------------------------------------------------------------
+int dsac_refstream_init(dsac_ctx* c, unsigned seed, int threads) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refstream_init: ctx is NULL");
+    if (threads < 1 || threads > 1024) return fail(c, DSAC_ERR_INVALID, "dsac_refstream_init: threads must be 1..1024");
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    HIP_TRY(c, c->rs_states.reserve((size_t)threads * sizeof(dk::RefStreamState)));
+    HIP_TRY(c, dk::refstream_init(c->stream, c->rs_states.as<dk::RefStreamState>(), seed, threads));
+    c->rs_threads = threads;
+    return DSAC_OK;
+}
+
+int dsac_refstream_discard(dsac_ctx* c, int thread, unsigned long long n32) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_refstream_discard: ctx is NULL");
+    if (c->rs_threads <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_refstream_discard: call dsac_refstream_init first");
+    if (thread < 0 || thread >= c->rs_threads) return fail(c, DSAC_ERR_INVALID, "dsac_refstream_discard: thread %d of %d", thread, c->rs_threads);
+    if (n32 > (1ull << 36)) return fail(c, DSAC_ERR_INVALID, "dsac_refstream_discard: at most 2^36 outputs per call");
+    if (n32 == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    HIP_TRY(c, dk::refstream_discard(c->stream, c->rs_states.as<dk::RefStreamState>(), thread, n32));
+    return DSAC_OK;
+}
+
+int dsac_sample_refstream(dsac_ctx* c, int N, float thr, long long max_attempts, double* poses, int32_t* sets_out, uint8_t* ok, unsigned long long* consumed32_or_null,
+                          long long* attempts_or_null) {
+    if (!c) return fail(nullptr, DSAC_ERR_INVALID, "dsac_sample_refstream: ctx is NULL");
+    if (!c->have_frame) return fail(c, DSAC_ERR_NO_FRAME, "dsac_sample_refstream: no frame set");
+    if (c->rs_threads <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_sample_refstream: call dsac_refstream_init first");
+    if (c->F.frames > 1) return fail(c, DSAC_ERR_INVALID, "dsac_sample_refstream: one frame at a time (the reference's streams run through its images in sequence)");
+    if (N < 0 || !poses || !sets_out || !ok) return fail(c, DSAC_ERR_INVALID, "dsac_sample_refstream: N >= 0 and poses/sets_out/ok must be non-NULL");
+    if (max_attempts <= 0) return fail(c, DSAC_ERR_INVALID, "dsac_sample_refstream: max_attempts (per stream) must be > 0");
+    if (c->F.P < 4) return fail(c, DSAC_ERR_INVALID, "dsac_sample_refstream: frame has fewer than 4 cells");
+    if (N == 0) return DSAC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    begin_call(c);
+    const int T = c->rs_threads;
+    double* d_poses;
+    int32_t* d_sets_out;
+    uint8_t* d_ok;
+    ARG_TRY(out_arg(c, poses, (size_t)N * 6, &d_poses));
+    ARG_TRY(out_arg(c, sets_out, (size_t)N * 4, &d_sets_out));
+    ARG_TRY(out_arg(c, ok, (size_t)N, &d_ok));
+    // per-stream bookkeeping on the device: first | served | need | parsed (int32 each), consumed (uint64), attempts (int64)
+    const size_t small_bytes = (size_t)T * (4 * 4 + 8 + 8);
+    HIP_TRY(c, c->rs_small.reserve(small_bytes));
+    std::vector<char> hs(small_bytes, 0);
+    int32_t* h_first = reinterpret_cast<int32_t*>(hs.data());
+    int32_t* h_need = h_first + 2 * T;
+    int max_need = 0;
+    for (int t = 0; t < T; t++) {
+        int f, n;
+        rs::static_chunk(N, T, t, f, n);  // #pragma omp parallel for, static schedule (core/cnn_softam.h:1010)
+        h_first[t] = f;
+        h_need[t] = n;
+        max_need = std::max(max_need, n);
+    }
+    char* ds = c->rs_small.as<char>();
+    int32_t *d_first = reinterpret_cast<int32_t*>(ds), *d_served = d_first + T, *d_need = d_first + 2 * T, *d_parsed = d_first + 3 * T;
+    unsigned long long* d_consumed = reinterpret_cast<unsigned long long*>(ds + (size_t)T * 16);
+    long long* d_attempts = reinterpret_cast<long long*>(ds + (size_t)T * 24);
+    HIP_TRY(c, hipMemcpyAsync(ds, hs.data(), small_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // hs is a local
+    // windows: 16 attempts per wanted hypothesis to begin with (a frame with 70 % inliers accepts one attempt in ~20), doubling while a stream is unserved
+    long long spent = 0;
+    int A = 256;
+    while (A < 16 * max_need && A < 16384) A *= 2;
+    std::vector<int32_t> need_now(T);
+    for (int round = 0; round < 4096; round++) {
+        if ((long long)A > max_attempts - spent) A = (int)std::max(1ll, max_attempts - spent);
+        HIP_TRY(c, c->rs_scratch.reserve(dk::refstream_window_bytes(T, A)));
+        HIP_TRY(c, dk::refstream_window(c->stream, c->rs_states.as<dk::RefStreamState>(), T, A, c->rs_mode, c->rs_scratch.p, c->F, (int)thr, d_first, d_served, d_need, d_parsed,
+                                        d_consumed, d_attempts, d_poses, d_sets_out, d_ok, nullptr));
+        spent += A;
+        HIP_TRY(c, hipMemcpyAsync(need_now.data(), d_need, (size_t)T * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int open = 0;
+        for (int t = 0; t < T; t++) open = std::max(open, need_now[t]);
+        if (open == 0 || spent >= max_attempts) break;
+        if (A < 16384) A *= 2;
+    }
+    HIP_TRY(c, dk::refstream_unserved(c->stream, T, d_first, d_served, d_need, c->F, d_poses, d_sets_out, d_ok, nullptr));
+    if (consumed32_or_null) HIP_TRY(c, hipMemcpyAsync(consumed32_or_null, d_consumed, (size_t)T * 8, hipMemcpyDefault, c->stream));
+    if (attempts_or_null) HIP_TRY(c, hipMemcpyAsync(attempts_or_null, d_attempts, (size_t)T * 8, hipMemcpyDefault, c->stream));
+    if (consumed32_or_null || attempts_or_null) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return end_call(c);
 }
 
@@ -893,6 +998,11 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     }
     else if (k == "k2_order") c->k2.pixel_minor = value != 0;
     else if (k == "k2_flags") c->k2.flags = value;
+    else if (k == "k2_diag") c->k2.diag = value;
+    else if (k == "refstream_mode") {
+        if (value < -1 || value > 1) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: refstream_mode is 0 (libstdc++ >= 11), 1 (libstdc++ <= 10) or -1 (this build's)");
+        c->rs_mode = value < 0 ? DSAC_RS_DEFAULT_MODE : value;
+    }
     else if (k == "k1_wpb") c->k1.wpb = value;
     else if (k == "k1_prio") c->k1.prio = value;
     else if (k == "k1_hpw") c->k1.hpw = value;

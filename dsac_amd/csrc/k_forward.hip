@@ -22,6 +22,7 @@ namespace dk {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pose_prep(int N, const double* __restrict__ poses, float fx, float fy, float* __restrict__ staged) {
@@ -57,6 +58,73 @@ __global__ __launch_bounds__(256) void k_pose_prep_lo(int N, const double* __res
 hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_lo) {
     if (N <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_pose_prep_lo, dim3((N + 255) / 256), dim3(256), 0, st, N, poses, F.fx, F.fy, staged_lo);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// Round 6: the pose records in THREE fp16 pieces on fixed binary grids, for the exact-transform form of K2 (k2_flags bit 28; k_reproject_st<.., EX>).
+// The reference projects in double (core/cnn_softam.h:319-362).  E = R.X + t is evaluated without any rounding that matters by writing every factor as a
+// sum of 11-bit fixed-point pieces, a = aA + aB + aC (grids 2^(E-10), 2^(E-21), 2^(E-32); E = 0 for the z row, `ex` = ceil(log2 f) for the focal-length-folded x / y
+// rows) and X = XA + XB + XC (grids 2^5, 2^-6, 2^-17 mm): a product of two pieces is exact in fp32, and
+//   * the HIGH products aA XA (+ tA) lie on one grid and sum to < 2^23 grid units: ONE v_mfma_f32_16x16x16_f16 per row adds them EXACTLY;
+//   * all other products (aA XB, aB XA, aA XC, aB XB, aC XA, aB XC, aC XB, tB, tC, tD: |sum| < ~100 mm) go through ONE v_mfma_f32_16x16x32_f16 per row, scaled by
+//     2^10 so that every fp16 operand is a normal number (the matrix core flushes subnormal halves); its fp32 accumulation is good to ~1e-6 mm;
+//   * E = D_hi + 2^-10 D_cross is one fused multiply-add: the single rounding to float of the camera-frame point.
+// What this kernel writes is the A-operand image in the matrix core's own lane layout: for hypothesis h, row r in (x, y, z), quarter q (= coordinate X, Y, Z,
+// or the translation for q = 3): eight halves for the K = 32 instruction (k = 8q .. 8q + 7) and four for the K = 16 one (k = 4q .. 4q + 3).
+//   cross[q < 3] = (aA 2^2, aB 2^12, aA, aB 2^10, aC 2^18, aB 2^7, aC 2^18, 0)   against   B = (XB 2^8, XA 2^-2, XC 2^10, XB, XA 2^-8, XC 2^3, XB 2^-8, 0)
+//   cross[q = 3] = (tB 2^-3, tC 2^8, tD 2^13, 0, ...)                            against   B = (2^13, 2^2, 2^-3, 2^14, 0, ...)
+//   hi[q < 3]    = (0, aA 2^2, 0, 0),   hi[q = 3] = (0, 0, 0, tA 2^-14)          against   the FIRST FOUR halves of the same B
+// The x and y rows carry the minus sign of hp_chunk's (-xc, -yc, zc).  Valid for focal lengths up to 2^13 px, |t| < 2^16 mm, |X| < 2^16 mm (the kernel
+// sends chunks with larger coordinates down the fp32 path); pieces are clamped to +-2047 grid units, so out-of-range input degrades, it does not overflow.
+// --------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int SPLIT_CROSS_BYTES = 12 * 16, SPLIT_HI_BYTES = 12 * 8;  // per hypothesis: 3 rows x 4 quarters
+DM_INLINE double split_piece(double& rem, int grid_exp) {  // the multiple of 2^grid_exp nearest to rem (at most 2047 units), which is taken out of rem
+    double n = rint(ldexp(rem, -grid_exp));
+    n = fmin(fmax(n, -2047.0), 2047.0);
+    const double p = ldexp(n, grid_exp);
+    rem -= p;
+    return p;
+}
+__global__ __launch_bounds__(256) void k_pose_prep_split(int N, const double* __restrict__ poses, float fx, float fy, int ex, h8* __restrict__ cross, h4* __restrict__ hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (hypothesis, row)
+    const int h = i / 3, r = i - 3 * h;
+    if (h >= N) return;
+    double rv[3] = {poses[6 * h], poses[6 * h + 1], poses[6 * h + 2]};
+    double R[9];
+    dm::rodrigues_v2m<false>(rv, R, nullptr);
+    const double f = r == 0 ? -(double)fx : r == 1 ? -(double)fy : 1.0;
+    const int E = r < 2 ? ex : 0;
+    const double a[4] = {f * R[3 * r], f * R[3 * r + 1], f * R[3 * r + 2], f * poses[6 * h + 3 + r]};
+    h8* oc = cross + ((size_t)h * 3 + r) * 4;
+    h4* oh = hi + ((size_t)h * 3 + r) * 4;
+    const _Float16 z = (_Float16)0.f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        double rem = a[q];
+        const double aA = split_piece(rem, E - 10), aB = split_piece(rem, E - 21), aC = split_piece(rem, E - 32);
+        oc[q] = h8{(_Float16)(float)ldexp(aA, 2), (_Float16)(float)ldexp(aB, 12), (_Float16)(float)aA, (_Float16)(float)ldexp(aB, 10),
+                   (_Float16)(float)ldexp(aC, 18), (_Float16)(float)ldexp(aB, 7), (_Float16)(float)ldexp(aC, 18), z};
+        oh[q] = h4{z, (_Float16)(float)ldexp(aA, 2), z, z};
+    }
+    double rem = a[3];
+    const double tA = split_piece(rem, E + 6), tB = split_piece(rem, E - 5), tC = split_piece(rem, E - 16), tD = split_piece(rem, E - 27);
+    oc[3] = h8{(_Float16)(float)ldexp(tB, -3), (_Float16)(float)ldexp(tC, 8), (_Float16)(float)ldexp(tD, 13), z, z, z, z, z};
+    oh[3] = h4{z, z, z, (_Float16)(float)ldexp(tA, -14)};
+}
+
+size_t pose_split_bytes(int N) { return (size_t)N * (SPLIT_CROSS_BYTES + SPLIT_HI_BYTES); }
+int pose_split_exponent(const FrameDev& F) {  // ceil(log2(max focal length)), at least 0; > 13: the exact form is not available
+    int e = 0;
+    while (ldexp(1.0, e) < (double)fmaxf(F.fx, F.fy)) e++;
+    return e;
+}
+hipError_t pose_prep_split(hipStream_t st, int N, const double* poses, const FrameDev& F, void* split) {
+    if (N <= 0) return hipSuccess;
+    h8* cross = reinterpret_cast<h8*>(split);
+    h4* hi = reinterpret_cast<h4*>(reinterpret_cast<char*>(split) + (size_t)N * SPLIT_CROSS_BYTES);
+    hipLaunchKernelGGL(k_pose_prep_split, dim3((3 * N + 255) / 256), dim3(256), 0, st, N, poses, F.fx, F.fy, pose_split_exponent(F), cross, hi);
     return hipGetLastError();
 }
 
@@ -301,7 +369,6 @@ DM_INLINE float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, res
 //   3. soft-inlier sigmoid packed over PIXEL pairs of one hypothesis, accumulated per hypothesis.
 // Z == 0 detection of the fast path: zacc accumulates iz^2 -- rcp(0) = inf sticks (as would a NaN), anything finite stays finite unless
 // |z| < 5e-20, which only sends the wave down the (always exact) slow path once more.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // The low parts of the pose records through the matrix core as well (k2_flags bit 27): per 1 024 pairs twelve v_mfma_f32_16x16x16_f16 chained through
 // the accumulator of the fp32 ones, D = A_lo 2^16 . B 2^-16 + (A_hi . B).  Only the k = 0..3 slice of the 16-deep fp16 product is used (the operands of the
 // lanes 16..63 are zero).  What it removes is the SYSTEMATIC part of the fast form's error -- the fp32 rounding of a hypothesis' record shifts all of its
@@ -355,6 +422,77 @@ DM_INLINE bool hp_chunk(float ax, float ay, float az, const float (&Bm)[4], cons
         if (SOFT) sloc[r] = soft_inlier2(f2{ev[r].x, ev[r].y}, kA, kB) + soft_inlier2(f2{ev[r].z, ev[r].w}, kA, kB);
     }
     return EXACT_Z ? false : !(zacc.x + zacc.y <= 3.0e38f);
+}
+
+// The exact-transform chunk (round 6, k2_flags bit 28): hp_chunk with E = R.X + t from the split records (k_pose_prep_split) -- per row one K = 32 fp16 MFMA
+// for the cross terms, one K = 16 fp16 MFMA for the exactly summed high products (its B operand is the first half of the other's), one packed fma per
+// register pair for E = D_hi + 2^-10 D_cross: the camera-frame point is rounded to float ONCE.  Then hp_chunk's tail with one Newton step on v_rcp_f32:
+// the hardware reciprocal's error is not zero-mean, and a biased 1 / z scales every projection of a hypothesis about the principal point the same way --
+// measured (scripts/r06_k2_diag.py, profiles/r06_k2_diag.txt): with an exact E and the plain v_rcp_f32 the softmax weight of two unrelated hypotheses in a tie is
+// still off by 5.7e-4 (stated 1e-4), with the Newton step by 5.3e-5; max |err - oracle| over all cells 7.6e-5 px.
+struct ExOps { h8 cx, cy, cz; h4 hx, hy, hz; };
+template <bool EXACT_Z, bool SOFT>
+DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4], f2 (&sloc)[4]) {
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f2 k10 = splat(0.0009765625f);  // 2^-10
+    f2 qq[4][2];
+    f2 zacc = splat(0.f);
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const h4 b4 = __builtin_shufflevector(B8[m], B8[m], 0, 1, 2, 3);
+        const f4 cx = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.cx, B8[m], z4, 0, 0, 0);
+        const f4 cy = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.cy, B8[m], z4, 0, 0, 0);
+        const f4 cz = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.cz, B8[m], z4, 0, 0, 0);
+        const f4 hx = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hx, b4, z4, 0, 0, 0);
+        const f4 hy = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hy, b4, z4, 0, 0, 0);
+        const f4 hz = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hz, b4, z4, 0, 0, 0);
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const f2 x = pk_fma(pr ? f2{cx.z, cx.w} : f2{cx.x, cx.y}, k10, pr ? f2{hx.z, hx.w} : f2{hx.x, hx.y});
+            const f2 y = pk_fma(pr ? f2{cy.z, cy.w} : f2{cy.x, cy.y}, k10, pr ? f2{hy.z, hy.w} : f2{hy.x, hy.y});
+            const f2 z = pk_fma(pr ? f2{cz.z, cz.w} : f2{cz.x, cz.y}, k10, pr ? f2{hz.z, hz.w} : f2{hz.x, hz.y});
+            f2 iz = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
+            iz = pk_fma(pk_fma(-z, iz, splat(1.0f)), iz, iz);  // z == 0: inf -> NaN, which sticks in zacc like the inf of the plain form
+            if (EXACT_Z) {  // projectPoints: z = Z ? 1/Z : 1
+                iz.x = (z.x == 0.0f) ? 1.0f : iz.x;
+                iz.y = (z.y == 0.0f) ? 1.0f : iz.y;
+            } else {
+                zacc = pk_fma(iz, iz, zacc);
+            }
+            const f2 du = pk_fma(x, iz, splat(ppix[m].x));
+            const f2 dv = pk_fma(y, iz, splat(ppix[m].y));
+            qq[m][pr] = pk_fma(dv, dv, du * du);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pr = r >> 1;
+        ev[r].x = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[0][pr].y : qq[0][pr].x), clampv);
+        ev[r].y = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[1][pr].y : qq[1][pr].x), clampv);
+        ev[r].z = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[2][pr].y : qq[2][pr].x), clampv);
+        ev[r].w = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[3][pr].y : qq[3][pr].x), clampv);
+        if (SOFT) sloc[r] = soft_inlier2(f2{ev[r].x, ev[r].y}, kA, kB) + soft_inlier2(f2{ev[r].z, ev[r].w}, kA, kB);
+    }
+    return EXACT_Z ? false : !(zacc.x + zacc.y <= 3.0e38f);
+}
+
+// The B operand of hp_chunk_ex for one (chunk, m): lane (g, c) holds coordinate g of pixel 4c + m (g = 3: the constants the translation pieces multiply).
+// X = XA + XB + XC with XA = 32 rint(X / 32), XB = rint(64 (X - XA)) / 64, XC the rest -- both remainders are exact in fp32.  oor: |X| >= 2^16 mm (or NaN).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+// round to nearest (v_cvt_pk_f16_f32): every piece but XC is exactly representable, and XC must not be TRUNCATED -- a round-toward-zero conversion shrinks every
+// coordinate by ~2^-19 mm on average, a systematic shift that the near-tie test sees (the budget for a systematic error is ~1e-6 mm, see hp_chunk_ex)
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+DM_INLINE unsigned pk_h2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, h2v)); }
+DM_INLINE h8 split_B(float X, bool is_const, bool& oor) {
+    const float r1 = __builtin_rintf(X * 0.03125f);
+    const float rem1 = fmaf(-32.f, r1, X);
+    const float r2 = __builtin_rintf(rem1 * 64.f);
+    const float rem2 = fmaf(-0.015625f, r2, rem1);
+    oor = oor || (!is_const && !(fabsf(r1) <= 2047.f));
+    u4v v = {pk_h2(r2 * 4.f, r1 * 8.f), pk_h2(rem2 * 1024.f, r2 * 0.015625f), pk_h2(r1 * 0.125f, rem2 * 8.f), pk_h2(r2 * 6.103515625e-05f, 0.f)};
+    const u4v kc = {pk_h2(8192.f, 4.f), pk_h2(0.125f, 16384.f), 0u, 0u};
+    v.x = is_const ? kc.x : v.x; v.y = is_const ? kc.y : v.y; v.z = is_const ? 0u : v.z; v.w = is_const ? 0u : v.w;
+    return __builtin_bit_cast(h8, v);
 }
 
 template <int HT, bool ERR, bool SOFT, bool UV, int KM_CH>
@@ -536,12 +674,13 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
 // component, L2-resident -- no LDS image, no barrier before the first MFMA), the pixel positions of the implicit grid from a
 // wave-uniform row / column (W % 64 == 0), and the only barrier is the one before the 16 NG partial soft sums leave the workgroup.
 // --------------------------------------------------------------------------------------------------
-template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW, bool LO = false>
+template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW, bool LO = false, bool EX = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                              const float* __restrict__ uv, float* __restrict__ err,
                                                              float* __restrict__ soft_part, int N, int P, int W, int PT, float cx, float cy,
                                                              float clampv, float kA, float kB, int kflags, int Nf, long long xyz_stride,
-                                                             long long uv_stride, const float* __restrict__ staged_lo = nullptr) {
+                                                             long long uv_stride, const float* __restrict__ staged_lo = nullptr,
+                                                             const void* __restrict__ split = nullptr) {
     constexpr int HT = 16 * NG;
     const int b = blockIdx.x;
     int ht, pt;
@@ -594,6 +733,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             Bm[ch][m] = (g < 3) ? xyz[(size_t)pc * 3 + g] : 1.0f;
         }
     }
+    // EX: the split fp16 B operands of every (chunk, m); a chunk with a coordinate beyond 2^16 mm takes the fp32 path (wave-uniform flag per chunk)
+    h8 B8[EX ? CHW : 1][4];
+    bool oor[EX ? CHW : 1];
+    if (EX) {
+#pragma unroll
+        for (int ch = 0; ch < CHW; ch++) {
+            bool o = false;
+#pragma unroll
+            for (int m = 0; m < 4; m++) B8[ch][m] = split_B(Bm[ch][m], g == 3, o);
+            oor[ch] = __any(o);
+        }
+    }
     // LO: the fp16 B operands of every (chunk, m) -- (X, Y, Z, 1) 2^-16 of pixel column c in the lanes of row 0, zero elsewhere.  Row 0 holds X itself;
     // Y and Z come over from rows 1 and 2 with one lane swap each
     h4 B16[LO ? CHW : 1][4];
@@ -617,10 +768,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
     // A operands: with up to two groups all of them are loaded up front; with four they are fetched one group ahead (two register sets instead of
     // four: the 128-register build of the <64 hypotheses, 256 pixels> form needs the six registers)
     constexpr bool A_AHEAD = NG > 2;
-    float ax[NG], ay[NG], az[NG];
+    float ax[EX ? 1 : NG], ay[EX ? 1 : NG], az[EX ? 1 : NG];
     LoOps alo[LO ? NG : 1];
+    ExOps aex[EX ? NG : 1];
     auto load_A = [&](int gi) {
         const int hyp = min(16 * gi + c, nh - 1);  // beyond the ragged end: repeat the last valid hypothesis (never stored)
+        if (EX) {
+            // the split records in the matrix core's lane layout: quarter g of rows x, y, z of hypothesis c -- 16 bytes (K = 32 operand) + 8 bytes (K = 16) each
+            const h8* rc = reinterpret_cast<const h8*>(split) + (size_t)(h0 + hyp) * 12 + g;
+            const h4* rh = reinterpret_cast<const h4*>(reinterpret_cast<const char*>(split) + (size_t)N * SPLIT_CROSS_BYTES) + (size_t)(h0 + hyp) * 12 + g;
+            aex[gi].cx = rc[0]; aex[gi].cy = rc[4]; aex[gi].cz = rc[8];
+            aex[gi].hx = rh[0]; aex[gi].hy = rh[4]; aex[gi].hz = rh[8];
+            return;
+        }
         const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
         ax[gi] = rec[0]; ay[gi] = rec[4]; az[gi] = rec[8];
         if (LO) {
@@ -671,7 +831,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
             asm volatile("" ::: "memory");  // keeps the compiler from hoisting the fetch to the top of the kernel (that is the up-front form)
             load_A(gi + 1);
         }
-        const float nax = -ax[gi], nay = -ay[gi];  // x and y rows negated: the MFMA yields (-xc, -yc, zc)
+        const float nax = EX ? 0.f : -ax[EX ? 0 : gi], nay = EX ? 0.f : -ay[EX ? 0 : gi];  // x and y rows negated: the MFMA yields (-xc, -yc, zc)
         const int hyp0 = 16 * gi + 4 * g;
         f2 ssum[4] = {splat(0.f), splat(0.f), splat(0.f), splat(0.f)};
 #pragma unroll
@@ -685,11 +845,23 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
                 for (int m = 0; m < 4; m++) ppix[0][m] = f2{pb.x + (float)m, pb.y};
             }
             const f2 (&pp)[4] = ppix[G64 ? 0 : ch];
-            if (kflags & 2) {  // store schedule alone (measurement)
-                ev[0] = ev[1] = ev[2] = ev[3] = f4{nax, nay, az[gi], (float)ch};
+            if (EX) {
+                if (__builtin_expect(oor[ch], 0)) {
+                    // a coordinate beyond the split's range: this chunk through the fp32 transform (operands fetched here, the rare path)
+                    const int hyp = min(16 * gi + c, nh - 1);
+                    const float* rec = staged + (size_t)(h0 + hyp) * POSE_STRIDE + g;
+                    float Bf[4];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) Bf[m] = (g < 3) ? xyz[(size_t)min(p0[ch] + m, P - 1) * 3 + g] : 1.0f;
+                    (void)hp_chunk<true, SOFT, false>(-rec[0], -rec[4], rec[8], Bf, pp, clampv, kA, kB, ev, sloc);
+                } else if (__builtin_expect(__any(hp_chunk_ex<false, SOFT>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
+                    (void)hp_chunk_ex<true, SOFT>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc);
+                }
+            } else if (kflags & 2) {  // store schedule alone (measurement)
+                ev[0] = ev[1] = ev[2] = ev[3] = f4{nax, nay, az[EX ? 0 : gi], (float)ch};
                 sloc[0] = sloc[1] = sloc[2] = sloc[3] = splat(0.f);
-            } else if (__builtin_expect(__any(hp_chunk<false, SOFT, LO>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0])), 0)) {
-                (void)hp_chunk<true, SOFT, LO>(nax, nay, az[gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0]);
+            } else if (__builtin_expect(__any(hp_chunk<false, SOFT, LO>(nax, nay, az[EX ? 0 : gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0])), 0)) {
+                (void)hp_chunk<true, SOFT, LO>(nax, nay, az[EX ? 0 : gi], Bm[ch], pp, clampv, kA, kB, ev, sloc, &alo[LO ? gi : 0], B16[LO ? ch : 0]);
             }
             if (SOFT) {
                 const f2 vf = splat(valid[ch] ? 1.0f : 0.0f);
@@ -914,9 +1086,10 @@ static hipError_t launch_reproject_ps(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
-template <int NG, int CHW, int WAVES, bool PW, int MINW = 1, bool LO = false>
+template <int NG, int CHW, int WAVES, bool PW, int MINW = 1, bool LO = false, bool EX = false>
 static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
-                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB, const float* staged_lo = nullptr) {
+                                      float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB, const float* staged_lo = nullptr,
+                                      const void* split = nullptr) {
     constexpr int HT = 16 * NG;
     const int tile = WAVES * CHW * 64;
     static_assert(PW || WAVES > 1, "one-wave workgroups write per-wave partial sums");
@@ -927,8 +1100,8 @@ static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
     const bool G64 = !UV && (F.W & 63) == 0;
 #define DSAC_K2S(E, S, U, G)                                                                                                               \
-    hipExtLaunchKernelGGL((k_reproject_st<NG, CHW, WAVES, PW, E, S, U, G, MINW, LO>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, \
-                          soft_part, N, F.P, F.W, PT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride, staged_lo)
+    hipExtLaunchKernelGGL((k_reproject_st<NG, CHW, WAVES, PW, E, S, U, G, MINW, LO, EX>), dim3(grid), dim3(WAVES * 64), 0, st, evA, evB, 0, staged, F.xyz, F.uv, err, \
+                          soft_part, N, F.P, F.W, PT, F.cx, F.cy, clampv, kA, kB, kflags, Nf, F.xyz_stride, F.uv_stride, staged_lo, split)
     if (ERR && SOFT) { if (UV) DSAC_K2S(true, true, true, false); else if (G64) DSAC_K2S(true, true, false, true); else DSAC_K2S(true, true, false, false); }
     else if (ERR) { if (UV) DSAC_K2S(true, false, true, false); else if (G64) DSAC_K2S(true, false, false, true); else DSAC_K2S(true, false, false, false); }
     else if (SOFT) { if (UV) DSAC_K2S(false, true, true, false); else if (G64) DSAC_K2S(false, true, false, true); else DSAC_K2S(false, true, false, false); }
@@ -961,11 +1134,12 @@ DM_INLINE f2 soft_inlier2_hl(f2 e, float kA, float kAl, float kB, float kBl) {
     return pk_fma(pk_fma(-d, r, splat(1.0f)), r, r);
 }
 
-template <int HT, bool ERR, bool SOFT, bool UV>
+template <int HT, bool ERR, bool SOFT, bool UV, bool DIAG>
 __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __restrict__ poses, const float* __restrict__ xyz, const float* __restrict__ uv,
                                                                float* __restrict__ err, float* __restrict__ soft_part, int N, int P, int W, int PT,
                                                                float fx, float fy, float cx, float cy, float clampv, float kA, float kB, int Nf,
-                                                               long long xyz_stride, long long uv_stride, float kAl, float kBl, int rec32) {
+                                                               long long xyz_stride, long long uv_stride, float kAl, float kBl, int rec32, int diag_arg) {
+    const int diag = DIAG ? diag_arg : 0;  // the diagnostic switches only exist in the DIAG instantiation: the parity mode itself pays nothing for them
     const int b = blockIdx.x;
     const int q = b >> 3, PTG = (PT + 7) >> 3;
     const int ht = q / PTG, pt = (q % PTG) * 8 + (b & 7);  // XCD-aware, pixel tiles innermost
@@ -1034,11 +1208,25 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
             const double zc = fma(c0, X[k], fma(c1, Y[k], fma(c2, Z[k], c3)));
             // 1 / zc in double: v_rcp_f32's seed (1 ulp, 2^-23) and one Newton step (2^-46: a relative 1.4e-14, i.e. 6e-12 px at the image border -- far
             // below the float the difference is rounded to); projectPoints: z = Z ? 1/Z : 1
-            double iz = (double)__builtin_amdgcn_rcpf((float)zc);
-            iz = fma(fma(-zc, iz, 1.0), iz, iz);
-            iz = (zc == 0.0) ? 1.0 : iz;
-            const float du = (float)fma(-xc, iz, pu[k]);  // cell position minus projection: one rounding to float, like the reference's Point2f difference
-            const float dv = (float)fma(-yc, iz, pv[k]);
+            float du, dv;
+            if (diag & 4) {
+                // diagnostic (k2_diag bit 2, round 6): the exact camera-frame point rounded ONCE to float, then the fast forms' fp32 tail -- what a form
+                // with an exact transform in front of hp_chunk's arithmetic would compute (bit 3: one Newton step on v_rcp_f32's result)
+                const float xf = (float)xc, yf = (float)yc, zf = (float)zc;
+                float izf = __builtin_amdgcn_rcpf(zf);
+                if (diag & 8) izf = fmaf(fmaf(-zf, izf, 1.0f), izf, izf);
+                izf = (zf == 0.0f) ? 1.0f : izf;
+                du = fmaf(-xf, izf, (float)pu[k]);
+                dv = fmaf(-yf, izf, (float)pv[k]);
+            } else {
+                double xq = xc, yq = yc, zq = zc;
+                if (diag & 2) { xq = (double)(float)xc; yq = (double)(float)yc; zq = (double)(float)zc; }  // bit 1: the point rounded to float, the tail exact
+                double iz = (double)__builtin_amdgcn_rcpf((float)zq);
+                iz = fma(fma(-zq, iz, 1.0), iz, iz);
+                iz = (zq == 0.0) ? 1.0 : iz;
+                du = (float)fma(-xq, iz, pu[k]);  // cell position minus projection: one rounding to float, like the reference's Point2f difference
+                dv = (float)fma(-yq, iz, pv[k]);
+            }
             e[k] = fminf(__builtin_amdgcn_sqrtf(fmaf(dv, dv, du * du)), clampv);
         }
         if (ERR && valid) __builtin_nontemporal_store(f4{e[0], e[1], e[2], e[3]}, reinterpret_cast<f4*>(erow + (size_t)h * P));
@@ -1047,10 +1235,21 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
             // ~2e4 -- 2e-4 on a softmax weight in a tie, twice the stated 1e-4
             // ... and the sigmoid without the systematic part of its fp32 error: the exponent from (high, low) pairs of the two constants (a rounded kA / kB shifts
             // every cell's exponent the same way: ~1e-3 on a score), the reciprocal polished by one Newton step
-            const f2 s2 = soft_inlier2_hl(f2{e[0], e[1]}, kA, kAl, kB, kBl) + soft_inlier2_hl(f2{e[2], e[3]}, kA, kAl, kB, kBl);
-            double s = valid ? (double)s2.x + (double)s2.y : 0.0;
+            // k2_diag bit 4: the sigmoid's constants as single floats; bit 5: its reciprocal unpolished; bit 6: the wave's sum in fp32 (the fast forms' sums)
+            const float kAl_ = (diag & 16) ? 0.f : kAl, kBl_ = (diag & 16) ? 0.f : kBl;
+            f2 s2;
+            if (diag & 32) s2 = soft_inlier2(f2{e[0], e[1]}, kA, kB) + soft_inlier2(f2{e[2], e[3]}, kA, kB);
+            else s2 = soft_inlier2_hl(f2{e[0], e[1]}, kA, kAl_, kB, kBl_) + soft_inlier2_hl(f2{e[2], e[3]}, kA, kAl_, kB, kBl_);
+            double s;
+            if (diag & 64) {
+                float sf = valid ? s2.x + s2.y : 0.f;
+                sf = wave_sum(sf);
+                s = (double)sf;
+            } else {
+                s = valid ? (double)s2.x + (double)s2.y : 0.0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            }
             if (lane == 0) s_red[wave * HT + h] = s;
         }
     }
@@ -1070,7 +1269,7 @@ __global__ __launch_bounds__(K2_THREADS) void k_reproject_prec(const double* __r
 
 template <int HT>
 static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* poses, const FrameDev& F, float clampv, float* err, double kAd, double kBd,
-                                        float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB, int rec32) {
+                                        float* soft_part, int* tiles_used, int Nf, hipEvent_t evA, hipEvent_t evB, int rec32, int diag) {
     const float kA = (float)kAd, kB = (float)kBd, kAl = (float)(kAd - (double)kA), kBl = (float)(kBd - (double)kB);
     const int PT = (F.P + K2_THREADS * 4 - 1) / (K2_THREADS * 4);
     const int NTa = (N + HT - 1) / HT;
@@ -1078,8 +1277,10 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
     if (tiles_used) *tiles_used = 2 * PT;  // a (high, low) pair of partial rows per pixel tile; 2 ceil(P / 1024) <= reproject_num_pixel_tiles(P)
     const bool ERR = err != nullptr, SOFT = soft_part != nullptr, UV = F.uv != nullptr;
 #define DSAC_K2P(E, S, U)                                                                                                                       \
-    hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
-                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl, rec32)
+    do { if (diag) hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U, true>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
+                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl, rec32, diag); \
+         else hipExtLaunchKernelGGL((k_reproject_prec<HT, E, S, U, false>), dim3(grid), dim3(K2_THREADS), 0, st, evA, evB, 0, poses, F.xyz, F.uv, err, soft_part, N, F.P, \
+                          F.W, PT, F.fx, F.fy, F.cx, F.cy, clampv, kA, kB, Nf, F.xyz_stride, F.uv_stride, kAl, kBl, rec32, 0); } while (0)
     if (ERR && SOFT) { if (UV) DSAC_K2P(true, true, true); else DSAC_K2P(true, true, false); }
     else if (ERR) { if (UV) DSAC_K2P(true, false, true); else DSAC_K2P(true, false, false); }
     else if (SOFT) { if (UV) DSAC_K2P(false, true, true); else DSAC_K2P(false, true, false); }
@@ -1088,7 +1289,7 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
 }
 
 bool reproject_variant_known(int v) {
-    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 83);
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 89);
 }
 
 // the largest count of partial-sum rows over all forms: one row per 64-pixel wave chunk, and the per-wave-sum forms with several waves per workgroup write
@@ -1143,8 +1344,8 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         const double kAd = (double)beta * 1.4426950408889634, kBd = -(double)beta * (double)tau * 1.4426950408889634;
         // hypothesis tile by size as the VALU forms: 32 for big launches, 16 for a single small frame (more workgroups)
         const int rec32 = (opts.flags >> 26) & 1;
-        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32)
-                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32);
+        return nhp > 2.0e8 ? launch_reproject_prec<32>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32, opts.diag)
+                           : launch_reproject_prec<16>(st, N, opts.poses64, F, clampv, err, kAd, kBd, soft_part, tiles_used, Nf, evA, evB, rec32, opts.diag);
     }
     // records in two pieces (k2_flags bit 27): the one-wave streaming form <64 hypotheses, 256 pixels> with the fp16 correction instructions, whatever the size
     if ((opts.flags & K2_FLAG_RECLO) && opts.staged_lo && vec && (opts.variant < 0 || (opts.variant >= 80 && opts.variant <= 83))) {
@@ -1156,6 +1357,15 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
             case 81: default: return DSAC_LO(4, 4, 2);  // <64, 256>, 2 waves per SIMD, no scratch: the fastest of the four (profiles/r05_k2_reclo_ab.txt)
         }
 #undef DSAC_LO
+    }
+    // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84..87 = its tile / occupancy trades
+    if ((opts.flags & K2_FLAG_EXACT) && opts.split && vec && (opts.variant < 0 || (opts.variant >= 84 && opts.variant <= 89))) {
+#define DSAC_EX(NG_, CH_, MW_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, true>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
+        switch (opts.variant) {
+            case 89: return DSAC_EX(2, 4, 2);   // <32 hypotheses, 256 pixels>, 2 waves per SIMD
+            case 84: default: return DSAC_EX(4, 4, 2);  // <64, 256>, 2 waves per SIMD (three or four waves per SIMD spill: 1.4-2.8 ms, profiles/r06_k2_exact_ab.txt)
+        }
+#undef DSAC_EX
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
     const bool pm = opts.variant < 0 ? true : opts.pixel_minor;  // the auto policy's forms were all measured with pixel tiles innermost
@@ -1222,7 +1432,7 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 55: return DSAC_ST(4, 1, 4, true);
         case 56: return DSAC_ST(2, 4, 4, true);
         case 57: return DSAC_ST(4, 2, 4, true);
-        case 58: case 80: case 81: case 82: case 83:  // 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
+        case 58: case 80: case 81: case 82: case 83: case 84: case 85: case 86: case 87: case 88: case 89:  // 84..89: the exact-transform forms when k2_flags bit 28 is set (above); 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
             return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
         case 59: return launch_reproject_st<2, 4, 1, true, 5>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <2,4,1>, >= 5 waves per SIMD
         case 65: return launch_reproject_st<4, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,4> per-wave sums

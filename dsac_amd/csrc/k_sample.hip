@@ -12,6 +12,7 @@
 // 96 lanes = one two-wave workgroup per hypothesis; central differences are formed after a wave-local exchange.
 #include "kernels.h"
 #include "dmath.h"
+#include "refstream.h"
 
 namespace dk {
 
@@ -530,6 +531,229 @@ hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, 
         else { if (wpb >= 8) DSAC_K1(8, 1, false); else if (wpb >= 4) DSAC_K1(4, 1, false); else DSAC_K1(1, 1, false); }
 #undef DSAC_K1
     }
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
+// K1 in the REFERENCE'S OWN random stream (round 6; refstream.h has the stream's arithmetic).  The reference serves the hypotheses of OpenMP thread t one
+// after the other from std::mt19937(seed + t): which attempt draws which cells is a function of the stream alone, only WHICH attempt goes to which hypothesis
+// depends on P3P.  So: (1) one workgroup per stream generates a window of raw outputs (the MT19937 twist in three data-parallel phases) and parses it into
+// attempts -- a wave at a time, 64 attempts speculatively at 8 outputs each, the valid prefix ends at the first attempt that needed more (a duplicate cell,
+// a rejected draw); (2) every attempt of every stream is evaluated in parallel by K1's own solve_and_check, one lane per attempt; (3) one workgroup per
+// stream prefix-counts the accepted flags: the j-th accepted attempt is the stream's j-th hypothesis, exactly what the sequential loop would have kept;
+// the generator advances to the output behind the last attempt used.  A window that does not serve every hypothesis is followed by another (host loop).
+// --------------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+
+__global__ __launch_bounds__(64) void k_refstream_init(RefStreamState* st, uint32_t seed, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    rs::mt_seed(st[t].mt, seed + (uint32_t)t);
+    st[t].idx = rs::MT_N;  // std::mt19937 after seed(): the first output twists
+}
+
+// the next block in place, by the whole workgroup (mt in LDS).  x[k + n] needs x[k], x[k + 1], x[k + m]: k < 227 read only old words, 227 <= k < 454 the new
+// words of the first phase, the rest those of the second
+DM_INLINE void rs_twist_lds(uint32_t* mt, int tid) {
+    constexpr int D = rs::MT_N - rs::MT_M;  // 227
+    for (int ph = 0; ph < 3; ph++) {
+        const int k = ph * D + tid;
+        const bool act = tid < D && k < rs::MT_N;
+        uint32_t v = 0;
+        if (act) v = rs::mt_twist_word(mt[k], mt[k + 1 == rs::MT_N ? 0 : k + 1], ph == 0 ? mt[k + rs::MT_M] : mt[k - D]);
+        __syncthreads();
+        if (act) mt[k] = v;
+        __syncthreads();
+    }
+}
+
+// advance a generator by n outputs (std::mt19937::discard)
+DM_INLINE void rs_advance_lds(uint32_t* mt, uint32_t& idx, unsigned long long n, int tid) {
+    const unsigned long long total = (unsigned long long)idx + n;
+    if (total <= (unsigned long long)rs::MT_N) { idx = (uint32_t)total; return; }
+    const unsigned long long twists = (total - 1) / rs::MT_N;
+    for (unsigned long long i = 0; i < twists; i++) rs_twist_lds(mt, tid);
+    idx = (uint32_t)(total - twists * rs::MT_N);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_refstream_discard(RefStreamState* st, int t, unsigned long long n) {
+    __shared__ uint32_t mt[rs::MT_N];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < rs::MT_N; i += RS_THREADS) mt[i] = st[t].mt[i];
+    uint32_t idx = st[t].idx;
+    __syncthreads();
+    rs_advance_lds(mt, idx, n, tid);
+    for (int i = tid; i < rs::MT_N; i += RS_THREADS) st[t].mt[i] = mt[i];
+    if (tid == 0) st[t].idx = idx;
+}
+
+// (1) window of stream t = blockIdx.x: raw[t][0 .. D) and its attempts.  need[t] == 0: nothing to do (parsed = 0).
+__global__ __launch_bounds__(RS_THREADS) void k_refstream_parse(const RefStreamState* __restrict__ st, int W, int H, int mode, int A, int D, uint32_t* __restrict__ raw_all,
+                                                                int32_t* __restrict__ sets_all, uint32_t* __restrict__ offs_all, int32_t* __restrict__ parsed,
+                                                                const int32_t* __restrict__ need) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (need[t] <= 0) { if (tid == 0) parsed[t] = 0; return; }
+    __shared__ uint32_t mt[rs::MT_N];
+    uint32_t* raw = raw_all + (size_t)t * D;
+    for (int i = tid; i < rs::MT_N; i += RS_THREADS) mt[i] = st[t].mt[i];
+    const int idx0 = (int)st[t].idx;
+    __syncthreads();
+    int o = 0;
+    for (int i = idx0 + tid; i < rs::MT_N && o + (i - idx0) < D; i += RS_THREADS) raw[o + (i - idx0)] = rs::mt_temper(mt[i]);
+    o += rs::MT_N - idx0;
+    while (o < D) {
+        rs_twist_lds(mt, tid);
+        for (int i = tid; i < rs::MT_N && o + i < D; i += RS_THREADS) raw[o + i] = rs::mt_temper(mt[i]);
+        o += rs::MT_N;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid >= 64) return;
+    int32_t* sets = sets_all + (size_t)t * A * 4;
+    uint32_t* offs = offs_all + (size_t)t * (A + 1);
+    const int lane = tid;
+    long long cur = 0;
+    int a = 0;
+    while (a < A) {
+        const long long start = cur + 8 * lane;
+        int32_t set4[4];
+        const int len = rs::parse_attempt([&](long long i) { return raw[i]; }, start, (long long)D, (uint32_t)W, (uint32_t)H, mode, set4);
+        const unsigned long long odd = __ballot(len != 8);
+        const int k0 = odd ? __ffsll((long long)odd) - 1 : 64;
+        const int len_k0 = __shfl(len, k0 & 63, 64);
+        int nv = odd ? (len_k0 > 0 ? k0 + 1 : k0) : 64;  // the attempts of lanes 0 .. k0 start where the speculation put them; a starved / degenerate one is not an attempt
+        nv = min(nv, A - a);
+        if (lane < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sets[(size_t)(a + lane) * 4 + k] = set4[k];
+            offs[a + lane] = (uint32_t)start;
+        }
+        if (nv == 0) break;
+        const long long st_last = cur + 8 * (nv - 1);
+        const int len_last = __shfl(len, nv - 1, 64);
+        cur = st_last + len_last;
+        a += nv;
+        if (odd && len_k0 <= 0) break;
+    }
+    if (lane == 0) { offs[a] = (uint32_t)cur; parsed[t] = a; }
+}
+
+// (2) one lane per attempt
+__global__ __launch_bounds__(64) void k_refstream_eval(int A, const int32_t* __restrict__ parsed, const int32_t* __restrict__ sets_all, FrameDev F, int thr_int,
+                                                       double* __restrict__ poses_tmp, uint8_t* __restrict__ ok_tmp) {
+    const int t = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= parsed[t]) return;
+    const size_t i = (size_t)t * A + a;
+    int32_t set4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) set4[k] = sets_all[i * 4 + k];
+    double cv6[6] = {0, 0, 0, 0, 0, 0};
+    const bool good = solve_and_check<false>(F, set4, thr_int, cv6);
+#pragma unroll
+    for (int k = 0; k < 6; k++) poses_tmp[i * 6 + k] = good ? cv6[k] : 0.0;
+    ok_tmp[i] = good ? 1 : 0;
+}
+
+// (3) stream t = blockIdx.x: its next need[t] hypotheses are its first need[t] accepted attempts of the window
+__global__ __launch_bounds__(RS_THREADS) void k_refstream_select(RefStreamState* __restrict__ st, int A, const int32_t* __restrict__ parsed, const int32_t* __restrict__ sets_all,
+                                                                 const uint32_t* __restrict__ offs_all, const double* __restrict__ poses_tmp, const uint8_t* __restrict__ ok_tmp,
+                                                                 const int32_t* __restrict__ first, int32_t* __restrict__ served, int32_t* __restrict__ need,
+                                                                 unsigned long long* __restrict__ consumed, long long* __restrict__ attempts, FrameDev F,
+                                                                 double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int n = parsed[t], want = need[t];
+    if (want <= 0 || n <= 0) return;
+    __shared__ int s_cnt[RS_THREADS];
+    __shared__ int s_last;
+    __shared__ uint32_t mt[rs::MT_N];
+    const size_t base = (size_t)t * A;
+    const int per = (n + RS_THREADS - 1) / RS_THREADS, a0 = tid * per, a1 = min(n, a0 + per);
+    int cnt = 0;
+    for (int a = a0; a < a1; a++) cnt += ok_tmp[base + a];
+    s_cnt[tid] = cnt;
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < RS_THREADS; i++) { const int v = s_cnt[i]; if (i < tid) before += v; total += v; }
+    const int row0 = first[t] + served[t];
+    int r = before;
+    for (int a = a0; a < a1 && r < want; a++) {
+        if (!ok_tmp[base + a]) continue;
+        const int h = row0 + r;
+        double cv6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cv6[k] = poses_tmp[(base + a) * 6 + k]; poses[(size_t)h * 6 + k] = cv6[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = sets_all[(base + a) * 4 + k];
+        ok[h] = 1;
+        if (staged) write_staged(F, cv6, staged + (size_t)h * POSE_STRIDE);
+        if (r == want - 1) s_last = a;
+        r++;
+    }
+    __syncthreads();
+    const int got = min(total, want);
+    const int used = total >= want ? s_last + 1 : n;  // every attempt of the window is spent when it did not serve the stream
+    const unsigned long long took = offs_all[(size_t)t * (A + 1) + used];
+    for (int i = tid; i < rs::MT_N; i += RS_THREADS) mt[i] = st[t].mt[i];
+    uint32_t idx = st[t].idx;
+    __syncthreads();
+    rs_advance_lds(mt, idx, took, tid);
+    for (int i = tid; i < rs::MT_N; i += RS_THREADS) st[t].mt[i] = mt[i];
+    if (tid == 0) {
+        st[t].idx = idx;
+        served[t] += got;
+        need[t] = want - got;
+        consumed[t] += took;
+        attempts[t] += used;
+    }
+}
+
+// hypotheses a stream could not serve within the attempt budget: zero pose, ok = 0 (as K1 reports a hypothesis that ran out of tries)
+__global__ __launch_bounds__(64) void k_refstream_unserved(int T, const int32_t* __restrict__ first, const int32_t* __restrict__ served, const int32_t* __restrict__ need, FrameDev F,
+                                                           double* __restrict__ poses, int32_t* __restrict__ sets_out, uint8_t* __restrict__ ok, float* __restrict__ staged) {
+    const int t = blockIdx.x;
+    for (int j = threadIdx.x; j < need[t]; j += blockDim.x) {
+        const int h = first[t] + served[t] + j;
+#pragma unroll
+        for (int k = 0; k < 6; k++) poses[(size_t)h * 6 + k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sets_out[(size_t)h * 4 + k] = 0;
+        ok[h] = 0;
+        if (staged) { const double z6[6] = {0, 0, 0, 0, 0, 0}; write_staged(F, z6, staged + (size_t)h * POSE_STRIDE); }
+    }
+}
+
+hipError_t refstream_init(hipStream_t st, RefStreamState* states, uint32_t seed, int T) {
+    hipLaunchKernelGGL(k_refstream_init, dim3((T + 63) / 64), dim3(64), 0, st, states, seed, T);
+    return hipGetLastError();
+}
+hipError_t refstream_discard(hipStream_t st, RefStreamState* states, int t, unsigned long long n) {
+    hipLaunchKernelGGL(k_refstream_discard, dim3(1), dim3(RS_THREADS), 0, st, states, t, n);
+    return hipGetLastError();
+}
+size_t refstream_window_bytes(int T, int A) {
+    const size_t D = refstream_window_outputs(A);
+    return (size_t)T * (D * 4 + (size_t)A * 16 + ((size_t)A + 1) * 4 + (size_t)A * 48 + (size_t)A) + 64;
+}
+hipError_t refstream_window(hipStream_t st, RefStreamState* states, int T, int A, int mode, void* scratch, const FrameDev& F, int thr_int, const int32_t* first,
+                            int32_t* served, int32_t* need, int32_t* parsed, unsigned long long* consumed, long long* attempts, double* poses, int32_t* sets_out,
+                            uint8_t* ok, float* staged) {
+    const int D = refstream_window_outputs(A);
+    char* p = reinterpret_cast<char*>(scratch);
+    double* poses_tmp = reinterpret_cast<double*>(p); p += (size_t)T * A * 48;
+    uint32_t* raw = reinterpret_cast<uint32_t*>(p); p += (size_t)T * D * 4;
+    int32_t* sets = reinterpret_cast<int32_t*>(p); p += (size_t)T * A * 16;
+    uint32_t* offs = reinterpret_cast<uint32_t*>(p); p += (size_t)T * (A + 1) * 4;
+    uint8_t* ok_tmp = reinterpret_cast<uint8_t*>(p);
+    hipLaunchKernelGGL(k_refstream_parse, dim3(T), dim3(RS_THREADS), 0, st, states, F.W, F.H, mode, A, D, raw, sets, offs, parsed, need);
+    hipLaunchKernelGGL(k_refstream_eval, dim3((A + 63) / 64, T), dim3(64), 0, st, A, parsed, sets, F, thr_int, poses_tmp, ok_tmp);
+    hipLaunchKernelGGL(k_refstream_select, dim3(T), dim3(RS_THREADS), 0, st, states, A, parsed, sets, offs, poses_tmp, ok_tmp, first, served, need, consumed, attempts, F, poses,
+                       sets_out, ok, staged);
+    return hipGetLastError();
+}
+hipError_t refstream_unserved(hipStream_t st, int T, const int32_t* first, const int32_t* served, const int32_t* need, const FrameDev& F, double* poses, int32_t* sets_out,
+                              uint8_t* ok, float* staged) {
+    hipLaunchKernelGGL(k_refstream_unserved, dim3(T), dim3(64), 0, st, T, first, served, need, F, poses, sets_out, ok, staged);
     return hipGetLastError();
 }
 

@@ -27,6 +27,10 @@ constexpr int POSE_STRIDE = 12;
 // fp64 Rodrigues of N cv poses -> staged float records.
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
 hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_lo);  // what the float records leave behind
+// the records of the exact-transform form (k2_flags bit 28): pose_split_bytes(N) bytes; available for focal lengths up to 2^13 (pose_split_exponent <= 13)
+size_t pose_split_bytes(int N);
+int pose_split_exponent(const FrameDev& F);
+hipError_t pose_prep_split(hipStream_t st, int N, const double* poses, const FrameDev& F, void* split);
 
 // K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
 // Launch knobs of K2; they live in the context (read once from the environment in dsac_create), never in process-wide state.
@@ -34,11 +38,14 @@ struct K2Opts {
     bool pixel_minor = true;  // block order: pixel tiles innermost (DSAC_K2_ORDER)
     int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
     int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
+    int diag = 0;             // "k2_diag": diagnostic switches of the precise form (which fp32 step costs what; k_reproject_prec), 0 = none
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // per call: timing events attached to the K2 dispatch itself (profiling), else null
     const float* staged_lo = nullptr;  // per call: the low parts of the staged records (pose_prep_lo), for flags bit 27
+    const void* split = nullptr;      // per call: the split fp16 records (pose_prep_split), for flags bit 28
     const double* poses64 = nullptr;  // per call: the cv poses (N x 6 doubles) the staged records were made from -- the precise form (flags bit 25) works from these
 };
 constexpr int K2_FLAG_RECLO = 1 << 27;    // k2_flags: pose records in two pieces -- the low parts through fp16 matrix-core instructions chained onto the fp32 ones
+constexpr int K2_FLAG_EXACT = 1 << 28;    // k2_flags: exact transform -- split fp16 records through the fp16 matrix core, the camera-frame point rounded to float once (round 6)
 constexpr int K2_FLAG_PRECISE = 1 << 25;  // k2_flags: the fp64 projection of the reference (k_reproject_prec) instead of the fp32 matrix-core transform
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
@@ -71,6 +78,19 @@ struct K1Opts {
 hipError_t sample(hipStream_t st, int N, uint64_t seed, const int32_t* sets_in, const FrameDev& F, int thr_int, int max_tries,
                   double* poses, int32_t* sets_out, uint8_t* ok, float* staged_or_null = nullptr, int Nf = 0,
                   const K1Opts& opts = K1Opts());  // staged: K2 records (N x 12)
+// K1 in the reference's own random stream (round 6; core/thread_rand.cpp:40-69, core/cnn_softam.h:1010-1060; refstream.h): T generators std::mt19937(seed + t)
+// on the device; a window = A attempts per stream parsed, evaluated and handed to the stream's next hypotheses in order.
+struct RefStreamState { uint32_t mt[624]; uint32_t idx; uint32_t pad[3]; };
+inline int refstream_window_outputs(int A) { return 9 * A + 128; }  // raw outputs generated per window (an attempt takes 8, rarely more)
+size_t refstream_window_bytes(int T, int A);
+hipError_t refstream_init(hipStream_t st, RefStreamState* states, uint32_t seed, int T);
+hipError_t refstream_discard(hipStream_t st, RefStreamState* states, int t, unsigned long long n);
+// first / served / need / parsed [T] int32, consumed [T] uint64, attempts [T] int64: device arrays (served / need / consumed / attempts are updated)
+hipError_t refstream_window(hipStream_t st, RefStreamState* states, int T, int A, int mode, void* scratch, const FrameDev& F, int thr_int, const int32_t* first,
+                            int32_t* served, int32_t* need, int32_t* parsed, unsigned long long* consumed, long long* attempts, double* poses, int32_t* sets_out,
+                            uint8_t* ok, float* staged);
+hipError_t refstream_unserved(hipStream_t st, int T, const int32_t* first, const int32_t* served, const int32_t* need, const FrameDev& F, double* poses, int32_t* sets_out,
+                              uint8_t* ok, float* staged);
 // Nf (frame batch): hypotheses per frame, hypothesis h reads frame h / Nf
 hipError_t dpnp(hipStream_t st, int N, const int32_t* sets, const FrameDev& F, float eps, double* J, int Nf = 0);
 

@@ -309,6 +309,27 @@ class Engine:
                                          ptr(sets_out), ptr(ok)))
         return poses, sets_out, ok
 
+    # ---- K1 in the reference's own random stream ----------------------------------------------------
+    def refstreamInit(self, seed=1305, threads=1):
+        """ThreadRand::forceInit(seed) with `threads` OpenMP threads (core/thread_rand.cpp:40-57): generator t = std::mt19937(seed + t), kept in the context."""
+        check(self._ctx, lib.dsac_refstream_init(self._ctx, int(seed) & 0xFFFFFFFF, int(threads)))
+        self._rs_threads = int(threads)
+
+    def refstreamDiscard(self, thread, n32):
+        """Generator `thread` skips n32 32-bit outputs (draws the reference made outside the sampling loop: stochasticSubSample takes 4 per cell)."""
+        check(self._ctx, lib.dsac_refstream_discard(self._ctx, int(thread), int(n32)))
+
+    def sampleRefstream(self, N, thr=10.0, max_attempts=1 << 24, out=None):
+        """The sampling loop of processImage (cnn_softam.h:1010-1060) drawing from the reference's generators (dsac_sample_refstream).
+        Returns (poses N x 6, sets N x 4, ok N, consumed32[threads], attempts[threads])."""
+        if out is None:
+            out = (np.zeros((N, 6)), np.zeros((N, 4), np.int32), np.zeros(N, np.uint8))
+        poses, sets_out, ok = out
+        T = getattr(self, "_rs_threads", 0)
+        consumed, attempts = np.zeros(max(T, 1), np.uint64), np.zeros(max(T, 1), np.int64)
+        check(self._ctx, lib.dsac_sample_refstream(self._ctx, int(N), float(thr), int(max_attempts), ptr(poses), ptr(sets_out), ptr(ok), ptr(consumed), ptr(attempts)))
+        return poses, sets_out, ok, consumed, attempts
+
     # ---- K2 ---------------------------------------------------------------------------------------
     def reproject(self, poses, N=None, clamp=CNN_OBJ_MAXINPUT, err=None, soft=None, tau=10.0, beta=0.5):
         """err[h] = getDiffMap(pose_h) (cnn_softam.h:319-362) and/or soft[h] = sum_p sigmoid(beta*(tau - err))."""

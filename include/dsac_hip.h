@@ -195,6 +195,27 @@ DSAC_API int dsac_score_hypotheses_frames(dsac_ctx* ctx, int hyps_per_frame, uin
 DSAC_API int dsac_sample(dsac_ctx* ctx, int N, uint64_t seed, const int32_t* sets_or_null, float thr, int max_tries, double* poses,
                 int32_t* sets_out, uint8_t* ok);
 
+/* K1 in the REFERENCE'S OWN random stream (round 6).  The reference draws from ThreadRand (core/thread_rand.cpp:40-69): one std::mt19937(seed + t) per
+ * OpenMP thread t, irand(0, n) = std::uniform_int_distribution<int>(0, n - 1) (:59-69, :95-98), x before y, a re-draw for a cell already in the set, a new
+ * attempt after a failed P3P / re-projection check, no cap (core/cnn_softam.h:1010-1060); `#pragma omp parallel for` (static schedule) gives thread t the
+ * hypotheses [t q + min(t, r), + q + (t < r)), q = N / threads, r = N % threads, which it serves in order from its stream.
+ *   dsac_refstream_init     = ThreadRand::forceInit(seed) with omp_get_max_threads() == threads: the generators live in the context, like the reference's
+ *                             static ones, and run on through successive images.
+ *   dsac_refstream_discard  : generator `thread` skips n32 32-bit outputs -- what reference code OUTSIDE this path drew from it (stochasticSubSample,
+ *                             core/cnn_softam.h:283-309: two drand = four outputs per cell, 6 400 for its 40 x 40 grid; irand(0, n) for the training frame: one).
+ *   dsac_sample_refstream   : dsac_sample with the sets drawn from those generators.  The attempt sequence of a stream is a function of the stream alone,
+ *                             so a window of attempts per stream is parsed, evaluated in parallel (K1's own P3P + check) and handed out in order; the
+ *                             generators advance exactly as far as the sequential loop would have read.  max_attempts caps the attempts per stream (the
+ *                             reference has none); hypotheses left unserved report ok = 0.  consumed32_or_null / attempts_or_null [threads]: outputs taken
+ *                             from / attempts made on each stream by this call.  Synchronises the context's stream (a window that served too few is followed
+ *                             by another).  One frame at a time.  "refstream_mode" (dsac_set_option): 0 = std::uniform_int_distribution as libstdc++ >= 11
+ *                             computes it (Lemire's method), 1 = as libstdc++ <= 10 did (scaling + division), -1 = as the libstdc++ this library was built with.
+ * Bit-identical minimal sets to the real reference's processImage on both golden frames, threads = 1 and 4 (tests/test_gpu_refstream.py). */
+DSAC_API int dsac_refstream_init(dsac_ctx* ctx, unsigned seed, int threads);
+DSAC_API int dsac_refstream_discard(dsac_ctx* ctx, int thread, unsigned long long n32);
+DSAC_API int dsac_sample_refstream(dsac_ctx* ctx, int N, float thr, long long max_attempts, double* poses, int32_t* sets_out, uint8_t* ok,
+                                   unsigned long long* consumed32_or_null, long long* attempts_or_null);
+
 /* ---- K2: batched reprojection -> error images and/or soft-inlier scores -------------------------- */
 /* Replaces the N getDiffMap calls of core/cnn_softam.h:1067-1069 (getDiffMap :319-362):
  * err[h][p] = min(|uv_p - project(K, pose_h, xyz_p)|, clamp)  (clamp = CNN_OBJ_MAXINPUT = 100, lua_calls.h:36).

@@ -24,6 +24,7 @@
 //   * the hypothesis score may be a soft-inlier count instead of the score CNN (north_star).
 #include "cvlike.h"
 #include <cstdint>
+#include <random>
 #include <cstdio>
 #include <chrono>
 #ifdef _OPENMP
@@ -552,6 +553,63 @@ void orc_sample(int N, uint64_t seed, const int32_t* sets_in, const float* xyz, 
         std::memcpy(sets_out + 4 * h, set4, sizeof(set4));
         ok[h] = good ? 1 : 0;
         if (tries) tries[h] = a;
+    }
+}
+
+}  // extern "C"
+struct CountingMt {  // std::mt19937 that counts its outputs (same result_type, min and max: the distribution takes the same path through it)
+    typedef std::mt19937::result_type result_type;
+    std::mt19937 g;
+    uint64_t n = 0;
+    static constexpr result_type min() { return std::mt19937::min(); }
+    static constexpr result_type max() { return std::mt19937::max(); }
+    result_type operator()() { n++; return g(); }
+};
+extern "C" {
+// The same loop in the REFERENCE'S OWN random stream (round 6): ThreadRand (core/thread_rand.cpp:40-69) keeps one std::mt19937(seed + t) per OpenMP thread and
+// irand(0, n) is std::uniform_int_distribution<int>(0, n - 1) on it (:59-69, :95-98); the sampling loop (core/cnn_softam.h:1010-1060) draws x before y,
+// re-draws a cell that is already in the set, and starts over after a failed P3P or re-projection check -- with no cap.  `#pragma omp parallel for` with
+// the default static schedule hands thread t the hypotheses [t q + min(t, r), ...) (q = N / T, r = N % T, the first r threads one more), which it serves
+// one after the other from its stream.  This restatement uses the standard library's generator and distribution themselves (whatever libstdc++ this
+// checker is built with -- the same one oracle/_ref is built with), so it pins the product's own restatement of them (dsac_amd/csrc/refstream.h).
+// skip32[t]: 32-bit outputs generator t has already produced (e.g. the drand calls of stochasticSubSample on thread 0: two each); consumed32[t] (out):
+// outputs this call took from it.  max_attempts caps the attempts per stream (the reference has no cap); hypotheses it leaves unserved get ok = 0.
+void orc_sample_refstream(int N, uint32_t seed, int T, const uint64_t* skip32, const float* xyz, const float* uv, int H, int W, const double* cam, float thr,
+                          long long max_attempts, double* poses, int32_t* sets_out, uint8_t* ok, uint64_t* consumed32, int64_t* attempts_out) {
+    Frame F{xyz, uv, H, W, Cam{cam[0], cam[1], cam[2], cam[3]}};
+    const int thr_int = (int)thr;
+    const int q = N / T, r = N % T;
+    for (int t = 0; t < T; t++) {
+        CountingMt gen;
+        gen.g.seed(seed + (uint32_t)t);
+        if (skip32 && skip32[t]) gen.g.discard(skip32[t]);
+        const int h0 = t * q + std::min(t, r), nh = q + (t < r ? 1 : 0);
+        long long attempts = 0;
+        for (int h = h0; h < h0 + nh; h++) {
+            double cv6[6] = {0, 0, 0, 0, 0, 0};
+            int32_t set4[4] = {0, 0, 0, 0};
+            bool good = false;
+            while (!good && attempts < max_attempts) {
+                attempts++;
+                int cnt = 0;
+                while (cnt < 4) {
+                    const int x = std::uniform_int_distribution<int>(0, W - 1)(gen);
+                    const int y = std::uniform_int_distribution<int>(0, H - 1)(gen);
+                    const int idx = y * W + x;
+                    bool dup = false;
+                    for (int k = 0; k < cnt; k++) dup = dup || set4[k] == idx;
+                    if (dup) continue;
+                    set4[cnt++] = idx;
+                }
+                good = eval_set(F, set4, thr_int, cv6);
+            }
+            if (!good) for (int k = 0; k < 6; k++) cv6[k] = 0;
+            std::memcpy(poses + 6 * h, cv6, sizeof(cv6));
+            std::memcpy(sets_out + 4 * h, set4, sizeof(set4));
+            ok[h] = good ? 1 : 0;
+        }
+        if (consumed32) consumed32[t] = gen.n;
+        if (attempts_out) attempts_out[t] = attempts;
     }
 }
 

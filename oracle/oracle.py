@@ -347,6 +347,25 @@ def sample(N, seed, xyz, uv, H, W, cam, thr=10.0, max_tries=1000000, sets=None):
     return poses, sets_out, ok, tries
 
 
+def sample_refstream(N, seed, xyz, uv, H, W, cam, threads=1, skip32=None, thr=10.0, max_attempts=1 << 40):
+    """The sampling loop in the reference's own random stream (ThreadRand: std::mt19937(seed + t) per OpenMP thread through
+    std::uniform_int_distribution, core/thread_rand.cpp:40-69; core/cnn_softam.h:1010-1060).  Returns (poses, sets, ok, consumed32[threads], attempts[threads])."""
+    xyz, xp = _f(np.asarray(xyz).reshape(-1, 3))
+    uv, up = _f(np.asarray(uv).reshape(-1, 2))
+    cam, cp = _cam(cam)
+    poses = np.zeros((N, 6))
+    sets_out = np.zeros((N, 4), np.int32)
+    ok = np.zeros(N, np.uint8)
+    skip = np.ascontiguousarray(np.zeros(threads, np.uint64) if skip32 is None else np.asarray(skip32, np.uint64).reshape(threads))
+    consumed = np.zeros(threads, np.uint64)
+    attempts = np.zeros(threads, np.int64)
+    u64p, i64p = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+    lib().orc_sample_refstream.argtypes = [C.c_int, C.c_uint32, C.c_int, u64p, c_fp, c_fp, C.c_int, C.c_int, c_dp, C.c_float, C.c_longlong, c_dp, c_ip, c_bp, u64p, i64p]
+    lib().orc_sample_refstream(N, int(seed) & 0xFFFFFFFF, threads, skip.ctypes.data_as(u64p), xp, up, H, W, cp, thr, max_attempts, poses.ctypes.data_as(c_dp),
+                               sets_out.ctypes.data_as(c_ip), ok.ctypes.data_as(c_bp), consumed.ctypes.data_as(u64p), attempts.ctypes.data_as(i64p))
+    return poses, sets_out, ok, consumed, attempts
+
+
 def refine(init_poses, perm, xyz, uv, H, W, cam, inlier_count=100, min_inliers=50, thr=10.0, pert_px_c=None, pert_value=None,
            want_inlier_map=False):
     init_poses, ip = _d(np.asarray(init_poses).reshape(-1, 6))
