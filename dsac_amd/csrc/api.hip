@@ -233,7 +233,7 @@ struct ProfScope {
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
         o.poses64 = poses64;  // the cv poses of this launch: what the precise form ("k2_flags" bit 25) projects with
         o.staged_lo = (poses64 && (o.flags & dk::K2_FLAG_RECLO)) ? c->staged_lo.as<float>() : nullptr;  // filled by k2_records_lo() before the launch
-        o.split = (poses64 && (o.flags & dk::K2_FLAG_EXACT) && dk::pose_split_exponent(c->F) <= 13) ? c->staged_split.as<char>() : nullptr;  // likewise
+        o.split = (poses64 && (o.flags & dk::K2_FLAG_EXACT) && dk::pose_split_exponent(c->F) <= 10) ? c->staged_split.as<char>() : nullptr;  // likewise
         return o;
     }
     void commit() { launched = true; }
@@ -248,7 +248,7 @@ struct ProfScope {
 
 // "k2_flags" bit 27: the low parts of the N staged records, derived from the cv poses on `st` right in front of the K2 launch that reads them
 static hipError_t k2_records_lo(dsac_ctx* c, hipStream_t st, int N, const double* d_poses) {
-    if ((c->k2.flags & dk::K2_FLAG_EXACT) && d_poses && N > 0 && dk::pose_split_exponent(c->F) <= 13) {  // "k2_flags" bit 28: the split records of the exact-transform form
+    if ((c->k2.flags & dk::K2_FLAG_EXACT) && d_poses && N > 0 && dk::pose_split_exponent(c->F) <= 10) {  // "k2_flags" bit 28: the split records of the exact-transform form
         hipError_t e = c->staged_split.reserve(dk::pose_split_bytes(N));
         if (e != hipSuccess) return e;
         e = dk::pose_prep_split(st, N, d_poses, c->F, c->staged_split.as<char>());

@@ -62,24 +62,37 @@ hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameD
 }
 
 // --------------------------------------------------------------------------------------------------
-// Round 6: the pose records in THREE fp16 pieces on fixed binary grids, for the exact-transform form of K2 (k2_flags bit 28; k_reproject_st<.., EX>).
-// The reference projects in double (core/cnn_softam.h:319-362).  E = R.X + t is evaluated without any rounding that matters by writing every factor as a
-// sum of 11-bit fixed-point pieces, a = aA + aB + aC (grids 2^(E-10), 2^(E-21), 2^(E-32); E = 0 for the z row, `ex` = ceil(log2 f) for the focal-length-folded x / y
-// rows) and X = XA + XB + XC (grids 2^5, 2^-6, 2^-17 mm): a product of two pieces is exact in fp32, and
-//   * the HIGH products aA XA (+ tA) lie on one grid and sum to < 2^23 grid units: ONE v_mfma_f32_16x16x16_f16 per row adds them EXACTLY;
-//   * all other products (aA XB, aB XA, aA XC, aB XB, aC XA, aB XC, aC XB, tB, tC, tD: |sum| < ~100 mm) go through ONE v_mfma_f32_16x16x32_f16 per row, scaled by
-//     2^10 so that every fp16 operand is a normal number (the matrix core flushes subnormal halves); its fp32 accumulation is good to ~1e-6 mm;
-//   * E = D_hi + 2^-10 D_cross is one fused multiply-add: the single rounding to float of the camera-frame point.
+// Round 6: the pose records as fp16 PIECES on fixed binary grids, for the exact-transform form of K2 (k2_flags bit 28; k_reproject_st<.., EX>).
+// The reference projects in double (core/cnn_softam.h:319-362).  E = R.X + t is evaluated here without any rounding that matters by writing both factors as
+// sums of short fixed-point pieces whose products are exact in fp32 and by sorting the products into TWO matrix-core accumulations:
+//   * the HIGH group -- every product that is a multiple of 2^(E-5) -- is summed EXACTLY by one v_mfma_f32_16x16x16_f16 per row (all addends on one grid,
+//     |sum| < 2^23 grid units):  aA XA + aT XM + aBT XT + tA + tA2;
+//   * the CROSS group -- what is left, |sum| of a few millimetres -- by one v_mfma_f32_16x16x32_f16 per row, scaled by 2^14 so that every half is a
+//     NORMAL number (the matrix core flushes subnormal halves):  aC XA + aA' XM + aB' XT + aA XL1 + aA XL2 + aB XA' + aB XM + aB XL1 + tC + tD;
+//   * E = D_hi + 2^-14 D_cross: one fused multiply-add, the single rounding to float of the camera-frame point.
+// Why the split is where it is: the fp16 matrix core aligns the products of one instruction to the LARGEST of them, keeps ~24 bits and TRUNCATES the rest
+// (profiles/r06_mfma_f16_numerics.txt: 2^14 + 0.75 ulp -> 2^14; 2^14 - 2^14 + 2^-12 -> 0).  The first design of this form put every product but aA XA + tA
+// into the cross group (largest addends ~2^5 mm): the truncation of its small addends, whose signs follow the hypothesis, shifted a hypothesis' points by
+// ~1e-6 mm systematically -- enough to move the softmax weight of two tied hypotheses by 1.5-2.2e-4 (stated 1e-4; profiles/r06_k2_diag.txt).  With the three
+// largest remainders moved into the exact group the cross sum stays below ~4 mm and what its window drops is below 2^-22 mm.
+// Pieces (E = 0 for the z row, `ex` = ceil(log2 f) <= 10 for the focal-length-folded x / y rows; n x 2^g = an integer |n| <= 2047 times the grid 2^g):
+//   a = aA + aB + aC     aA: 2^(E-10)   aB: 2^(E-21)   aC: 2^(E-32)        aA = aT + aA', aT: 2^(E-5)        aB = aBT + aB', aBT: 2^(E-15)
+//   X = XA + XM + XL1 + XL2    XA: 32 rint(X / 32) = XT + XA', XT: 1024 rint(X / 1024)    XM: rint(X - XA)    XL1: 2^-12 rint(.)    XL2: the rest (< 2^-13)
+//   t = tA + tA2 + tC + tD     tA: 2^(E+6)   tA2: 2^(E-5)   tC: 2^(E-16)   tD: 2^(E-27)
 // What this kernel writes is the A-operand image in the matrix core's own lane layout: for hypothesis h, row r in (x, y, z), quarter q (= coordinate X, Y, Z,
-// or the translation for q = 3): eight halves for the K = 32 instruction (k = 8q .. 8q + 7) and four for the K = 16 one (k = 4q .. 4q + 3).
-//   cross[q < 3] = (aA 2^2, aB 2^12, aA, aB 2^10, aC 2^18, aB 2^7, aC 2^18, 0)   against   B = (XB 2^8, XA 2^-2, XC 2^10, XB, XA 2^-8, XC 2^3, XB 2^-8, 0)
-//   cross[q = 3] = (tB 2^-3, tC 2^8, tD 2^13, 0, ...)                            against   B = (2^13, 2^2, 2^-3, 2^14, 0, ...)
-//   hi[q < 3]    = (0, aA 2^2, 0, 0),   hi[q = 3] = (0, 0, 0, tA 2^-14)          against   the FIRST FOUR halves of the same B
-// The x and y rows carry the minus sign of hp_chunk's (-xc, -yc, zc).  Valid for focal lengths up to 2^13 px, |t| < 2^16 mm, |X| < 2^16 mm (the kernel
+// or the translation for q = 3): eight halves for the K = 32 instruction (k = 8q .. 8q + 7) and four for the K = 16 one (k = 4q .. 4q + 3), whose B operand
+// is the FIRST HALF of the other's:
+//   B[q < 3]     = (XA 2^-5,   XM 2^3,    XT 2^-4,   XL1 2^10,  XL2 2^10,  XA',     XM,       XL1   )
+//   hi[q < 3]    = (aA 2^5,    aT 2^-3,   aBT 2^4,   0)
+//   cross[q < 3] = (aC 2^19,   aA' 2^11,  aB' 2^18,  aA 2^4,    aA 2^4,    aB 2^14, aB 2^14,  aB 2^14)
+//   B[q = 3]     = (2^10, 2^3, 2^11, 0, 0, 0, 1, 0) -- the pieces of the constant 2^15 + 1 run through the same code as a coordinate
+//   hi[q = 3]    = (0, tA2 2^-3, tA 2^-11, 0)          cross[q = 3] = (0, tC 2^11, 0, 0, 0, 0, tD 2^14, 0)
+// The x and y rows carry the minus sign of hp_chunk's (-xc, -yc, zc).  Valid for focal lengths up to 2^10 px, |t| < 2^16 mm, |X| < 2^16 mm (the kernel
 // sends chunks with larger coordinates down the fp32 path); pieces are clamped to +-2047 grid units, so out-of-range input degrades, it does not overflow.
 // --------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 constexpr int SPLIT_CROSS_BYTES = 12 * 16, SPLIT_HI_BYTES = 12 * 8;  // per hypothesis: 3 rows x 4 quarters
+constexpr int SPLIT_MAX_EX = 10;  // pose_split_exponent above this: no exact form (api.hip falls back to the fp32 records)
 DM_INLINE double split_piece(double& rem, int grid_exp) {  // the multiple of 2^grid_exp nearest to rem (at most 2047 units), which is taken out of rem
     double n = rint(ldexp(rem, -grid_exp));
     n = fmin(fmax(n, -2047.0), 2047.0);
@@ -87,6 +100,7 @@ DM_INLINE double split_piece(double& rem, int grid_exp) {  // the multiple of 2^
     rem -= p;
     return p;
 }
+DM_INLINE _Float16 hf(double v, int e) { return (_Float16)(float)ldexp(v, e); }
 __global__ __launch_bounds__(256) void k_pose_prep_split(int N, const double* __restrict__ poses, float fx, float fy, int ex, h8* __restrict__ cross, h4* __restrict__ hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (hypothesis, row)
     const int h = i / 3, r = i - 3 * h;
@@ -104,18 +118,21 @@ __global__ __launch_bounds__(256) void k_pose_prep_split(int N, const double* __
     for (int q = 0; q < 3; q++) {
         double rem = a[q];
         const double aA = split_piece(rem, E - 10), aB = split_piece(rem, E - 21), aC = split_piece(rem, E - 32);
-        oc[q] = h8{(_Float16)(float)ldexp(aA, 2), (_Float16)(float)ldexp(aB, 12), (_Float16)(float)aA, (_Float16)(float)ldexp(aB, 10),
-                   (_Float16)(float)ldexp(aC, 18), (_Float16)(float)ldexp(aB, 7), (_Float16)(float)ldexp(aC, 18), z};
-        oh[q] = h4{z, (_Float16)(float)ldexp(aA, 2), z, z};
+        double t1 = aA, t2 = aB;
+        const double aT = split_piece(t1, E - 5), aBT = split_piece(t2, E - 15);  // t1 = aA' (|aA'| <= 2^(E-6)), t2 = aB' (<= 2^(E-16))
+        oh[q] = h4{hf(aA, 5), hf(aT, -3), hf(aBT, 4), z};
+        oc[q] = h8{hf(aC, 19), hf(t1, 11), hf(t2, 18), hf(aA, 4), hf(aA, 4), hf(aB, 14), hf(aB, 14), hf(aB, 14)};
     }
     double rem = a[3];
-    const double tA = split_piece(rem, E + 6), tB = split_piece(rem, E - 5), tC = split_piece(rem, E - 16), tD = split_piece(rem, E - 27);
-    oc[3] = h8{(_Float16)(float)ldexp(tB, -3), (_Float16)(float)ldexp(tC, 8), (_Float16)(float)ldexp(tD, 13), z, z, z, z, z};
-    oh[3] = h4{z, z, z, (_Float16)(float)ldexp(tA, -14)};
+    const double tA = split_piece(rem, E + 6), tA2 = split_piece(rem, E - 5), tC = split_piece(rem, E - 16), tD = split_piece(rem, E - 27);
+    // against B[q = 3] = the pieces of SPLIT_T_COORD = (2^10, 2^3, 2^11, 0, 0, 0, 1, 0)
+    oh[3] = h4{z, hf(tA2, -3), hf(tA, -11), z};
+    oc[3] = h8{z, hf(tC, 11), z, z, z, z, hf(tD, 14), z};
 }
 
 size_t pose_split_bytes(int N) { return (size_t)N * (SPLIT_CROSS_BYTES + SPLIT_HI_BYTES); }
-int pose_split_exponent(const FrameDev& F) {  // ceil(log2(max focal length)), at least 0; > 13: the exact form is not available
+bool pose_split_available(const FrameDev& F) { return pose_split_exponent(F) <= SPLIT_MAX_EX; }
+int pose_split_exponent(const FrameDev& F) {  // ceil(log2(max focal length)), at least 0; > SPLIT_MAX_EX = 10: the exact form is not available
     int e = 0;
     while (ldexp(1.0, e) < (double)fmaxf(F.fx, F.fy)) e++;
     return e;
@@ -426,15 +443,22 @@ DM_INLINE bool hp_chunk(float ax, float ay, float az, const float (&Bm)[4], cons
 
 // The exact-transform chunk (round 6, k2_flags bit 28): hp_chunk with E = R.X + t from the split records (k_pose_prep_split) -- per row one K = 32 fp16 MFMA
 // for the cross terms, one K = 16 fp16 MFMA for the exactly summed high products (its B operand is the first half of the other's), one packed fma per
-// register pair for E = D_hi + 2^-10 D_cross: the camera-frame point is rounded to float ONCE.  Then hp_chunk's tail with one Newton step on v_rcp_f32:
+// register pair for E = D_hi + 2^-14 D_cross: the camera-frame point is rounded to float ONCE.  Then hp_chunk's tail with one Newton step on v_rcp_f32:
 // the hardware reciprocal's error is not zero-mean, and a biased 1 / z scales every projection of a hypothesis about the principal point the same way --
 // measured (scripts/r06_k2_diag.py, profiles/r06_k2_diag.txt): with an exact E and the plain v_rcp_f32 the softmax weight of two unrelated hypotheses in a tie is
 // still off by 5.7e-4 (stated 1e-4), with the Newton step by 5.3e-5; max |err - oracle| over all cells 7.6e-5 px.
 struct ExOps { h8 cx, cy, cz; h4 hx, hy, hz; };
-template <bool EXACT_Z, bool SOFT>
+// E = D_hi + 2^-14 D_cross on a register pair of the two accumulators: v_pk_fma_f32 spelled out -- left to the compiler half of these came out as two
+// v_fma_f32 each (384 scalar fused multiply-adds in the <64 hypotheses, 256 pixels> kernel: 12 issue slots per 1 024 pairs more than needed)
+DM_INLINE f2 ex_combine(f2 c, f2 k, f2 h) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(c), "v"(k), "v"(h));
+    return r;
+}
+template <bool EXACT_Z, bool SOFT, bool FENCE = false>
 DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4], f2 (&sloc)[4]) {
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const f2 k10 = splat(0.0009765625f);  // 2^-10
+    const f2 k10 = splat(6.103515625e-05f);  // 2^-14: the cross group's scale
     f2 qq[4][2];
     f2 zacc = splat(0.f);
 #pragma unroll
@@ -448,9 +472,9 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
         const f4 hz = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hz, b4, z4, 0, 0, 0);
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) {
-            const f2 x = pk_fma(pr ? f2{cx.z, cx.w} : f2{cx.x, cx.y}, k10, pr ? f2{hx.z, hx.w} : f2{hx.x, hx.y});
-            const f2 y = pk_fma(pr ? f2{cy.z, cy.w} : f2{cy.x, cy.y}, k10, pr ? f2{hy.z, hy.w} : f2{hy.x, hy.y});
-            const f2 z = pk_fma(pr ? f2{cz.z, cz.w} : f2{cz.x, cz.y}, k10, pr ? f2{hz.z, hz.w} : f2{hz.x, hz.y});
+            const f2 x = ex_combine(pr ? f2{cx.z, cx.w} : f2{cx.x, cx.y}, k10, pr ? f2{hx.z, hx.w} : f2{hx.x, hx.y});
+            const f2 y = ex_combine(pr ? f2{cy.z, cy.w} : f2{cy.x, cy.y}, k10, pr ? f2{hy.z, hy.w} : f2{hy.x, hy.y});
+            const f2 z = ex_combine(pr ? f2{cz.z, cz.w} : f2{cz.x, cz.y}, k10, pr ? f2{hz.z, hz.w} : f2{hz.x, hz.y});
             f2 iz = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
             iz = pk_fma(pk_fma(-z, iz, splat(1.0f)), iz, iz);  // z == 0: inf -> NaN, which sticks in zacc like the inf of the plain form
             if (EXACT_Z) {  // projectPoints: z = Z ? 1/Z : 1
@@ -463,6 +487,9 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
             const f2 dv = pk_fma(y, iz, splat(ppix[m].y));
             qq[m][pr] = pk_fma(dv, dv, du * du);
         }
+        // FENCE: nothing moves across the end of an m -- the six accumulators of one m are live at a time instead of up to twenty-four (register diet for
+        // three waves per SIMD, an A/B: k2_variant 85 / 86)
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -477,21 +504,27 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
 }
 
 // The B operand of hp_chunk_ex for one (chunk, m): lane (g, c) holds coordinate g of pixel 4c + m (g = 3: the constants the translation pieces multiply).
-// X = XA + XB + XC with XA = 32 rint(X / 32), XB = rint(64 (X - XA)) / 64, XC the rest -- both remainders are exact in fp32.  oor: |X| >= 2^16 mm (or NaN).
+// X = XT + XA' + XM + XL1 + XL2 (k_pose_prep_split); every remainder below is exact in fp32.  oor: |X| >= 2^16 mm (or NaN).
+// Conversions round to nearest (v_cvt_pk_f16_f32): every piece but XL2 is exactly representable, and XL2 must not be TRUNCATED -- the budget for a systematic
+// error of the camera-frame point is ~1e-6 mm (k_pose_prep_split).
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-// round to nearest (v_cvt_pk_f16_f32): every piece but XC is exactly representable, and XC must not be TRUNCATED -- a round-toward-zero conversion shrinks every
-// coordinate by ~2^-19 mm on average, a systematic shift that the near-tie test sees (the budget for a systematic error is ~1e-6 mm, see hp_chunk_ex)
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 DM_INLINE unsigned pk_h2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, h2v)); }
-DM_INLINE h8 split_B(float X, bool is_const, bool& oor) {
-    const float r1 = __builtin_rintf(X * 0.03125f);
-    const float rem1 = fmaf(-32.f, r1, X);
-    const float r2 = __builtin_rintf(rem1 * 64.f);
-    const float rem2 = fmaf(-0.015625f, r2, rem1);
-    oor = oor || (!is_const && !(fabsf(r1) <= 2047.f));
-    u4v v = {pk_h2(r2 * 4.f, r1 * 8.f), pk_h2(rem2 * 1024.f, r2 * 0.015625f), pk_h2(r1 * 0.125f, rem2 * 8.f), pk_h2(r2 * 6.103515625e-05f, 0.f)};
-    const u4v kc = {pk_h2(8192.f, 4.f), pk_h2(0.125f, 16384.f), 0u, 0u};
-    v.x = is_const ? kc.x : v.x; v.y = is_const ? kc.y : v.y; v.z = is_const ? 0u : v.z; v.w = is_const ? 0u : v.w;
+// The lanes of quarter 3 (the translation) run the same code on the constant SPLIT_T_COORD = 2^15 + 1, whose pieces are the powers of two
+// (2^10, 2^3, 2^11, 0, 0, 0, 1, 0) that the translation pieces of k_pose_prep_split are scaled against -- no select between coordinates and constants.
+constexpr float SPLIT_T_COORD = 32769.0f;
+DM_INLINE h8 split_B(float X, bool& oor) {
+    const float kt = __builtin_rintf(X * 0.0009765625f);      // XT / 1024
+    const float r1 = fmaf(-1024.f, kt, X);                     // X - XT, |.| <= 512
+    const float ka = __builtin_rintf(r1 * 0.03125f);           // XA' / 32
+    const float r2 = fmaf(-32.f, ka, r1);                      // X - XA, |.| <= 16
+    const float xm = __builtin_rintf(r2);                      // XM
+    const float xl = r2 - xm;                                  // |.| <= 0.5
+    const float kl = __builtin_rintf(xl * 4096.f);             // XL1 2^12
+    const float xl2 = fmaf(-0.000244140625f, kl, xl);          // XL2
+    const float ja = fmaf(32.f, kt, ka);                       // XA / 32
+    oor = oor || !(fabsf(ja) <= 2047.f);
+    const u4v v = {pk_h2(ja, xm * 8.f), pk_h2(kt * 64.f, kl * 0.25f), pk_h2(xl2 * 1024.f, ka * 32.f), pk_h2(xm, kl * 0.000244140625f)};
     return __builtin_bit_cast(h8, v);
 }
 
@@ -674,7 +707,7 @@ static hipError_t launch_reproject_hp(hipStream_t st, int N, const float* staged
 // component, L2-resident -- no LDS image, no barrier before the first MFMA), the pixel positions of the implicit grid from a
 // wave-uniform row / column (W % 64 == 0), and the only barrier is the one before the 16 NG partial soft sums leave the workgroup.
 // --------------------------------------------------------------------------------------------------
-template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW, bool LO = false, bool EX = false>
+template <int NG, int CHW, int WAVES, bool PW, bool ERR, bool SOFT, bool UV, bool G64, int MINW, bool LO = false, int EXF = 0>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* __restrict__ staged, const float* __restrict__ xyz,
                                                              const float* __restrict__ uv, float* __restrict__ err,
                                                              float* __restrict__ soft_part, int N, int P, int W, int PT, float cx, float cy,
@@ -682,6 +715,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
                                                              long long uv_stride, const float* __restrict__ staged_lo = nullptr,
                                                              const void* __restrict__ split = nullptr) {
     constexpr int HT = 16 * NG;
+    constexpr bool EX = EXF != 0, FENCE = EXF == 2;  // EXF: 0 = fp32 transform, 1 = exact transform (split fp16 records), 2 = the same with a scheduling fence per m
     const int b = blockIdx.x;
     int ht, pt;
     if (kflags & 32) { pt = b % PT; ht = b / PT; }  // plain pixel-minor order
@@ -741,7 +775,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
         for (int ch = 0; ch < CHW; ch++) {
             bool o = false;
 #pragma unroll
-            for (int m = 0; m < 4; m++) B8[ch][m] = split_B(Bm[ch][m], g == 3, o);
+            for (int m = 0; m < 4; m++) B8[ch][m] = split_B((g < 3) ? Bm[ch][m] : SPLIT_T_COORD, o);
             oor[ch] = __any(o);
         }
     }
@@ -854,7 +888,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
 #pragma unroll
                     for (int m = 0; m < 4; m++) Bf[m] = (g < 3) ? xyz[(size_t)min(p0[ch] + m, P - 1) * 3 + g] : 1.0f;
                     (void)hp_chunk<true, SOFT, false>(-rec[0], -rec[4], rec[8], Bf, pp, clampv, kA, kB, ev, sloc);
-                } else if (__builtin_expect(__any(hp_chunk_ex<false, SOFT>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
+                } else if (__builtin_expect(__any(hp_chunk_ex<false, SOFT, FENCE>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
                     (void)hp_chunk_ex<true, SOFT>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc);
                 }
             } else if (kflags & 2) {  // store schedule alone (measurement)
@@ -1086,7 +1120,7 @@ static hipError_t launch_reproject_ps(hipStream_t st, int N, const float* staged
     return hipGetLastError();
 }
 
-template <int NG, int CHW, int WAVES, bool PW, int MINW = 1, bool LO = false, bool EX = false>
+template <int NG, int CHW, int WAVES, bool PW, int MINW = 1, bool LO = false, int EX = 0>
 static hipError_t launch_reproject_st(hipStream_t st, int N, const float* staged, const FrameDev& F, float clampv, float* err, float kA, float kB,
                                       float* soft_part, int* tiles_used, int Nf, int kflags, hipEvent_t evA, hipEvent_t evB, const float* staged_lo = nullptr,
                                       const void* split = nullptr) {
@@ -1360,10 +1394,13 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     }
     // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84..87 = its tile / occupancy trades
     if ((opts.flags & K2_FLAG_EXACT) && opts.split && vec && (opts.variant < 0 || (opts.variant >= 84 && opts.variant <= 89))) {
-#define DSAC_EX(NG_, CH_, MW_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, true>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
+#define DSAC_EX(NG_, CH_, MW_, F_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
         switch (opts.variant) {
-            case 89: return DSAC_EX(2, 4, 2);   // <32 hypotheses, 256 pixels>, 2 waves per SIMD
-            case 84: default: return DSAC_EX(4, 4, 2);  // <64, 256>, 2 waves per SIMD (three or four waves per SIMD spill: 1.4-2.8 ms, profiles/r06_k2_exact_ab.txt)
+            case 85: return DSAC_EX(4, 4, 3, 2);   // <64 hypotheses, 256 pixels>, 3 waves per SIMD, scheduling fence per m
+            case 86: return DSAC_EX(4, 2, 3, 2);   // <64, 128>, 3 waves per SIMD, fence
+            case 87: return DSAC_EX(4, 4, 2, 2);   // <64, 256>, 2 waves per SIMD, fence
+            case 89: return DSAC_EX(2, 4, 2, 1);   // <32 hypotheses, 256 pixels>, 2 waves per SIMD
+            case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD (three or four waves per SIMD WITHOUT the fence spill: 1.4-2.8 ms, profiles/r06_k2_exact_ab.txt)
         }
 #undef DSAC_EX
     }

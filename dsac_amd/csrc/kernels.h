@@ -27,7 +27,7 @@ constexpr int POSE_STRIDE = 12;
 // fp64 Rodrigues of N cv poses -> staged float records.
 hipError_t pose_prep(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged);
 hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameDev& F, float* staged_lo);  // what the float records leave behind
-// the records of the exact-transform form (k2_flags bit 28): pose_split_bytes(N) bytes; available for focal lengths up to 2^13 (pose_split_exponent <= 13)
+// the records of the exact-transform form (k2_flags bit 28): pose_split_bytes(N) bytes; available for focal lengths up to 2^10 (pose_split_exponent <= 10)
 size_t pose_split_bytes(int N);
 int pose_split_exponent(const FrameDev& F);
 hipError_t pose_prep_split(hipStream_t st, int N, const double* poses, const FrameDev& F, void* split);

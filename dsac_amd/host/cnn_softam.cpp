@@ -102,6 +102,19 @@ std::vector<uint8_t> Frame::sampleHypotheses(int objHyps, uint64_t seed, int inl
     return ok;
 }
 
+std::vector<uint8_t> Frame::sampleHypothesesRefStream(int objHyps, int inlierThreshold2D, std::vector<cv_trans_t>& hyps, std::vector<std::array<int32_t, 4>>& imgIdx,
+                                                      unsigned long long subSampleOutputs, long long maxAttempts) {
+    bind();
+    std::vector<double> poses((size_t)objHyps * 6);
+    std::vector<uint8_t> ok(objHyps);
+    imgIdx.assign(objHyps, {0, 0, 0, 0});
+    if (subSampleOutputs) check(dsac_refstream_discard(ctx_, 0, subSampleOutputs), "dsac_refstream_discard");
+    check(dsac_sample_refstream(ctx_, objHyps, (float)inlierThreshold2D, maxAttempts, poses.data(), &imgIdx[0][0], ok.data(), nullptr, nullptr), "dsac_sample_refstream");
+    hyps.resize(objHyps);
+    for (int h = 0; h < objHyps; h++) hyps[h] = unpack({poses[h * 6], poses[h * 6 + 1], poses[h * 6 + 2], poses[h * 6 + 3], poses[h * 6 + 4], poses[h * 6 + 5]});
+    return ok;
+}
+
 std::vector<float> Frame::getDiffMaps(const std::vector<cv_trans_t>& hyps) {
     bind();
     std::vector<float> err(hyps.size() * (size_t)H_ * W_);

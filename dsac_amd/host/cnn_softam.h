@@ -67,6 +67,10 @@ public:
     dsac_ctx* get() { return ctx_; }
     void check(int rc, const char* what);
     void synchronize();
+    // ThreadRand::forceInit(seed) with `threads` OpenMP threads (core/thread_rand.cpp:33-57): the reference's generators, kept in the context and run on through
+    // successive images by Frame::sampleHypothesesRefStream; discardRand = draws reference code outside the sampling loop took from generator `thread`
+    void forceInitRand(unsigned seed = 1305, int threads = 1) { check(dsac_refstream_init(ctx_, seed, threads), "dsac_refstream_init"); }
+    void discardRand(int thread, unsigned long long outputs32) { check(dsac_refstream_discard(ctx_, thread, outputs32), "dsac_refstream_discard"); }
     void setOption(const char* key, int value);
     int option(const char* key, int unset = 0) const;  // the value last given to setOption (the C ABI has no getter; scopes that change a knob restore it from here)
     // HBM / page-locked host buffers and stream-ordered copies (dsac_device_alloc, dsac_host_alloc, dsac_copy_async)
@@ -133,6 +137,12 @@ public:
     // sampling loop of processImage (cnn_softam.h:1010-1060); returns the per-hypothesis success flags
     std::vector<uint8_t> sampleHypotheses(int objHyps, uint64_t seed, int inlierThreshold2D, std::vector<cv_trans_t>& hyps,
                                           std::vector<std::array<int32_t, 4>>& imgIdx, int maxTries = 1 << 20);
+    // the same loop drawing from the REFERENCE'S OWN generators (ThreadRand, core/thread_rand.cpp:40-69: std::mt19937(seed + t) per OpenMP thread; set up with
+    // forceInitRand below): minimal sets bit-identical to the reference's for the same seed and thread count, no replay file needed.  subSampleOutputs: what
+    // thread 0 drew BEFORE the loop in the reference's processImage -- stochasticSubSample's two drand per cell = 6400 32-bit outputs for its 40 x 40 grid
+    // (core/cnn_softam.h:283-309, :1003); 0 when the sampling grid was not drawn from the stream
+    std::vector<uint8_t> sampleHypothesesRefStream(int objHyps, int inlierThreshold2D, std::vector<cv_trans_t>& hyps, std::vector<std::array<int32_t, 4>>& imgIdx,
+                                                   unsigned long long subSampleOutputs = 0, long long maxAttempts = 1ll << 24);
     std::vector<float> getDiffMap(const cv_trans_t& hyp);                            // H*W floats
     std::vector<float> getDiffMaps(const std::vector<cv_trans_t>& hyps);             // N*H*W floats
     std::vector<double> softInlierScores(const std::vector<cv_trans_t>& hyps, float tau, float beta);

@@ -65,6 +65,8 @@ bool GlobalProperties::readArguments(std::vector<std::string> argv) {
         if (s == "-dev") { eP.device = std::atoi(next().c_str()); std::cout << "device: " << eP.device << "\n"; continue; }
         if (s == "-quirk") { eP.indexQuirk = std::atoi(next().c_str()) != 0; std::cout << "path II index quirk: " << eP.indexQuirk << "\n"; continue; }
         if (s == "-batch") { eP.batchGiven = true; eP.batch = std::atoi(next().c_str()); std::cout << "images per launch chain: " << eP.batch << "\n"; continue; }
+        if (s == "-refstream") { eP.refstream = std::atoi(next().c_str()); std::cout << "reference random streams (threads): " << eP.refstream << "\n"; continue; }
+        if (s == "-refsub") { eP.refsub = std::atoi(next().c_str()); std::cout << "skip the sub-sampler's draws: " << eP.refsub << "\n"; continue; }
         if (s == "-passes") { eP.passes = std::atoi(next().c_str()); std::cout << "passes over the data set: " << eP.passes << "\n"; continue; }
         if (s == "-warmup") { eP.warmupMs = std::atoi(next().c_str()); std::cout << "warm-up: " << eP.warmupMs << " ms\n"; continue; }
         if (s == "-gradstats") { eP.gradStats = std::atoi(next().c_str()); std::cout << "gradient statistics every: " << eP.gradStats << "\n"; continue; }

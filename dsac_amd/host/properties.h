@@ -46,6 +46,10 @@ struct EngineParameters {
     int batch = 16;                   // -batch  : images per launch chain of the evaluation program (FrameBatch); 0 = one image per call (Frame::processImage).
                                       //           Training program: frames per round, device-resident (default there: 0 = the reference's per-image loop)
     bool batchGiven = false;          //           (set when -batch is on the command line)
+    int refstream = 0;                // -refstream T : draw the minimal sets from the reference's own generators, std::mt19937(seed + t) of T OpenMP threads (core/thread_rand.cpp:40-69;
+                                      //           dsac_sample_refstream): the evaluation program's sets equal the reference's for the same seed and thread count, no <stem>.sets
+                                      //           replay file needed; frames with a stochastic sub-sampling grid skip the 6400 outputs it drew (-refsub 0: do not)
+    int refsub = 1;
     int passes = 1;                   // -passes : process the data set this many times (the first pass warms the device up; timing is reported per pass)
     bool errorImages = true;          // -errimg : write the N error images of every image (the score CNN's input) as the reference does
     int warmupMs = 0;                 // -warmup : run untimed (and unlogged) passes / rounds for this many milliseconds first -- a GPU that idled while the host made

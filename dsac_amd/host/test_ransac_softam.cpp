@@ -74,7 +74,7 @@ int main(int argc, const char* argv[]) {
         // hypothesis counts take the per-image path.  Both give the same numbers image by image (tests/test_gpu_drivers.py).
         bool batchable = gp->eP.batch > 0 && nImg > 0 && (gp->eP.batch == 1 || objHyps % 128 == 0);
         for (const DriverFrame& fr : testDataset)
-            batchable = batchable && fr.H == testDataset[0].H && fr.W == testDataset[0].W && fr.sets.empty() && fr.sampling.empty() == testDataset[0].sampling.empty() &&
+            batchable = batchable && gp->eP.refstream <= 0 && fr.H == testDataset[0].H && fr.W == testDataset[0].W && fr.sets.empty() && fr.sampling.empty() == testDataset[0].sampling.empty() &&
                         (fr.pixelIdxs.empty() || fr.permSteps < refSteps);
         const int passes = std::max(1, gp->eP.passes);
         if (batchable) {
@@ -131,11 +131,21 @@ int main(int argc, const char* argv[]) {
                     Frame frame(engine, fr.estObj.data(), fr.sampling.empty() ? nullptr : fr.sampling.data(), fr.H, fr.W, camMat);
                     const bool replayPerm = !fr.pixelIdxs.empty() && fr.permSteps >= refSteps;
                     ProcessImageResult r;
+                    // -refstream T: the minimal sets from the reference's own generators (they run on from image to image, as ThreadRand's do); the rest of the
+                    // image is the replay path on those sets
+                    std::vector<std::array<int32_t, 4>> drawn;
+                    if (gp->eP.refstream > 0 && fr.sets.empty()) {
+                        if (i == 0) engine.forceInitRand((unsigned)gp->eP.seed, gp->eP.refstream);
+                        std::vector<cv_trans_t> hypsDrawn;
+                        const unsigned long long sub = (gp->eP.refsub && !fr.sampling.empty()) ? 4ull * fr.H * fr.W : 0ull;
+                        frame.sampleHypothesesRefStream(objHyps, inlierThreshold2D, hypsDrawn, drawn, sub);
+                    }
+                    const std::vector<std::array<int32_t, 4>>* useSets = !fr.sets.empty() ? &fr.sets : (!drawn.empty() ? &drawn : nullptr);
                     // process frame (same function used in training)
-                    if (replayPerm || !fr.sets.empty()) {
+                    if (replayPerm || useSets) {
                         const std::vector<int32_t> pixelIdxs = replayPerm ? fr.pixelIdxs : refinePermutations(fr.H * fr.W, refSteps);
                         r = frame.processImage(fr.poseGT, objHyps, gp->eP.seed + i, inlierThreshold2D, refInlierCount, refSteps, pixelIdxs, gp->eP.tau, gp->eP.beta,
-                                               gp->eP.alpha, fr.sets.empty() ? nullptr : &fr.sets);
+                                               gp->eP.alpha, useSets);
                     } else {
                         if (permH != fr.H || permW != fr.W) {
                             const std::vector<int32_t> pixelIdxs = refinePermutations(fr.H * fr.W, refSteps);
