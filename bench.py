@@ -476,6 +476,7 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
         host_ex = host_enqueue[0]
         barrier()
         per_s = rmax(per_s)
+        host_ex_max = rmax(host_ex)  # the slowest rank's host: N processes share the node's cores (a 16-core cgroup for 8 ranks), and a step is ~0.5 ms
         per_rank, Dw = rr.ex.per, rr.ex.D
         rr.close()
         # ---- the same steps without the collective (the rank's own part copied instead): what the gather adds to a step
@@ -496,6 +497,7 @@ def strong_scaling_leg(args, rank, local_rank, world, backend, dist, emulate_wor
                    "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s, "efficiency": one_s / per_s / world,
                    "collective_bytes_per_step": int(world * per_rank * Dw * 8), "per_rank_ms_without_collective": noex_s * 1e3,
                    "collective_exposed_us": max(0.0, (per_s - noex_s) * 1e6), "rows_ok": ok, "host_enqueue_ms_per_step_rank0": host_ex * 1e3,
+                   "host_enqueue_ms_per_step": host_ex_max * 1e3, "host_bound": bool(host_ex_max > 0.8 * per_s),
                    "how": "one_gpu_ms: rank 0 alone, all 64 images per step, before the ranks ran their shares (same process and engine); per_rank_ms: every rank "
                           "its share, barrier + max over ranks, %d steps, the gather of step i on a side stream beside step i + 1" % K}
     elif emulate_world > 1:
@@ -560,10 +562,11 @@ def dry_strong(args, rank, world, dist):
     if rank != 0:
         return None
     ok = bool(torch.equal(rows[:, 0], torch.arange(CONFIG3_IMAGES, dtype=torch.float64))) if world > 1 else True
+    host_field = {"host_enqueue_ms_per_step": per_s * 1e3} if world > 1 else {}  # the stand-in engine IS the host: the field of the real leg, max over ranks
     return {"workload": "DRY RUN of BASELINE.json configs[3] (stand-in engine): %d images fixed over %d rank(s)" % (CONFIG3_IMAGES, Wsh), "dry_run": True,
             "emulated": world == 1, "ranks_joined": world, "backend": ("gloo (dry run)" if world > 1 else "none"), "steps": K,
             "images_per_rank_step": CONFIG3_IMAGES // Wsh, "one_gpu_ms": one_s * 1e3, "per_rank_ms": per_s * 1e3, "speedup": one_s / per_s,
-            "efficiency": one_s / per_s / Wsh, "collective_bytes_per_step": int(Wsh * ex.per * ex.D * 8), "collective_exposed_us": None, "rows_ok": ok}
+            "efficiency": one_s / per_s / Wsh, "collective_bytes_per_step": int(Wsh * ex.per * ex.D * 8), "collective_exposed_us": None, "rows_ok": ok, **host_field}
 
 
 def run_dry(args, rank, world, dist):

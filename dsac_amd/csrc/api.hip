@@ -59,6 +59,7 @@ struct dsac_ctx {
     // scratch, one buffer per role so that calls can be chained without aliasing
     DevBuf rs_states, rs_scratch, rs_small;  // the reference's random streams (dsac_refstream_init) and the scratch of a sampling window
     int rs_threads = 0, rs_mode = DSAC_RS_DEFAULT_MODE;
+    int k6_waves = 0;  // "k6_waves": waves per refinement problem of K6's walk (0 = by the problem count)
     DevBuf staged, staged_lo, staged_split, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
     int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
     // staging for host-pointer arguments: slots are bump-allocated per call.  A deque: next_slot() hands out references that
@@ -233,7 +234,7 @@ struct ProfScope {
         if (on && attached) { o.ev_start = p.a; o.ev_stop = p.b; }
         o.poses64 = poses64;  // the cv poses of this launch: what the precise form ("k2_flags" bit 25) projects with
         o.staged_lo = (poses64 && (o.flags & dk::K2_FLAG_RECLO)) ? c->staged_lo.as<float>() : nullptr;  // filled by k2_records_lo() before the launch
-        o.split = (poses64 && (o.flags & dk::K2_FLAG_EXACT) && dk::pose_split_exponent(c->F) <= 10) ? c->staged_split.as<char>() : nullptr;  // likewise
+        o.split = (poses64 && dk::k2_wants_exact(o) && dk::pose_split_available(c->F)) ? c->staged_split.as<char>() : nullptr;  // likewise
         return o;
     }
     void commit() { launched = true; }
@@ -248,7 +249,7 @@ struct ProfScope {
 
 // "k2_flags" bit 27: the low parts of the N staged records, derived from the cv poses on `st` right in front of the K2 launch that reads them
 static hipError_t k2_records_lo(dsac_ctx* c, hipStream_t st, int N, const double* d_poses) {
-    if ((c->k2.flags & dk::K2_FLAG_EXACT) && d_poses && N > 0 && dk::pose_split_exponent(c->F) <= 10) {  // "k2_flags" bit 28: the split records of the exact-transform form
+    if (dk::k2_wants_exact(c->k2) && d_poses && N > 0 && dk::pose_split_available(c->F)) {  // the split records of the exact-transform form (the default; "k2_flags" bit 28)
         hipError_t e = c->staged_split.reserve(dk::pose_split_bytes(N));
         if (e != hipSuccess) return e;
         e = dk::pose_prep_split(st, N, d_poses, c->F, c->staged_split.as<char>());
@@ -323,6 +324,7 @@ int dsac_create(dsac_ctx** out, int device) {
     if (const char* v = getenv("DSAC_TAIL_PRIO")) c->tail_prio = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K2_ORDER")) c->k2.pixel_minor = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K2_FLAGS")) c->k2.flags = atoi(v);
+    if (const char* v = getenv("DSAC_K2_EXACT_AUTO")) c->k2.exact_auto = atoi(v) != 0;
     if (const char* v = getenv("DSAC_K1_WPB")) c->k1.wpb = atoi(v);
     if (const char* v = getenv("DSAC_K1_PRIO")) c->k1.prio = atoi(v);
     if (const char* v = getenv("DSAC_K1_HPW")) c->k1.hpw = atoi(v);
@@ -999,6 +1001,11 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k2_order") c->k2.pixel_minor = value != 0;
     else if (k == "k2_flags") c->k2.flags = value;
     else if (k == "k2_diag") c->k2.diag = value;
+    else if (k == "k2_exact_auto") c->k2.exact_auto = value != 0;
+    else if (k == "k6_waves") {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k6_waves is 0 (auto), 1, 2, 4 or 8");
+        c->k6_waves = value;
+    }
     else if (k == "refstream_mode") {
         if (value < -1 || value > 1) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: refstream_mode is 0 (libstdc++ >= 11), 1 (libstdc++ <= 10) or -1 (this build's)");
         c->rs_mode = value < 0 ? DSAC_RS_DEFAULT_MODE : value;
@@ -1239,7 +1246,7 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
     ARG_TRY(out_arg(c, inlier_map, frames > 1 ? (size_t)B * P : P, &d_map, /*preload=*/true));
     ARG_TRY(out_arg(c, steps_done, (size_t)B, &d_sd));
     HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
-                          frames > 1 ? B / frames : 0));
+                          frames > 1 ? B / frames : 0, nullptr, nullptr, c->k6_waves));
     return end_call(c);
 }
 
@@ -1448,7 +1455,7 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
     ARG_TRY(out_arg(c, steps_done_or_null, (size_t)N, &d_sd));
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)N * P * sizeof(int32_t), c->stream));
     HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
-                          frames_ra > 1 ? N / frames_ra : 0));
+                          frames_ra > 1 ? N / frames_ra : 0, nullptr, nullptr, c->k6_waves));
     if (d_maps && d_sets) HIP_TRY(c, dk::zero_set_cells(c->stream, N, d_sets, (int)P, d_maps));
     return end_call(c);
 }
@@ -1759,7 +1766,7 @@ static int pi_refine_tail(dsac_ctx* c, hipStream_t ts, bool defer, int tk, int f
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)frames * P * sizeof(int32_t), ts));
     // K7 rides at the end of K6's wave: the loss of a refined pose is computed by the lane that holds it (one launch less behind the refinement chain)
     HIP_TRY(c, dk::refine(ts, frames, d_avg, d_perm, steps, max_inl, min_inl, (float)(int)thr, nullptr, nullptr, c->F, d_ref, d_maps, d_sd,
-                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4));
+                          d_maps ? (int)P : 0, frames > 1 ? 1 : 0, d_out4 ? d_gt : nullptr, d_out4, c->k6_waves));
     if (defer) {
         HIP_TRY(c, hipEventRecord(c->tail_done[tk], ts));
         c->tail_pending[tk] = true;

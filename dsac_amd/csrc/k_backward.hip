@@ -364,7 +364,7 @@ __global__ __launch_bounds__(K4_THREADS, MINW) void k_score_backward_mfma(const 
     const int ngi = (nh + 15) >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, gq = lane >> 4;
-    if (frame_Nf > 0) {  // frame batch: one hypothesis tile per frame -- its coordinate map, pixel positions and gradient
+    if (frame_Nf > 0) {  // frame batch: the tile's frame (no tile straddles two: HT divides the hypotheses per frame) -- its coordinate map, pixel positions and gradient
         const int fr = h0 / frame_Nf;
         xyz += (long long)fr * xyz_stride;
         if (UV) uv += (long long)fr * uv_stride;
@@ -707,7 +707,14 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant, 
     K4Plan pl{};
     pl.glayers = 1;
     const bool batch = Nf > 0 && F.frames > 1;
-    if (batch && (Nf % 16 != 0 || Nf > K4M_HT_MAX || N % Nf != 0 || (variant >= 0 && variant % 10 == 0) || variant >= 1000)) { pl.variant = 0; pl.Nf = -1; return pl; }
+    // a frame's hypotheses as ONE tile up to 256, beyond that (round 6) as several equal tiles of the same launch: the largest multiple of 16 up to 256 that
+    // divides the count (384 -> 192, 512 -> 256, 1024 -> 256); the tiles of a frame add into its gradient with fp64 atomics like the tiles of one big frame
+    int batch_ht = 0;
+    if (batch && Nf % 16 == 0) {
+        for (int t = min(Nf, K4M_HT_MAX); t >= 64 || t == Nf; t -= 16)
+            if (t > 0 && Nf % t == 0) { batch_ht = t; break; }
+    }
+    if (batch && (batch_ht == 0 || N % Nf != 0 || (variant >= 0 && variant % 10 == 0) || variant >= 1000)) { pl.variant = 0; pl.Nf = -1; return pl; }
     const bool vec = (F.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_err) & 15) == 0) && ((reinterpret_cast<uintptr_t>(F.xyz) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(F.uv) & 15) == 0) && F.P >= 4;
     // experiment knobs folded into the value: variant = form + 10 * tile code (0 auto, 1: 64, 2: 128, 3: 256) + 100 * workgroups per CU (0 auto = 2)
@@ -756,7 +763,7 @@ K4Plan backward_plan(int N, const FrameDev& F, const float* d_err, int variant, 
         const bool hi_occ = variant >= 6;
         const int ht_max = ht_code == 1 ? 64 : (ht_code == 2 || (hi_occ && ht_code == 0)) ? 128 : K4M_HT_MAX;
         pl.HT = min(ht_small > 0 ? ht_small : ht_max, ((max(N, 1) + 15) / 16) * 16);
-        if (batch) pl.HT = Nf;  // one hypothesis tile per frame
+        if (batch) pl.HT = batch_ht;  // one hypothesis tile per frame up to 256 hypotheses, several equal ones beyond
         pl.NT = (max(N, 1) + pl.HT - 1) / pl.HT;
         pl.rows = max(1, min(PT, ((wg_per_cu > 0 ? wg_per_cu : hi_occ ? k4m_min_waves(variant) : 2) * 256 + pl.NT - 1) / pl.NT));
         // every workgroup takes the same number of (tile, 16-hypothesis group) items: at least one group each

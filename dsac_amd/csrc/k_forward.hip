@@ -448,13 +448,9 @@ DM_INLINE bool hp_chunk(float ax, float ay, float az, const float (&Bm)[4], cons
 // measured (scripts/r06_k2_diag.py, profiles/r06_k2_diag.txt): with an exact E and the plain v_rcp_f32 the softmax weight of two unrelated hypotheses in a tie is
 // still off by 5.7e-4 (stated 1e-4), with the Newton step by 5.3e-5; max |err - oracle| over all cells 7.6e-5 px.
 struct ExOps { h8 cx, cy, cz; h4 hx, hy, hz; };
-// E = D_hi + 2^-14 D_cross on a register pair of the two accumulators: v_pk_fma_f32 spelled out -- left to the compiler half of these came out as two
-// v_fma_f32 each (384 scalar fused multiply-adds in the <64 hypotheses, 256 pixels> kernel: 12 issue slots per 1 024 pairs more than needed)
-DM_INLINE f2 ex_combine(f2 c, f2 k, f2 h) {
-    f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(c), "v"(k), "v"(h));
-    return r;
-}
+// E = D_hi + 2^-14 D_cross on a register pair of the two accumulators.  (Spelled out as inline assembly -- the compiler emits half of these as two
+// v_fma_f32 each -- it returned garbage: the hazard recogniser does not see an asm statement's read of a matrix-core result, and gfx950 has no interlock there.)
+DM_INLINE f2 ex_combine(f2 c, f2 k, f2 h) { return pk_fma(c, k, h); }
 template <bool EXACT_Z, bool SOFT, bool FENCE = false>
 DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4], f2 (&sloc)[4]) {
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -1372,6 +1368,12 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
     // timing events (dsac_profile_enable): attached to the kernel's own dispatch (hipExtLaunchKernelGGL) instead of two event records on the
     // stream, which cost ~7 us of bubble each (one 640x480 frame: 100 us per step with them, 86 without)
     hipEvent_t evA = opts.ev_start, evB = opts.ev_stop;
+    // An arithmetic form that was ASKED for (k2_flags bits 25 / 27 / 28) and cannot run on this map -- its kernels read 16-byte vectors: H*W % 4, aligned buffers
+    // and, on the implicit grid, four cells of a lane in one row; the exact form also needs a focal length <= 2^10 -- is an error, not a silent fp32 launch
+    // (a parity run must not measure the fast form unknowingly).  The auto policy's exact form simply falls back.
+    if (opts.poses64 && (((opts.flags & K2_FLAG_PRECISE) && !(vec && (F.uv || F.W % 4 == 0))) || ((opts.flags & K2_FLAG_RECLO) && !vec) ||
+                         ((opts.flags & K2_FLAG_EXACT) && !(vec && opts.split))))
+        return hipErrorNotSupported;
     // the precise form (k2_flags bit 25): needs the cv poses themselves, 16-byte vectors and -- on the implicit grid -- four cells of a lane in one row
     if ((opts.flags & K2_FLAG_PRECISE) && opts.poses64 && vec && (F.uv || F.W % 4 == 0)) {
         const double nhp = (double)N * (double)F.P;
@@ -1393,15 +1395,18 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
 #undef DSAC_LO
     }
     // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84..87 = its tile / occupancy trades
-    if ((opts.flags & K2_FLAG_EXACT) && opts.split && vec && (opts.variant < 0 || (opts.variant >= 84 && opts.variant <= 89))) {
+    if (k2_wants_exact(opts) && opts.split && vec && (opts.variant < 0 || (opts.variant >= 84 && opts.variant <= 89))) {
 #define DSAC_EX(NG_, CH_, MW_, F_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
+#define DSAC_EXW(NG_, CH_, WV_, MW_, F_) launch_reproject_st<NG_, CH_, WV_, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
         switch (opts.variant) {
-            case 85: return DSAC_EX(4, 4, 3, 2);   // <64 hypotheses, 256 pixels>, 3 waves per SIMD, scheduling fence per m
-            case 86: return DSAC_EX(4, 2, 3, 2);   // <64, 128>, 3 waves per SIMD, fence
-            case 87: return DSAC_EX(4, 4, 2, 2);   // <64, 256>, 2 waves per SIMD, fence
-            case 89: return DSAC_EX(2, 4, 2, 1);   // <32 hypotheses, 256 pixels>, 2 waves per SIMD
-            case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD (three or four waves per SIMD WITHOUT the fence spill: 1.4-2.8 ms, profiles/r06_k2_exact_ab.txt)
+            case 85: return DSAC_EXW(4, 2, 2, 3, 2);  // <64 hypotheses, 2 waves x 128 pixels>, 3 waves per SIMD, scheduling fence per m
+            case 86: return DSAC_EX(4, 2, 3, 2);      // <64, 128>, one-wave workgroups, 3 waves per SIMD, fence
+            case 87: return DSAC_EX(4, 4, 2, 2);      // <64, 256>, 2 waves per SIMD, fence
+            case 88: return DSAC_EXW(4, 2, 4, 3, 2);  // <64, 4 waves x 128 pixels>, 3 waves per SIMD, fence
+            case 89: return DSAC_EX(2, 4, 2, 1);      // <32 hypotheses, 256 pixels>, 2 waves per SIMD
+            case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
         }
+#undef DSAC_EXW
 #undef DSAC_EX
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);

@@ -27,6 +27,8 @@ namespace dk {
 
 constexpr int RF_MAX_INL = 256;  // LDS capacity for the collected correspondences
 
+// a frame index that came from device memory (frame_of of the DSAC-variant batch calls): never trusted beyond the batch
+DM_INLINE int clamp_frame(int f, const FrameDev& F) { return min(max(f, 0), max(F.frames, 1) - 1); }
 DM_INLINE dm::Cam make_cam_r(const FrameDev& F) { return dm::Cam{(double)F.fx, (double)F.fy, (double)F.cx, (double)F.cy}; }
 
 // ---- wave-wide sums of fp64 values without the LDS crossbar (round 1 used 6 ds_bpermute round trips per value) ----
@@ -130,10 +132,12 @@ DM_INLINE double drcp(double d) {
 #ifdef DSAC_K6_IEEE_DIV
     return 1.0 / d;
 #else
-    double r = __builtin_amdgcn_rcp(d);
+    const double r0 = __builtin_amdgcn_rcp(d);
+    double r = fma(fma(-d, r0, 1.0), r0, r0);
     r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
+    // the IEEE edge cases of 1.0 / d: d = 0 or a denormal whose reciprocal is inf would turn into NaN in the Newton steps (0 x inf); keep the
+    // hardware's inf / 0 there, so that degenerate inputs take the branches they took with the division
+    return (r == r) ? r : r0;
 #endif
 }
 DM_INLINE bool solve6_spd(const double A[36], const double b[6], double x[6]) {
@@ -303,7 +307,14 @@ DM_INLINE void lm_step(const double JtJ[21], const double JtE[6], int lambdaLg10
 // CvLevMarq's sequence per iteration is: solve -> residual at the trial pose -> (accepted) Jacobian at the same pose.  Whether an accepted
 // trial ends the iteration (20 iterations or a relative parameter change below FLT_EPSILON) is known before the residual is: unless it
 // does, residual and normal equations of the trial are computed in one pass and simply dropped if the trial is rejected.
-DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, RodCache& rc, double pose[6]) {
+// K6_LM_STATS (an instrumented build, `make lmstats`; scripts/micro/k6_lm_accept_hist.py): accepted and rejected trial steps are counted and leave the kernel in
+// the upper bits of steps_done -- VERDICT r5 item 5: how often does CvLevMarq reject a step (a rejected step is one more dependent solve + residual pass)?
+#ifdef K6_LM_STATS
+#define K6_STAT(x) x
+#else
+#define K6_STAT(x)
+#endif
+DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red, const dm::Cam& K, RodCache& rc, double pose[6], int* lm_stats = nullptr) {
     double param[6], prev[6], JtJ[21], JtE[6], JtJn[21], JtEn[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) param[i] = pose[i];
@@ -326,10 +337,11 @@ DM_INLINE void lm_pnp(int n, const float* s_X, const float* s_uv, double* s_red,
             if (last) errNorm = lm_eval<false>(n, s_X, s_uv, s_red, K, rc, param, nullptr, nullptr);
             else errNorm = lm_eval<true>(n, s_X, s_uv, s_red, K, rc, param, JtJn, JtEn);
             if (errNorm > prevErrNorm) {
-                if (++lambdaLg10 <= 16) { lm_step(JtJ, JtE, lambdaLg10, prev, param); continue; }
+                if (++lambdaLg10 <= 16) { K6_STAT(lm_stats[1]++;) lm_step(JtJ, JtE, lambdaLg10, prev, param); continue; }
             }
             lambdaLg10 = max(lambdaLg10 - 1, -16);
             iters++;
+            K6_STAT(lm_stats[0]++;)
             if (last) { done = true; break; }
             prevErrNorm = errNorm;
             e_at_param = errNorm;
@@ -379,7 +391,15 @@ DM_INLINE void walk_cell_uv(const FrameDev& F, const WalkCells& c, int s, float&
     v = (float)y;
 }
 
-__global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict__ n_live, int live_base, int live_mul,
+// S waves per problem (round 6).  Wave 0 is the problem's wave as before: it walks the first 256 cells of a step's permutation and runs
+// the whole LM chain.  When those 256 cells did not give max_inl inliers the walk goes on in rounds of S x 256 cells, wave w taking the w-th 256 of a round:
+// fp64 residuals, threshold and ballots as in the serial walk; the waves' inlier counts meet in LDS, every wave knows the number of inliers in front of its
+// own cells and compacts into those slots -- the list is the one the serial walk produces (the first max_inl inliers in permutation order), so inlier maps,
+// step counts and refined poses are bit-identical.  A wave that walks a whole 640 x 480 map alone spends 2.3 ms of a 2.4 ms refinement in the walk
+// (profiles/r05_k6_phases.txt: the DSAC variant refines EVERY hypothesis, 128 one-wave problems occupy an eighth of the chip); with S = 8 the same launch
+// fills it.  The helper waves of a problem whose first 256 cells suffice (the soft-argmax pose on an ordinary frame) only meet wave 0 at one barrier per step.
+template <int S>
+__global__ __launch_bounds__(64 * S) void k_refine(int B, const int32_t* __restrict__ n_live, int live_base, int live_mul,
                                                const double* __restrict__ init_poses, const int32_t* __restrict__ perm, int steps, int max_inl,
                                                int min_inl, float thr, const int32_t* __restrict__ pert_px_c, const float* __restrict__ pert_value,
                                                FrameDev F, double* __restrict__ out_poses, int32_t* __restrict__ inlier_map,
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
     // a latency chain on one wave: whatever shares its SIMD (K5 beside the replicas in dsac_backward_path1, K1 / K2 beside a deferred tail) issues after it
     __builtin_amdgcn_s_setprio(3);
     if (frame_of_group) {  // DSAC variant on a frame batch: replica list m = b / group belongs to hypothesis m, which lives in frame frame_of_group[m]
-        const int f = frame_of_group[group > 0 ? b / group : 0];
+        const int f = clamp_frame(frame_of_group[group > 0 ? b / group : 0], F);
         F.xyz += (long long)f * F.xyz_stride;
         if (F.uv) F.uv += (long long)f * F.uv_stride;
     } else if (per_frame > 0) {  // frame batch: one wave per (frame, problem) -- the per-image refinement of test_ransac_softam.cpp:97-157 for F images at once
@@ -404,10 +424,18 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
         const int m = group > 0 ? b / group : 0, local = group > 0 ? b - m * group : b;
         if (local >= live_base + live_mul * n_live[m]) return;
     }
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = S > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     __shared__ float s_X[RF_MAX_INL * 3];
     __shared__ float s_uv[RF_MAX_INL * 2];
     __shared__ double s_red[32];
+    __shared__ double s_pose[2][6];  // S > 1: the pose of the step, from wave 0 (by step parity: a helper reads a step's values while wave 0 may already write the next)
+    __shared__ int s_head[2];        // S > 1: inliers among the step's first 256 cells (wave 0)
+    // S > 1: wave 0's word to the helpers, monotonic: 4 (step + 1) + code, code 0 = this step's first 256 cells sufficed (nothing to do), 1 = walk on together,
+    // 2 = the problem is over.  The helpers POLL it (s_sleep between reads): wave 0 -- the latency chain of an image -- meets no barrier on a step that
+    // needs no help (a barrier per step cost the good-pose refinement 2.5 us of 83)
+    __shared__ int s_word;
+    __shared__ int s_wcnt[2][S > 1 ? S : 1];  // S > 1: the waves' inlier counts of a round (two sets: a round's counts are read while the next's are written)
     const dm::Cam K = make_cam_r(F);
     double pose[6];
 #pragma unroll
@@ -417,41 +445,136 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
     const float pval = pert_value ? pert_value[b] : 0.f;
     const int P = F.P;
     int done = 0;
+#ifdef K6_LM_STATS
+    int lm_stats[2] = {0, 0};
+#endif
     RodCache rc;
     WalkCells cells;
-    if (steps > 0) load_walk_cells(perm, 0, lane, F, cells);
+    if (S > 1) {
+        if (threadIdx.x == 0) s_word = 0;
+        __syncthreads();
+    }
+    if (steps > 0 && wave == 0) load_walk_cells(perm, 0, lane, F, cells);
     for (int step = 0; step < steps; step++) {
-        rod_at(rc, pose);
-        const double* R = rc.R;
         const int32_t* pidx = perm + (size_t)step * P;
         int cnt = 0;
-        for (int base = 0; base < P && cnt < max_inl; base += 64 * WALK_AHEAD) {
-            if (base > 0) load_walk_cells(pidx, base, lane, F, cells);
-            // the residuals of the four sub-batches are independent of the running count: all four first (their divisions and
-            // square roots interleave), then the in-order compaction
-            float e[WALK_AHEAD], pu[WALK_AHEAD], pv[WALK_AHEAD];
+        if (wave == 0) {
+            rod_at(rc, pose);
+            const double* R = rc.R;
+            // wave 0 walks serially: all of the permutation when it is alone (S == 1), the first 256 cells otherwise
+            for (int base = 0; base < (S == 1 ? P : min(P, 64 * WALK_AHEAD)) && cnt < max_inl; base += 64 * WALK_AHEAD) {
+                if (base > 0) load_walk_cells(pidx, base, lane, F, cells);
+                // the residuals of the four sub-batches are independent of the running count: all four first (their divisions and
+                // square roots interleave), then the in-order compaction
+                float e[WALK_AHEAD], pu[WALK_AHEAD], pv[WALK_AHEAD];
 #pragma unroll
-            for (int s = 0; s < WALK_AHEAD; s++) {
-                if (ppx >= 0 && cells.p[s] == ppx) { if (pch == 0) cells.X[s] = pval; else if (pch == 1) cells.Y[s] = pval; else cells.Z[s] = pval; }
-                walk_cell_uv(F, cells, s, pu[s], pv[s]);
-                e[s] = dm::residual_f(R, pose + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
-            }
-#pragma unroll
-            for (int s = 0; s < WALK_AHEAD; s++) {
-                if (cnt >= max_inl) break;  // uniform: the walk stops at max_inl taken cells (core/cnn_softam.h:1121-1135)
-                const int p = cells.p[s];
-                const bool inl = (p >= 0) && (e[s] < thr);
-                const unsigned long long m = __ballot(inl);
-                const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-                const bool take = inl && (cnt + prefix < max_inl);
-                if (take) {
-                    const int slot = cnt + prefix;
-                    s_X[slot * 3] = cells.X[s]; s_X[slot * 3 + 1] = cells.Y[s]; s_X[slot * 3 + 2] = cells.Z[s];
-                    s_uv[slot * 2] = pu[s]; s_uv[slot * 2 + 1] = pv[s];
-                    if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
+                for (int s = 0; s < WALK_AHEAD; s++) {
+                    if (ppx >= 0 && cells.p[s] == ppx) { if (pch == 0) cells.X[s] = pval; else if (pch == 1) cells.Y[s] = pval; else cells.Z[s] = pval; }
+                    walk_cell_uv(F, cells, s, pu[s], pv[s]);
+                    e[s] = dm::residual_f(R, pose + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
                 }
-                cnt += __popcll(m);
+#pragma unroll
+                for (int s = 0; s < WALK_AHEAD; s++) {
+                    if (cnt >= max_inl) break;  // uniform: the walk stops at max_inl taken cells (core/cnn_softam.h:1121-1135)
+                    const int p = cells.p[s];
+                    const bool inl = (p >= 0) && (e[s] < thr);
+                    const unsigned long long m = __ballot(inl);
+                    const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+                    const bool take = inl && (cnt + prefix < max_inl);
+                    if (take) {
+                        const int slot = cnt + prefix;
+                        s_X[slot * 3] = cells.X[s]; s_X[slot * 3 + 1] = cells.Y[s]; s_X[slot * 3 + 2] = cells.Z[s];
+                        s_uv[slot * 2] = pu[s]; s_uv[slot * 2 + 1] = pv[s];
+                        if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + p], 1);
+                    }
+                    cnt += __popcll(m);
+                }
             }
+            if (S > 1) {
+                const bool help = cnt < max_inl && 64 * WALK_AHEAD < P;
+                if (lane == 0) {
+                    s_head[step & 1] = cnt;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) s_pose[step & 1][i] = pose[i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&s_word, 4 * (step + 1) + (help ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (S > 1) {
+            bool help;
+            if (wave > 0) {
+                int word;
+                do {
+                    word = __hip_atomic_load(&s_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (word < 4 * (step + 1)) __builtin_amdgcn_s_sleep(8);
+                } while (word < 4 * (step + 1));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (word >= 4 * (steps + 2)) break;    // the problem is over
+                if (word >= 4 * (step + 2)) continue;  // wave 0 is already past this step: it needed no help (wave 0 cannot pass a step that does -- it waits in the round's barrier)
+                help = (word & 3) == 1;
+                if (!help) continue;
+                cnt = s_head[step & 1];
+            } else {
+                help = cnt < max_inl && 64 * WALK_AHEAD < P;
+            }
+            if (help) {
+                // the walk goes on in rounds of S x 256 cells.  A wave first COUNTS the inliers of its 256 cells; once the counts of the round have met in LDS
+                // it knows how many inliers lie in front of its cells and compacts into those slots (a second pass over four ballots, no second residual)
+                double hp[6];
+                if (wave > 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hp[i] = s_pose[step & 1][i];
+                    rod_at(rc, hp);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) hp[i] = pose[i];
+                }
+                unsigned long long masks[WALK_AHEAD];
+                int set = 0;
+                for (int base = 64 * WALK_AHEAD; base < P && cnt < max_inl; base += 64 * WALK_AHEAD * S, set ^= 1) {
+                    const int mine = base + 64 * WALK_AHEAD * wave;
+                    int found = 0;
+                    float pu[WALK_AHEAD], pv[WALK_AHEAD];
+                    if (mine < P) {
+                        load_walk_cells(pidx, mine, lane, F, cells);
+                        float e[WALK_AHEAD];
+#pragma unroll
+                        for (int s = 0; s < WALK_AHEAD; s++) {
+                            if (ppx >= 0 && cells.p[s] == ppx) { if (pch == 0) cells.X[s] = pval; else if (pch == 1) cells.Y[s] = pval; else cells.Z[s] = pval; }
+                            walk_cell_uv(F, cells, s, pu[s], pv[s]);
+                            e[s] = dm::residual_f(rc.R, hp + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
+                        }
+#pragma unroll
+                        for (int s = 0; s < WALK_AHEAD; s++) {
+                            masks[s] = __ballot((cells.p[s] >= 0) && (e[s] < thr));
+                            found += __popcll(masks[s]);
+                        }
+                    }
+                    if (lane == 0) s_wcnt[set][wave] = found;
+                    __syncthreads();
+                    int before = cnt, total = 0;
+#pragma unroll
+                    for (int w = 0; w < S; w++) { const int v = s_wcnt[set][w]; if (w < wave) before += v; total += v; }
+                    if (mine < P && found > 0 && before < max_inl) {
+#pragma unroll
+                        for (int s = 0; s < WALK_AHEAD; s++) {
+                            const unsigned long long m = masks[s];
+                            const bool inl = (m >> lane) & 1ull;
+                            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+                            if (inl && slot < max_inl) {
+                                s_X[slot * 3] = cells.X[s]; s_X[slot * 3 + 1] = cells.Y[s]; s_X[slot * 3 + 2] = cells.Z[s];
+                                s_uv[slot * 2] = pu[s]; s_uv[slot * 2 + 1] = pv[s];
+                                if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + cells.p[s]], 1);
+                            }
+                            before += __popcll(m);
+                        }
+                    }
+                    cnt += total;
+                }
+                __syncthreads();  // the collected correspondences of all waves are in LDS before wave 0 reads them
+            }
+            if (wave > 0) continue;  // the helpers wait for wave 0's word of the next step
         }
         // the head of the next step's walk does not depend on the pose: its loads fly under the LM solve
         if (step + 1 < steps) load_walk_cells(pidx + P, 0, lane, F, cells);
@@ -461,7 +584,11 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
         double upd[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) upd[i] = pose[i];
+#ifdef K6_LM_STATS
+        lm_pnp(n, s_X, s_uv, s_red, K, rc, upd, lm_stats);
+#else
         lm_pnp(n, s_X, s_uv, s_red, K, rc, upd);
+#endif
         bool nan = false;
 #pragma unroll
         for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
@@ -471,10 +598,19 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
         done++;
         __builtin_amdgcn_wave_barrier();
     }
+    if (S > 1) {
+        if (wave > 0) return;
+        // the helpers poll for the word of a step that will not come (the problem ended early) or have left already (all steps done): tell them
+        if (lane == 0) __hip_atomic_store(&s_word, 4 * (steps + 2) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; i++) out_poses[(size_t)b * 6 + i] = pose[i];
+#ifdef K6_LM_STATS
+        if (steps_done) steps_done[b] = done | (min(lm_stats[0], 4095) << 8) | (min(lm_stats[1], 2047) << 20);  // accepted, rejected trial steps of the whole refinement
+#else
         if (steps_done) steps_done[b] = done;
+#endif
         // processImage's last stage (core/cnn_softam.h:1160-1179): maxLoss of the refined pose against this problem's ground truth, by the lane that
         // holds it -- K7's arithmetic (loss_math.h) without K7's launch behind a 90 us chain
         if (loss_out4) {
@@ -486,11 +622,18 @@ __global__ __launch_bounds__(64) void k_refine(int B, const int32_t* __restrict_
 
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride, int per_frame, const double* loss_gt_jp6, double* loss_out4) {
+                  int32_t* steps_done, int map_stride, int per_frame, const double* loss_gt_jp6, double* loss_out4, int waves_per_problem) {
     if (B <= 0) return hipSuccess;
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_refine, dim3(B), dim3(64), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c,
-                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4, (const int32_t*)nullptr);
+    // waves per problem: as many as fill the chip's 1 024 SIMDs twice over, and no more than the map has 256-cell batches behind the first one
+    // (eight waves per problem would need the 380-register LM chain in 256 registers: 512 B of scratch, the good-pose refinement 83 -> 135 us -- measured, kept
+    // selectable for the record: profiles/r06_k6_walk.txt)
+    int S = waves_per_problem >= 1 ? waves_per_problem : (B <= 512 ? 4 : B <= 1024 ? 2 : 1);
+    while (S > 1 && (long long)64 * WALK_AHEAD * (S / 2 + 1) > (long long)F.P) S /= 2;
+#define DSAC_K6(S_) hipLaunchKernelGGL((k_refine<S_>), dim3(B), dim3(64 * S_), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c, \
+                       pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4, (const int32_t*)nullptr)
+    if (S >= 8) DSAC_K6(8); else if (S >= 4) DSAC_K6(4); else if (S >= 2) DSAC_K6(2); else DSAC_K6(1);
+#undef DSAC_K6
     return hipGetLastError();
 }
 
@@ -656,7 +799,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_emit(const double* _
     if (SET) {  // hypothesis m of a batch (blockIdx.y): its set, inlier map, counts and slice of the replica arrays (18 + 6*cap replicas each)
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; inlier_map += m * F.P; scratch += m * F.W * (PLAN_SEGS + 1); rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
-        if (frame_of) F.xyz += (long long)frame_of[m] * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
+        if (frame_of) F.xyz += (long long)clamp_frame(frame_of[m], F) * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
         if (blockIdx.x == 0 && tid < 18) {
             const int pt = tid / 6, c = (tid % 6) >> 1;
             const int p = min(max(set4[pt], 0), F.P - 1);
@@ -741,11 +884,11 @@ hipError_t refine_fd_run(hipStream_t st, int cap, const int32_t* n_obj, const do
     if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
     const int R = 12 + 6 * cap;
     if (frames > 1) {  // one replica list per frame: list m = b / R refines against frame m, replicas beyond 12 + 6 * n_obj[m] exit at once
-        hipLaunchKernelGGL(k_refine, dim3(R * frames), dim3(64), 0, st, R * frames, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
+        hipLaunchKernelGGL(k_refine<1>, dim3(R * frames), dim3(64), 0, st, R * frames, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
                            rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, R, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_refine, dim3(R), dim3(64), 0, st, R, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
+    hipLaunchKernelGGL(k_refine<1>, dim3(R), dim3(64), 0, st, R, n_obj, 12, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F, rep_out,
                        (int32_t*)nullptr, (int32_t*)nullptr, 0, 0, 0, (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr);
     return hipGetLastError();
 }
@@ -766,7 +909,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_refine_fd_plan_set(const int32
     {   // hypothesis m of a batch (blockIdx.y): its set, inlier map and slice of the replica arrays (18 + 6*cap replicas each)
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; inlier_map += m * P; rep_px_c += m * R * 2; rep_value += m * R; obj_pixels += m * cap; n_obj += m;
-        if (frame_of) F.xyz += (long long)frame_of[m] * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
+        if (frame_of) F.xyz += (long long)clamp_frame(frame_of[m], F) * F.xyz_stride;  // frame batch: hypothesis m reads its own frame's coordinates
     }
     if (lane < 18) {
         const int pt = lane / 6, c = (lane % 6) >> 1;
@@ -809,7 +952,7 @@ __global__ __launch_bounds__(64) void k_refine_fd_init_set(int cap, const int32_
         const size_t m = blockIdx.y, R = 18 + 6 * (size_t)cap;
         set4 += 4 * m; rep_px_c += m * R * 2; rep_value += m * R; rep_poses += m * R * 6; n_obj += m;
         if (frame_of) {
-            const long long f = frame_of[m];
+            const long long f = clamp_frame(frame_of[m], F);
             F.xyz += f * F.xyz_stride;
             if (F.uv) F.uv += f * F.uv_stride;
         }
@@ -876,7 +1019,7 @@ hipError_t refine_fd_run_set(hipStream_t st, int cap, const int32_t* n_obj, cons
     const int R = 18 + 6 * cap;
     const long long B = (long long)R * M;
     if (B > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_refine, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
+    hipLaunchKernelGGL(k_refine<1>, dim3((unsigned)B), dim3(64), 0, st, (int)B, n_obj, 18, 6, rep_poses, perm, steps, max_inl, min_inl, thr, rep_px_c, rep_value, F,
                        rep_out, (int32_t*)nullptr, (int32_t*)nullptr, 0, R, 0, (const double*)nullptr, (double*)nullptr, frame_of);
     return hipGetLastError();
 }

@@ -30,6 +30,7 @@ hipError_t pose_prep_lo(hipStream_t st, int N, const double* poses, const FrameD
 // the records of the exact-transform form (k2_flags bit 28): pose_split_bytes(N) bytes; available for focal lengths up to 2^10 (pose_split_exponent <= 10)
 size_t pose_split_bytes(int N);
 int pose_split_exponent(const FrameDev& F);
+bool pose_split_available(const FrameDev& F);
 hipError_t pose_prep_split(hipStream_t st, int N, const double* poses, const FrameDev& F, void* split);
 
 // K2.  err (N x P) and/or soft partials.  soft_part must hold reproject_num_pixel_tiles(P) * N floats.
@@ -38,6 +39,8 @@ struct K2Opts {
     bool pixel_minor = true;  // block order: pixel tiles innermost (DSAC_K2_ORDER)
     int flags = 0;            // bit0: plain (cached) stores instead of non-temporal (DSAC_K2_FLAGS)
     int variant = -1;         // -1 = auto policy, otherwise a fixed kernel form (DSAC_K2_VARIANT), see reproject()
+    bool exact_auto = true;   // "k2_exact_auto" (DSAC_K2_EXACT_AUTO): the auto policy (variant -1, no other arithmetic flag) takes the exact-transform form wherever it
+                              // applies -- round 6: the default K2 is the form that holds every stated tolerance; 0 = the fp32 matrix-core forms
     int diag = 0;             // "k2_diag": diagnostic switches of the precise form (which fp32 step costs what; k_reproject_prec), 0 = none
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // per call: timing events attached to the K2 dispatch itself (profiling), else null
     const float* staged_lo = nullptr;  // per call: the low parts of the staged records (pose_prep_lo), for flags bit 27
@@ -45,8 +48,14 @@ struct K2Opts {
     const double* poses64 = nullptr;  // per call: the cv poses (N x 6 doubles) the staged records were made from -- the precise form (flags bit 25) works from these
 };
 constexpr int K2_FLAG_RECLO = 1 << 27;    // k2_flags: pose records in two pieces -- the low parts through fp16 matrix-core instructions chained onto the fp32 ones
+constexpr int K2_FLAG_STORE_ONLY = 1 << 1;  // k2_flags: store schedule only (measurement)
 constexpr int K2_FLAG_EXACT = 1 << 28;    // k2_flags: exact transform -- split fp16 records through the fp16 matrix core, the camera-frame point rounded to float once (round 6)
 constexpr int K2_FLAG_PRECISE = 1 << 25;  // k2_flags: the fp64 projection of the reference (k_reproject_prec) instead of the fp32 matrix-core transform
+// does a K2 launch with these options want the split records?  (bit 28 asks for them; the auto policy wants them unless another arithmetic form or a measurement flag is set)
+inline bool k2_wants_exact(const K2Opts& o) {
+    if (o.flags & K2_FLAG_EXACT) return true;
+    return o.exact_auto && o.variant < 0 && !(o.flags & (K2_FLAG_PRECISE | K2_FLAG_RECLO | K2_FLAG_STORE_ONLY | (1 << 26)));
+}
 int reproject_num_pixel_tiles(int P);  // upper bound over both code paths
 // *tiles_used receives the number of pixel tiles actually written to soft_part (<= reproject_num_pixel_tiles).
 // Nf: hypotheses per frame of a frame batch (hypothesis h scores frame h / Nf; Nf must be a multiple of K2_NF_MULTIPLE = 128 then: no
@@ -144,7 +153,9 @@ hipError_t path1_assemble(hipStream_t st, const double* dL, const double* J_hyp,
 // per_frame > 0 (frame batch): problem b refines against frame b / per_frame (F.xyz_stride / F.uv_stride)
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
-                  int32_t* steps_done, int map_stride = 0, int per_frame = 0, const double* loss_gt_jp6 = nullptr, double* loss_out4 = nullptr);
+                  int32_t* steps_done, int map_stride = 0, int per_frame = 0, const double* loss_gt_jp6 = nullptr, double* loss_out4 = nullptr,
+                  int waves_per_problem = 0);
+// waves_per_problem: 0 = by the problem count (4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8 = fixed ("k6_waves"); the same results bit for bit
 // loss_gt_jp6 (B x 6) / loss_out4 (B x 4): maxLoss of every refined pose against its ground truth in the same launch (K7's arithmetic, loss_math.h)
 // inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)
 hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps);

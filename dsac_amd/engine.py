@@ -709,12 +709,33 @@ class Engine:
         score_fn(err) -> N scores is given (the seam where the reference's score CNN sits, cnn_softam.h:1072): err is the N x H x W float32
         error images as a torch DEVICE tensor (processImagesScored: the maps never leave HBM), the result a torch tensor or an array.
         `perm` = refSteps x P pixel permutations (the reference's pixelIdxs)."""
+        if score_fn is not None and perm is None:
+            # no permutations = no refinement (ADVICE r5): the seam's first half only -- K1 + K2 into HBM, score_fn on the device tensor, K3; the soft-argmax
+            # pose is returned as the refined pose with zero steps, as the path without score_fn does
+            import torch
+            dev = torch.device("cuda", self.device)
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(self.stream), device=dev)):
+                hyps_d = torch.zeros(N, 6, dtype=torch.float64, device=dev)
+                sets_d, ok_d = torch.zeros(N, 4, dtype=torch.int32, device=dev), torch.zeros(N, dtype=torch.uint8, device=dev)
+                err_d = torch.empty(N, self.H, self.W, dtype=torch.float32, device=dev)
+                self.processImagesBegin(N, err_d, seed=seed, thr=thr, max_tries=max_tries, out=(hyps_d, sets_d, ok_d))
+                sc = score_fn(err_d)
+                if not hasattr(sc, "data_ptr"):
+                    sc = torch.as_tensor(np.ascontiguousarray(sc, dtype=np.float64))
+                sc = sc.detach().to(device=dev, dtype=torch.float64).reshape(N).contiguous()
+            self.synchronize()
+            poses, scores = hyps_d.cpu().numpy(), sc.cpu().numpy()
+            w, ent, avg = self.softMax(scores, 1.0, poses)
+            out = dict(hyps=poses, sampledPoints=sets_d.cpu().numpy(), ok=ok_d.cpu().numpy(), scores=scores, score_scale=1.0, sfScores=w, sfEntropy=float(ent[0]), avgHyp=avg,
+                       diffMaps=err_d if keep_err else None, soft=None, refAvgHyp=avg.copy(), refSteps=0, inlierMap=np.zeros(self.P, np.int32), pixelIdxs=None)
+            if gt_jp6 is not None:
+                out.update(self.maxLoss(out["refAvgHyp"], gt_jp6))
+            return out
         if score_fn is not None:
             # the score-CNN seam (cnn_softam.h:1066-1078) on device tensors: K1 + K2 write the error images into HBM, score_fn reads them there, K3 / K6 / K7
             # continue from its scores -- dsac_process_images_begin / _finish; only the small results come back (round 4 shipped the N x H x W error images
             # through host NumPy here: 314 MB per 640 x 480 image)
-            r = self.processImagesScored(N, np.ascontiguousarray(perm[:refSteps], dtype=np.int32) if perm is not None else np.zeros((0, self.P), np.int32),
-                                         score_fn, gt_jp6=gt_jp6, seed=seed, thr=thr, max_tries=max_tries, max_inl=inlierCount, min_inl=minInliers,
+            r = self.processImagesScored(N, np.ascontiguousarray(perm[:refSteps], dtype=np.int32), score_fn, gt_jp6=gt_jp6, seed=seed, thr=thr, max_tries=max_tries, max_inl=inlierCount, min_inl=minInliers,
                                          want_inlier_maps=True)
             self.synchronize()
             h = {k: v.cpu().numpy() for k, v in r.items() if k != "diffMaps"}

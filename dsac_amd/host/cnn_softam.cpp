@@ -406,11 +406,13 @@ void FrameBatch::scoreImages(int first, int count, uint64_t seedOfFrame0, int in
     C_.setOption("pi_defer_tail", opt_.deferTail ? (opt_.deferScoreTail ? 2 : 1) : 0);
     if (opt_.deferTail && opt_.deferScoreTail && first < lastFirst_ + lastCount_ && lastFirst_ < first + count) C_.check(dsac_join_tail(c), "dsac_join_tail");
     lastFirst_ = first; lastCount_ = count;
-    if (soft_.size() == 0) soft_.resize(C_, (size_t)maxCall_ * N);
+    // one slice per FRAME (like scores_ / w_), not one buffer per call: with the score tail deferred (pi_defer_tail = 2) K3 of this call reads its scores on
+    // the tail stream while the NEXT call's begin already writes its sums -- consecutive calls on different ranges must not share the array
+    if (soft_.size() == 0) soft_.resize(C_, (size_t)F_ * N);
     bindRange(first, count);
     const DeviceArgsScope devArgs(C_);
     C_.check(dsac_process_images_begin(c, N_, seedOfFrame0 + (uint64_t)first, (float)inlierThreshold2D, 1 << 20, (float)CNN_OBJ_MAXINPUT, tau, beta, poses_.data() + f0 * N * 6,
-                                       sets_.data() + f0 * N * 4, ok_.data() + f0 * N, err_.data(), soft_.data()),
+                                       sets_.data() + f0 * N * 4, ok_.data() + f0 * N, err_.data(), soft_.data() + f0 * N),
              "dsac_process_images_begin");
     seamFirst_ = first; seamCount_ = count;
 }
@@ -439,7 +441,7 @@ ScoreModel FrameBatch::softInlierModel(float tau, float beta, double alpha) {
     ScoreModel m;
     m.scale = alpha;
     // scoreImages evaluated the sums with its own (tau, beta): the model's must be the same pair (the defaults are)
-    m.forward = [this](const float*, int, int, int) { return soft_.data(); };
+    m.forward = [this](const float*, int, int, int) { return soft_.data() + (size_t)seamFirst_ * N_; };
     m.backward = [this, tau, beta](const double* g, const float* err, int nMaps, int, int) -> const float* {
         const size_t P = (size_t)H_ * W_;
         if (dErr_.size() == 0) dErr_.resize(C_, (size_t)maxCall_ * N_ * P);
@@ -524,6 +526,10 @@ void FrameBatch::gatherFramesFrom(const FrameBatch& src, const std::vector<int32
 
 void FrameBatch::processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau, float beta, double alpha) {
     for (int f = 0; f < F_; f += maxCall_) processImages(f, std::min(maxCall_, F_ - f), seedOfFrame0, inlierThreshold2D, inlierCount, tau, beta, alpha);
+}
+
+void FrameBatch::processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, const ScoreModel& model, float tau, float beta) {
+    for (int f = 0; f < F_; f += maxCall_) processImages(f, std::min(maxCall_, F_ - f), seedOfFrame0, inlierThreshold2D, inlierCount, model, tau, beta);
 }
 
 void FrameBatch::synchronize() {

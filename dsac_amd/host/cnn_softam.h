@@ -212,7 +212,10 @@ struct FrameBatchOptions {
 
 // The score model at the seam of the batched path -- the reference's score CNN (core/cnn_softam.h:1072: forward(diffMaps); core/train_ransac_softam.cpp:
 // 378-383: backward -> dScore), or anything else that turns error images into scores.  Both functions are called with DEVICE pointers and must enqueue their
-// work on the engine's stream (dsac_get_stream) or order themselves against it; the pointers they return must stay valid until the batch's next call.
+// work on the engine's stream (dsac_get_stream) or order themselves against it; the pointers they return must stay valid until the batch's next call --
+// and with FrameBatchOptions::deferScoreTail (the default) the SCORES of call k are read by K3 on the tail stream while call k + 1 is already running: a
+// model must then hand out a buffer that it does not rewrite before the call AFTER the next (two alternating buffers, or one slice per frame as
+// softInlierModel does), or the batch must be made with deferScoreTail = false.
 //   forward : nMaps x H*W float32 error images (hypothesis-major, each map row-major: the order of core/lua_calls.h:98-104) -> nMaps scores (double)
 //   backward: nMaps score gradients (double) and the same error images -> nMaps x H*W float32 gradient images, (n, y, x) order
 struct ScoreModel {
@@ -237,12 +240,13 @@ public:
     void scoreImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, float tau = 10.f, float beta = 0.5f);
     void finishImages(int first, int count, const double* scoresDevice, int inlierThreshold2D, int inlierCount, double scale = 1.0);
     void processImages(int first, int count, uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, const ScoreModel& model, float tau = 10.f, float beta = 0.5f);
-    const double* softInlierSumsDevice() const { return soft_.data(); }  // of the most recent scoreImages, count*objHyps
+    const double* softInlierSumsDevice() const { return soft_.data() + (size_t)(seamFirst_ < 0 ? 0 : seamFirst_) * N_; }  // of the most recent scoreImages, count*objHyps
     // the soft-inlier score dressed as an external model (forward: the sums scoreImages left; backward: dsac_soft_score_derr) -- the stand-in a host without
     // device code uses to drive the seam end to end; results equal the built-in score's to fp32 rounding
     ScoreModel softInlierModel(float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
     // convenience: all frames in calls of maxFramesPerCall
     void processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, float tau = 10.f, float beta = 0.5f, double alpha = 0.1);
+    void processAll(uint64_t seedOfFrame0, int inlierThreshold2D, int inlierCount, const ScoreModel& model, float tau = 10.f, float beta = 0.5f);  // through the seam
     void synchronize();  // joins the deferred tail and waits
     // waits and copies the results back; perHypothesis = false leaves hyps / imgIdx / sfScores empty (the evaluation program needs none of them)
     std::vector<ProcessImageResult> results(bool perHypothesis = true);
@@ -280,7 +284,7 @@ private:
     DeviceArray<uint8_t> ok_;
     DeviceArray<double> gt_, poses_, scores_, w_, entropy_, avg_, ref_, out4_;
     DeviceArray<double> grad_, dpnp_, g_;  // training: F x H*W x 3 gradient, maxCall x objHyps x 72 dPNP, maxCall x objHyps score gradients
-    DeviceArray<double> soft_;             // the seam: soft-inlier sums of the most recent scoreImages (maxCall x objHyps)
+    DeviceArray<double> soft_;             // the seam: soft-inlier sums, one slice per frame (frames x objHyps): a deferred score tail reads call k's while call k + 1 writes its own
     DeviceArray<float> dErr_;              // softInlierModel's gradient images (maxCall x objHyps x H*W), allocated on first use
     int seamFirst_ = -1, seamCount_ = 0;   // the range whose error images err_ holds
     void bindRange(int first, int count);

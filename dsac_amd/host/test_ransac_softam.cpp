@@ -80,7 +80,7 @@ int main(int argc, const char* argv[]) {
         if (batchable) {
             const int H = testDataset[0].H, W = testDataset[0].W;
             FrameBatchOptions opt;
-            opt.errorImages = gp->eP.errorImages;
+            opt.errorImages = gp->eP.errorImages || gp->eP.seam;  // the seam is the error images
             opt.sampling = !testDataset[0].sampling.empty();  // sub-sampled maps: every image has its own table of image positions
             opt.deferTail = gp->eP.defer >= 1;
             opt.deferScoreTail = gp->eP.defer >= 2;
@@ -89,23 +89,32 @@ int main(int argc, const char* argv[]) {
             for (size_t i = 0; i < nImg; i++) batch.setFrame((int)i, testDataset[i].estObj.data(), testDataset[i].poseGT, opt.sampling ? testDataset[i].sampling.data() : nullptr);
             engine.synchronize();
             const double upMs = ms_since(tUp);
+            // -seam 1: every batch's score comes from OUTSIDE the library (FrameBatch::processImages with a ScoreModel: error images out, scores in) -- here the
+            // soft-inlier score dressed as an external model, so the run reproduces -seam 0; with -defer 2 the score tail of a batch reads its scores while
+            // the next batch is already being scored
+            const ScoreModel scoreModel = batch.softInlierModel(gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+            auto runAll = [&]() {
+                if (gp->eP.seam) batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, scoreModel, gp->eP.tau, gp->eP.beta);
+                else batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+            };
+            if (gp->eP.seam) std::cout << "score through the external seam" << std::endl;
             double firstMs = 0, restMs = 0;
             // the first pass (device warm-up) is timed on its own; the timed passes are enqueued back to back and waited for ONCE -- a loop over a
             // longer data set has no host synchronisation between its batches either, and the deferred tail of a pass's last batch then runs
             // under the next pass's first batch like any other
             {
                 const clk::time_point t0 = clk::now();
-                batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                runAll();
                 batch.synchronize();
                 firstMs = ms_since(t0);
             }
             for (const clk::time_point tw = clk::now(); ms_since(tw) < gp->eP.warmupMs;) {  // -warmup: let the clock settle before the timed passes
-                batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                runAll();
                 batch.synchronize();
             }
             if (passes > 1) {
                 const clk::time_point t0 = clk::now();
-                for (int pass = 1; pass < passes; pass++) batch.processAll(gp->eP.seed, inlierThreshold2D, refInlierCount, gp->eP.tau, gp->eP.beta, gp->eP.alpha);
+                for (int pass = 1; pass < passes; pass++) runAll();
                 batch.synchronize();
                 restMs = ms_since(t0);
             }

@@ -28,14 +28,16 @@ for (H, W, outl, B, spread, what) in ((480, 640, 0.3, 1, 0.0, "one problem, good
     sd = torch.zeros(B, dtype=torch.int32, device=dev)
     def call():
         check(eng._ctx, lib.dsac_refine(eng._ctx, B, ptr(init_d), ptr(perm), 8, 100, 50, 10.0, None, None, ptr(out), None, ptr(sd)))
-    for i in range(3): call()
-    eng.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20 if B * P < 5e7 else 5
-    with torch.cuda.stream(st):
-        a.record(st)
-        for i in range(reps): call()
-        b.record(st)
-    eng.synchronize(); torch.cuda.synchronize()
-    o = out.cpu().numpy()
-    print("K6 %3dx%-3d %-28s: %9.1f us per launch; steps done mean %.2f; checksum %.17e" % (W, H, what, a.elapsed_time(b) * 1e3 / reps, sd.float().mean().item(), float(np.abs(o).sum())), flush=True)
+    for waves in [int(v) for v in os.environ.get("DSAC_K6_WAVES", "0").split(",")]:  # round 6: waves per problem of the walk ("k6_waves": 0 = auto, 1, 2, 4, 8)
+        eng.set_option("k6_waves", waves)
+        for i in range(3): call()
+        eng.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20 if B * P < 5e7 else 5
+        with torch.cuda.stream(st):
+            a.record(st)
+            for i in range(reps): call()
+            b.record(st)
+        eng.synchronize(); torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        print("K6 %3dx%-3d %-28s k6_waves %d: %9.1f us per launch; steps done mean %.2f; checksum %.17e" % (W, H, what, waves, a.elapsed_time(b) * 1e3 / reps, sd.float().mean().item(), float(np.abs(o).sum())), flush=True)

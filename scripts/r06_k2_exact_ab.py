@@ -18,8 +18,8 @@ dev = torch.device("cuda", 0)
 PRECISE = 1 << 25
 RECLO = 1 << 27
 EXACT = 1 << 28
-MODES = [("default", 0, -1), ("precise", PRECISE, -1), ("reclo<64,256,2w>", RECLO, 81), ("exact<64,256,2w>", EXACT, 84), ("exact<64,256,3w,fence>", EXACT, 85),
-         ("exact<64,128,3w,fence>", EXACT, 86), ("exact<64,256,2w,fence>", EXACT, 87), ("exact<32,256,2w>", EXACT, 89)]
+MODES = [("default", 0, -1), ("precise", PRECISE, -1), ("reclo<64,256,2w>", RECLO, 81), ("exact<64,256,2w>", EXACT, 84), ("exact<64,2x128,3w,fence>", EXACT, 85),
+         ("exact<64,128,3w,fence>", EXACT, 86), ("exact<64,256,2w,fence>", EXACT, 87), ("exact<64,4x128,3w,fence>", EXACT, 88), ("exact<32,256,2w>", EXACT, 89)]
 if os.environ.get("DSAC_AB_MODES"):
     MODES = [m for m in MODES if m[0].split("<")[0] in os.environ["DSAC_AB_MODES"].split(",")]
 

@@ -135,6 +135,21 @@ def test_gpus_flag_launches_the_ranks_itself():
     _check_strong(d["strong"], ranks=2, shards=2)
 
 
+def test_the_command_the_driver_runs_at_eight_ranks():
+    """`bench.py --gpus 8` as the driver launches it on an 8-GPU node -- 8 processes, one rendezvous, the weak line plus the `strong` object
+    (configs[3]: 64 images, 8 per rank and step, one gather of 8 x 8 x (10 + N) doubles) -- exercised here with 8 CPU ranks over gloo (--dry-run: the stand-in
+    engine; launch, sharding, exchange, max-over-ranks timing and reporting are the real code)."""
+    r = _run_bench("--gpus", "8", "--steps", "2", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["frames_per_step_all_ranks"] == 8 * 16
+    s = d["strong"]
+    _check_strong(s, ranks=8, shards=8)
+    assert s["ranks_joined"] == 8 and s["images_per_rank_step"] == 8 and s["collective_bytes_per_step"] == 8 * 8 * (10 + 256) * 8 and s["rows_ok"] is True
+    assert s["host_enqueue_ms_per_step"] > 0  # the slowest rank's host time per step (the real leg: whether 8 processes on the node's cores are the limiter)
+
+
 STRONG_FIELDS = ("workload", "ranks_joined", "backend", "steps", "images_per_rank_step", "one_gpu_ms", "per_rank_ms", "speedup", "efficiency",
                  "collective_bytes_per_step", "collective_exposed_us", "rows_ok")
 

@@ -175,9 +175,9 @@ def test_score_backward_into_managed_memory(engine, synth):
         hip.hipFree(managed)
 
 
-@pytest.mark.parametrize("Nf", [120, 384])
+@pytest.mark.parametrize("Nf", [120, 72])
 def test_score_backward_on_a_batch_with_any_hypothesis_count_and_in_parity_mode(engine, orc, synth, Nf):
-    """One launch for all frames needs 16 | hypotheses per frame <= 256.  Other counts (120: not a multiple of 16; 384: two hypothesis tiles) and the fp64
+    """One launch for all frames needs 16 | hypotheses per frame (several tiles per frame beyond 256: the test below).  Other counts (120, 72: not multiples of 16) and the fp64
     parity mode run frame by frame inside the call: the batch's gradient and pose sums equal the single-frame calls' -- bit for bit in parity mode
     (a sequential fp64 recurrence; the single-frame mode is pinned against the oracle in tests/test_gpu_backward.py), to the last bit of the fp64 atomics
     otherwise."""
@@ -213,4 +213,43 @@ def test_score_backward_on_a_batch_with_any_hypothesis_count_and_in_parity_mode(
         if g_p is not None:
             gp1 = engine.dScore(poses[hs], sets[hs], d_err[hs], dpnp=J[hs], parity_fp64=True)
             assert np.array_equal(g_p[cs], gp1)
+        engine.set_frames(xyz, uv, H, W, cam)
+
+
+@pytest.mark.parametrize("Nf", [384, 512])
+def test_more_than_256_hypotheses_per_frame_in_one_launch(engine, orc, synth, Nf):
+    """Round 6 (core/train_ransac_softam.cpp:380-383): a frame batch with MORE than 256 hypotheses per frame runs its score backward as ONE
+    main-pass launch -- several equal hypothesis tiles per frame (384 -> 2 x 192, 512 -> 2 x 256), every tile adding into its frame's gradient with fp64
+    atomics as the tiles of a single big frame do -- instead of frame by frame.  Against the single-frame calls: the fp32 partial sums are grouped by other
+    tiles (a single frame of 384 runs as 256 + 128), so the agreement is fp32 rounding, as for the other batch shapes."""
+    H, W, F = 40, 40, 3
+    P = H * W
+    frames = [synth.chess_like_frame(H, W, seed=880 + f, quantise_int16=True) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    uv, cam = frames[0]["uv"], frames[0]["cam"]
+    rng = np.random.default_rng(Nf)
+    d_err = (rng.standard_normal((F * Nf, P)) * 1e-3).astype(np.float32)
+    engine.set_frames(xyz, uv, H, W, cam)
+    poses, sets, ok = engine.sample(F * Nf, seed=9)
+    J = np.asarray(engine.dPNP(sets))
+    engine.profile_enable(True, stride=1)
+    engine.profile_read(1, reset=True)
+    g_b = engine.dScore(poses, sets, d_err, dpnp=J)
+    ms, n = engine.profile_read(1, reset=True)
+    assert n == 1, "the batch's score backward took %d main-pass launches" % n
+    G6_b = engine.lastPoseGradients(F * Nf)
+    engine.profile_enable(False)
+    for f in range(F):
+        hs, cs = slice(f * Nf, (f + 1) * Nf), slice(f * P, (f + 1) * P)
+        engine.set_frame(xyz[f], uv, H, W, cam)
+        g1 = engine.dScore(poses[hs], sets[hs], d_err[hs], dpnp=J[hs])
+        G6_1 = engine.lastPoseGradients(Nf)
+        margin("a15", "frame batch with %d hypotheses per frame in ONE launch vs single-frame calls, K4 gradient: max |d| / max |g|" % Nf,
+               np.abs(g_b[cs] - g1).max() / np.abs(g1).max(), 1e-5)
+        margin("a10", "frame batch with %d hypotheses per frame in ONE launch vs single-frame calls, pose sums G6: max |d| / max |G6|" % Nf,
+               np.abs(G6_b[hs] - G6_1).max() / np.abs(G6_1).max(), 1e-5)
+        if f == 0:  # ... and frame 0 against the oracle's dScore (the engine's dPNP of the same sets is oracle-tested on its own)
+            ref, _, _ = orc.dScore(sets[hs], d_err[hs].astype(np.float64), frames[0]["xyz"], uv, H, W, cam)
+            margin("a15", "frame batch with %d hypotheses per frame in ONE launch, frame 0 against the oracle's dScore: max |d| / max |g|" % Nf,
+                   np.abs(g_b[cs] - ref).max() / np.abs(ref).max(), 1e-3)
         engine.set_frames(xyz, uv, H, W, cam)

@@ -171,3 +171,42 @@ def test_training_rounds_through_the_external_score_seam(tmp_path, mw, mh, batch
     assert grads["1"].shape == grads["0"].shape == (4, 5) and (grads["0"][:, 1] > 0).all()
     assert np.array_equal(grads["1"][:, 0], grads["0"][:, 0]) and np.abs(grads["1"][:, 4] - grads["0"][:, 4]).max() <= 2
     assert np.allclose(grads["1"][:, 1:4], grads["0"][:, 1:4], rtol=1e-4, atol=0)
+
+
+@pytest.mark.parametrize("mw,mh,k,batch", [(64, 48, 9, 2), (640, 480, 6, 2)])
+def test_evaluation_through_the_seam_with_the_score_tail_deferred(tmp_path, mw, mh, k, batch):
+    """with the default options (refinement AND score tail deferred, pi_defer_tail = 2) K3 of a batch reads its scores on the tail stream
+    while the NEXT batch's begin already writes its soft-inlier sums.  The seam's sums live in one slice per frame now; several consecutive ranges through
+    the seam (-seam 1 -defer 2, small batches so that many calls are in flight, three passes back to back) must write the result files of the built-in score
+    in stream order (-seam 0 -defer 0), byte for byte."""
+    outs = {}
+    for seam, defer in (("1", "2"), ("0", "0")):
+        d = tmp_path / ("s" + seam)
+        d.mkdir()
+        out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", str(k), "-mw", str(mw), "-mh", str(mh), "-rI", "128", "-batch", str(batch),
+                              "-passes", "3", "-defer", defer, "-seam", seam], cwd=str(d), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert ("score through the external seam" in out.stdout) == (seam == "1")
+        outs[seam] = [open(os.path.join(str(d), f)).read() for f in ("ransac_test_errors_obj_model_init.net_rdraw1_softam.txt",
+                                                                     "ransac_test_loss_obj_model_init.net_rdraw1_softam.txt")]
+    assert outs["1"] == outs["0"]
+
+
+def test_evaluation_in_the_reference_random_stream(tmp_path):
+    """test_ransac_softam -refstream T: the minimal sets come from the reference's own generators (std::mt19937(seed + t) per OpenMP thread,
+    core/thread_rand.cpp:40-69) on the device -- no <stem>.sets replay file.  The run is deterministic, differs from the counter-RNG run (other sets), gives
+    the same accuracy class, and two thread counts differ from each other as the reference's runs do."""
+    res = {}
+    for tag, extra in (("t1", ["-refstream", "1"]), ("t1b", ["-refstream", "1"]), ("t4", ["-refstream", "4"]), ("ctr", [])):
+        d = tmp_path / tag
+        d.mkdir()
+        out = subprocess.run([os.path.join(HOST, "test_ransac_softam"), "-synth", "4", "-mw", "40", "-mh", "40", "-rI", "64", "-batch", "0"] + extra,
+                             cwd=str(d), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        if extra:
+            assert "reference random streams (threads): %s" % extra[1] in out.stdout
+        res[tag] = np.loadtxt(os.path.join(str(d), "ransac_test_errors_obj_model_init.net_rdraw1_softam.txt")).reshape(-1, 10)
+    assert np.array_equal(res["t1"], res["t1b"])
+    assert not np.array_equal(res["t1"], res["ctr"]) and not np.array_equal(res["t1"], res["t4"])
+    for r in res.values():
+        assert r.shape[0] == 4 and np.isfinite(r).all()

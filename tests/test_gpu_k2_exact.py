@@ -24,6 +24,43 @@ def exact_engine(engine):
     yield engine
     engine.set_option("k2_flags", 0)
     engine.set_option("k2_variant", -1)
+    engine.set_option("k2_exact_auto", 1)
+
+
+def test_the_default_policy_is_the_exact_form(engine, orc, synth):
+    """Round 6: with no option set the auto policy launches the exact-transform form wherever it applies (vectorisable map, focal length <= 1024) -- the
+    default K2 holds every stated tolerance; k2_exact_auto = 0 gives the fp32 matrix-core forms of rounds 2-5 back.  An arithmetic form that is ASKED for and
+    cannot run (a map the vector kernels cannot read) is an error, not a silent fp32 launch."""
+    import dsac_amd
+    fr = synth.chess_like_frame(H, W, seed=2305)
+    engine.set_option("k2_variant", -1)
+    engine.set_option("k2_flags", 0)
+    engine.set_option("k2_exact_auto", 1)
+    engine.set_frame(fr["xyz"], None, H, W, fr["cam"])
+    poses, _, _ = engine.sample(128, seed=4711, thr=10.0, max_tries=1 << 16)
+    e_def, e_ex, e_fast = (np.zeros((128, P), np.float32) for _ in range(3))
+    engine.reproject(poses, err=e_def)
+    engine.set_option("k2_flags", EXACT)
+    engine.reproject(poses, err=e_ex)
+    engine.set_option("k2_flags", 0)
+    engine.set_option("k2_exact_auto", 0)
+    engine.reproject(poses, err=e_fast)
+    engine.set_option("k2_exact_auto", 1)
+    assert np.array_equal(e_def, e_ex) and not np.array_equal(e_def, e_fast)
+    # 53 x 37: H*W is odd -- no 16-byte vectors
+    fo = synth.chess_like_frame(37, 53, seed=5, grid_uv=True)
+    engine.set_frame(fo["xyz"], None, 37, 53, fo["cam"])
+    po, _, _ = engine.sample(64, seed=1, thr=10.0, max_tries=1 << 16)
+    eo = np.zeros((64, 37 * 53), np.float32)
+    engine.reproject(po, err=eo)  # the default falls back quietly
+    ref = orc.get_diff_maps(po, fo["xyz"], fo["uv"], 37, 53, fo["cam"])
+    m = excl_clamp_edge(eo, ref, CLAMP)
+    assert np.abs(eo - ref)[m].max() <= 1e-3
+    for flag in (EXACT, 1 << 25, 1 << 27):
+        engine.set_option("k2_flags", flag)
+        with pytest.raises(dsac_amd.capi.DsacError):
+            engine.reproject(po, err=eo)
+    engine.set_option("k2_flags", 0)
 
 
 def near_tie_pairs(soft_ref):
@@ -56,8 +93,10 @@ def test_all_cells_and_unrelated_ties_at_640x480(exact_engine, orc, synth, seed)
     margin("a4", "K2 EXACT form: softmax-weight error in a tie of two UNRELATED hypotheses, scale 0.1 -- 0.25 x scale x max |d_i - d_j| over the near-tie pairs", tie, 1e-4)
     # the fast form on the same poses: what the exact form buys
     eng.set_option("k2_flags", 0)
+    eng.set_option("k2_exact_auto", 0)  # the auto policy takes the exact form by default (round 6): switch it off for the fp32 matrix-core form
     soft_f = np.zeros(256)
     eng.reproject(poses, soft=soft_f, tau=TAU, beta=BETA)
+    eng.set_option("k2_exact_auto", 1)
     eng.set_option("k2_flags", EXACT)
     tie_f = 0.25 * SCALE * max(abs((soft_f - soft_ref)[i] - (soft_f - soft_ref)[j]) for i, j in pairs)
     print("near-tie weight error: exact %.2e, fast %.2e; max |err - oracle| exact %.2e px" % (tie, tie_f, d.max()))

@@ -77,3 +77,24 @@ def test_two_real_ranks_share_the_gpu_over_gloo():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert "sharded round-robin over 2 rank" in line["config"]["workload"]
+
+
+def test_eight_ranks_over_gloo_refuse_the_strong_number():
+    """the driver's own command at 8 ranks -- `bench.py --gpus 8 --steps K --warmup W` -- launched with 8 real processes.  On this one-GPU box
+    the ranks can only join over gloo (DSAC_BENCH_BACKEND=gloo; all eight drive the same GPU): the weak line must still be printed with n_gpus = 8, and the
+    `strong` object must say `refused` -- never a scaling number measured over something that is not RCCL on eight GPUs.  (Small maps: eight engines share
+    one GPU and the host's cores.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSAC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--hyps", "128", "--height", "96", "--width", "128",
+                          "--frames-per-step", "4", "--no-cpu-baseline", "--no-host-driver", "--no-single-frame", "--no-k2-forms", "--prewarm-ms", "10"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert "refused" in line["strong"] and "RCCL" in line["strong"]["refused"]
+    assert "speedup" not in line["strong"] and "per_rank_ms" not in line["strong"]
