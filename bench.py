@@ -41,15 +41,15 @@ CONFIG3_IMAGES = 64    # BASELINE.json configs[3]
 # K2's arithmetic forms (include/dsac_hip.h "k2_flags") and what each is tested at (tests/test_gpu_k2_precise.py, tests/test_gpu_k2_exact.py).
 # The reference projects in double and rounds the image-plane difference to float once (core/cnn_softam.h:319-362).
 K2_FLAG_PRECISE, K2_FLAG_EXACT = 1 << 25, 1 << 28
-DEFAULT_K2_FLAGS = 0
-K2_FORM_NAMES = {0: "fast", K2_FLAG_EXACT: "exact", K2_FLAG_PRECISE: "precise"}
+# form name -> (k2_flags, k2_exact_auto).  Since round 6 the library's auto policy takes the exact-transform form; "fast" switches that off
+K2_FORMS = {"exact": (0, 1), "fast": (0, 0), "precise": (K2_FLAG_PRECISE, 1)}
 K2_TOLERANCES = {
     "stated": {"residual_px": 1e-3, "softmax_weight": 1e-4, "source": "BASELINE.md 3 / SURVEY.md 8(c)"},
     "fast": {"what": "fp32 pose records, exact-fp32 matrix-core transform (v_mfma_f32_16x16x4_f32), fp32 tail",
              "all_cells_max_px": 4.2e-3, "cells_above_1e-3_px": "3 of 78.6 M (within ~100 mm of a camera centre)", "near_tie_weight_error": 4.4e-3},
     "exact": {"what": "pose records and coordinates as fp16 fixed-point pieces, two fp16 matrix-core accumulations per row (one exact), the camera-frame point "
                       "rounded to float once, Newton-polished reciprocal, fp32 tail",
-              "all_cells_max_px": 1.1e-4, "cells_above_1e-3_px": "0", "near_tie_weight_error": 7e-5},
+              "all_cells_max_px": 5.7e-4, "cells_above_1e-3_px": "0", "near_tie_weight_error": 8.3e-5},
     "precise": {"what": "fp64 records, fp64 transform and perspective division on the vector ALU, one rounding per image-plane difference",
                 "all_cells_max_px": 4.6e-5, "cells_above_1e-3_px": "0", "near_tie_weight_error": 4.5e-5},
     "note": "near_tie_weight_error = 0.25 x 0.1 x max |d_i - d_j| of the soft-inlier scores over pairs of UNRELATED hypotheses within 5 % of the top score "
@@ -65,13 +65,19 @@ def algorithmic_bytes_k2(N, P, explicit_uv, write_err=True):
 # issue rates of the VALU classes on this chip, wall cycles per wave64 instruction and SIMD at a nominal 2.4 GHz (profiles/r03_valu_rate.txt,
 # r03_valu_rate_trans.txt, r03_valu_rate_mfma.txt: measured with scripts/micro/valu_rate.hip; MFMAs do not overlap the VALU stream)
 ISSUE_CYCLES = {"packed_fp32": 5.3, "transcendental": 8.8, "plain_valu": 2.9, "mfma": 38.0}
+# the exact-transform form issues fp16 matrix-core instructions (K = 32 and K = 16): 17.7 cycles each (profiles/r06_mfma_f64_probe.txt: six alone 102-110 cycles)
+ISSUE_CYCLES_EXACT = dict(ISSUE_CYCLES, mfma=17.7)
+SOFT_ONLY_FORM = ["exact"]  # the K2 form of the run (set by main): which kernel a soft-inlier-only launch takes
 
 
 def soft_only_isa_mix(n_hyps, P):
     """Instruction counts per 16 hypotheses x 64 pixels of the kernel the auto policy runs for a soft-inlier-only launch of this size, as
     dsac_amd/csrc/Makefile read them from the built ISA (scripts/isa_mix.py).  None when the launch takes a form that is not priced."""
     nbytes = float(n_hyps) * float(P) * 4.0
-    form = 58 if nbytes > 4.4e9 else 45 if nbytes > 1.0e9 else None  # k_forward.hip reproject(): the auto policy by size
+    if SOFT_ONLY_FORM[0] == "exact":
+        form = 84  # the exact-transform form is one kernel at every size: <64 hypotheses, 256 pixels>, one-wave workgroups
+    else:
+        form = 58 if nbytes > 4.4e9 else 45 if nbytes > 1.0e9 else None  # k_forward.hip reproject(): the fp32 forms' auto policy by size
     if form is None:
         return None
     path = os.path.join(ROOT, "dsac_amd", "csrc", "build", "k2_soft_isa_%d.json" % form)
@@ -94,9 +100,10 @@ def soft_only_roofline(n_hyps, P, k2_s, launches):
     # when the kernel changes -- priced with the issue rates measured on this chip: the time the arithmetic cannot go below
     mix = soft_only_isa_mix(n_hyps, P)
     if mix is not None:
-        cyc = sum(mix[k] * ISSUE_CYCLES[k] for k in ISSUE_CYCLES)
+        rates = ISSUE_CYCLES_EXACT if mix["form"] == 84 else ISSUE_CYCLES
+        cyc = sum(mix[k] * rates[k] for k in rates)
         priced_s = float(n_hyps) * float(P) / 1024.0 * cyc / (1024 * 2.4e9)
-        out["issue_model"] = {"instructions_per_1024_pairs": {k: mix[k] for k in ISSUE_CYCLES}, "cycles_per_instruction": ISSUE_CYCLES,
+        out["issue_model"] = {"instructions_per_1024_pairs": {k: mix[k] for k in rates}, "cycles_per_instruction": rates,
                               "cycles_per_1024_pairs": cyc, "priced_us": priced_s * 1e6, "frac": priced_s / k2_s if k2_s > 0 else None,
                               "kernel_form": mix["form"], "source": mix["source"] + "; issue rates: profiles/r03_valu_rate*.txt"}
     return out
@@ -150,8 +157,9 @@ def parse_args(argv=None):
                          "config3 on ONE GPU: besides the whole 64-image step, time exactly the share rank --emulate-rank of W ranks would run (8 images at "
                          "W = 8; its gather replaced by the rank's own part) and report per_rank_ms next to one_gpu_ms / W -> predicted efficiency")
     ap.add_argument("--emulate-rank", type=int, default=0)
-    ap.add_argument("--k2-flags", type=int, default=int(os.environ.get("DSAC_BENCH_K2_FLAGS", str(DEFAULT_K2_FLAGS))),
-                    help="dsac_set_option('k2_flags'): the arithmetic form of K2 the line's `value` is measured on (0 fast, %d exact, %d precise)" % (K2_FLAG_EXACT, K2_FLAG_PRECISE))
+    ap.add_argument("--k2-form", choices=tuple(K2_FORMS), default=os.environ.get("DSAC_BENCH_K2_FORM", "exact"),
+                    help="the arithmetic form of K2 the line's `value` is measured on: exact (the library's default since round 6: every stated tolerance holds), "
+                         "fast (fp32 matrix-core transform, rounds 2-5), precise (fp64 on the vector ALU)")
     ap.add_argument("--no-k2-forms", action="store_true", help="skip the measurement of K2's other arithmetic forms (`k2_forms`)")
     ap.add_argument("--dry-run", action="store_true", help="exercise launch / shard / gather / reporting without touching a GPU (CPU tests, gloo)")
     return ap.parse_args(argv)
@@ -834,8 +842,9 @@ def main(argv=None):
     for i in range(n_ctx):
         st = torch.cuda.Stream(device=dev)
         eng = dsac_amd.Engine(local_rank, stream=st)
-        if args.k2_flags:
-            eng.set_option("k2_flags", args.k2_flags)
+        eng.set_option("k2_flags", K2_FORMS[args.k2_form][0])
+        eng.set_option("k2_exact_auto", K2_FORMS[args.k2_form][1])
+        SOFT_ONLY_FORM[0] = args.k2_form
         set_frames_of(eng, xyz_batches[0])
         eng.profile_enable(stride > 0, stride=max(1, stride))
         engines.append((eng, st))
@@ -1084,7 +1093,7 @@ def main(argv=None):
     if rank == 0 and not config3 and args.k2_mode != "soft" and not args.separate_calls:
         try:
             for eng, _ in engines:
-                eng.set_option("k2_flags", args.k2_flags | 2)
+                eng.set_option("k2_flags", K2_FORMS[args.k2_form][0] | 2)
                 eng.profile_read(0, reset=True)
             for i in range(6):
                 step(ctr)
@@ -1098,7 +1107,7 @@ def main(argv=None):
             store_only_us = so_ms / max(1, so_n) * 1e3 if so_n else None
         finally:
             for eng, _ in engines:
-                eng.set_option("k2_flags", args.k2_flags)
+                eng.set_option("k2_flags", K2_FORMS[args.k2_form][0])
             step(ctr)  # leave real results in the buffers
             ctr += 1
             sync_all()
@@ -1109,13 +1118,13 @@ def main(argv=None):
     k2_forms = None
     if rank == 0 and not config3 and args.k2_mode != "soft" and not args.separate_calls and not args.kernel_only and not args.no_k2_forms:
         k2_forms = {}
-        base_flags = args.k2_flags
-        for name, flags in (("fast", 0), ("exact", K2_FLAG_EXACT), ("precise", K2_FLAG_PRECISE)):
-            if flags == base_flags:
+        for name, (flags, auto) in K2_FORMS.items():
+            if name == args.k2_form:
                 continue
             try:
                 for eng, _ in engines:
                     eng.set_option("k2_flags", flags)
+                    eng.set_option("k2_exact_auto", auto)
                 for i in range(3):
                     step(ctr)
                     ctr += 1
@@ -1137,11 +1146,12 @@ def main(argv=None):
                 if f_n:
                     us = f_ms / f_n * 1e3
                     ab = B * algorithmic_bytes_k2(N, P, explicit_uv=False, write_err=True)
-                    k2_forms[name] = {"k2_flags": flags, "avg_launch_us": us, "achieved": ab / us / 1e3, "unit": "GB/s", "frac": ab / us / 1e3 / HBM_PEAK_GBS,
+                    k2_forms[name] = {"avg_launch_us": us, "achieved": ab / us / 1e3, "unit": "GB/s", "frac": ab / us / 1e3 / HBM_PEAK_GBS,
                                       "per_image_hyp_s": N * B / dt, "ms_per_step": dt * 1e3, "launches_timed": f_n}
             finally:
                 for eng, _ in engines:
-                    eng.set_option("k2_flags", base_flags)
+                    eng.set_option("k2_flags", K2_FORMS[args.k2_form][0])
+                    eng.set_option("k2_exact_auto", K2_FORMS[args.k2_form][1])
         step(ctr)  # leave the line's own form's results in the buffers
         ctr += 1
         sync_all()
@@ -1481,7 +1491,7 @@ def main(argv=None):
             "rates": {"per_image_hyp_s": value, "kernel_only_k2_hyp_s": (N * frames_per_launch / k2_avg_s * world) if k2_avg_s > 0 else None,
                       "unit": "hyp/s", "note": "per_image = whole step (K1 sample+P3P, K2, soft reduce, K3); kernel_only = hypotheses per K2 launch / its duration"},
         }
-        out["tolerance"] = dict(K2_TOLERANCES, value_measured_on=K2_FORM_NAMES.get(args.k2_flags, "k2_flags %d" % args.k2_flags))
+        out["tolerance"] = dict(K2_TOLERANCES, value_measured_on=args.k2_form)
         if k2_forms:
             out["k2_forms"] = k2_forms
         if repeats is not None:

@@ -1319,7 +1319,7 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
 }
 
 bool reproject_variant_known(int v) {
-    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 89);
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 84) || v == 89 || v == 93;
 }
 
 // the largest count of partial-sum rows over all forms: one row per 64-pixel wave chunk, and the per-wave-sum forms with several waves per workgroup write
@@ -1394,19 +1394,21 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         }
 #undef DSAC_LO
     }
-    // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84..87 = its tile / occupancy trades
-    if (k2_wants_exact(opts) && opts.split && vec && (opts.variant < 0 || (opts.variant >= 84 && opts.variant <= 89))) {
+    // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84 / 89 / 93 = its tile / occupancy trades
+    if (k2_wants_exact(opts) && opts.split && vec && (opts.variant < 0 || (opts.variant == 84 || opts.variant == 89 || opts.variant == 93))) {
 #define DSAC_EX(NG_, CH_, MW_, F_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
-#define DSAC_EXW(NG_, CH_, WV_, MW_, F_) launch_reproject_st<NG_, CH_, WV_, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
         switch (opts.variant) {
-            case 85: return DSAC_EXW(4, 2, 2, 3, 2);  // <64 hypotheses, 2 waves x 128 pixels>, 3 waves per SIMD, scheduling fence per m
-            case 86: return DSAC_EX(4, 2, 3, 2);      // <64, 128>, one-wave workgroups, 3 waves per SIMD, fence
-            case 87: return DSAC_EX(4, 4, 2, 2);      // <64, 256>, 2 waves per SIMD, fence
-            case 88: return DSAC_EXW(4, 2, 4, 3, 2);  // <64, 4 waves x 128 pixels>, 3 waves per SIMD, fence
+            // (85 .. 88: <64, 128 / 256> with a scheduling fence per m at three waves per SIMD, one / two / four waves per workgroup -- 44-480 B of scratch, 1.08-1.7 ms:
+            //  measured and removed, profiles/r06_k2_exact_ab.txt)
             case 89: return DSAC_EX(2, 4, 2, 1);      // <32 hypotheses, 256 pixels>, 2 waves per SIMD
+            case 93: return DSAC_EX(4, 1, 3, 1);      // <64, 64>, one-wave workgroups, 168 registers: 3 waves per SIMD
+            // (90 .. 92: <64, 4 waves x 64>, <64, 2 x 128> at two / three waves per SIMD: 1 098-1 206 us at the bench shape, 67.5-77 us for one frame -- measured
+            //  and removed, profiles/r06_k2_exact_tiles.txt)
+            case -1:  // auto: one frame of 256 hypotheses 66.5 against 68.2 us with the small tile; the bench shape 1 048-1 059 against 1 101-1 107
+                if ((double)N * (double)F.P * 4.0 < 1.0e9) return DSAC_EX(4, 1, 3, 1);
+                return DSAC_EX(4, 4, 2, 1);
             case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
         }
-#undef DSAC_EXW
 #undef DSAC_EX
     }
     if (!vec) return launch_reproject<1, 32, false>(st, N, staged, F, clampv, err, kA, kB, soft_part, Nf, opts.pixel_minor, kf, evA, evB);
@@ -1474,7 +1476,7 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 55: return DSAC_ST(4, 1, 4, true);
         case 56: return DSAC_ST(2, 4, 4, true);
         case 57: return DSAC_ST(4, 2, 4, true);
-        case 58: case 80: case 81: case 82: case 83: case 84: case 85: case 86: case 87: case 88: case 89:  // 84..89: the exact-transform forms when k2_flags bit 28 is set (above); 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
+        case 58: case 80: case 81: case 82: case 83: case 84: case 89: case 93:  // 84 / 89 / 93: the exact-transform forms when k2_flags bit 28 is set (above); 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
             return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
         case 59: return launch_reproject_st<2, 4, 1, true, 5>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <2,4,1>, >= 5 waves per SIMD
         case 65: return launch_reproject_st<4, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,4> per-wave sums

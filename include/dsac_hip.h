@@ -103,6 +103,22 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *   "k2_variant"  K2 kernel form: -1 auto; 0-3, 10-13 VALU forms; 20-27 matrix-core forms <hypothesis tile, chunks per wave>
  *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
  *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments); bits 16-19 / 20-23: error-images-only streaming forms idle for that many units of 64 / 16 clocks after a chunk's stores (pacing experiment); bit 24: error images only on a big launch do NOT take the fused kernel; bit 25 (0x2000000): PRECISE -- K2 projects as the reference does, in double (fp64 pose records from the cv poses, fp64 transform and perspective division, one rounding to float of each image-plane difference; core/cnn_softam.h:319-362): residuals within 2e-4 px of the oracle at 640 x 480 where the fp32 matrix-core forms reach 6e-4, softmax weights in a tie of unrelated hypotheses within the stated 1e-4; 15-25 % slower (profiles/r05_k2_precise_ab.txt), every call that launches K2 honours it; bit 27 (0x8000000): RECORDS IN TWO PIECES -- the fast matrix-core form with the low parts of the pose records carried through twelve fp16 matrix-core instructions per 1 024 pairs chained onto the fp32 ones: measured: 85 % of the fast form's score error gone (0.112 -> 0.017 on scores of 1.5e5; softmax weights in a tie of unrelated hypotheses 4.4e-3 -> 7.2e-4) for +16 % of K2's time (profiles/r05_k2_reclo_ab.txt) -- a middle mode that does NOT reach the stated 1e-4 in ties (bit 25 does); k2_variant 80..83 select its register / occupancy trades; bit 26 (with bit 25, diagnostic): the precise form with ONLY its pose records rounded to float -- isolates what the fp32 record costs (it is 96 % of the fast forms' score error)
+ *                 bit 28 (0x10000000): EXACT TRANSFORM (round 6) -- E = R.X + t from fixed-point fp16 pieces of the pose records and of the coordinates on the fp16
+ *                 matrix core (one accumulation per row exact, the other below a few millimetres), the camera-frame point rounded to float ONCE, the hardware
+ *                 reciprocal polished by one Newton step: no cell above 1e-3 px over all cells of 256 x 640x480 (max 5.7e-4, mean 8.7e-6), softmax weights in a
+ *                 tie of unrelated hypotheses within the stated 1e-4 (6.8e-5 .. 8.3e-5) at 1.19x the fast form's time (1 025-1 050 us = 0.61-0.62 of the HBM
+ *                 peak at the bench shape, profiles/r06_k2_exact_ab.txt; the precise mode: 1.85x).  Needs a map the vector kernels can read and a focal length
+ *                 <= 1 024 px; coordinates beyond +-65.5 m take the fp32 transform chunk by chunk.  An arithmetic form that is ASKED for by bit 25 / 27 / 28 and
+ *                 cannot run on the frame is an error (round 6), never a silent launch of another form.  k2_variant 84 / 87 / 89 are its tile trades.
+ *   "k2_exact_auto"  1 (default since round 6): the auto policy (k2_variant -1, none of the bits 1 / 25 / 26 / 27 set) launches the exact-transform form wherever
+ *                 it applies and falls back to the fp32 matrix-core forms where it does not -- the library's default K2 holds every stated tolerance; 0: the
+ *                 fp32 forms of rounds 2-5 (DSAC_K2_EXACT_AUTO in the environment of dsac_create)
+ *   "k2_diag"     diagnostic switches of the precise form (bit 25): degrade ONE step at a time towards the fast forms' arithmetic (scripts/r06_k2_diag.py)
+ *   "k6_waves"    waves per refinement problem of K6's inlier walk: 0 (default) = by the problem count (4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8
+ *                 fixed.  Wave 0 runs the problem as before; when the first 256 cells of a step's permutation do not give max_inl inliers the walk goes on in
+ *                 rounds of waves x 256 cells (counts meet in LDS, every wave compacts behind the inliers in front of its cells): the same list, inlier maps, step
+ *                 counts and poses bit for bit; 128 whole-map walks on 640 x 480 15.3 -> 5.4 ms (profiles/r06_k6_walk.txt)
+ *   "refstream_mode"  see dsac_sample_refstream
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_rl"       lanes per sampling attempt: 1 (default) = one lane per attempt, the quartic's roots in sequence, 64 attempts per round and
  *                 hypothesis; 4 = one lane per root, 16 attempts per round (the form the wpb / hpw / minw / share knobs below act on)
@@ -163,7 +179,8 @@ DSAC_API int dsac_set_frame(dsac_ctx* ctx, const float* xyz, const float* uv_or_
  * every per-image argument (start / refined pose, ground truth, inlier map, J_hyp, obj_pixels, J_obj, n_obj, dL, v6) holds one slice per frame, grad_xyz
  * is frames x H*W x 3, and every stage is ONE launch over all frames; the results equal `frames` single-frame calls bit for bit
  * (core/train_ransac_softam.cpp:288-394 is one image per round; a batch is what the data-parallel step of SURVEY.md 5 puts on one GPU).  The score
- * backward is ONE launch for all frames when 16 | hypotheses per frame <= 256; with any other count, on maps its matrix-core form cannot read as vectors
+ * backward is ONE launch for all frames when 16 | hypotheses per frame (up to 256 as one hypothesis tile per frame, beyond that -- round 6 -- as several equal tiles of
+ * the same launch: 384 = 2 x 192, 512 = 2 x 256, their gradients meeting in fp64 atomics); with any other count, on maps its matrix-core form cannot read as vectors
  * (H*W or -- with the implicit grid -- W not a multiple of 4, buffers not 16-byte aligned), with the staged forms ("k4_variant" 0 or >= 1000) and in the
  * fp64 parity mode it runs frame by frame inside the call (F times the launches, the results of F single-frame calls).  Since round 5 the stages work on a batch one by one as well -- dsac_sample (sets drawn
  * here), dsac_reproject (128 | hypotheses per frame), dsac_softmax_frames, and the pair dsac_process_images_begin / dsac_process_images_finish, the

@@ -188,13 +188,18 @@ struct RefFrameOut {
     double loss, sfEntropy, tErr, rotErr;
     int correct, n_hyps, ref_steps;
 };
+// OpenMP threads of the next ref_processImage calls (default 1: ThreadRand's per-thread generators then give ONE reproducible stream; T > 1: the reference's
+// own `#pragma omp parallel for` over the hypotheses with its static schedule, generator t = mt19937(seed + t) -- deterministic as well, and what
+// dsac_sample_refstream reproduces for T threads)
+static int g_ref_threads = 1;
+void ref_set_omp_threads(int n) { g_ref_threads = n < 1 ? 1 : n; }
 int ref_processImage(unsigned seed, int objHyps, int inlierThreshold2D, int inlierCount, int refSteps, const float* pred_mm, const double* gt_jp6,
                      RefFrameOut* out, double* hyps_cv6 /*N x 6*/, int32_t* sampledPoints /*N x 4 x 2*/, double* sfScores /*N*/, double* avg_cv6, double* ref_cv6,
                      int32_t* sampling_uv /*1600 x 2*/, float* estObj_mm /*1600 x 3*/, int32_t* inlierMap /*1600*/, int32_t* pixelIdxs /*refSteps x 1600*/,
                      double* dLoss_dObj /*1600 x 3 or NULL: run the backward pass too*/, float refSubSample) {
     const int S = CNN_OBJ_PATCHSIZE, P = S * S;
     const int saved_threads = omp_get_max_threads();
-    omp_set_num_threads(1);
+    omp_set_num_threads(g_ref_threads);
     ThreadRand::forceInit(seed);
     GlobalProperties* gp = GlobalProperties::getInstance();
     cv::Mat_<float> camMat = gp->getCamMat();

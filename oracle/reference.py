@@ -209,6 +209,15 @@ def dLossMax(est6, gt6):
     return J
 
 
+def set_omp_threads(n):
+    """OpenMP threads of the following processImage calls (default 1).  With n > 1 the reference's sampling loop runs as its `#pragma omp parallel for`
+    with the static schedule, thread t drawing from mt19937(seed + t) (core/thread_rand.cpp:40-57)."""
+    L = lib()
+    L.ref_set_omp_threads.argtypes = [C.c_int]
+    L.ref_set_omp_threads.restype = None
+    L.ref_set_omp_threads(int(n))
+
+
 def processImage(seed, pred_mm, gt_jp6, hyps=256, thr=10, inlier_count=100, ref_steps=8, backward=False, sub_sample=0.01):
     """One frame through the reference's processImage (and, optionally, the backward pass of its training loop)."""
     L = lib()

@@ -4,7 +4,7 @@
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes; KB = 1024 B; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B).
 # usage (on the GPU box): bash scripts/r04_k2_pmc.sh   -> gpurun_out/r04/k2_pmc.txt, gpurun_out/r04/k2_traffic.json (copy the latter to profiles/)
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; OUT="$REPO/gpurun_out/r04"; mkdir -p "$OUT"; cd /tmp; export TMPDIR=/tmp
-K2F="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-single-frame --no-host-driver --event-stride 0 --prewarm-ms 0"
+K2F="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-single-frame --no-host-driver --event-stride 0 --prewarm-ms 0 $DSAC_PMC_EXTRA"
 : > "$OUT/k2_pmc.txt"
 for c in WRITE_SIZE FETCH_SIZE; do
   rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o p -- $K2F > /tmp/pmc_$c.log 2>&1

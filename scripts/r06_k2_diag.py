@@ -50,6 +50,7 @@ def main():
         for name, flags, diag in variants:
             eng.set_option("k2_flags", flags)
             eng.set_option("k2_diag", diag)
+            eng.set_option("k2_exact_auto", 0 if name == "fast form" else 1)  # the auto policy's default is the exact form since round 6
             err, soft = np.zeros((256, P), np.float32), np.zeros(256)
             eng.reproject(poses, err=err, soft=soft, tau=TAU, beta=BETA)
             m = (np.abs(err - CLAMP) > 1e-3) & (np.abs(ref - CLAMP) > 1e-3)
@@ -59,6 +60,7 @@ def main():
             sys.stdout.flush()
     eng.set_option("k2_flags", 0)
     eng.set_option("k2_diag", 0)
+    eng.set_option("k2_exact_auto", 1)
     eng.close()
 
 

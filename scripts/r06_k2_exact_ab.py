@@ -18,10 +18,11 @@ dev = torch.device("cuda", 0)
 PRECISE = 1 << 25
 RECLO = 1 << 27
 EXACT = 1 << 28
-MODES = [("default", 0, -1), ("precise", PRECISE, -1), ("reclo<64,256,2w>", RECLO, 81), ("exact<64,256,2w>", EXACT, 84), ("exact<64,2x128,3w,fence>", EXACT, 85),
-         ("exact<64,128,3w,fence>", EXACT, 86), ("exact<64,256,2w,fence>", EXACT, 87), ("exact<64,4x128,3w,fence>", EXACT, 88), ("exact<32,256,2w>", EXACT, 89)]
+# (name, k2_flags, k2_variant, k2_exact_auto): since round 6 the auto policy takes the exact form, "fast" switches that off
+MODES = [("fast", 0, -1, 0), ("precise", PRECISE, -1, 1), ("reclo<64,256,2w>", RECLO, 81, 1), ("exact (auto policy)", 0, -1, 1), ("exact<64,256,2w>", EXACT, 84, 1),
+         ("exact<32,256,2w>", EXACT, 89, 1), ("exact<64,64,3w>", EXACT, 93, 1)]
 if os.environ.get("DSAC_AB_MODES"):
-    MODES = [m for m in MODES if m[0].split("<")[0] in os.environ["DSAC_AB_MODES"].split(",")]
+    MODES = [m for m in MODES if m[0].split("<")[0].split(" ")[0] in os.environ["DSAC_AB_MODES"].split(",")]
 
 
 def bytes_k2(N, frames=1, err=True):
@@ -61,9 +62,10 @@ def main():
     print("# K2 exact-transform form A/B (scripts/r06_k2_exact_ab.py), us per launch, HIP events on the K2 dispatch, alternating on one box")
     rows = []
     for rnd in range(int(os.environ.get('DSAC_AB_ROUNDS', '3'))):
-        for name, flags, var in MODES:
+        for name, flags, var, auto in MODES:
             eng.set_option("k2_variant", var)
             eng.set_option("k2_flags", flags)
+            eng.set_option("k2_exact_auto", auto)
             us = timed(eng, lambda: eng.scoreHypothesesFrames(N, seed=7, max_tries=1 << 16, err=err, out=out))
             rows.append(("16 x 256 x 640x480, err + soft", name, us, bytes_k2(N, F) / us / 1e3))
     rp = torch.from_numpy(synth.random_poses(4096, seed=7) + np.array([0, 0, 0, 0, 0, 2500.0])).to(dev)
@@ -71,9 +73,10 @@ def main():
     eng.set_frame(torch.from_numpy(fr["xyz"]).to(dev), None, H, W, fr["cam"], borrow=True)
     soft = torch.zeros(4096, **f64)
     for rnd in range(int(os.environ.get('DSAC_AB_ROUNDS2', '2'))):
-        for name, flags, var in MODES:
+        for name, flags, var, auto in MODES:
             eng.set_option("k2_variant", var)
             eng.set_option("k2_flags", flags)
+            eng.set_option("k2_exact_auto", auto)
             us = timed(eng, lambda: eng.reproject(rp, N=4096, err=err, soft=soft), reps=8)
             rows.append(("configs[2] N = 4096, err + soft", name, us, bytes_k2(4096) / us / 1e3))
             us = timed(eng, lambda: eng.reproject(rp, N=4096, err=err), reps=8)
@@ -82,6 +85,7 @@ def main():
             rows.append(("configs[2] N = 4096, soft only (no stores)", name, us, float("nan")))
     eng.set_option("k2_flags", 0)
     eng.set_option("k2_variant", -1)
+    eng.set_option("k2_exact_auto", 1)
     for r in rows:
         print("%-44s %-18s %8.1f us   %6.0f GB/s (algorithmic bytes)" % r)
     eng.close()

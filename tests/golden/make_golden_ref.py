@@ -74,6 +74,18 @@ def main(version=1):
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024), "| loss %.4f rotErr %.4f tErr %.3f entropy %.4f" %
           (r["loss"], r["rotErr"], r["tErr"], r["sfEntropy"]))
 
+    # ---- the sampling loop with T OpenMP threads (round 6): the reference's own `#pragma omp parallel for` (static schedule), thread t drawing from
+    # mt19937(seed + t) -- what dsac_sample_refstream must reproduce for T threads.  Only the minimal sets and P3P poses are kept.
+    thr = {}
+    for T in (3, 4):
+        ref.set_omp_threads(T)
+        rt = ref.processImage(draw_seed, fr["xyz"], gt_jp6, hyps=N, backward=False, sub_sample=SUB_SAMPLE)
+        thr["t%d_sets" % T] = (rt["sampledPoints"][:, :, 1] * 40 + rt["sampledPoints"][:, :, 0]).astype(np.int32)
+        thr["t%d_hyps" % T] = rt["hyps"]
+    ref.set_omp_threads(1)
+    thr.update(seed=draw_seed, threads=np.array([3, 4]))
+    np.savez_compressed(os.path.join(HERE, "ref_threads_v%d.npz" % version), **thr)
+
     # ---- the DSAC (probabilistic selection) variant, core/cnn.h + the backward section of core/train_ransac.cpp ----------
     from oracle import reference_dsac as refd
     refd.lib(random_draw=False)

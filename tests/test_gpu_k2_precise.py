@@ -36,8 +36,10 @@ def test_residuals_and_tied_weights_at_640x480(precise_engine, orc, synth):
     margin("a3", "K2 PRECISE mode, residuals at 640x480 x 256 hypotheses (all cells): max |err - oracle| px", np.abs(err - ref)[m].max(), 2e-4, stated=1e-3)
     # the fast form on the same poses, for the record (asserted at 1e-3 elsewhere)
     eng.set_option("k2_flags", 0)
+    eng.set_option("k2_exact_auto", 0)  # round 6: the auto policy would take the exact form
     err_f, soft_f = np.zeros((256, P), np.float32), np.zeros(256)
     eng.reproject(poses, err=err_f, soft=soft_f, tau=TAU, beta=BETA)
+    eng.set_option("k2_exact_auto", 1)
     eng.set_option("k2_flags", PRECISE)
     mf = excl_clamp_edge(err_f, ref, CLAMP)
     fast = np.abs(err_f - ref)[mf].max()
@@ -174,6 +176,7 @@ def test_records_in_two_pieces(engine, orc, synth):
         for name, flags, var in (("fast", 0, -1), ("two-piece records", RECLO, -1), ("two-piece records, 3 waves per SIMD", RECLO, 80)):
             engine.set_option("k2_variant", var)
             engine.set_option("k2_flags", flags)
+            engine.set_option("k2_exact_auto", 0 if name == "fast" else 1)  # round 6: the auto policy's default is the exact form; "fast" = the fp32 matrix-core form
             err, soft = np.zeros((256, P), np.float32), np.zeros(256)
             engine.reproject(poses, err=err, soft=soft, tau=TAU, beta=BETA)
             m = excl_clamp_edge(err, ref, CLAMP)
@@ -189,3 +192,4 @@ def test_records_in_two_pieces(engine, orc, synth):
     finally:
         engine.set_option("k2_flags", 0)
         engine.set_option("k2_variant", -1)
+        engine.set_option("k2_exact_auto", 1)

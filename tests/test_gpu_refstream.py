@@ -36,6 +36,21 @@ def test_sets_identical_to_the_real_reference_without_replay(engine, v, seed):
     assert np.array_equal(p2, poses) and ok2.all()
 
 
+@pytest.mark.parametrize("v", [1, 2])
+@pytest.mark.parametrize("threads", [3, 4])
+def test_sets_identical_to_the_real_reference_run_with_several_openmp_threads(engine, v, threads):
+    """tests/golden/ref_threads_v<K>.npz: the REAL reference's processImage run with omp_set_num_threads(T) -- its sets for T = 3 and 4, reproduced on the
+    device from nothing but the seed and the thread count."""
+    g, _, xyz, uv = golden(v)
+    t = np.load(os.path.join(HERE, "golden", "ref_threads_v%d.npz" % v))
+    engine.set_frame(xyz, uv, 40, 40, g["cam"])
+    engine.refstreamInit(int(t["seed"]), threads)
+    engine.refstreamDiscard(0, SUBSAMPLE_OUTPUTS)
+    poses, sets, ok, consumed, attempts = engine.sampleRefstream(64, thr=10.0)
+    assert ok.all() and np.array_equal(sets, t["t%d_sets" % threads])
+    assert np.abs(poses - t["t%d_hyps" % threads]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("threads", [1, 3, 4, 7])
 def test_threads_and_running_generators_against_the_oracle(engine, orc, threads):
     g, _, xyz, uv = golden(2)

@@ -132,3 +132,19 @@ def test_attempt_parser_equals_the_oracle_loop(rsh, orc):
             j += 1
     assert j == 64
     assert np.array_equal(sets[A - 1], s[63])  # the loop stopped on its last accepted attempt
+
+
+def test_oracle_loop_reproduces_the_real_reference_with_several_openmp_threads(orc):
+    """The REAL reference run with omp_set_num_threads(T), T = 3 and 4 (tests/golden/make_golden_ref.py -> ref_threads_v<K>.npz: its own `#pragma omp
+    parallel for` with the static schedule, thread t drawing from mt19937(seed + t), thread 0 behind the sub-sampler's 6400 outputs): the oracle's loop
+    draws the same 64 sets and poses."""
+    for v in (1, 2):
+        g = np.load(os.path.join(HERE, "golden", "ref_frame_v%d.npz" % v))
+        t = np.load(os.path.join(HERE, "golden", "ref_threads_v%d.npz" % v))
+        for T in (3, 4):
+            skip = np.zeros(T, np.uint64)
+            skip[0] = 6400
+            p, s, ok, cons, att = orc.sample_refstream(64, int(t["seed"]), g["estObj"].astype(np.float32), g["sampling"].astype(np.float32), 40, 40, g["cam"], threads=T, skip32=skip)
+            assert ok.all() and np.array_equal(s, t["t%d_sets" % T]), (v, T)
+            assert np.abs(p - t["t%d_hyps" % T]).max() <= 1e-9
+            assert not np.array_equal(t["t%d_sets" % T], g["sampledPoints"][:, :, 1] * 40 + g["sampledPoints"][:, :, 0])  # another thread count, other sets
