@@ -57,7 +57,7 @@ struct dsac_ctx {
     DevBuf frame_xyz, frame_uv;
 
     // scratch, one buffer per role so that calls can be chained without aliasing
-    DevBuf rs_states, rs_scratch, rs_small;  // the reference's random streams (dsac_refstream_init) and the scratch of a sampling window
+    DevBuf rs_states, rs_scratch, rs_small, k6_scratch;  // the reference's random streams (dsac_refstream_init) and the scratch of a sampling window
     int rs_threads = 0, rs_mode = DSAC_RS_DEFAULT_MODE;
     int k6_waves = 0;  // "k6_waves": waves per refinement problem of K6's walk (0 = by the problem count)
     DevBuf staged, staged_lo, staged_split, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
@@ -349,7 +349,7 @@ void dsac_destroy(dsac_ctx* c) {
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     if (c->aux2) (void)hipStreamSynchronize(c->aux2);
     c->frame_xyz.release(); c->frame_uv.release();
-    c->staged.release(); c->staged_lo.release(); c->staged_split.release(); c->rs_states.release(); c->rs_scratch.release(); c->rs_small.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
+    c->staged.release(); c->staged_lo.release(); c->staged_split.release(); c->rs_states.release(); c->rs_scratch.release(); c->rs_small.release(); c->k6_scratch.release(); c->soft_part.release(); c->bwd_staged.release(); c->dRdH.release();
     c->grad_part.release(); c->g12_part.release(); c->g6.release();
     for (auto& s : c->slots) s.release();
     if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
@@ -1245,6 +1245,12 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
     // one frame: the map of problem 0 (H*W counters, += 1 per selection); frame batch: one map per problem (B x H*W)
     ARG_TRY(out_arg(c, inlier_map, frames > 1 ? (size_t)B * P : P, &d_map, /*preload=*/true));
     ARG_TRY(out_arg(c, steps_done, (size_t)B, &d_sd));
+    if (dk::refine_split_applies(B, c->F, d_px, nullptr, c->k6_waves)) {  // many problems, long walks: a step as two launches (k_refine.hip)
+        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(B)));
+        HIP_TRY(c, dk::refine_split(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
+                                    frames > 1 ? B / frames : 0, c->k6_scratch.p));
+        return end_call(c);
+    }
     HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
                           frames > 1 ? B / frames : 0, nullptr, nullptr, c->k6_waves));
     return end_call(c);
@@ -1454,6 +1460,11 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
     ARG_TRY(out_arg(c, inlier_maps_or_null, (size_t)N * P, &d_maps, /*preload=*/false));
     ARG_TRY(out_arg(c, steps_done_or_null, (size_t)N, &d_sd));
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)N * P * sizeof(int32_t), c->stream));
+    if (dk::refine_split_applies(N, c->F, nullptr, nullptr, c->k6_waves)) {  // the DSAC variant on a big map: every hypothesis walks most of it -- walk and LM as separate launches
+        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(N)));
+        HIP_TRY(c, dk::refine_split(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
+                                    frames_ra > 1 ? N / frames_ra : 0, c->k6_scratch.p));
+    } else
     HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
                           frames_ra > 1 ? N / frames_ra : 0, nullptr, nullptr, c->k6_waves));
     if (d_maps && d_sets) HIP_TRY(c, dk::zero_set_cells(c->stream, N, d_sets, (int)P, d_maps));

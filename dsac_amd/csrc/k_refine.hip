@@ -620,6 +620,153 @@ __global__ __launch_bounds__(64 * S) void k_refine(int B, const int32_t* __restr
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// Many problems with LONG walks (round 6): the DSAC variant refines every hypothesis (core/cnn.h:1154-1230), most of them from poses that never collect
+// max_inl inliers, so a refinement step is a walk over the whole map and one short LM solve.  The fused kernel above carries the LM chain's 370-380 registers
+// on every wave (one workgroup per SIMD quarter: four waves per problem at most).  Here a step is TWO launches: k_refine_walk -- S = 8 or 16 light waves per
+// problem (no LM code: two waves per SIMD and more), the same rounds of S x 256 cells with counts meeting in LDS, the inlier list (<= max_inl correspondences
+// in permutation order) written to HBM -- and k_refine_lm, one wave per problem, which reads the list into LDS and runs the same lm_pnp.  Same arithmetic,
+// same lists: poses, step counts and inlier maps equal the fused kernel's bit for bit (tests/test_gpu_refine.py).  2 x steps launches instead of one:
+// only taken for >= 32 problems on maps of >= 16 384 cells (refine()).
+// state per problem: pose = out_poses[b] (running), alive[b] (1 while the loop of core/cnn_softam.h:1104-1154 would go on), steps_done[b], list_n[b],
+// list_X [b][RF_MAX_INL][3], list_uv [b][RF_MAX_INL][2]
+// --------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(64 * S) void k_refine_walk(int B, const double* __restrict__ poses, const int32_t* __restrict__ alive, const int32_t* __restrict__ pidx,
+                                                        int max_inl, float thr, FrameDev F, int32_t* __restrict__ inlier_map, int map_stride, int per_frame,
+                                                        int32_t* __restrict__ list_n, float* __restrict__ list_X, float* __restrict__ list_uv) {
+    const int b = blockIdx.x;
+    if (b >= B || !alive[b]) return;
+    if (per_frame > 0) {
+        const int f = b / per_frame;
+        F.xyz += (long long)f * F.xyz_stride;
+        if (F.uv) F.uv += (long long)f * F.uv_stride;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    __shared__ int s_wcnt[2][S];
+    const dm::Cam K = make_cam_r(F);
+    double pose[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) pose[i] = poses[(size_t)b * 6 + i];
+    RodCache rc;
+    rod_at(rc, pose);
+    const int P = F.P;
+    float* lX = list_X + (size_t)b * RF_MAX_INL * 3;
+    float* lU = list_uv + (size_t)b * RF_MAX_INL * 2;
+    WalkCells cells;
+    int cnt = 0, set = 0;
+    for (int base = 0; base < P && cnt < max_inl; base += 64 * WALK_AHEAD * S, set ^= 1) {
+        const int mine = base + 64 * WALK_AHEAD * wave;
+        int found = 0;
+        float pu[WALK_AHEAD], pv[WALK_AHEAD];
+        unsigned long long masks[WALK_AHEAD];
+        if (mine < P) {
+            load_walk_cells(pidx, mine, lane, F, cells);
+            float e[WALK_AHEAD];
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                walk_cell_uv(F, cells, s, pu[s], pv[s]);
+                e[s] = dm::residual_f(rc.R, pose + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
+            }
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                masks[s] = __ballot((cells.p[s] >= 0) && (e[s] < thr));
+                found += __popcll(masks[s]);
+            }
+        }
+        if (lane == 0) s_wcnt[set][wave] = found;
+        __syncthreads();
+        int before = cnt, total = 0;
+#pragma unroll
+        for (int w = 0; w < S; w++) { const int v = s_wcnt[set][w]; if (w < wave) before += v; total += v; }
+        if (mine < P && found > 0 && before < max_inl) {
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                const unsigned long long m = masks[s];
+                const bool inl = (m >> lane) & 1ull;
+                const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
+                if (inl && slot < max_inl) {
+                    lX[slot * 3] = cells.X[s]; lX[slot * 3 + 1] = cells.Y[s]; lX[slot * 3 + 2] = cells.Z[s];
+                    lU[slot * 2] = pu[s]; lU[slot * 2 + 1] = pv[s];
+                    if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + cells.p[s]], 1);
+                }
+                before += __popcll(m);
+            }
+        }
+        cnt += total;
+    }
+    if (threadIdx.x == 0) list_n[b] = cnt;
+}
+
+__global__ __launch_bounds__(64) void k_refine_lm(int B, double* __restrict__ poses, int32_t* __restrict__ alive, int32_t* __restrict__ steps_done, int max_inl, int min_inl,
+                                                  FrameDev F, const int32_t* __restrict__ list_n, const float* __restrict__ list_X, const float* __restrict__ list_uv) {
+    const int b = blockIdx.x;
+    if (b >= B || !alive[b]) return;
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    __shared__ float s_X[RF_MAX_INL * 3];
+    __shared__ float s_uv[RF_MAX_INL * 2];
+    __shared__ double s_red[32];
+    const int n = min(list_n[b], max_inl);
+    if (n < min_inl) { if (lane == 0) alive[b] = 0; return; }  // abort for stability: too few inliers (core/cnn_softam.h:700, 1136)
+    for (int i = lane; i < n * 3; i += 64) s_X[i] = list_X[(size_t)b * RF_MAX_INL * 3 + i];
+    for (int i = lane; i < n * 2; i += 64) s_uv[i] = list_uv[(size_t)b * RF_MAX_INL * 2 + i];
+    wave_sync_lds();
+    const dm::Cam K = make_cam_r(F);
+    double upd[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) upd[i] = poses[(size_t)b * 6 + i];
+    RodCache rc;
+    rod_at(rc, upd);
+    lm_pnp(n, s_X, s_uv, s_red, K, rc, upd);
+    bool nan = false;
+#pragma unroll
+    for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
+    if (lane == 0) {
+        if (nan) alive[b] = 0;
+        else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) poses[(size_t)b * 6 + i] = upd[i];
+            steps_done[b] += 1;
+        }
+    }
+}
+
+__global__ void k_refine_split_init(int B, const double* __restrict__ init_poses, double* __restrict__ out_poses, int32_t* __restrict__ alive, int32_t* __restrict__ steps_done) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int i = 0; i < 6; i++) out_poses[(size_t)b * 6 + i] = init_poses[(size_t)b * 6 + i];
+    alive[b] = 1;
+    steps_done[b] = 0;
+}
+
+size_t refine_split_scratch_bytes(int B) { return (size_t)B * (4 + 4 + 4 + RF_MAX_INL * 5 * 4) + 64; }
+bool refine_split_applies(int B, const FrameDev& F, const int32_t* pert_px_c, const double* loss_out4, int waves_per_problem) {
+    return waves_per_problem == 0 && B >= 32 && F.P >= 16384 && !pert_px_c && !loss_out4;
+}
+// scratch: refine_split_scratch_bytes(B) of device memory; steps_done may be null (a slice of the scratch is used then)
+hipError_t refine_split(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const FrameDev& F,
+                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch) {
+    if (B <= 0) return hipSuccess;
+    if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
+    char* p = reinterpret_cast<char*>(scratch);
+    int32_t* alive = reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
+    int32_t* list_n = reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
+    int32_t* sd = steps_done ? steps_done : reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
+    float* list_X = reinterpret_cast<float*>(p); p += (size_t)B * RF_MAX_INL * 3 * 4;
+    float* list_uv = reinterpret_cast<float*>(p);
+    hipLaunchKernelGGL(k_refine_split_init, dim3((B + 255) / 256), dim3(256), 0, st, B, init_poses, out_poses, alive, sd);
+    const int S = B <= 128 ? 16 : 8;  // 2 048 light waves: two per SIMD
+    for (int step = 0; step < steps; step++) {
+        const int32_t* pidx = perm + (size_t)step * F.P;
+        if (S == 16) hipLaunchKernelGGL((k_refine_walk<16>), dim3(B), dim3(1024), 0, st, B, out_poses, alive, pidx, max_inl, thr, F, inlier_map, map_stride, per_frame, list_n, list_X, list_uv);
+        else hipLaunchKernelGGL((k_refine_walk<8>), dim3(B), dim3(512), 0, st, B, out_poses, alive, pidx, max_inl, thr, F, inlier_map, map_stride, per_frame, list_n, list_X, list_uv);
+        hipLaunchKernelGGL(k_refine_lm, dim3(B), dim3(64), 0, st, B, out_poses, alive, sd, max_inl, min_inl, F, list_n, list_X, list_uv);
+    }
+    return hipGetLastError();
+}
+
 hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr,
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
                   int32_t* steps_done, int map_stride, int per_frame, const double* loss_gt_jp6, double* loss_out4, int waves_per_problem) {
@@ -628,7 +775,9 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
     // waves per problem: as many as fill the chip's 1 024 SIMDs twice over, and no more than the map has 256-cell batches behind the first one
     // (eight waves per problem would need the 380-register LM chain in 256 registers: 512 B of scratch, the good-pose refinement 83 -> 135 us -- measured, kept
     // selectable for the record: profiles/r06_k6_walk.txt)
-    int S = waves_per_problem >= 1 ? waves_per_problem : (B <= 512 ? 4 : B <= 1024 ? 2 : 1);
+    // ONE problem keeps one wave: the four-wave build's LM chain is 2.6 us slower on the good-pose refinement of a single image (380 against 370 registers;
+    // 84.7 -> 87.3 us, the same with a barrier or a poll for the hand-off), and that chain is the latency of an image; "k6_waves" 4 buys a hard single frame 143 -> 123 us
+    int S = waves_per_problem >= 1 ? waves_per_problem : (B <= 1 ? 1 : B <= 512 ? 4 : B <= 1024 ? 2 : 1);
     while (S > 1 && (long long)64 * WALK_AHEAD * (S / 2 + 1) > (long long)F.P) S /= 2;
 #define DSAC_K6(S_) hipLaunchKernelGGL((k_refine<S_>), dim3(B), dim3(64 * S_), 0, st, B, (const int32_t*)nullptr, 0, 0, init_poses, perm, steps, max_inl, min_inl, thr, pert_px_c, \
                        pert_value, F, out_poses, inlier_map, steps_done, map_stride, 0, per_frame, loss_gt_jp6, loss_out4, (const int32_t*)nullptr)

@@ -155,7 +155,13 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
                   int32_t* steps_done, int map_stride = 0, int per_frame = 0, const double* loss_gt_jp6 = nullptr, double* loss_out4 = nullptr,
                   int waves_per_problem = 0);
-// waves_per_problem: 0 = by the problem count (4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8 = fixed ("k6_waves"); the same results bit for bit
+// many problems with long walks (the DSAC variant on big maps): a refinement step as two launches, walk (8 / 16 light waves per problem) + LM (k_refine.hip); the
+// same results bit for bit.  refine_split_applies: >= 32 problems, >= 16 384 cells, no perturbation, no fused loss, "k6_waves" 0
+size_t refine_split_scratch_bytes(int B);
+bool refine_split_applies(int B, const FrameDev& F, const int32_t* pert_px_c, const double* loss_out4, int waves_per_problem);
+hipError_t refine_split(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const FrameDev& F,
+                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch);
+// waves_per_problem: 0 = by the problem count (1 for a single problem, 4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8 = fixed ("k6_waves"); the same results bit for bit
 // loss_gt_jp6 (B x 6) / loss_out4 (B x 4): maxLoss of every refined pose against its ground truth in the same launch (K7's arithmetic, loss_math.h)
 // inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)
 hipError_t zero_set_cells(hipStream_t st, int N, const int32_t* sets, int P, int32_t* inlier_maps);

@@ -178,3 +178,31 @@ def test_loss_and_gradient(engine, orc, synth):
         if rot + tr > 1e-3:  # at exactly zero error the gradient is 0/0 on both sides
             Jr = orc.dLossMax(orc.cv_to_jp6(est), gt_jp)
             margin("a8", "K7 dLossMax vs oracle: max-rel", np.abs(r["grad"] - Jr).max() / max(1.0, np.abs(Jr).max()), 1e-8)
+
+
+def test_many_long_walks_as_two_launches_per_step_equal_the_fused_kernel(engine, synth):
+    """Round 6 (core/cnn.h:1154-1230: the DSAC variant refines EVERY hypothesis): from 32 problems on a map of >= 16 384 cells a refinement step runs as two
+    launches -- k_refine_walk (8 / 16 light waves per problem, the list of the first max_inl inliers in permutation order into HBM) and k_refine_lm (one wave
+    per problem) -- instead of the fused kernel whose LM registers allow four waves per problem at most.  Same arithmetic, same lists: refined poses, step
+    counts and per-problem inlier maps are bit-identical to the fused kernel with one ("k6_waves" 1) and with four waves per problem."""
+    H, W = 120, 160
+    P = H * W
+    fr = synth.chess_like_frame(H, W, seed=41, outlier_frac=0.5, grid_uv=True)
+    engine.set_frame(fr["xyz"], None, H, W, fr["cam"])
+    perm = synth.fast_permutations(P, 8)
+    rng = np.random.default_rng(3)
+    B = 96
+    scale = np.where(np.arange(B)[:, None] % 3 == 0, 1.0, 25.0)  # a third near the pose (walks that stop early), the rest far off (walks over the whole map)
+    init = fr["gt_pose"][None, :] + rng.normal(size=(B, 6)) * np.array([0.01, 0.01, 0.01, 8.0, 8.0, 8.0]) * scale
+    res = {}
+    try:
+        for waves in (0, 1, 4):
+            engine.set_option("k6_waves", waves)
+            res[waves] = engine.refineAll(init, perm, max_inl=100, min_inl=50, thr=10.0, want_inlier_maps=True)
+    finally:
+        engine.set_option("k6_waves", 0)
+    p0, s0, m0 = res[0]
+    assert 0 < int((s0 == 8).sum()) < B or int(s0.max()) > 0  # a mix of finished and aborted refinements
+    for waves in (1, 4):
+        p, s, m = res[waves]
+        assert np.array_equal(p0, p) and np.array_equal(s0, s) and np.array_equal(m0, m), "k6_waves %d" % waves
