@@ -58,6 +58,14 @@ def big_case(request, orc, synth, engine):
     d_err = np.zeros((N, P), np.float32)
     d_err[active] = rng.standard_normal((len(active), P), dtype=np.float32) * np.float32(1e-3)
     d_err[np.arange(N)[:, None], sets] = 0  # a hypothesis' own four cells carry a unit vector of round-off (EPS guard, cnn_softam.h:430,490)
+    # no weight on CLAMP-EDGE cells either: the guard err > 100 -> 0 (cnn_softam.h:425,485) is a discontinuity, a cell within the fp32
+    # rounding of the clamp may fall on either side of it in any fp32 implementation -- the forward tests exclude such cells the same way (excl_clamp_edge).
+    # Cells beyond the clamp contribute nothing on either side, so the whole band e >= 100 - 0.01 px loses its weight
+    for s_ in range(0, len(active), 64):
+        idx = active[s_:s_ + 64]
+        e_ = orc.get_diff_maps(poses[idx], fr["xyz"], uv, H, W, fr["cam"])
+        d_err[idx] = np.where(e_ >= 99.99, np.float32(0), d_err[idx])
+        del e_
     g = np.zeros(N)
     g[active] = rng.normal(size=len(active))
     ref_d, G6_d = _oracle(orc, fr, uv, sets, active, lambda idx: d_err[idx].astype(np.float64))
@@ -121,9 +129,9 @@ def test_k4_at_the_benchmarked_shapes(engine, big_case, variant):
         # with the twelve sums accumulated and wave-reduced in DOUBLE the figure is the same 2.624e-3 (gpurun_out/r05g) --: it is the guard err > 100 -> 0
         # (cnn_softam.h:425,485), a discontinuity.  The fallback decides it on err = sqrt(..) of an fp32 reciprocal, the matrix-core forms on the squared,
         # division-free quantities; a cell that sits within the fp32 rounding of the clamp flips, and when that cell lies close to the hypothesis' camera
-        # plane (a coefficient ~ 1 / E.z^2) it alone is 2.6e-3 of the hypothesis' largest sum.  Asserted at 5e-3 for the fallback, stated 1e-3 beside it
+        # plane (a coefficient ~ 1 / E.z^2) it alone is 2.6e-3 of the hypothesis' largest sum.  Round 6: the case carries no weight on clamp-edge cells (big_case), every form is asserted at the stated 1e-3
         margin("a10", "K4 d_err N=%d, %s: pose sums, median over hypotheses of max-rel error" % (N, form), np.median(relp), 1e-4)
-        margin("a10", "K4 d_err N=%d, %s: pose sums, max over hypotheses of max-rel error" % (N, form), relp.max(), 5e-3 if variant == 0 else 1e-3, stated=1e-3)
+        margin("a10", "K4 d_err N=%d, %s: pose sums, max over hypotheses of max-rel error" % (N, form), relp.max(), 1e-3)
         del d_err
         # fused soft-inlier form: the same sums with d_err formed in the kernel.  The hypotheses' own cells have |r| = 0 exactly on the oracle's
         # side and a few 1e-5 px on the fp32 side, where sigmoid' is not zero: their weight is what the own-cell exclusion removes in the oracle,
@@ -146,8 +154,7 @@ def test_k4_at_the_benchmarked_shapes(engine, big_case, variant):
         excess = np.maximum(diff - 1.01 * c["own_bound"][act], 0.0).max(1) / scale
         margin("a9", "K4 fused soft N=%d x 640x480, %s: gradient max-rel (own cells excluded)" % (N, form), emax, 1e-3)
         margin("a9", "K4 fused soft N=%d x 640x480, %s: gradient relative l2 error" % (N, form), el2, 5e-4)
-        margin("a10", "K4 fused soft N=%d, %s: pose sums, max over hypotheses of the error BEYOND the own-cell round-off bound" % (N, form), excess.max(),
-               5e-3 if variant == 0 else 1e-3, stated=1e-3)
+        margin("a10", "K4 fused soft N=%d, %s: pose sums, max over hypotheses of the error BEYOND the own-cell round-off bound" % (N, form), excess.max(), 1e-3)
         margin("a10", "K4 fused soft N=%d, %s: pose sums, median raw max-rel error (own-cell term included)" % (N, form), np.median(relp), 1e-3)
         print("K4 N=%d k4_variant %d fused soft: raw pose-sum error median %.2e p95 %.2e max %.2e; own-cell bound / scale: median %.2e max %.2e" %
               (N, variant, np.median(relp), np.quantile(relp, 0.95), relp.max(), np.median(c["own_bound"][act].max(1) / scale), (c["own_bound"][act].max(1) / scale).max()))
