@@ -59,6 +59,7 @@ struct dsac_ctx {
     // scratch, one buffer per role so that calls can be chained without aliasing
     DevBuf rs_states, rs_scratch, rs_small, k6_scratch;  // the reference's random streams (dsac_refstream_init) and the scratch of a sampling window
     int rs_threads = 0, rs_mode = DSAC_RS_DEFAULT_MODE;
+    int k6_walk_exact = 0;  // "k6_walk_exact": 1 = the split walk decides every cell by the fp64 residual (no fp32 filter; A/B)
     int k6_waves = 0;  // "k6_waves": waves per refinement problem of K6's walk (0 = by the problem count)
     DevBuf staged, staged_lo, staged_split, soft_part, bwd_staged, dRdH, grad_part, g12_part, g6;
     int g6_n = 0;  // hypotheses held by g6 (dsac_last_pose_gradients)
@@ -1002,6 +1003,12 @@ int dsac_set_option(dsac_ctx* c, const char* key, int value) {
     else if (k == "k2_flags") c->k2.flags = value;
     else if (k == "k2_diag") c->k2.diag = value;
     else if (k == "k2_exact_auto") c->k2.exact_auto = value != 0;
+    else if (k == "k6_walk_exact") c->k6_walk_exact = value != 0;
+    else if (k == "k6_scan_tune") {  // A/B of the scan (process-wide): problems per wave | chunk cells << 8 | no skip check << 24
+        const int g = value & 255, chunk = (value >> 8) & 0xffff;
+        if ((g != 0 && g != 1 && g != 2 && g != 4) || chunk % 256 != 0 || (value >> 25) != 0) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k6_scan_tune is g | chunk << 8 | noskip << 24 with g in {0, 1, 2, 4} and chunk a multiple of 256");
+        dk::refine_scan_tune(value);
+    }
     else if (k == "k6_waves") {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, DSAC_ERR_INVALID, "dsac_set_option: k6_waves is 0 (auto), 1, 2, 4 or 8");
         c->k6_waves = value;
@@ -1246,9 +1253,9 @@ int dsac_refine(dsac_ctx* c, int B, const double* init_poses, const int32_t* per
     ARG_TRY(out_arg(c, inlier_map, frames > 1 ? (size_t)B * P : P, &d_map, /*preload=*/true));
     ARG_TRY(out_arg(c, steps_done, (size_t)B, &d_sd));
     if (dk::refine_split_applies(B, c->F, d_px, nullptr, c->k6_waves)) {  // many problems, long walks: a step as two launches (k_refine.hip)
-        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(B)));
+        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(B, steps, frames > 1 ? frames : 1, (int)P, max_inl)));
         HIP_TRY(c, dk::refine_split(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
-                                    frames > 1 ? B / frames : 0, c->k6_scratch.p));
+                                    frames > 1 ? B / frames : 0, c->k6_scratch.p, c->k6_walk_exact));
         return end_call(c);
     }
     HIP_TRY(c, dk::refine(c->stream, B, d_init, d_perm, steps, max_inl, min_inl, thr, d_px, d_pv, c->F, d_out, d_map, d_sd, frames > 1 ? (int)P : 0,
@@ -1461,9 +1468,9 @@ int dsac_refine_all(dsac_ctx* c, int N, const double* init_poses, const int32_t*
     ARG_TRY(out_arg(c, steps_done_or_null, (size_t)N, &d_sd));
     if (d_maps) HIP_TRY(c, hipMemsetAsync(d_maps, 0, (size_t)N * P * sizeof(int32_t), c->stream));
     if (dk::refine_split_applies(N, c->F, nullptr, nullptr, c->k6_waves)) {  // the DSAC variant on a big map: every hypothesis walks most of it -- walk and LM as separate launches
-        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(N)));
+        HIP_TRY(c, c->k6_scratch.reserve(dk::refine_split_scratch_bytes(N, steps, frames_ra > 1 ? frames_ra : 1, (int)P, max_inl)));
         HIP_TRY(c, dk::refine_split(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
-                                    frames_ra > 1 ? N / frames_ra : 0, c->k6_scratch.p));
+                                    frames_ra > 1 ? N / frames_ra : 0, c->k6_scratch.p, c->k6_walk_exact));
     } else
     HIP_TRY(c, dk::refine(c->stream, N, d_init, d_perm, steps, max_inl, min_inl, thr, nullptr, nullptr, c->F, d_out, d_maps, d_sd, d_maps ? (int)P : 0,
                           frames_ra > 1 ? N / frames_ra : 0, nullptr, nullptr, c->k6_waves));

@@ -621,86 +621,255 @@ __global__ __launch_bounds__(64 * S) void k_refine(int B, const int32_t* __restr
 }
 
 // --------------------------------------------------------------------------------------------------
-// Many problems with LONG walks (round 6): the DSAC variant refines every hypothesis (core/cnn.h:1154-1230), most of them from poses that never collect
-// max_inl inliers, so a refinement step is a walk over the whole map and one short LM solve.  The fused kernel above carries the LM chain's 370-380 registers
-// on every wave (one workgroup per SIMD quarter: four waves per problem at most).  Here a step is TWO launches: k_refine_walk -- S = 8 or 16 light waves per
-// problem (no LM code: two waves per SIMD and more), the same rounds of S x 256 cells with counts meeting in LDS, the inlier list (<= max_inl correspondences
-// in permutation order) written to HBM -- and k_refine_lm, one wave per problem, which reads the list into LDS and runs the same lm_pnp.  Same arithmetic,
-// same lists: poses, step counts and inlier maps equal the fused kernel's bit for bit (tests/test_gpu_refine.py).  2 x steps launches instead of one:
-// only taken for >= 32 problems on maps of >= 16 384 cells (refine()).
-// state per problem: pose = out_poses[b] (running), alive[b] (1 while the loop of core/cnn_softam.h:1104-1154 would go on), steps_done[b], list_n[b],
-// list_X [b][RF_MAX_INL][3], list_uv [b][RF_MAX_INL][2]
+// Many problems with LONG walks (round 6): a refinement step as TWO launches, k_refine_walk (a scan of the step's permuted cells in chunks, G problems per wave;
+// described at the kernel) and k_refine_lm (one wave per problem: the first max_inl inliers in chunk order, then the same lm_pnp), after one k_refine_permute per
+// call.  The fused kernel above carries the LM chain's 370-380 registers on every wave (four waves per problem at most) and chases permutation entry ->
+// scattered coordinate for every problem separately.  Same arithmetic, same lists: poses, step counts and inlier maps equal the fused kernel's bit for bit
+// (tests/test_gpu_refine.py).  Taken for >= 32 problems on maps of >= 16 384 cells (refine_split_applies).
+// state per problem: pose = out_poses[b] (running), alive[b] (1 while the loop of core/cnn_softam.h:1104-1154 would go on), steps_done[b]; per problem and
+// chunk: a word (step tag | inlier count) and a list of <= max_inl records {X, Y, Z, cell, u, v}
 // --------------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(64 * S) void k_refine_walk(int B, const double* __restrict__ poses, const int32_t* __restrict__ alive, const int32_t* __restrict__ pidx,
-                                                        int max_inl, float thr, FrameDev F, int32_t* __restrict__ inlier_map, int map_stride, int per_frame,
-                                                        int32_t* __restrict__ list_n, float* __restrict__ list_X, float* __restrict__ list_uv) {
-    const int b = blockIdx.x;
-    if (b >= B || !alive[b]) return;
-    if (per_frame > 0) {
-        const int f = b / per_frame;
-        F.xyz += (long long)f * F.xyz_stride;
-        if (F.uv) F.uv += (long long)f * F.uv_stride;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    __shared__ int s_wcnt[2][S];
-    const dm::Cam K = make_cam_r(F);
-    double pose[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) pose[i] = poses[(size_t)b * 6 + i];
-    RodCache rc;
-    rod_at(rc, pose);
+// The cells of every step's permutation laid out in walking order, once per call: cell record {X, Y, Z, bits(cell index)} + pixel position.  All problems of a
+// frame walk the same permutations (core/cnn_softam.h:1108-1118 shuffles once per step), so the dependent pair of loads permutation entry -> scattered 12-byte
+// coordinate (307 200 scattered reads per problem and step, the latency each round of the serial walk waits for) becomes one coalesced 16 + 8 byte read.  Every
+// step's array is padded to whole rounds of 256 cells with NaN coordinates: such a cell is never "certainly an outlier" and never an inlier of the fp64 residual.
+constexpr int SCAN_BOUND_SLOTS = 64, SCAN_BOUND_STRIDE = 32;  // the frame's bounds are met in 64 slots on separate cache lines (one address serialises its atomics)
+__global__ __launch_bounds__(256) void k_refine_permute(int steps, int P256, FrameDev F, const int32_t* __restrict__ perm, float4* __restrict__ cells, float2* __restrict__ uvs,
+                                                        int32_t* __restrict__ bounds) {
+    const int i = blockIdx.x * 256 + threadIdx.x, step = blockIdx.y, f = blockIdx.z;
     const int P = F.P;
-    float* lX = list_X + (size_t)b * RF_MAX_INL * 3;
-    float* lU = list_uv + (size_t)b * RF_MAX_INL * 2;
-    WalkCells cells;
-    int cnt = 0, set = 0;
-    for (int base = 0; base < P && cnt < max_inl; base += 64 * WALK_AHEAD * S, set ^= 1) {
-        const int mine = base + 64 * WALK_AHEAD * wave;
-        int found = 0;
-        float pu[WALK_AHEAD], pv[WALK_AHEAD];
-        unsigned long long masks[WALK_AHEAD];
-        if (mine < P) {
-            load_walk_cells(pidx, mine, lane, F, cells);
-            float e[WALK_AHEAD];
-#pragma unroll
-            for (int s = 0; s < WALK_AHEAD; s++) {
-                walk_cell_uv(F, cells, s, pu[s], pv[s]);
-                e[s] = dm::residual_f(rc.R, pose + 3, K, cells.X[s], cells.Y[s], cells.Z[s], pu[s], pv[s], 100.0);
-            }
-#pragma unroll
-            for (int s = 0; s < WALK_AHEAD; s++) {
-                masks[s] = __ballot((cells.p[s] >= 0) && (e[s] < thr));
-                found += __popcll(masks[s]);
-            }
+    const size_t o = ((size_t)f * steps + step) * P256 + i;
+    float m = 0.f, dd = 0.f;
+    if (i < P) {
+        const int p = min(max(perm[(size_t)step * P + i], 0), P - 1);
+        const float* xyz = F.xyz + (long long)f * F.xyz_stride;
+        float2 w;
+        if (F.uv) {
+            const float* uv = F.uv + (long long)f * F.uv_stride;
+            w = make_float2(uv[(size_t)p * 2], uv[(size_t)p * 2 + 1]);
+        } else {
+            const int y = p / F.W;
+            w = make_float2((float)(p - y * F.W), (float)y);
         }
-        if (lane == 0) s_wcnt[set][wave] = found;
-        __syncthreads();
-        int before = cnt, total = 0;
-#pragma unroll
-        for (int w = 0; w < S; w++) { const int v = s_wcnt[set][w]; if (w < wave) before += v; total += v; }
-        if (mine < P && found > 0 && before < max_inl) {
-#pragma unroll
-            for (int s = 0; s < WALK_AHEAD; s++) {
-                const unsigned long long m = masks[s];
-                const bool inl = (m >> lane) & 1ull;
-                const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
-                if (inl && slot < max_inl) {
-                    lX[slot * 3] = cells.X[s]; lX[slot * 3 + 1] = cells.Y[s]; lX[slot * 3 + 2] = cells.Z[s];
-                    lU[slot * 2] = pu[s]; lU[slot * 2 + 1] = pv[s];
-                    if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + cells.p[s]], 1);
-                }
-                before += __popcll(m);
-            }
-        }
-        cnt += total;
+        const float X = xyz[(size_t)p * 3], Y = xyz[(size_t)p * 3 + 1], Z = xyz[(size_t)p * 3 + 2];
+        cells[o] = make_float4(X, Y, Z, __int_as_float(p));
+        uvs[o] = w;
+        m = fabsf(X) + fabsf(Y) + fabsf(Z);
+        dd = fabsf(w.x - F.cx) + fabsf(w.y - F.cy);
+    } else {
+        const float nan = __builtin_nanf("");
+        cells[o] = make_float4(nan, nan, nan, __int_as_float(0));
+        uvs[o] = make_float2(0.f, 0.f);
     }
-    if (threadIdx.x == 0) list_n[b] = cnt;
+    // the frame's bounds for the scan's outlier test: max (|X| + |Y| + |Z|) and max (|u - cx| + |v - cy|) over its cells, as the integer order of non-negative
+    // floats (a NaN orders above every number and switches the test off: every cell is then decided in fp64)
+    if (step == 0) {
+        int mi = __float_as_int(m) & 0x7fffffff, di = __float_as_int(dd) & 0x7fffffff;
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) { mi = max(mi, __shfl_xor(mi, o2)); di = max(di, __shfl_xor(di, o2)); }
+        if ((threadIdx.x & 63) == 0) {
+            int32_t* slot = bounds + ((size_t)f * SCAN_BOUND_SLOTS + (blockIdx.x * 4 + (threadIdx.x >> 6)) % SCAN_BOUND_SLOTS) * SCAN_BOUND_STRIDE;
+            atomicMax(slot, mi);
+            atomicMax(slot + 1, di);
+        }
+    }
 }
 
+struct WalkRound {
+    float4 c[WALK_AHEAD];
+    float2 w[WALK_AHEAD];
+};
+DM_INLINE void load_walk_round(const float4* __restrict__ cells, const float2* __restrict__ uvs, int base, int lane, WalkRound& r) {
+#pragma unroll
+    for (int s = 0; s < WALK_AHEAD; s++) {
+        r.c[s] = cells[base + s * 64 + lane];
+        r.w[s] = uvs[base + s * 64 + lane];
+    }
+}
+
+// A problem's pose as the scan reads it: R | t in double (the fp64 residual's operands, rodrigues_R of the running pose) and, for the outlier test, the rows
+// fx R0 | fx t0, fy R1 | fy t1, R2 | t2 rounded to float with max |t|; written by the thread that sets the pose (k_refine_split_init, lane 0 of k_refine_lm).
+constexpr int SCAN_REC = 16;
+DM_INLINE void write_scan_record(const double pose[6], const double R[9], const dm::Cam& K, double* __restrict__ Rt, float* __restrict__ rec) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rt[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) Rt[9 + i] = pose[3 + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        rec[i] = (float)(K.fx * R[i]);
+        rec[4 + i] = (float)(K.fy * R[3 + i]);
+        rec[8 + i] = (float)R[6 + i];
+    }
+    rec[3] = (float)(K.fx * pose[3]);
+    rec[7] = (float)(K.fy * pose[4]);
+    rec[11] = (float)pose[5];
+    rec[12] = fmaxf(fabsf((float)pose[3]), fmaxf(fabsf((float)pose[4]), fabsf((float)pose[5]))) * 1.0001f + 1e-30f;
+    rec[13] = rec[14] = rec[15] = 0.f;
+}
+
+constexpr int SCAN_WAVES = 4;           // waves per workgroup, each with its own chunk of the permutation
+constexpr int SCAN_CNT_BITS = 12;       // count field of a chunk word (counts are capped at max_inl <= RF_MAX_INL); the bits above hold the step tag
+constexpr int SCAN_MAX_CHUNKS = 2048;   // prefix table of k_refine_lm (LDS)
+typedef float sf2 __attribute__((ext_vector_type(2)));
+typedef float sf4 __attribute__((ext_vector_type(4)));
+DM_INLINE sf2 sfma(sf2 a, sf2 b, sf2 c) { return __builtin_elementwise_fma(a, b, c); }
+DM_INLINE sf2 ssplat(float a) { return sf2{a, a}; }
+
+// "These two cells are certainly NOT inliers" in fp32 (two cells per lane: v_pk_fma_f32), with a proven distance from the reference's decision (dm::residual_f:
+// projection in double, float difference, double norm, compared in float).  eps = 2^-24.  A >= |error of each fp32 camera-frame coordinate|: the record's rounding
+// (eps (|X| + |Y| + |Z| + |t|), times the focal length in the rows that carry it) and the three roundings of the fma chain (each <= eps x the same sum) are 4 eps M;
+// A = 16 eps M with M = the frame's largest |X| + |Y| + |Z| + the pose's largest |t|.  With |zc| >= 16 A:  |x~/z~ - X/Z| <= A (1 + |x~/z~|) / (|z~| - A) <=
+// T (1 + |q|), T = 2 A |1/z~| <= 1/8, so the projection is off by at most T (fx + fy + |u - cx| + |v - cy|) over both axes; v_rcp_f32's 1 ulp, the roundings of the
+// products, of pu - cx and of the fused differences and the reference's float rounding of u are below rho (|u| + |cx|), rho = 2^-20; the norm adds 4 eps d.  With
+// |u - cx| <= d + |pu - cx| and D = the frame's largest |pu - cx| + |pv - cy| the reference's distance is at least
+// d (1 - kappa) - T (fx + fy + D) - rho (D + 2 (|cx| + |cy|)), kappa = 2 T + 2^-18 < 1/2, and the cell is no inlier if
+//   d >= (thr' + T C1) (1 + 2 kappa),   thr' = thr (1 + 1e-6) + 1.01 rho C2,  C1 = fx + fy + D,  C2 = D + 2 (|cx| + |cy|)
+// (squares compared, with another 2e-6 of slack).  Everything else -- inliers, cells near the threshold, points near the camera plane, NaN -- is "not certain" and
+// the sub-batch is decided by residual_f.  Poses that walk the whole map have a few inliers among 300 000 cells: ~2 % of their sub-batches take the fp64 path.
+// Returns the ballots of the lanes that are NOT certain, for the first and the second cell.
+DM_INLINE void uncertain2(const sf4 r0, const sf4 r1, const sf4 r2, float A2, float A8, float thr1, float C1, sf2 X, sf2 Y, sf2 Z, sf2 pu_c, sf2 pv_c,
+                          unsigned long long& m0, unsigned long long& m1) {
+    const sf2 xs = sfma(ssplat(r0.x), X, sfma(ssplat(r0.y), Y, sfma(ssplat(r0.z), Z, ssplat(r0.w))));
+    const sf2 ys = sfma(ssplat(r1.x), X, sfma(ssplat(r1.y), Y, sfma(ssplat(r1.z), Z, ssplat(r1.w))));
+    const sf2 zc = sfma(ssplat(r2.x), X, sfma(ssplat(r2.y), Y, sfma(ssplat(r2.z), Z, ssplat(r2.w))));
+    sf2 iz;
+    iz.x = __builtin_amdgcn_rcpf(zc.x);
+    iz.y = __builtin_amdgcn_rcpf(zc.y);
+    const sf2 dx = sfma(-xs, iz, pu_c), dy = sfma(-ys, iz, pv_c);
+    const sf2 d2 = sfma(dx, dx, dy * dy);
+    sf2 aiz;
+    aiz.x = fabsf(iz.x);
+    aiz.y = fabsf(iz.y);
+    const sf2 T = ssplat(A2) * aiz;
+    const sf2 rhs = sfma(T, ssplat(C1), ssplat(thr1)) * sfma(T, ssplat(4.0f), ssplat(1.0000096f));  // 1 + 2 kappa = 1 + 4 T + 2^-17, + 2e-6
+    const sf2 rhs2 = rhs * rhs;
+    m0 = __ballot(!(fabsf(zc.x) >= A8) || !(d2.x > rhs2.x));
+    m1 = __ballot(!(fabsf(zc.y) >= A8) || !(d2.y > rhs2.y));
+}
+
+// The walk as a SCAN: the step's permuted cells (k_refine_permute) are cut into chunks of `chunk_cells`; a wave takes one chunk and G problems of the same frame
+// at once -- one coalesced read of the cells serves G poses -- and writes, per problem, the chunk's inliers in permutation order (at most max_inl) with their
+// count.  k_refine_lm then takes the first max_inl inliers in chunk order: the list the serial walk of core/cnn_softam.h:1108-1134 collects.  A chunk is skipped
+// for a problem when the chunks in front of it that have ALREADY finished hold max_inl inliers (a sufficient condition: results never depend on it, only the
+// work does -- problems on a good pose stop after their first chunks).  Grid: x = problem group, y = 4 chunks: workgroups that read the same cells are
+// dispatched together (L2).
+template <int G>
+__global__ __launch_bounds__(64 * SCAN_WAVES) void k_refine_walk(int B, const double* __restrict__ Rt, const float* __restrict__ rec, const int32_t* __restrict__ alive,
+                                                                 const float4* __restrict__ cells_step, const float2* __restrict__ uvs_step, long long frame_stride,
+                                                                 int chunk_cells, int nchunks, int P256, int tag, int max_inl, float thr, FrameDev F, int per_frame,
+                                                                 int32_t* __restrict__ cnt, float* __restrict__ lists, const int32_t* __restrict__ bounds, int exact_only,
+                                                                 int no_skip) {
+    // workgroups go to the 8 XCDs round robin by their linear index: with the group in x alone every XCD would keep the same groups for the whole launch (and
+    // groups differ: some stop after their first chunks, some scan the whole map) -- the group is rotated by the chunk row
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b0 = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * G;
+    const int kc = (int)blockIdx.y * SCAN_WAVES + wave;
+    __shared__ __attribute__((aligned(16))) float s_rec[G][SCAN_REC];
+    if (threadIdx.x < G * SCAN_REC) s_rec[threadIdx.x / SCAN_REC][threadIdx.x % SCAN_REC] = rec[(size_t)b0 * SCAN_REC + threadIdx.x];  // records are padded to whole groups
+    __syncthreads();
+    if (kc >= nchunks) return;
+    const int f = per_frame > 0 ? b0 / per_frame : 0;
+    cells_step += (long long)f * frame_stride;
+    uvs_step += (long long)f * frame_stride;
+    const int cbase = kc * chunk_cells, cend = min(cbase + chunk_cells, P256);
+    WalkRound cur, nxt;
+    load_walk_round(cells_step, uvs_step, cbase, lane, cur);
+    int mi = bounds[((size_t)f * SCAN_BOUND_SLOTS + lane) * SCAN_BOUND_STRIDE], di = bounds[((size_t)f * SCAN_BOUND_SLOTS + lane) * SCAN_BOUND_STRIDE + 1];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mi = max(mi, __shfl_xor(mi, o)); di = max(di, __shfl_xor(di, o)); }
+    const float Mmax = __int_as_float(__builtin_amdgcn_readfirstlane(mi)), Dmax = __int_as_float(__builtin_amdgcn_readfirstlane(di));
+    const float C1 = (F.fx + F.fy + Dmax) * 1.000001f;
+    const float thr1 = (float)((double)thr * (1.0 + 1e-6) + 1.01 * 9.5367431640625e-07 * ((double)Dmax + 2.0 * (fabs((double)F.cx) + fabs((double)F.cy)))) * 1.0000002f;
+    // per problem of the wave: bit g of `live` / `act`, the chunk's inlier count in LDS (the loop over the problems is NOT unrolled: one copy of the fp64 path)
+    __shared__ int s_count[SCAN_WAVES][G];
+    unsigned live = 0, act = 0;
+    for (int g = 0; g < G; g++) {
+        if (lane == 0) s_count[wave][g] = 0;
+        if (alive[b0 + g] == 0) continue;  // alive is padded to whole groups
+        live |= 1u << g;
+        bool skip = false;
+        if (kc > 0 && !no_skip) {  // inliers of the finished chunks in front of this one (words of this step only)
+            int have = 0;
+            for (int j = lane; j < kc; j += 64) {
+                const int w = __hip_atomic_load(&cnt[(size_t)(b0 + g) * nchunks + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                have += ((w >> SCAN_CNT_BITS) == tag) ? (w & ((1 << SCAN_CNT_BITS) - 1)) : 0;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) have += __shfl_xor(have, o);
+            skip = __builtin_amdgcn_readfirstlane(have) >= max_inl;
+        }
+        if (!skip) act |= 1u << g;
+    }
+    const dm::Cam K = make_cam_r(F);
+    // thresholds at or beyond the clamp (min(d, 100) < thr) and the A/B switch take the fp64 residual for every cell
+    const bool use_exact = !(thr < 99.0f) || exact_only;
+    for (int base = cbase; base < cend && act != 0; base += 64 * WALK_AHEAD) {
+        if (base + 64 * WALK_AHEAD < cend) load_walk_round(cells_step, uvs_step, base + 64 * WALK_AHEAD, lane, nxt);  // travels under this round's arithmetic
+        sf2 X[2], Y[2], Z[2], pu_c[2], pv_c[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            X[h] = sf2{cur.c[2 * h].x, cur.c[2 * h + 1].x};
+            Y[h] = sf2{cur.c[2 * h].y, cur.c[2 * h + 1].y};
+            Z[h] = sf2{cur.c[2 * h].z, cur.c[2 * h + 1].z};
+            pu_c[h] = sf2{cur.w[2 * h].x, cur.w[2 * h + 1].x} - ssplat(F.cx);
+            pv_c[h] = sf2{cur.w[2 * h].y, cur.w[2 * h + 1].y} - ssplat(F.cy);
+        }
+#pragma nounroll
+        for (int g = 0; g < G; g++) {
+            if (!((act >> g) & 1u)) continue;
+            unsigned long long m[WALK_AHEAD];
+            if (use_exact) {
+#pragma unroll
+                for (int s = 0; s < WALK_AHEAD; s++) m[s] = ~0ull;
+            } else {
+                const sf4 r0 = *reinterpret_cast<const sf4*>(&s_rec[g][0]), r1 = *reinterpret_cast<const sf4*>(&s_rec[g][4]), r2 = *reinterpret_cast<const sf4*>(&s_rec[g][8]);
+                const float A2 = (Mmax + s_rec[g][12]) * 1.9073486328125e-06f;  // 2 A = 32 eps M
+                const float A8 = 8.0f * A2;
+#pragma unroll
+                for (int h = 0; h < 2; h++) uncertain2(r0, r1, r2, A2, A8, thr1, C1, X[h], Y[h], Z[h], pu_c[h], pv_c[h], m[2 * h], m[2 * h + 1]);
+            }
+            if ((m[0] | m[1] | m[2] | m[3]) == 0ull) continue;
+            // some lane is not certainly an outlier: the reference's arithmetic for its sub-batch
+            double R[9], t[3];
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[i] = Rt[(size_t)(b0 + g) * 12 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) t[i] = Rt[(size_t)(b0 + g) * 12 + 9 + i];
+            float* lst = lists + ((size_t)(b0 + g) * nchunks + kc) * max_inl * 6;
+            int count = s_count[wave][g];
+#pragma unroll
+            for (int s = 0; s < WALK_AHEAD; s++) {
+                if (m[s] == 0ull) continue;
+                const bool inl = dm::residual_f(R, t, K, cur.c[s].x, cur.c[s].y, cur.c[s].z, cur.w[s].x, cur.w[s].y, 100.0) < thr;
+                const unsigned long long mm = __ballot(inl);
+                if (mm) {
+                    const int slot = count + __popcll(mm & ((1ull << lane) - 1ull));
+                    if (inl && slot < max_inl) {
+                        float* e = lst + (size_t)slot * 6;
+                        e[0] = cur.c[s].x; e[1] = cur.c[s].y; e[2] = cur.c[s].z; e[3] = cur.c[s].w; e[4] = cur.w[s].x; e[5] = cur.w[s].y;
+                    }
+                    count += __popcll(mm);
+                }
+            }
+            count = __builtin_amdgcn_readfirstlane(count);
+            if (lane == 0) s_count[wave][g] = count;
+            if (count >= max_inl) act &= ~(1u << g);  // later inliers of this chunk cannot be among the first max_inl
+        }
+        cur = nxt;
+    }
+    if (lane == 0) {
+        for (int g = 0; g < G; g++)
+            if ((live >> g) & 1u) __hip_atomic_store(&cnt[(size_t)(b0 + g) * nchunks + kc], (tag << SCAN_CNT_BITS) | min(s_count[wave][g], max_inl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The LM half of a step: the first max_inl inliers in chunk order out of the scan's lists (a prefix over the chunk counts, then every list entry finds its chunk
+// by bisection), the selected cells' map counters, lm_pnp.
 __global__ __launch_bounds__(64) void k_refine_lm(int B, double* __restrict__ poses, int32_t* __restrict__ alive, int32_t* __restrict__ steps_done, int max_inl, int min_inl,
-                                                  FrameDev F, const int32_t* __restrict__ list_n, const float* __restrict__ list_X, const float* __restrict__ list_uv) {
+                                                  FrameDev F, const int32_t* __restrict__ cnt, int nchunks, int tag, const float* __restrict__ lists,
+                                                  int32_t* __restrict__ inlier_map, int map_stride, double* __restrict__ Rt, float* __restrict__ rec) {
     const int b = blockIdx.x;
     if (b >= B || !alive[b]) return;
     __builtin_amdgcn_s_setprio(3);
@@ -708,10 +877,36 @@ __global__ __launch_bounds__(64) void k_refine_lm(int B, double* __restrict__ po
     __shared__ float s_X[RF_MAX_INL * 3];
     __shared__ float s_uv[RF_MAX_INL * 2];
     __shared__ double s_red[32];
-    const int n = min(list_n[b], max_inl);
+    __shared__ int s_start[SCAN_MAX_CHUNKS];
+    int run = 0, used = 0;
+    for (int j0 = 0; j0 < nchunks && run < max_inl; j0 += 64) {
+        const int j = j0 + lane;
+        const int w = j < nchunks ? cnt[(size_t)b * nchunks + j] : 0;
+        const int c = ((w >> SCAN_CNT_BITS) == tag) ? (w & ((1 << SCAN_CNT_BITS) - 1)) : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (j < nchunks) s_start[j] = run + incl - c;
+        run += __builtin_amdgcn_readlane(incl, 63);
+        used = min(j0 + 64, nchunks);
+    }
+    wave_sync_lds();
+    const int n = min(run, max_inl);
+    for (int e = lane; e < n; e += 64) {
+        int lo = 0, hi = used - 1;  // the last chunk whose first entry is at or before e (empty chunks share their successor's start and lose to it)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_start[mid] <= e) lo = mid; else hi = mid - 1;
+        }
+        const float* r = lists + (((size_t)b * nchunks + lo) * max_inl + (e - s_start[lo])) * 6;
+        s_X[e * 3] = r[0]; s_X[e * 3 + 1] = r[1]; s_X[e * 3 + 2] = r[2];
+        s_uv[e * 2] = r[4]; s_uv[e * 2 + 1] = r[5];
+        if (inlier_map && (map_stride > 0 || b == 0)) atomicAdd(&inlier_map[(size_t)b * map_stride + __float_as_int(r[3])], 1);
+    }
     if (n < min_inl) { if (lane == 0) alive[b] = 0; return; }  // abort for stability: too few inliers (core/cnn_softam.h:700, 1136)
-    for (int i = lane; i < n * 3; i += 64) s_X[i] = list_X[(size_t)b * RF_MAX_INL * 3 + i];
-    for (int i = lane; i < n * 2; i += 64) s_uv[i] = list_uv[(size_t)b * RF_MAX_INL * 2 + i];
     wave_sync_lds();
     const dm::Cam K = make_cam_r(F);
     double upd[6];
@@ -723,46 +918,110 @@ __global__ __launch_bounds__(64) void k_refine_lm(int B, double* __restrict__ po
     bool nan = false;
 #pragma unroll
     for (int i = 0; i < 6; i++) nan = nan || (upd[i] != upd[i]);
+    rod_at(rc, upd);  // the next step's scan reads the pose as a record
     if (lane == 0) {
         if (nan) alive[b] = 0;
         else {
 #pragma unroll
             for (int i = 0; i < 6; i++) poses[(size_t)b * 6 + i] = upd[i];
             steps_done[b] += 1;
+            write_scan_record(upd, rc.R, K, Rt + (size_t)b * 12, rec + (size_t)b * SCAN_REC);
         }
     }
 }
 
-__global__ void k_refine_split_init(int B, const double* __restrict__ init_poses, double* __restrict__ out_poses, int32_t* __restrict__ alive, int32_t* __restrict__ steps_done) {
+__global__ void k_refine_split_init(int B, int Bp, FrameDev F, const double* __restrict__ init_poses, double* __restrict__ out_poses, int32_t* __restrict__ alive,
+                                    int32_t* __restrict__ steps_done, double* __restrict__ Rt, float* __restrict__ rec) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    for (int i = 0; i < 6; i++) out_poses[(size_t)b * 6 + i] = init_poses[(size_t)b * 6 + i];
+    if (b >= Bp) return;
+    if (b >= B) {  // padding up to a whole group of the scan
+        alive[b] = 0;
+        for (int i = 0; i < SCAN_REC; i++) rec[(size_t)b * SCAN_REC + i] = 0.f;
+        return;
+    }
+    const dm::Cam K = make_cam_r(F);
+    double pose[6];
+    for (int i = 0; i < 6; i++) { pose[i] = init_poses[(size_t)b * 6 + i]; out_poses[(size_t)b * 6 + i] = pose[i]; }
     alive[b] = 1;
     steps_done[b] = 0;
+    RodCache rc;
+    rod_at(rc, pose);
+    write_scan_record(pose, rc.R, K, Rt + (size_t)b * 12, rec + (size_t)b * SCAN_REC);
 }
 
-size_t refine_split_scratch_bytes(int B) { return (size_t)B * (4 + 4 + 4 + RF_MAX_INL * 5 * 4) + 64; }
-bool refine_split_applies(int B, const FrameDev& F, const int32_t* pert_px_c, const double* loss_out4, int waves_per_problem) {
-    return waves_per_problem == 0 && B >= 32 && F.P >= 16384 && !pert_px_c && !loss_out4;
+static int g_scan_tune = 0;  // A/B ("k6_scan_tune"): bits 0-7 problems per wave (1, 2, 4; 0 = by the problem count), bits 8-23 chunk cells (multiple of 256; 0 = auto), bit 24: no skip check
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// chunk of the scan: 2 048 cells (eight reads of 256), smaller on maps that would not give the chip 8 192 waves otherwise
+static int scan_chunk_cells(int B, int P) {
+    int c = 2048;
+    if ((g_scan_tune >> 8) & 0xffff) return (g_scan_tune >> 8) & 0xffff;
+    while (c > 256 && (long long)((P + c - 1) / c) * B < 8192) c >>= 1;  // one wave per chunk and problem
+    return c;
 }
-// scratch: refine_split_scratch_bytes(B) of device memory; steps_done may be null (a slice of the scratch is used then)
+// experiments: bits 0-7 problems per wave (1, 2, 4), bits 8-23 chunk cells, bit 24: no skip check  ("k6_scan_tune")
+void refine_scan_tune(int v) { g_scan_tune = v; }
+// problems per wave: one up to 256 problems (19 200 light waves on a 640 x 480 map: 128 problems 36 us per step against 44 / 60 with two / four), four from
+// 512 problems of frames that hold a multiple of four (the cells then cross L2 -> L1 once per four problems: 16 frames x 128 3.20 -> 2.65 ms)
+static int scan_group(int B, int per_frame) {
+    if (g_scan_tune & 255) {
+        const int g = g_scan_tune & 255;
+        return (per_frame == 0 || per_frame % g == 0) ? g : 1;
+    }
+    if (B < 512) return 1;
+    return (per_frame == 0 || per_frame % 4 == 0) ? 4 : (per_frame % 2 == 0 ? 2 : 1);
+}
+static size_t scan_bounds_bytes(int frames) { return (size_t)max(frames, 1) * SCAN_BOUND_SLOTS * SCAN_BOUND_STRIDE * 4; }
+size_t refine_split_scratch_bytes(int B, int steps, int frames, int P, int max_inl) {
+    const int nchunks = (P + scan_chunk_cells(B, P) - 1) / scan_chunk_cells(B, P);
+    const size_t Bp = (size_t)(B + 3) / 4 * 4, P256 = (size_t)(P + 255) / 256 * 256;
+    return align256(Bp * 12) + align256(Bp * (12 * 8 + SCAN_REC * 4)) + align256(Bp * nchunks * 4) + scan_bounds_bytes(frames) + align256(Bp * nchunks * (size_t)max_inl * 24) +
+           (size_t)max(frames, 1) * max(steps, 1) * P256 * (16 + 8) + 512;
+}
+bool refine_split_applies(int B, const FrameDev& F, const int32_t* pert_px_c, const double* loss_out4, int waves_per_problem) {
+    return waves_per_problem == 0 && B >= 32 && F.P >= 16384 && (F.P + 255) / 256 <= SCAN_MAX_CHUNKS && !pert_px_c && !loss_out4;
+}
+// scratch: refine_split_scratch_bytes(B, steps, frames, P, max_inl) of device memory (frames = B / per_frame, 1 when per_frame is 0); steps_done may be null (a
+// slice of the scratch is used then)
 hipError_t refine_split(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const FrameDev& F,
-                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch) {
+                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch, int exact_only) {
     if (B <= 0) return hipSuccess;
-    if (max_inl > RF_MAX_INL) return hipErrorInvalidValue;
+    if (max_inl > RF_MAX_INL || max_inl >= (1 << SCAN_CNT_BITS) || steps >= (1 << (30 - SCAN_CNT_BITS))) return hipErrorInvalidValue;
+    const int frames = per_frame > 0 ? B / per_frame : 1;
+    const int chunk = scan_chunk_cells(B, F.P), nchunks = (F.P + chunk - 1) / chunk;
+    if (nchunks > SCAN_MAX_CHUNKS) return hipErrorInvalidValue;
+    const size_t Bp = (size_t)(B + 3) / 4 * 4;
     char* p = reinterpret_cast<char*>(scratch);
-    int32_t* alive = reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
-    int32_t* list_n = reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
-    int32_t* sd = steps_done ? steps_done : reinterpret_cast<int32_t*>(p); p += (size_t)B * 4;
-    float* list_X = reinterpret_cast<float*>(p); p += (size_t)B * RF_MAX_INL * 3 * 4;
-    float* list_uv = reinterpret_cast<float*>(p);
-    hipLaunchKernelGGL(k_refine_split_init, dim3((B + 255) / 256), dim3(256), 0, st, B, init_poses, out_poses, alive, sd);
-    const int S = B <= 128 ? 16 : 8;  // 2 048 light waves: two per SIMD
+    int32_t* alive = reinterpret_cast<int32_t*>(p);
+    int32_t* sd = steps_done ? steps_done : alive + Bp;
+    p += align256(Bp * 12);
+    double* Rt = reinterpret_cast<double*>(p);
+    float* rec = reinterpret_cast<float*>(p + Bp * 12 * 8);
+    p += align256(Bp * (12 * 8 + SCAN_REC * 4));
+    int32_t* cnt = reinterpret_cast<int32_t*>(p);
+    int32_t* bounds = cnt + align256(Bp * nchunks * 4) / 4;  // [frames][64 slots][32 words], cleared with the chunk words
+    p += align256(Bp * nchunks * 4) + scan_bounds_bytes(frames);
+    float* lists = reinterpret_cast<float*>(p); p += align256(Bp * nchunks * (size_t)max_inl * 24);
+    const int P256 = (F.P + 255) / 256 * 256;
+    float4* cells = reinterpret_cast<float4*>(p); p += (size_t)frames * max(steps, 1) * P256 * 16;
+    float2* uvs = reinterpret_cast<float2*>(p);
+    hipLaunchKernelGGL(k_refine_split_init, dim3(((int)Bp + 63) / 64), dim3(64), 0, st, B, (int)Bp, F, init_poses, out_poses, alive, sd, Rt, rec);
+    if (steps <= 0) return hipGetLastError();
+    hipError_t e = hipMemsetAsync(cnt, 0, align256(Bp * nchunks * 4) + scan_bounds_bytes(frames), st);  // chunk words carry the step's tag (step + 1): none is current
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_refine_permute, dim3(P256 / 256, steps, frames), dim3(256), 0, st, steps, P256, F, perm, cells, uvs, bounds);
+    const long long frame_stride = (long long)steps * P256;
+    const int G = scan_group(B, per_frame);
+    const dim3 grid((B + G - 1) / G, (nchunks + SCAN_WAVES - 1) / SCAN_WAVES);
     for (int step = 0; step < steps; step++) {
-        const int32_t* pidx = perm + (size_t)step * F.P;
-        if (S == 16) hipLaunchKernelGGL((k_refine_walk<16>), dim3(B), dim3(1024), 0, st, B, out_poses, alive, pidx, max_inl, thr, F, inlier_map, map_stride, per_frame, list_n, list_X, list_uv);
-        else hipLaunchKernelGGL((k_refine_walk<8>), dim3(B), dim3(512), 0, st, B, out_poses, alive, pidx, max_inl, thr, F, inlier_map, map_stride, per_frame, list_n, list_X, list_uv);
-        hipLaunchKernelGGL(k_refine_lm, dim3(B), dim3(64), 0, st, B, out_poses, alive, sd, max_inl, min_inl, F, list_n, list_X, list_uv);
+        const float4* cs = cells + (size_t)step * P256;
+        const float2* us = uvs + (size_t)step * P256;
+        const int tag = step + 1;
+#define WALK_ARGS B, Rt, rec, alive, cs, us, frame_stride, chunk, nchunks, P256, tag, max_inl, thr, F, per_frame, cnt, lists, bounds, exact_only, (g_scan_tune >> 24) & 1
+        if (G == 4) hipLaunchKernelGGL((k_refine_walk<4>), grid, dim3(64 * SCAN_WAVES), 0, st, WALK_ARGS);
+        else if (G == 2) hipLaunchKernelGGL((k_refine_walk<2>), grid, dim3(64 * SCAN_WAVES), 0, st, WALK_ARGS);
+        else hipLaunchKernelGGL((k_refine_walk<1>), grid, dim3(64 * SCAN_WAVES), 0, st, WALK_ARGS);
+#undef WALK_ARGS
+        hipLaunchKernelGGL(k_refine_lm, dim3(B), dim3(64), 0, st, B, out_poses, alive, sd, max_inl, min_inl, F, cnt, nchunks, tag, lists, inlier_map, map_stride, Rt, rec);
     }
     return hipGetLastError();
 }

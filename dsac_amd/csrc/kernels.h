@@ -157,10 +157,12 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
                   int waves_per_problem = 0);
 // many problems with long walks (the DSAC variant on big maps): a refinement step as two launches, walk (8 / 16 light waves per problem) + LM (k_refine.hip); the
 // same results bit for bit.  refine_split_applies: >= 32 problems, >= 16 384 cells, no perturbation, no fused loss, "k6_waves" 0
-size_t refine_split_scratch_bytes(int B);
+size_t refine_split_scratch_bytes(int B, int steps, int frames, int P, int max_inl);
+void refine_scan_tune(int v);  // experiments ("k6_scan_tune")
 bool refine_split_applies(int B, const FrameDev& F, const int32_t* pert_px_c, const double* loss_out4, int waves_per_problem);
 hipError_t refine_split(hipStream_t st, int B, const double* init_poses, const int32_t* perm, int steps, int max_inl, int min_inl, float thr, const FrameDev& F,
-                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch);
+                        double* out_poses, int32_t* inlier_map, int32_t* steps_done, int map_stride, int per_frame, void* scratch, int exact_only = 0);
+// exact_only ("k6_walk_exact"): the walk's fp32 filter off -- every cell by the fp64 residual (A/B; the decisions are the same)
 // waves_per_problem: 0 = by the problem count (1 for a single problem, 4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8 = fixed ("k6_waves"); the same results bit for bit
 // loss_gt_jp6 (B x 6) / loss_out4 (B x 4): maxLoss of every refined pose against its ground truth in the same launch (K7's arithmetic, loss_math.h)
 // inlier_maps[h][set cell] = 0 for the 4 cells of every hypothesis' minimal set (core/cnn.h:1208-1214)

@@ -114,6 +114,11 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 it applies and falls back to the fp32 matrix-core forms where it does not -- the library's default K2 holds every stated tolerance; 0: the
  *                 fp32 forms of rounds 2-5 (DSAC_K2_EXACT_AUTO in the environment of dsac_create)
  *   "k2_diag"     diagnostic switches of the precise form (bit 25): degrade ONE step at a time towards the fast forms' arithmetic (scripts/r06_k2_diag.py)
+ *   "k6_walk_exact" 1: the scan of the two-launch refinement step (k_refine_walk, >= 32 problems on >= 16 384 cells) decides every cell by the reference's fp64
+ *                 residual; 0 (default): an fp32 test with a proven error bound discards the cells that are certainly no inliers, the fp64 residual decides the
+ *                 rest -- the same decisions bit for bit (A/B switch; tests/test_gpu_refine.py builds a map against the test)
+ *   "k6_scan_tune" A/B of that scan, process-wide: problems per wave (0 = by the problem count, 1, 2, 4) | chunk cells << 8 (0 = auto, a multiple of 256) |
+ *                 1 << 24 to switch the skip of chunks behind max_inl finished inliers off.  Results never depend on it
  *   "k6_waves"    waves per refinement problem of K6's inlier walk: 0 (default) = by the problem count (1 for a single problem -- the four-wave build costs the good-pose refinement of one image 2.6 us --, 4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8
  *                 fixed.  Wave 0 runs the problem as before; when the first 256 cells of a step's permutation do not give max_inl inliers the walk goes on in
  *                 rounds of waves x 256 cells (counts meet in LDS, every wave compacts behind the inliers in front of its cells): the same list, inlier maps, step

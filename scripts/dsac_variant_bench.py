@@ -6,6 +6,7 @@ import dsac_amd
 from dsac_amd import synth
 fr = synth.chess_like_frame(40, 40, seed=1305, quantise_int16=True)
 eng = dsac_amd.Engine(0)
+if os.environ.get("DSAC_K6_SCAN_TUNE"): eng.set_option("k6_scan_tune", int(os.environ["DSAC_K6_SCAN_TUNE"], 0))  # experiments on the scan (k_refine.hip)
 eng.set_frame(fr["xyz"], fr["uv"], 40, 40, fr["cam"])
 perm = synth.fast_permutations(1600, 8)
 R = synth.rodrigues(fr["gt_pose"][:3]); F = np.diag([1.0, -1.0, -1.0]); Rj = F @ R; tj = F @ fr["gt_pose"][3:]

@@ -16,6 +16,7 @@ for (H, W, outl, B, spread, what) in ((480, 640, 0.3, 1, 0.0, "one problem, good
                                       (480, 640, 0.95, 16, 0.0, "16 problems, 5 % inliers"),
                                       (40, 40, 0.3, 256, 1.0, "256 problems, random poses"), (480, 640, 0.3, 128, 1.0, "128 problems, random poses"),
                                       (40, 40, 0.3, 4096, 1.0, "4096 problems, random poses")):
+    if os.environ.get("DSAC_K6_CASE") and os.environ["DSAC_K6_CASE"] not in what: continue
     P = H * W
     fr = synth.chess_like_frame(H, W, seed=1305, quantise_int16=(H == 40), outlier_frac=outl)
     xyz = torch.from_numpy(fr["xyz"]).to(dev)
@@ -29,7 +30,9 @@ for (H, W, outl, B, spread, what) in ((480, 640, 0.3, 1, 0.0, "one problem, good
     def call():
         check(eng._ctx, lib.dsac_refine(eng._ctx, B, ptr(init_d), ptr(perm), 8, 100, 50, 10.0, None, None, ptr(out), None, ptr(sd)))
     for waves in [int(v) for v in os.environ.get("DSAC_K6_WAVES", "0").split(",")]:  # round 6: waves per problem of the walk ("k6_waves": 0 = auto, 1, 2, 4, 8)
-        eng.set_option("k6_waves", waves)
+        eng.set_option("k6_waves", abs(waves) % 100)
+        eng.set_option("k6_walk_exact", 1 if waves == -100 else 0)
+        if os.environ.get("DSAC_K6_SCAN_TUNE"): eng.set_option("k6_scan_tune", int(os.environ["DSAC_K6_SCAN_TUNE"], 0))  # -100: auto with the walk's fp32 filter switched off (A/B)
         for i in range(3): call()
         eng.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

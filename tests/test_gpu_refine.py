@@ -182,8 +182,8 @@ def test_loss_and_gradient(engine, orc, synth):
 
 def test_many_long_walks_as_two_launches_per_step_equal_the_fused_kernel(engine, synth):
     """Round 6 (core/cnn.h:1154-1230: the DSAC variant refines EVERY hypothesis): from 32 problems on a map of >= 16 384 cells a refinement step runs as two
-    launches -- k_refine_walk (8 / 16 light waves per problem, the list of the first max_inl inliers in permutation order into HBM) and k_refine_lm (one wave
-    per problem) -- instead of the fused kernel whose LM registers allow four waves per problem at most.  Same arithmetic, same lists: refined poses, step
+    launches -- k_refine_walk (a scan of the step's permuted cells in chunks: every chunk's inliers in permutation order into HBM) and k_refine_lm (one wave
+    per problem: the first max_inl inliers in chunk order, then the LM solve) -- instead of the fused kernel.  Same arithmetic, same lists: refined poses, step
     counts and per-problem inlier maps are bit-identical to the fused kernel with one ("k6_waves" 1) and with four waves per problem."""
     H, W = 120, 160
     P = H * W
@@ -206,3 +206,73 @@ def test_many_long_walks_as_two_launches_per_step_equal_the_fused_kernel(engine,
     for waves in (1, 4):
         p, s, m = res[waves]
         assert np.array_equal(p0, p) and np.array_equal(s0, s) and np.array_equal(m0, m), "k6_waves %d" % waves
+    # the scan's shapes (results never depend on them): 1 / 2 / 4 problems per wave, chunks of 256 ... 4096 cells (one round ... a chunk longer than a wave's
+    # share of this map), the skip of chunks behind max_inl finished inliers off
+    try:
+        for tune in (1, 2, 4, 1 | 256 << 8, 4 | 256 << 8, 2 | 1024 << 8, 4 | 4096 << 8, 1 | 1 << 24, 4 | 512 << 8 | 1 << 24):
+            engine.set_option("k6_scan_tune", tune)
+            p, s, m = engine.refineAll(init, perm, max_inl=100, min_inl=50, thr=10.0, want_inlier_maps=True)
+            assert np.array_equal(p0, p) and np.array_equal(s0, s) and np.array_equal(m0, m), "k6_scan_tune %#x" % tune
+        with pytest.raises(Exception):
+            engine.set_option("k6_scan_tune", 3)
+        with pytest.raises(Exception):
+            engine.set_option("k6_scan_tune", 1 | 100 << 8)
+    finally:
+        engine.set_option("k6_scan_tune", 0)
+
+
+def test_the_walks_fp32_filter_never_changes_a_decision(engine, orc, synth):
+    """k_refine_walk discards a cell by an fp32 evaluation when that shows it further from the threshold than a proven error bound, and decides by the reference's fp64
+    arithmetic otherwise.  A map built AGAINST the filter: for each of 64 poses ~290 cells whose reprojection lands at thr (1 +- eps), eps from 0 to 1e-3 (the float
+    rounding of the coordinate scatters them a further ~1e-4 px to either side -- thousands of decisions within 1e-7 ... 1e-3 px of the threshold), and cells 1 um ...
+    1 mm from the camera plane, on it and behind it.  Poses, step counts and every problem's inlier map must equal the fused kernel's (one wave per problem, fp64
+    for every cell) and the walk with the filter switched off; four problems are also checked against the oracle's inlier maps."""
+    H, W = 128, 160
+    P = H * W
+    fx, fy, cx, cy = synth.CAM_7SCENES
+    rng = np.random.default_rng(2026)
+    B, per = 64, 300
+    uv = synth.pixel_grid(H, W, H, W).astype(np.float64)
+    xyz = np.zeros((P, 3), np.float32)
+    base = synth.chess_like_frame(H, W, seed=9, grid_uv=True)
+    poses = base["gt_pose"][None, :] + rng.normal(size=(B, 6)) * np.array([0.05, 0.05, 0.05, 60.0, 60.0, 60.0])
+    cells = rng.permutation(P)
+    thr = 10.0
+    n_close = 0
+    for b in range(B):
+        idx = cells[b * per:(b + 1) * per]
+        R, t = synth.rodrigues(poses[b, :3]), poses[b, 3:]
+        eps = rng.choice([0.0, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3], size=per) * rng.choice([-1.0, 1.0], size=per)
+        th = rng.uniform(0, 2 * np.pi, size=per)
+        depth = rng.uniform(300.0, 4000.0, size=per)
+        # the last 12 cells of every group: at, next to and behind the camera plane
+        depth[-12:] = np.array([0.0, 1e-3, -1e-3, 1e-2, 0.1, 1.0, -1.0, 1e-4, -1e-2, 3e-3, 0.5, -0.5])
+        u = uv[idx, 0] + thr * (1 + eps) * np.cos(th)
+        v = uv[idx, 1] + thr * (1 + eps) * np.sin(th)
+        Xc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], -1)
+        xyz[idx] = ((Xc - t) @ R).astype(np.float32)
+        e = orc.get_diff_maps(poses[b], xyz[idx], uv[idx].astype(np.float32), 1, per, synth.CAM_7SCENES)[0]
+        n_close += int((np.abs(e[:-12] - thr) < 1e-3).sum())
+    rest = cells[B * per:]
+    xyz[rest] = base["xyz"][rest]
+    assert n_close > 0.5 * B * (per - 12), n_close  # the construction works: most built cells are within 1e-3 px of the threshold in the reference's arithmetic
+    engine.set_frame(xyz, None, H, W, synth.CAM_7SCENES)
+    perm = synth.fast_permutations(P, 8, seed=77)
+    res = {}
+    try:
+        for name, waves, exact in (("walk", 0, 0), ("fused", 1, 0), ("walk-exact", 0, 1)):
+            engine.set_option("k6_waves", waves)
+            engine.set_option("k6_walk_exact", exact)
+            res[name] = engine.refineAll(poses, perm, max_inl=100, min_inl=50, thr=thr, want_inlier_maps=True)
+    finally:
+        engine.set_option("k6_waves", 0)
+        engine.set_option("k6_walk_exact", 0)
+    p0, s0, m0 = res["walk"]
+    assert int(m0.sum()) > 0
+    for name in ("fused", "walk-exact"):
+        p, s, m = res[name]
+        assert np.array_equal(s0, s) and np.array_equal(m0, m) and np.array_equal(p0, p), name
+    uvf = uv.astype(np.float32)
+    for b in (0, 21, 42, 63):
+        _, imap_r, sd_r = orc.refine(poses[b], perm, xyz, uvf, H, W, synth.CAM_7SCENES, want_inlier_map=True, inlier_count=100, min_inliers=50)
+        assert sd_r[0] == s0[b] and np.array_equal(np.asarray(imap_r).reshape(-1), m0[b].reshape(-1)), b
