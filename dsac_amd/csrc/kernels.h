@@ -155,7 +155,7 @@ hipError_t refine(hipStream_t st, int B, const double* init_poses, const int32_t
                   const int32_t* pert_px_c, const float* pert_value, const FrameDev& F, double* out_poses, int32_t* inlier_map,
                   int32_t* steps_done, int map_stride = 0, int per_frame = 0, const double* loss_gt_jp6 = nullptr, double* loss_out4 = nullptr,
                   int waves_per_problem = 0);
-// many problems with long walks (the DSAC variant on big maps): a refinement step as two launches, walk (8 / 16 light waves per problem) + LM (k_refine.hip); the
+// many problems with long walks (the DSAC variant on big maps): a refinement step as two launches, a scan of the step's pre-permuted cells + LM (k_refine.hip); the
 // same results bit for bit.  refine_split_applies: >= 32 problems, >= 16 384 cells, no perturbation, no fused loss, "k6_waves" 0
 size_t refine_split_scratch_bytes(int B, int steps, int frames, int P, int max_inl);
 void refine_scan_tune(int v);  // experiments ("k6_scan_tune")
