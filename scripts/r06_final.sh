@@ -14,7 +14,8 @@ import json; d=json.loads(open('$O/bench_em8_rank$r.json').read()); s=d['strong'
 echo "== K2 only: configs[2] N=4096, both / err / soft"; for m in both err soft; do timeout 600 python bench.py --steps 30 --warmup 5 --hyps 4096 --kernel-only --no-cpu-baseline --streams 1 --k2-mode $m 2>>$O/bench.err | tail -1 | tee $O/bench_k2only_4096_$m.json | cut -c1-160; done
 echo "== C++ host programs"; ( cd $O && for b in 16 0; do $REPO/dsac_amd/host/test_ransac_softam -synth 64 -mw 640 -mh 480 -batch $b -passes 12 -warmup 300 2>&1 | grep -E "Timing|Avg|Median" ; done; $REPO/dsac_amd/host/test_ransac_softam -synth 16 -mw 640 -mh 480 -batch 0 -refstream 1 -passes 3 2>&1 | grep -E "Timing|Avg|reference random"; for s in 0 1; do $REPO/dsac_amd/host/train_ransac_softam -synth 32 -mw 640 -mh 480 -rI 256 -rounds 60 -batch 16 -gradstats 0 -warmup 300 -seam $s 2>&1 | grep Timing; done ) | tee $O/host_driver.txt
 echo "== K2 forms A/B"; DSAC_AB_MODES=fast,precise,exact DSAC_AB_ROUNDS=3 DSAC_AB_ROUNDS2=1 timeout 600 python scripts/r06_k2_exact_ab.py 2>&1 | grep -v amdgpu | tee $O/k2_exact_ab.txt | head -12
-echo "== K6 walk"; DSAC_K6_WAVES=1,4,0 timeout 600 python scripts/micro/k6_walk_bench.py 2>&1 | grep -v amdgpu | tee $O/k6_walk.txt | head -30
+echo "== K6 walk"; DSAC_K6_WAVES=1,4,0,-100 timeout 600 python scripts/micro/k6_walk_bench.py 2>&1 | grep -v amdgpu | tee $O/k6_walk.txt | head -40
+echo "== K6 scan: kernel trace"; MODES=0 timeout 400 bash scripts/micro/k6_walk_trace.sh | tee $O/k6_walk_trace.txt
 echo "== K4 stage"; timeout 600 python scripts/k4_bench.py 2>&1 | grep "K4 N" | tee $O/k4_stage.txt
 echo "== training geometry on frame batches"; timeout 900 python scripts/train_geometry_bench.py 2>&1 | grep "device-resident" | tee $O/train_geometry.txt
 echo "== DSAC variant on frame batches"; timeout 600 python scripts/dsac_variant_bench.py 2>&1 | grep "DSAC variant" | tee $O/dsac_variant.txt
