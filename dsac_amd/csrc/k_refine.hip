@@ -654,8 +654,16 @@ __global__ __launch_bounds__(256) void k_refine_permute(int steps, int P256, Fra
         const float X = xyz[(size_t)p * 3], Y = xyz[(size_t)p * 3 + 1], Z = xyz[(size_t)p * 3 + 2];
         cells[o] = make_float4(X, Y, Z, __int_as_float(p));
         uvs[o] = w;
-        m = fabsf(X) + fabsf(Y) + fabsf(Z);
-        dd = fabsf(w.x - F.cx) + fabsf(w.y - F.cy);
+        if (step == 0) {  // the bounds over the frame's cells themselves (cell i, not the permuted one): whatever the index lists hold is covered
+            m = fabsf(xyz[(size_t)i * 3]) + fabsf(xyz[(size_t)i * 3 + 1]) + fabsf(xyz[(size_t)i * 3 + 2]);
+            if (F.uv) {
+                const float* uv = F.uv + (long long)f * F.uv_stride;
+                dd = fabsf(uv[(size_t)i * 2] - F.cx) + fabsf(uv[(size_t)i * 2 + 1] - F.cy);
+            } else {
+                const int y = i / F.W;
+                dd = fabsf((float)(i - y * F.W) - F.cx) + fabsf((float)y - F.cy);
+            }
+        }
     } else {
         const float nan = __builtin_nanf("");
         cells[o] = make_float4(nan, nan, nan, __int_as_float(0));

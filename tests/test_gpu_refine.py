@@ -219,6 +219,17 @@ def test_many_long_walks_as_two_launches_per_step_equal_the_fused_kernel(engine,
             engine.set_option("k6_scan_tune", 1 | 100 << 8)
     finally:
         engine.set_option("k6_scan_tune", 0)
+    # index lists that are no permutations (duplicates, a part of the map only): the scan's frame bounds are taken over the frame's cells, not the lists
+    perm2 = ((perm.astype(np.int64) * 7) % (P // 3)).astype(np.int32)
+    try:
+        res2 = {}
+        for waves in (0, 1):
+            engine.set_option("k6_waves", waves)
+            res2[waves] = engine.refineAll(init, perm2, max_inl=100, min_inl=50, thr=10.0, want_inlier_maps=True)
+    finally:
+        engine.set_option("k6_waves", 0)
+    for a, b in zip(res2[0], res2[1]):
+        assert np.array_equal(a, b)
 
 
 def test_the_walks_fp32_filter_never_changes_a_decision(engine, orc, synth):
