@@ -1448,7 +1448,8 @@ def main(argv=None):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("N") == N * B and tj.get("P") == P and tj.get("frames", 1) == B:
+                # the counters of THIS launch shape and of the K2 form that is timed (files from before round 6 carry no form: the fp32 one)
+                if tj.get("N") == N * B and tj.get("P") == P and tj.get("frames", 1) == B and tj.get("form", "fast") == args.k2_form:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -466,6 +466,7 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
         const f4 hx = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hx, b4, z4, 0, 0, 0);
         const f4 hy = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hy, b4, z4, 0, 0, 0);
         const f4 hz = __builtin_amdgcn_mfma_f32_16x16x16f16(A.hz, b4, z4, 0, 0, 0);
+        f2 iz0 = splat(0.f);
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) {
             const f2 x = ex_combine(pr ? f2{cx.z, cx.w} : f2{cx.x, cx.y}, k10, pr ? f2{hx.z, hx.w} : f2{hx.x, hx.y});
@@ -476,8 +477,10 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
             if (EXACT_Z) {  // projectPoints: z = Z ? 1/Z : 1
                 iz.x = (z.x == 0.0f) ? 1.0f : iz.x;
                 iz.y = (z.y == 0.0f) ? 1.0f : iz.y;
+            } else if (pr == 0) {
+                iz0 = iz;
             } else {
-                zacc = pk_fma(iz, iz, zacc);
+                zacc = pk_fma(iz0, iz, zacc);  // one fma for both register pairs of an m: a NaN or an inf in either survives the product (inf x 0 = NaN)
             }
             const f2 du = pk_fma(x, iz, splat(ppix[m].x));
             const f2 dv = pk_fma(y, iz, splat(ppix[m].y));
@@ -496,7 +499,7 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
         ev[r].w = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[3][pr].y : qq[3][pr].x), clampv);
         if (SOFT) sloc[r] = soft_inlier2(f2{ev[r].x, ev[r].y}, kA, kB) + soft_inlier2(f2{ev[r].z, ev[r].w}, kA, kB);
     }
-    return EXACT_Z ? false : !(zacc.x + zacc.y <= 3.0e38f);
+    return EXACT_Z ? false : !(fabsf(zacc.x + zacc.y) <= 3.0e38f);  // products of two reciprocals: -inf counts as well
 }
 
 // The B operand of hp_chunk_ex for one (chunk, m): lane (g, c) holds coordinate g of pixel 4c + m (g = 3: the constants the translation pieces multiply).
@@ -899,15 +902,18 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
                 for (int r = 0; r < 4; r++) ssum[r] = pk_fma(sloc[r], vf, ssum[r]);
             }
             if (ERR && valid[ch]) {
-                f4* dst = reinterpret_cast<f4*>(err + (size_t)(h0 + hyp0) * P + p0[ch]);
-                const size_t rs = (size_t)P / 4;
+                // buffer store: the address is a wave-uniform row base in a scalar resource (the tile's first hypothesis of this group) + a scalar row offset +
+                // a 32-bit lane offset (the lane's hypothesis quarter and pixel).  A global store's 64-bit vector address cost one vector instruction per store
+                // (v_lshl_add_u64), 16 per 1 024 pairs of a kernel that is bound by vector issue; this form steps the rows on the scalar unit
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(err + (size_t)(h0 + 16 * gi) * P, 0, 0xffffffffu, 0x00020000);
+                const unsigned loff = ((unsigned)(4 * g) * (unsigned)P + (unsigned)p0[ch]) * 4u;
                 if (nh == HT) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                    for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, ev[r]), rsrc, loff, (unsigned)r * (unsigned)P * 4u, 2);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        if (hyp0 + r < nh) __builtin_nontemporal_store(ev[r], dst + r * rs);
+                        if (hyp0 + r < nh) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, ev[r]), rsrc, loff, (unsigned)r * (unsigned)P * 4u, 2);
                 }
             }
             if (ERR && !SOFT) {

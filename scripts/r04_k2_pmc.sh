@@ -26,10 +26,13 @@ for line in open(sys.argv[1]):
     m = re.match(r"(WRITE_SIZE|FETCH_SIZE) (.+) n=(\d+) mean=([0-9.e+-]+)", line.strip())
     if m:
         rows.setdefault(m.group(2), {})[m.group(1)] = (float(m.group(4)), int(m.group(3)))
-# the step's launch = the instantiation that writes error images AND sums (ERR = SOFT = true): the one with the largest WRITE_SIZE
-name = max(rows, key=lambda k: rows[k].get("WRITE_SIZE", (0, 0))[0])
+# the step's launch = the instantiation that writes error images AND sums (ERR = SOFT = true) and runs in every timed step: of the kernels that write a whole
+# launch's error images, the one launched most often (since round 6 the line also times the other K2 forms a few times each)
+big = [k for k in rows if rows[k].get("WRITE_SIZE", (0, 0))[0] > 1e6 and "FETCH_SIZE" in rows[k]]
+name = max(big, key=lambda k: rows[k]["WRITE_SIZE"][1])
 w, f = rows[name]["WRITE_SIZE"][0], rows[name]["FETCH_SIZE"][0]
-out = {"N": 4096, "frames": 16, "P": 307200, "kernel": name, "WRITE_SIZE_KB": w, "FETCH_SIZE_KB_raw": f,
+form = "fast" if re.search(r", 0>$", name.strip()) else "exact"  # last template argument of k_reproject_st: 0 = fp32 transform, 1 / 2 = exact transform
+out = {"N": 4096, "frames": 16, "P": 307200, "kernel": name, "form": form, "WRITE_SIZE_KB": w, "FETCH_SIZE_KB_raw": f,
        "hbm_bytes_per_launch": int(round((w + 2.0 * f) * 1024.0)), "launches_averaged": rows[name]["WRITE_SIZE"][1],
        "note": "separate rocprofv3 --pmc passes for WRITE_SIZE and FETCH_SIZE of `bench.py --steps 6 --warmup 2` (16 frames x 256 hypotheses per launch), "
                "--kernel-trace only; KB = 1024 B; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section)",
