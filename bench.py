@@ -48,7 +48,7 @@ K2_TOLERANCES = {
     "fast": {"what": "fp32 pose records, exact-fp32 matrix-core transform (v_mfma_f32_16x16x4_f32), fp32 tail",
              "all_cells_max_px": 4.2e-3, "cells_above_1e-3_px": "3 of 78.6 M (within ~100 mm of a camera centre)", "near_tie_weight_error": 4.4e-3},
     "exact": {"what": "pose records and coordinates as fp16 fixed-point pieces, two fp16 matrix-core accumulations per row (one exact), the camera-frame point "
-                      "rounded to float once, Newton-polished reciprocal, fp32 tail",
+                      "rounded to float once, the distance as n rsq(n z^2) with n = (pu z - x)^2 + (pv z - y)^2 (one transcendental, none biased per hypothesis), fp32 sigmoid and sums",
               "all_cells_max_px": 5.7e-4, "cells_above_1e-3_px": "0", "near_tie_weight_error": 8.3e-5},
     "precise": {"what": "fp64 records, fp64 transform and perspective division on the vector ALU, one rounding per image-plane difference",
                 "all_cells_max_px": 4.6e-5, "cells_above_1e-3_px": "0", "near_tie_weight_error": 4.5e-5},

@@ -451,10 +451,17 @@ struct ExOps { h8 cx, cy, cz; h4 hx, hy, hz; };
 // E = D_hi + 2^-14 D_cross on a register pair of the two accumulators.  (Spelled out as inline assembly -- the compiler emits half of these as two
 // v_fma_f32 each -- it returned garbage: the hazard recogniser does not see an asm statement's read of a matrix-core result, and gfx950 has no interlock there.)
 DM_INLINE f2 ex_combine(f2 c, f2 k, f2 h) { return pk_fma(c, k, h); }
-template <bool EXACT_Z, bool SOFT, bool FENCE = false>
+// RSQ (EXF = 2): the tail without the reciprocal of z.  With nu = pu z - xc, nv = pv z - yc (one fma each on the once-rounded point):
+//   e = sqrt(nu^2 + nv^2) / |z| = n rsq(n z^2),  n = nu^2 + nv^2
+// -- ONE transcendental for reciprocal, Newton step and square root (3 instead of 4 per pair with the sigmoid's two; transcendentals are a third of the
+// kernel's issue cycles).  v_rsq_f32's error does not bias a hypothesis against another the way v_rcp_f32's did: its argument n z^2 spreads over many octaves
+// within every hypothesis (the reciprocal's argument z sits within two), so what is systematic in it is common to all.  z == 0 (and an exactly zero residual):
+// the argument is 0, rsq = inf, which sticks in the accumulated products and sends the chunk down the exact-z path as before.
+template <bool EXACT_Z, bool SOFT, bool RSQ = false>
 DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4], float clampv, float kA, float kB, f4 (&ev)[4], f2 (&sloc)[4]) {
     const f4 z4 = {0.f, 0.f, 0.f, 0.f};
     const f2 k10 = splat(6.103515625e-05f);  // 2^-14: the cross group's scale
+    constexpr bool TAIL_RSQ = RSQ && !EXACT_Z;
     f2 qq[4][2];
     f2 zacc = splat(0.f);
 #pragma unroll
@@ -472,6 +479,15 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
             const f2 x = ex_combine(pr ? f2{cx.z, cx.w} : f2{cx.x, cx.y}, k10, pr ? f2{hx.z, hx.w} : f2{hx.x, hx.y});
             const f2 y = ex_combine(pr ? f2{cy.z, cy.w} : f2{cy.x, cy.y}, k10, pr ? f2{hy.z, hy.w} : f2{hy.x, hy.y});
             const f2 z = ex_combine(pr ? f2{cz.z, cz.w} : f2{cz.x, cz.y}, k10, pr ? f2{hz.z, hz.w} : f2{hz.x, hz.y});
+            if (TAIL_RSQ) {
+                const f2 nu = pk_fma(splat(ppix[m].x), z, x), nv = pk_fma(splat(ppix[m].y), z, y);  // x, y carry -xc, -yc
+                const f2 n = pk_fma(nv, nv, nu * nu);
+                const f2 arg = n * (z * z);
+                const f2 r = {__builtin_amdgcn_rsqf(arg.x), __builtin_amdgcn_rsqf(arg.y)};
+                if (pr == 0) iz0 = r; else zacc = pk_fma(iz0, r, zacc);
+                qq[m][pr] = n * r;  // the distance itself
+                continue;
+            }
             f2 iz = {__builtin_amdgcn_rcpf(z.x), __builtin_amdgcn_rcpf(z.y)};
             iz = pk_fma(pk_fma(-z, iz, splat(1.0f)), iz, iz);  // z == 0: inf -> NaN, which sticks in zacc like the inf of the plain form
             if (EXACT_Z) {  // projectPoints: z = Z ? 1/Z : 1
@@ -486,17 +502,16 @@ DM_INLINE bool hp_chunk_ex(const ExOps& A, const h8 (&B8)[4], const f2 (&ppix)[4
             const f2 dv = pk_fma(y, iz, splat(ppix[m].y));
             qq[m][pr] = pk_fma(dv, dv, du * du);
         }
-        // FENCE: nothing moves across the end of an m -- the six accumulators of one m are live at a time instead of up to twenty-four (register diet for
-        // three waves per SIMD, an A/B: k2_variant 85 / 86)
-        if (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int pr = r >> 1;
-        ev[r].x = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[0][pr].y : qq[0][pr].x), clampv);
-        ev[r].y = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[1][pr].y : qq[1][pr].x), clampv);
-        ev[r].z = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[2][pr].y : qq[2][pr].x), clampv);
-        ev[r].w = fminf(__builtin_amdgcn_sqrtf((r & 1) ? qq[3][pr].y : qq[3][pr].x), clampv);
+        const float q0 = (r & 1) ? qq[0][pr].y : qq[0][pr].x, q1 = (r & 1) ? qq[1][pr].y : qq[1][pr].x;
+        const float q2 = (r & 1) ? qq[2][pr].y : qq[2][pr].x, q3 = (r & 1) ? qq[3][pr].y : qq[3][pr].x;
+        ev[r].x = fminf(TAIL_RSQ ? q0 : __builtin_amdgcn_sqrtf(q0), clampv);
+        ev[r].y = fminf(TAIL_RSQ ? q1 : __builtin_amdgcn_sqrtf(q1), clampv);
+        ev[r].z = fminf(TAIL_RSQ ? q2 : __builtin_amdgcn_sqrtf(q2), clampv);
+        ev[r].w = fminf(TAIL_RSQ ? q3 : __builtin_amdgcn_sqrtf(q3), clampv);
         if (SOFT) sloc[r] = soft_inlier2(f2{ev[r].x, ev[r].y}, kA, kB) + soft_inlier2(f2{ev[r].z, ev[r].w}, kA, kB);
     }
     return EXACT_Z ? false : !(fabsf(zacc.x + zacc.y) <= 3.0e38f);  // products of two reciprocals: -inf counts as well
@@ -714,7 +729,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
                                                              long long uv_stride, const float* __restrict__ staged_lo = nullptr,
                                                              const void* __restrict__ split = nullptr) {
     constexpr int HT = 16 * NG;
-    constexpr bool EX = EXF != 0, FENCE = EXF == 2;  // EXF: 0 = fp32 transform, 1 = exact transform (split fp16 records), 2 = the same with a scheduling fence per m
+    constexpr bool EX = EXF != 0, RSQ = EXF == 2;  // EXF: 0 = fp32 transform, 1 = exact transform (split fp16 records), 2 = the same with the one-transcendental tail (hp_chunk_ex)
     const int b = blockIdx.x;
     int ht, pt;
     if (kflags & 32) { pt = b % PT; ht = b / PT; }  // plain pixel-minor order
@@ -887,7 +902,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_reproject_st(const float* 
 #pragma unroll
                     for (int m = 0; m < 4; m++) Bf[m] = (g < 3) ? xyz[(size_t)min(p0[ch] + m, P - 1) * 3 + g] : 1.0f;
                     (void)hp_chunk<true, SOFT, false>(-rec[0], -rec[4], rec[8], Bf, pp, clampv, kA, kB, ev, sloc);
-                } else if (__builtin_expect(__any(hp_chunk_ex<false, SOFT, FENCE>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
+                } else if (__builtin_expect(__any(hp_chunk_ex<false, SOFT, RSQ>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc)), 0)) {
                     (void)hp_chunk_ex<true, SOFT>(aex[gi], B8[ch], pp, clampv, kA, kB, ev, sloc);
                 }
             } else if (kflags & 2) {  // store schedule alone (measurement)
@@ -1325,7 +1340,7 @@ static hipError_t launch_reproject_prec(hipStream_t st, int N, const double* pos
 }
 
 bool reproject_variant_known(int v) {
-    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 84) || v == 89 || v == 93;
+    return v == -1 || (v >= 0 && v <= 3) || (v >= 10 && v <= 13) || (v >= 20 && v <= 27) || (v >= 40 && v <= 62) || (v >= 65 && v <= 77) || (v >= 80 && v <= 85) || v == 89 || (v >= 93 && v <= 95);
 }
 
 // the largest count of partial-sum rows over all forms: one row per 64-pixel wave chunk, and the per-wave-sum forms with several waves per workgroup write
@@ -1401,19 +1416,23 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
 #undef DSAC_LO
     }
     // the exact-transform form (k2_flags bit 28, round 6): the one-wave streaming forms with the split records; k2_variant 84 / 89 / 93 = its tile / occupancy trades
-    if (k2_wants_exact(opts) && opts.split && vec && (opts.variant < 0 || (opts.variant == 84 || opts.variant == 89 || opts.variant == 93))) {
+    if (k2_wants_exact(opts) && opts.split && vec && (opts.variant < 0 || (opts.variant == 84 || opts.variant == 85 || opts.variant == 89 || (opts.variant >= 93 && opts.variant <= 95)))) {
 #define DSAC_EX(NG_, CH_, MW_, F_) launch_reproject_st<NG_, CH_, 1, true, MW_, false, F_>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf | 32, evA, evB, nullptr, opts.split)
         switch (opts.variant) {
             // (85 .. 88: <64, 128 / 256> with a scheduling fence per m at three waves per SIMD, one / two / four waves per workgroup -- 44-480 B of scratch, 1.08-1.7 ms:
             //  measured and removed, profiles/r06_k2_exact_ab.txt)
+            case 85: return DSAC_EX(4, 4, 2, 2);      // 84 with the one-transcendental tail (A/B)
+            case 94: return DSAC_EX(4, 1, 3, 2);      // 93 with the one-transcendental tail (A/B)
             case 89: return DSAC_EX(2, 4, 2, 1);      // <32 hypotheses, 256 pixels>, 2 waves per SIMD
             case 93: return DSAC_EX(4, 1, 3, 1);      // <64, 64>, one-wave workgroups, 168 registers: 3 waves per SIMD
             // (90 .. 92: <64, 4 waves x 64>, <64, 2 x 128> at two / three waves per SIMD: 1 098-1 206 us at the bench shape, 67.5-77 us for one frame -- measured
             //  and removed, profiles/r06_k2_exact_tiles.txt)
-            case -1:  // auto: one frame of 256 hypotheses 66.5 against 68.2 us with the small tile; the bench shape 1 048-1 059 against 1 101-1 107
-                if ((double)N * (double)F.P * 4.0 < 1.0e9) return DSAC_EX(4, 1, 3, 1);
-                return DSAC_EX(4, 4, 2, 1);
-            case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
+            case 95: return DSAC_EX(4, 1, 4, 2);      // 94 at four waves per SIMD (the one-transcendental tail needs 128 registers there)
+            case -1:  // auto: the one-transcendental tail (968-987 against 1 002-1 020 us at the bench shape, the same or smaller errors: profiles/r06_k2_rsq_ab.txt,
+                      // r06_k2_rsq_parity.txt); one frame of 256 hypotheses takes the small tile (66.5 against 68.2 us; the bench shape 1 048-1 059 against 1 101-1 107)
+                if ((double)N * (double)F.P * 4.0 < 1.0e9) return DSAC_EX(4, 1, 3, 2);
+                return DSAC_EX(4, 4, 2, 2);
+            case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD, reciprocal + Newton + square root (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
         }
 #undef DSAC_EX
     }
@@ -1482,7 +1501,7 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
         case 55: return DSAC_ST(4, 1, 4, true);
         case 56: return DSAC_ST(2, 4, 4, true);
         case 57: return DSAC_ST(4, 2, 4, true);
-        case 58: case 80: case 81: case 82: case 83: case 84: case 89: case 93:  // 84 / 89 / 93: the exact-transform forms when k2_flags bit 28 is set (above); 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
+        case 58: case 80: case 81: case 82: case 83: case 84: case 85: case 89: case 93: case 94: case 95:  // 84 / 89 / 93: the exact-transform forms when k2_flags bit 28 is set (above); 80..83: the two-piece-record forms when k2_flags bit 27 is set (above); without the flag the plain form
             return launch_reproject_st<4, 4, 1, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,1>, >= 4 waves per SIMD
         case 59: return launch_reproject_st<2, 4, 1, true, 5>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <2,4,1>, >= 5 waves per SIMD
         case 65: return launch_reproject_st<4, 4, 4, true, 4>(st, N, staged, F, clampv, err, kA, kB, soft_part, tiles_used, Nf, kf, evA, evB);  // <4,4,4> per-wave sums

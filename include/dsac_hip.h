@@ -104,12 +104,13 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *   "k2_order"    1 = pixel tiles innermost in K2's block order (default), 0 = hypothesis tiles innermost
  *   "k2_flags"    bit0: cached instead of non-temporal stores; bit1: store schedule only, no arithmetic (ceiling measurement); bits 2-4: cache policy of the error-image stores, 0 = nt (measurement: none of nt/plain/sc1/sc0 sc1/sc1 nt/sc0 differs by more than 1.5 %); bits 8-15: units of 8 KiB unused LDS per workgroup (occupancy cap, experiments); bits 16-19 / 20-23: error-images-only streaming forms idle for that many units of 64 / 16 clocks after a chunk's stores (pacing experiment); bit 24: error images only on a big launch do NOT take the fused kernel; bit 25 (0x2000000): PRECISE -- K2 projects as the reference does, in double (fp64 pose records from the cv poses, fp64 transform and perspective division, one rounding to float of each image-plane difference; core/cnn_softam.h:319-362): residuals within 2e-4 px of the oracle at 640 x 480 where the fp32 matrix-core forms reach 6e-4, softmax weights in a tie of unrelated hypotheses within the stated 1e-4; 15-25 % slower (profiles/r05_k2_precise_ab.txt), every call that launches K2 honours it; bit 27 (0x8000000): RECORDS IN TWO PIECES -- the fast matrix-core form with the low parts of the pose records carried through twelve fp16 matrix-core instructions per 1 024 pairs chained onto the fp32 ones: measured: 85 % of the fast form's score error gone (0.112 -> 0.017 on scores of 1.5e5; softmax weights in a tie of unrelated hypotheses 4.4e-3 -> 7.2e-4) for +16 % of K2's time (profiles/r05_k2_reclo_ab.txt) -- a middle mode that does NOT reach the stated 1e-4 in ties (bit 25 does); k2_variant 80..83 select its register / occupancy trades; bit 26 (with bit 25, diagnostic): the precise form with ONLY its pose records rounded to float -- isolates what the fp32 record costs (it is 96 % of the fast forms' score error)
  *                 bit 28 (0x10000000): EXACT TRANSFORM (round 6) -- E = R.X + t from fixed-point fp16 pieces of the pose records and of the coordinates on the fp16
- *                 matrix core (one accumulation per row exact, the other below a few millimetres), the camera-frame point rounded to float ONCE, the hardware
- *                 reciprocal polished by one Newton step: no cell above 1e-3 px over all cells of 256 x 640x480 (max 5.7e-4, mean 8.7e-6), softmax weights in a
- *                 tie of unrelated hypotheses within the stated 1e-4 (6.8e-5 .. 8.3e-5) at 1.19x the fast form's time (1 025-1 050 us = 0.61-0.62 of the HBM
- *                 peak at the bench shape, profiles/r06_k2_exact_ab.txt; the precise mode: 1.85x).  Needs a map the vector kernels can read and a focal length
+ *                 matrix core (one accumulation per row exact, the other below a few millimetres), the camera-frame point rounded to float ONCE, the distance
+ *                 without a reciprocal of z (whose hardware approximation biases one hypothesis against another): e = n rsq(n z^2), n = (pu z - x)^2 + (pv z - y)^2
+ *                 -- no cell above 1e-3 px over all cells of 256 x 640x480 (max 5.6e-4, mean 8.1e-6), softmax weights in a tie of unrelated hypotheses within
+ *                 the stated 1e-4 (5.5e-5 .. 8.3e-5) at 1.13-1.15x the fast form's time (970-1 005 us = 0.63-0.66 of the HBM peak at the bench shape,
+ *                 profiles/r06_k2_rsq_ab.txt; with reciprocal + Newton step + square root, k2_variant 84 / 93: 1 002-1 052; the precise mode: 1.85x).  Needs a map the vector kernels can read and a focal length
  *                 <= 1 024 px; coordinates beyond +-65.5 m take the fp32 transform chunk by chunk.  An arithmetic form that is ASKED for by bit 25 / 27 / 28 and
- *                 cannot run on the frame is an error (round 6), never a silent launch of another form.  k2_variant 84 / 87 / 89 are its tile trades.
+ *                 cannot run on the frame is an error (round 6), never a silent launch of another form.  k2_variant 84 / 85 / 89 / 93 / 94 / 95 are its tile and tail trades.
  *   "k2_exact_auto"  1 (default since round 6): the auto policy (k2_variant -1, none of the bits 1 / 25 / 26 / 27 set) launches the exact-transform form wherever
  *                 it applies and falls back to the fp32 matrix-core forms where it does not -- the library's default K2 holds every stated tolerance; 0: the
  *                 fp32 forms of rounds 2-5 (DSAC_K2_EXACT_AUTO in the environment of dsac_create)

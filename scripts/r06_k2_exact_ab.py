@@ -20,7 +20,8 @@ RECLO = 1 << 27
 EXACT = 1 << 28
 # (name, k2_flags, k2_variant, k2_exact_auto): since round 6 the auto policy takes the exact form, "fast" switches that off
 MODES = [("fast", 0, -1, 0), ("precise", PRECISE, -1, 1), ("reclo<64,256,2w>", RECLO, 81, 1), ("exact (auto policy)", 0, -1, 1), ("exact<64,256,2w>", EXACT, 84, 1),
-         ("exact<32,256,2w>", EXACT, 89, 1), ("exact<64,64,3w>", EXACT, 93, 1)]
+         ("exact<32,256,2w>", EXACT, 89, 1), ("exact<64,64,3w>", EXACT, 93, 1), ("exactrsq<64,256,2w> one-transcendental tail", EXACT, 85, 1),
+         ("exactrsq<64,64,3w> one-transcendental tail", EXACT, 94, 1), ("exactrsq<64,64,4w> one-transcendental tail", EXACT, 95, 1)]
 if os.environ.get("DSAC_AB_MODES"):
     MODES = [m for m in MODES if m[0].split("<")[0].split(" ")[0] in os.environ["DSAC_AB_MODES"].split(",")]
 

@@ -14,8 +14,9 @@ from dsac_amd import synth  # noqa: E402
 H, W = 480, 640
 P = H * W
 dev = torch.device("cuda", 0)
-MODES = [("fp32 forms, auto", 0, -1), ("exact <64,256> 1 wave/wg, 2w", 1, 84), ("exact <32,256>, 2w", 1, 89), ("exact <64, 4 x 64>, 2w", 1, 90), ("exact <64, 2 x 128>, 2w", 1, 91),
-         ("exact <64, 4 x 64>, 3w", 1, 92), ("exact <64, 64> 1 wave/wg, 3w", 1, 93)]
+# (90 .. 92, <64, 4 x 64> / <64, 2 x 128> with several waves per workgroup, were measured with this script and removed: profiles/r06_k2_exact_tiles.txt)
+MODES = [("fp32 forms, auto", 0, -1), ("exact, auto", 1, -1), ("exact <64,256> 1 wave/wg, 2w", 1, 84), ("exact <64,256>, 2w, one-transcendental tail", 1, 85), ("exact <32,256>, 2w", 1, 89),
+         ("exact <64, 64> 1 wave/wg, 3w", 1, 93), ("exact <64, 64>, 3w, one-transcendental tail", 1, 94), ("exact <64, 64>, 4w, one-transcendental tail", 1, 95)]
 
 
 def timed(eng, fn, reps=20):
@@ -52,7 +53,7 @@ def main():
                 eng.set_option("k2_flags", (1 << 28) if ex else 0)
                 eng.set_option("k2_variant", var)
                 us = timed(eng, lambda: eng.scoreHypothesesFrames(N, seed=7, max_tries=1 << 16, err=err, out=out), reps=20 if F == 1 else 10)
-                print("%2d frame(s) x 256 x 640x480, err + soft   %-34s %8.1f us   %6.0f GB/s" % (F, name, us, F * (12 * P + 48 * N + 4 * N * P + 4 * N) / us / 1e3), flush=True)
+                print("%2d frame(s) x 256 x 640x480, err + soft   %-46s %8.1f us   %6.0f GB/s" % (F, name, us, F * (12 * P + 48 * N + 4 * N * P + 4 * N) / us / 1e3), flush=True)
     eng.close()
 
 

@@ -207,3 +207,34 @@ def test_small_and_odd_shapes_and_far_coordinates(exact_engine, orc, synth):
     if m[:, ~near].any():
         margin("a3", "K2 EXACT form: the far band itself (fp32 transform at |X| ~ 100 m; its points project far outside the image), max |err - oracle| px",
                np.abs(err - ref)[:, ~near][m[:, ~near]].max(), 0.5)
+
+
+@pytest.mark.parametrize("variant", [84, 85, 89, 93, 94, 95])
+def test_every_exact_kernel_form_on_all_rows(exact_engine, orc, synth, variant):
+    """The selectable forms of the exact transform (k2_variant with k2_flags bit 28): tiles <64, 256> / <32, 256> / <64, 64>, the tail as reciprocal + Newton step +
+    square root (84, 89, 93) or as ONE transcendental, e = n rsq(n z^2) (85, 94, 95 -- the auto policy's since the end of round 6).  All rows of 64 hypotheses on a
+    640x480 frame with cells ON the camera plane of a hypothesis (z == 0: projectPoints' z = 1 rule, reached through the chunk's exact-z path) and a zero pose."""
+    eng = exact_engine
+    fr = synth.chess_like_frame(H, W, seed=77)
+    uv, cam = synth.pixel_grid(H, W), fr["cam"]
+    xyz = fr["xyz"].copy()
+    eng.set_frame(xyz, None, H, W, cam)
+    poses, sets, ok = eng.sample(64, seed=5, thr=10.0, max_tries=1 << 16)
+    poses[3] = 0.0  # the zero pose: camera frame = scene frame
+    xyz[1000:1064, 2] = 0.0  # ... so these cells have z == 0 for hypothesis 3
+    xyz[5000] = 0.0          # and this one is the camera centre itself
+    eng.set_frame(xyz, None, H, W, cam)
+    ref = orc.get_diff_maps(poses, xyz, uv, H, W, cam)
+    try:
+        eng.set_option("k2_variant", variant)
+        err, soft = np.zeros((64, P), np.float32), np.zeros(64)
+        eng.reproject(poses, err=err, soft=soft, tau=TAU, beta=BETA)
+    finally:
+        eng.set_option("k2_variant", -1)
+    m = excl_clamp_edge(err, ref, CLAMP)
+    d = np.abs(err - ref)
+    d[~m] = 0
+    assert d.max() <= 1e-3, "variant %d: %.3e" % (variant, d.max())
+    assert np.array_equal(err[3, 1000:1064] >= CLAMP - 1e-3, ref[3, 1000:1064] >= CLAMP - 1e-3)
+    soft_ref = orc.soft_inlier(ref, TAU, BETA)
+    assert np.abs(soft - soft_ref).max() <= 2e-7 * max(1.0, soft_ref.max())
