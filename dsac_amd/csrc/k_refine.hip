@@ -774,16 +774,16 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_refine_walk(int B, const do
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int b0 = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * G;
     const int kc = (int)blockIdx.y * SCAN_WAVES + wave;
+    const int f = per_frame > 0 ? b0 / per_frame : 0;
+    cells_step += (long long)f * frame_stride;
+    uvs_step += (long long)f * frame_stride;
+    const int cbase = min(kc, nchunks - 1) * chunk_cells, cend = min(cbase + chunk_cells, P256);
+    WalkRound cur, nxt;
+    load_walk_round(cells_step, uvs_step, cbase, lane, cur);  // the first round's cells are on their way while the records reach LDS
     __shared__ __attribute__((aligned(16))) float s_rec[G][SCAN_REC];
     if (threadIdx.x < G * SCAN_REC) s_rec[threadIdx.x / SCAN_REC][threadIdx.x % SCAN_REC] = rec[(size_t)b0 * SCAN_REC + threadIdx.x];  // records are padded to whole groups
     __syncthreads();
     if (kc >= nchunks) return;
-    const int f = per_frame > 0 ? b0 / per_frame : 0;
-    cells_step += (long long)f * frame_stride;
-    uvs_step += (long long)f * frame_stride;
-    const int cbase = kc * chunk_cells, cend = min(cbase + chunk_cells, P256);
-    WalkRound cur, nxt;
-    load_walk_round(cells_step, uvs_step, cbase, lane, cur);
     int mi = bounds[((size_t)f * SCAN_BOUND_SLOTS + lane) * SCAN_BOUND_STRIDE], di = bounds[((size_t)f * SCAN_BOUND_SLOTS + lane) * SCAN_BOUND_STRIDE + 1];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { mi = max(mi, __shfl_xor(mi, o)); di = max(di, __shfl_xor(di, o)); }
