@@ -1429,8 +1429,8 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
             //  and removed, profiles/r06_k2_exact_tiles.txt)
             case 95: return DSAC_EX(4, 1, 4, 2);      // 94 at four waves per SIMD (the one-transcendental tail needs 128 registers there)
             case -1:  // auto: the one-transcendental tail (968-987 against 1 002-1 020 us at the bench shape, the same or smaller errors: profiles/r06_k2_rsq_ab.txt,
-                      // r06_k2_rsq_parity.txt); one frame of 256 hypotheses takes the small tile (66.5 against 68.2 us; the bench shape 1 048-1 059 against 1 101-1 107)
-                if ((double)N * (double)F.P * 4.0 < 1.0e9) return DSAC_EX(4, 1, 3, 2);
+                      // r06_k2_rsq_parity.txt) on the <64, 256> tile at every size.  For one frame of 256 hypotheses the <64, 64> tile is 0.8 us faster by itself
+                      // (62.6 against 63.4) but leaves four times the partial-sum rows: k_reduce_soft 27.6 against 8.9 us (profiles/r06_one_image_trace.txt)
                 return DSAC_EX(4, 4, 2, 2);
             case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD, reciprocal + Newton + square root (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
         }
