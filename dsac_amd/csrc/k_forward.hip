@@ -1431,6 +1431,8 @@ hipError_t reproject(hipStream_t st, int N, const float* staged, const FrameDev&
             case -1:  // auto: the one-transcendental tail (968-987 against 1 002-1 020 us at the bench shape, the same or smaller errors: profiles/r06_k2_rsq_ab.txt,
                       // r06_k2_rsq_parity.txt) on the <64, 256> tile at every size.  For one frame of 256 hypotheses the <64, 64> tile is 0.8 us faster by itself
                       // (62.6 against 63.4) but leaves four times the partial-sum rows: k_reduce_soft 27.6 against 8.9 us (profiles/r06_one_image_trace.txt)
+                // small maps keep the small tile: a 40 x 40 map is 7 tiles of 256 pixels (one image per call 116 -> 127 us with them), and its partial sums are 25 rows
+                if (F.P <= 16384) return DSAC_EX(4, 1, 3, 2);
                 return DSAC_EX(4, 4, 2, 2);
             case 84: default: return DSAC_EX(4, 4, 2, 1);  // <64, 256>, 2 waves per SIMD, reciprocal + Newton + square root (<64, 256> at three waves per SIMD spills: 1.7 ms, profiles/r06_k2_exact_ab.txt)
         }
