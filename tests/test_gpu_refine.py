@@ -287,3 +287,41 @@ def test_the_walks_fp32_filter_never_changes_a_decision(engine, orc, synth):
     for b in (0, 21, 42, 63):
         _, imap_r, sd_r = orc.refine(poses[b], perm, xyz, uvf, H, W, synth.CAM_7SCENES, want_inlier_map=True, inlier_count=100, min_inliers=50)
         assert sd_r[0] == s0[b] and np.array_equal(np.asarray(imap_r).reshape(-1), m0[b].reshape(-1)), b
+
+
+@pytest.mark.parametrize("case", ["three frames x 174 (two problems per wave)", "three frames x 175 (one per wave)", "NaN / inf cells", "threshold beyond the clamp",
+                                  "256 inliers per step", "per-frame pixel positions"])
+def test_scan_corner_cases_equal_the_fused_kernel(engine, synth, case):
+    """The scan's less travelled branches against the fused kernel (k6_waves 1), bit for bit: frame batches whose hypotheses per frame are no multiple of four
+    (>= 512 problems: two problems per wave, or one), NaN and infinite coordinates (the frame bound becomes NaN / inf: every cell takes the fp64 residual),
+    thresholds at or beyond the error clamp (every cell an inlier: the fp64 path by rule), max_inl = 256 (the LM kernel's LDS capacity), sampled pixel positions
+    per frame."""
+    H, W = 128, 160
+    P = H * W
+    rng = np.random.default_rng(12)
+    F, per, kw, own_uv = 1, 64, dict(max_inl=100, min_inl=50, thr=10.0), False
+    if case.startswith("three frames x 174"): F, per = 3, 174
+    if case.startswith("three frames x 175"): F, per = 3, 175
+    if case == "threshold beyond the clamp": kw = dict(max_inl=100, min_inl=50, thr=120.0)
+    if case == "256 inliers per step": kw = dict(max_inl=256, min_inl=50, thr=10.0)
+    if case == "per-frame pixel positions": F, per, own_uv = 2, 32, True
+    frames = [synth.chess_like_frame(H, W, seed=300 + f, outlier_frac=0.6, grid_uv=not own_uv) for f in range(F)]
+    xyz = np.ascontiguousarray(np.stack([fr["xyz"] for fr in frames]))
+    if case == "NaN / inf cells":
+        xyz[0, rng.choice(P, 50, replace=False)] = np.nan
+        xyz[0, rng.choice(P, 50, replace=False), 0] = np.inf
+    uv = np.ascontiguousarray(np.stack([fr["uv"] for fr in frames])) if own_uv else None
+    engine.set_frames(xyz, uv, H, W, frames[0]["cam"], uv_per_frame=own_uv)
+    perm = synth.fast_permutations(P, 8, seed=5)
+    scale = np.where(np.arange(F * per)[:, None] % 4 == 0, 1.0, 20.0)
+    init = np.concatenate([np.repeat(fr["gt_pose"][None, :], per, 0) for fr in frames]) + rng.normal(size=(F * per, 6)) * np.array([0.01, 0.01, 0.01, 8.0, 8.0, 8.0]) * scale
+    res = {}
+    try:
+        for waves in (0, 1):
+            engine.set_option("k6_waves", waves)
+            res[waves] = engine.refineAll(init, perm, want_inlier_maps=True, **kw)
+    finally:
+        engine.set_option("k6_waves", 0)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b, equal_nan=True), case
+    assert int(res[0][1].max()) > 0
