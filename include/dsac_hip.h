@@ -107,7 +107,7 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *                 matrix core (one accumulation per row exact, the other below a few millimetres), the camera-frame point rounded to float ONCE, the distance
  *                 without a reciprocal of z (whose hardware approximation biases one hypothesis against another): e = n rsq(n z^2), n = (pu z - x)^2 + (pv z - y)^2
  *                 -- no cell above 1e-3 px over all cells of 256 x 640x480 (max 5.6e-4, mean 8.1e-6), softmax weights in a tie of unrelated hypotheses within
- *                 the stated 1e-4 (5.5e-5 .. 8.3e-5) at 1.13-1.15x the fast form's time (970-1 005 us = 0.63-0.66 of the HBM peak at the bench shape,
+ *                 the stated 1e-4 (5.5e-5 .. 8.3e-5) at 1.03-1.05x the fast form's time in the same process (984-995 against 940-958 us; 0.64-0.65 of the HBM peak at the bench shape,
  *                 profiles/r06_k2_rsq_ab.txt; with reciprocal + Newton step + square root, k2_variant 84 / 93: 1 002-1 052; the precise mode: 1.85x).  Needs a map the vector kernels can read and a focal length
  *                 <= 1 024 px; coordinates beyond +-65.5 m take the fp32 transform chunk by chunk.  An arithmetic form that is ASKED for by bit 25 / 27 / 28 and
  *                 cannot run on the frame is an error (round 6), never a silent launch of another form.  k2_variant 84 / 85 / 89 / 93 / 94 / 95 are its tile and tail trades.
