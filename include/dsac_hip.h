@@ -123,7 +123,9 @@ DSAC_API int dsac_device_info(dsac_ctx* ctx, int* cus, int* clock_khz, uint64_t*
  *   "k6_waves"    waves per refinement problem of K6's inlier walk: 0 (default) = by the problem count (1 for a single problem -- the four-wave build costs the good-pose refinement of one image 2.6 us --, 4 up to 512 problems, 2 up to 1 024, else 1), 1 / 2 / 4 / 8
  *                 fixed.  Wave 0 runs the problem as before; when the first 256 cells of a step's permutation do not give max_inl inliers the walk goes on in
  *                 rounds of waves x 256 cells (counts meet in LDS, every wave compacts behind the inliers in front of its cells): the same list, inlier maps, step
- *                 counts and poses bit for bit; 128 whole-map walks on 640 x 480 15.3 -> 5.4 ms (profiles/r06_k6_walk.txt)
+ *                 counts and poses bit for bit; 128 whole-map walks on 640 x 480 15.3 -> 5.4 ms (profiles/r06_k6_walk_v2.txt).  With 0, calls of >= 32 problems on a
+ *                 map of >= 16 384 cells (and no perturbed cells / fused loss) run every step as a scan of the step's cells + one LM launch instead (0.65 ms for the
+ *                 same 128 walks, bit-identical again; "k6_walk_exact", "k6_scan_tune" above; profiles/r06_k6_walk.txt); a non-zero value keeps the fused kernel
  *   "refstream_mode"  see dsac_sample_refstream
  *   "k1_wpb", "k1_prio", "k1_hpw", "k1_minw"   K1 waves per workgroup (1), wave priority (3), hypotheses per wave (1), register budget in waves per SIMD (1)
  *   "k1_rl"       lanes per sampling attempt: 1 (default) = one lane per attempt, the quartic's roots in sequence, 64 attempts per round and
