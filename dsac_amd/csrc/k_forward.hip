@@ -1542,7 +1542,7 @@ __global__ __launch_bounds__(KR_WAVES * 64) void k_reduce_soft(int N, int tiles,
     const int h = blockIdx.x * 64 + lane;
     double s = 0;
     if (h < N) {
-#pragma unroll 4
+#pragma unroll 16  // sixteen row reads in flight per wave (the adds stay in row order): 1 200 rows are 75 per wave, a chain of latencies at four
         for (int t = wave; t < tiles; t += KR_WAVES) s += (double)part[(size_t)t * N + h];
     }
     s_acc[wave][lane] = s;
