@@ -238,3 +238,24 @@ def test_every_exact_kernel_form_on_all_rows(exact_engine, orc, synth, variant):
     assert np.array_equal(err[3, 1000:1064] >= CLAMP - 1e-3, ref[3, 1000:1064] >= CLAMP - 1e-3)
     soft_ref = orc.soft_inlier(ref, TAU, BETA)
     assert np.abs(soft - soft_ref).max() <= 2e-7 * max(1.0, soft_ref.max())
+
+
+@pytest.mark.parametrize("cam", [(700.3, 651.7, 301.5, 255.25), (90.0, 90.0, 320.0, 240.0), (1024.0, 1024.0, 320.0, 240.0), (262.5, 262.5, 160.0, 120.0)])
+def test_other_intrinsics(exact_engine, orc, synth, cam):
+    """Focal lengths other than 7-Scenes' 525: unequal and fractional, short (exponent 7), the largest the split records take (2^10), and a half-resolution
+    camera.  All cells of 64 hypotheses on a 640x480 (320x240) map inside the stated 1e-3 px; scores within 2e-7 relative."""
+    eng = exact_engine
+    h, w = (240, 320) if cam[2] < 200 else (H, W)
+    fr = synth.chess_like_frame(h, w, seed=31, cam=cam, grid_uv=True)
+    uv = fr["uv"]
+    eng.set_frame(fr["xyz"], None, h, w, cam)
+    poses, _, _ = eng.sample(64, seed=9, thr=10.0, max_tries=1 << 16)
+    err, soft = np.zeros((64, h * w), np.float32), np.zeros(64)
+    eng.reproject(poses, err=err, soft=soft, tau=TAU, beta=BETA)
+    ref = orc.get_diff_maps(poses, fr["xyz"], uv, h, w, cam)
+    m = excl_clamp_edge(err, ref, CLAMP)
+    d = np.abs(err - ref)
+    d[~m] = 0
+    margin("a3", "K2 EXACT form, camera (%g, %g, %g, %g): max |err - oracle| px over all cells" % cam, d.max(), 1e-3)
+    sr = orc.soft_inlier(ref, TAU, BETA)
+    assert np.abs(soft - sr).max() <= 2e-7 * max(1.0, sr.max())
